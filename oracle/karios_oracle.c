@@ -1,0 +1,650 @@
+/*
+ * karios_oracle.c -- CPU restatement of the KARIOS image-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the bench's
+ * `cpu_baseline` leg.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline may load it.  The product path (karios_amd/) never links,
+ * imports or executes anything in oracle/.
+ *
+ * PARITY STATUS
+ *   - numpy-defined pieces (to_uint8, auto-mask, FB score, ZNCC, shift_image):
+ *     PINNED against the reference's own Python functions imported in the
+ *     build container (tests/golden/make_golden.py -> tests/golden/ *.npz).
+ *   - OpenCV-defined pieces (Laplacian, goodFeaturesToTrack,
+ *     calcOpticalFlowPyrLK): "parity unpinned".  The arithmetic lives in the
+ *     third-party dependency opencv=4.8.* (reference environment.yml:8), which
+ *     is absent from /root/reference and not installed here; the reference's
+ *     unit tests mock cv2 and the e2e golden inputs are stripped.  These
+ *     functions restate OpenCV 4.8's published algorithm
+ *     and are anchored on the reference call sites cited below.
+ *
+ * Deliberate deviations from OpenCV's float rounding:
+ *   - structure tensor sums are exact integers, converted once to f32;
+ *   - LK normal-matrix / mismatch-vector sums are exact int64, converted
+ *     once to f32 (OpenCV x86 accumulates in 4 f32 SIMD lanes).
+ *
+ * Build: gcc -O2 -fPIC -shared -ffp-contract=off -fopenmp (see Makefile).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define KO_U8 0
+#define KO_U16 1
+#define KO_I16 2
+#define KO_F32 3
+#define KO_F64 4
+
+/* OpenCV borderInterpolate(p, len, BORDER_REFLECT_101) */
+static inline int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+static inline double load_as_double(const void *img, int dtype, size_t idx)
+{
+    switch (dtype) {
+    case KO_U8: return (double)((const uint8_t *)img)[idx];
+    case KO_U16: return (double)((const uint16_t *)img)[idx];
+    case KO_I16: return (double)((const int16_t *)img)[idx];
+    case KO_F32: return (double)((const float *)img)[idx];
+    default: return ((const double *)img)[idx];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* np.nanmin / np.nanmax (klt.py:46).  Returns 0, or 1 if all-NaN.    */
+int ko_minmax(const void *img, int dtype, int H, int W, ptrdiff_t stride,
+              double *out_min, double *out_max)
+{
+    double mn = INFINITY, mx = -INFINITY;
+    int any = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double v = load_as_double(img, dtype, (size_t)y * stride + x);
+            if (v != v) continue;
+            any = 1;
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+    *out_min = mn;
+    *out_max = mx;
+    return any ? 0 : 1;
+}
+
+/* _to_uint8 (klt.py:42-49): u8 passthrough; integer/f64 dtypes in fp64,
+ * f32 in fp32 (numpy weak-scalar promotion); truncating cast; zeros if
+ * max<=min.  `invert` applies 255 - u8 (klt.py:419). NaN -> 0. */
+int ko_to_uint8(const void *img, int dtype, int H, int W, ptrdiff_t stride,
+                double mn, double mx, int invert, uint8_t *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        uint8_t *o = out + (size_t)y * W;
+        for (int x = 0; x < W; x++) {
+            size_t idx = (size_t)y * stride + x;
+            uint8_t r;
+            if (dtype == KO_U8) {
+                r = ((const uint8_t *)img)[idx];
+            } else if (!(mx > mn)) {
+                r = 0;
+            } else if (dtype == KO_F32) {
+                float v = ((const float *)img)[idx];
+                float t = (v - (float)mn) / (float)(mx - mn) * 255.0f;
+                r = (t != t) ? 0 : (uint8_t)(int)t;
+            } else {
+                double v = load_as_double(img, dtype, idx);
+                double t = (v - mn) / (mx - mn) * 255.0;
+                r = (t != t) ? 0 : (uint8_t)(int)t;
+            }
+            o[x] = invert ? (uint8_t)(255 - r) : r;
+        }
+    }
+    return 0;
+}
+
+/* auto validity mask (klt.py:268-273).  nodata pointers may be NULL.
+ * Returns the number of valid pixels (klt.py:276). */
+long ko_auto_mask(const void *mon, const void *ref, int dtype, int H, int W,
+                  ptrdiff_t stride_mon, ptrdiff_t stride_ref,
+                  const double *nodata_mon, const double *nodata_ref,
+                  uint8_t *mask)
+{
+    long valid = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double a = load_as_double(mon, dtype, (size_t)y * stride_mon + x);
+            double b = load_as_double(ref, dtype, (size_t)y * stride_ref + x);
+            int ok = (a != 0.0) && (b != 0.0) && isfinite(a) && isfinite(b);
+            if (nodata_mon && a == *nodata_mon) ok = 0;
+            if (nodata_ref && b == *nodata_ref) ok = 0;
+            mask[(size_t)y * W + x] = (uint8_t)ok;
+            valid += ok;
+        }
+    return valid;
+}
+
+/* ------------------------------------------------------------------ */
+/* OpenCV getSobelKernels recurrence (deriv.cpp), order 0..2, odd ksize>=3 */
+static void sobel_kernel(int ksize, int order, int *ker /* ksize+1 */)
+{
+    if (ksize == 1) { ker[0] = 1; return; }
+    if (ksize == 3) {
+        static const int k0[3] = {1, 2, 1}, k1[3] = {-1, 0, 1}, k2[3] = {1, -2, 1};
+        const int *s = order == 0 ? k0 : order == 1 ? k1 : k2;
+        memcpy(ker, s, 3 * sizeof(int));
+        return;
+    }
+    int oldval, newval;
+    ker[0] = 1;
+    for (int i = 0; i < ksize; i++) ker[i + 1] = 0;
+    for (int i = 0; i < ksize - order - 1; i++) {
+        oldval = ker[0];
+        for (int j = 1; j <= ksize; j++) {
+            newval = ker[j] + ker[j - 1];
+            ker[j - 1] = oldval;
+            oldval = newval;
+        }
+    }
+    for (int i = 0; i < order; i++) {
+        oldval = -ker[0];
+        for (int j = 1; j <= ksize; j++) {
+            newval = ker[j - 1] - ker[j];
+            ker[j - 1] = oldval;
+            oldval = newval;
+        }
+    }
+}
+
+int ko_sobel_kernel(int ksize, int order, int *out)
+{
+    int buf[40];
+    if (ksize < 1 || ksize > 31 || !(ksize & 1)) return -1;
+    sobel_kernel(ksize, order, buf);
+    memcpy(out, buf, ksize * sizeof(int));
+    return 0;
+}
+
+/* cv2.Laplacian(u8, CV_8U, ksize) (klt.py:359-360,427-434,480-483;
+ * SURVEY App. A.1): exact integer stencil, REFLECT_101, clip to [0,255]. */
+int ko_laplacian_u8(const uint8_t *src, int H, int W, int ksize, uint8_t *dst)
+{
+    if (ksize < 1 || ksize > 31 || !(ksize & 1)) return -1;
+    if (ksize == 1 || ksize == 3) {
+        static const int K[2][9] = {{0, 1, 0, 1, -4, 1, 0, 1, 0},
+                                    {2, 0, 2, 0, -8, 0, 2, 0, 2}};
+        const int *k = K[ksize == 3];
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                int s = 0;
+                for (int j = -1; j <= 1; j++) {
+                    const uint8_t *row = src + (size_t)reflect101(y + j, H) * W;
+                    for (int i = -1; i <= 1; i++)
+                        s += k[(j + 1) * 3 + i + 1] * row[reflect101(x + i, W)];
+                }
+                dst[(size_t)y * W + x] = (uint8_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+            }
+        return 0;
+    }
+    int kd[40], ks[40];
+    sobel_kernel(ksize, 2, kd);
+    sobel_kernel(ksize, 0, ks);
+    int r = ksize / 2;
+    /* horizontal passes into two int64 planes, then vertical combine */
+    int64_t *hd = (int64_t *)malloc((size_t)H * W * sizeof(int64_t));
+    int64_t *hs = (int64_t *)malloc((size_t)H * W * sizeof(int64_t));
+    if (!hd || !hs) { free(hd); free(hs); return -2; }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        const uint8_t *row = src + (size_t)y * W;
+        for (int x = 0; x < W; x++) {
+            int64_t a = 0, b = 0;
+            for (int i = -r; i <= r; i++) {
+                int v = row[reflect101(x + i, W)];
+                a += (int64_t)kd[i + r] * v;
+                b += (int64_t)ks[i + r] * v;
+            }
+            hd[(size_t)y * W + x] = a;
+            hs[(size_t)y * W + x] = b;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int64_t s = 0;
+            for (int j = -r; j <= r; j++) {
+                size_t yy = (size_t)reflect101(y + j, H) * W + x;
+                s += (int64_t)ks[j + r] * hd[yy] + (int64_t)kd[j + r] * hs[yy];
+            }
+            dst[(size_t)y * W + x] = (uint8_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+        }
+    free(hd);
+    free(hs);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* cornerMinEigenVal(u8, blockSize, ksize=3) inside cv2.goodFeaturesToTrack
+ * (klt.py:120).  Exact-integer structure tensor,
+ * one conversion to f32, then OpenCV's f32 formula (no FMA contraction). */
+int ko_min_eigen(const uint8_t *src, int H, int W, int block, float *eig)
+{
+    if (block < 1) return -1;
+    size_t n = (size_t)H * W;
+    int32_t *pxx = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *pxy = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *pyy = (int32_t *)malloc(n * sizeof(int32_t));
+    int64_t *hxx = (int64_t *)malloc(n * sizeof(int64_t));
+    int64_t *hxy = (int64_t *)malloc(n * sizeof(int64_t));
+    int64_t *hyy = (int64_t *)malloc(n * sizeof(int64_t));
+    if (!pxx || !pxy || !pyy || !hxx || !hxy || !hyy) {
+        free(pxx); free(pxy); free(pyy); free(hxx); free(hxy); free(hyy);
+        return -2;
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        const uint8_t *r0 = src + (size_t)reflect101(y - 1, H) * W;
+        const uint8_t *r1 = src + (size_t)y * W;
+        const uint8_t *r2 = src + (size_t)reflect101(y + 1, H) * W;
+        for (int x = 0; x < W; x++) {
+            int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+            int dx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
+            int dy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
+            size_t i = (size_t)y * W + x;
+            pxx[i] = dx * dx;
+            pxy[i] = dx * dy;
+            pyy[i] = dy * dy;
+        }
+    }
+    int anchor = block / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int64_t a = 0, b = 0, c = 0;
+            for (int i = 0; i < block; i++) {
+                size_t j = (size_t)y * W + reflect101(x - anchor + i, W);
+                a += pxx[j]; b += pxy[j]; c += pyy[j];
+            }
+            size_t i = (size_t)y * W + x;
+            hxx[i] = a; hxy[i] = b; hyy[i] = c;
+        }
+    const double scale = 1.0 / (4.0 * (double)block * 255.0);
+    const double scale2 = scale * scale;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int64_t sa = 0, sb = 0, sc = 0;
+            for (int i = 0; i < block; i++) {
+                size_t j = (size_t)reflect101(y - anchor + i, H) * W + x;
+                sa += hxx[j]; sb += hxy[j]; sc += hyy[j];
+            }
+            float cxx = (float)((double)sa * scale2);
+            float cxy = (float)((double)sb * scale2);
+            float cyy = (float)((double)sc * scale2);
+            float a = cxx * 0.5f, b = cxy, c = cyy * 0.5f;
+            float t = a - c;
+            float tt = t * t;
+            float bb = b * b;
+            float s = tt + bb;
+            eig[(size_t)y * W + x] = (a + c) - sqrtf(s);
+        }
+    free(pxx); free(pxy); free(pyy); free(hxx); free(hxy); free(hyy);
+    return 0;
+}
+
+typedef struct { float v; uint32_t idx; } cand_t;
+
+static int cand_cmp(const void *pa, const void *pb)
+{
+    const cand_t *a = (const cand_t *)pa, *b = (const cand_t *)pb;
+    /* greaterThanPtr: value desc, then address desc */
+    if (a->v > b->v) return -1;
+    if (a->v < b->v) return 1;
+    return a->idx > b->idx ? -1 : a->idx < b->idx ? 1 : 0;
+}
+
+/* Steps 4-8 of goodFeaturesToTrack on a given eig map (App. A.2).
+ * out_xy: 2*cap floats; returns corner count, or <0 on error.
+ * stats (nullable): [0]=n_candidates, [1]=maxVal bits as float. */
+int ko_select_corners(const float *eig, const uint8_t *mask, int H, int W,
+                      int max_corners, double quality, double min_dist,
+                      float *out_xy, int cap, double *stats)
+{
+    size_t n = (size_t)H * W;
+    double max_val = -INFINITY;
+    int any = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!mask || mask[i]) {
+            if (!any || eig[i] > max_val) max_val = eig[i];
+            any = 1;
+        }
+    if (!any) max_val = 0; /* minMaxLoc with an empty mask leaves 0 */
+    float thr = (float)(max_val * quality);
+    cand_t *c = NULL;
+    size_t nc = 0, capc = 0;
+    for (int y = 1; y < H - 1; y++)
+        for (int x = 1; x < W - 1; x++) {
+            size_t i = (size_t)y * W + x;
+            float v = eig[i] > thr ? eig[i] : 0.f;
+            if (v == 0.f) continue;
+            if (mask && !mask[i]) continue;
+            float m = 0.f; /* dilate of the thresholded map */
+            int first = 1;
+            for (int j = -1; j <= 1; j++)
+                for (int k = -1; k <= 1; k++) {
+                    float e = eig[i + (ptrdiff_t)j * W + k];
+                    e = e > thr ? e : 0.f;
+                    if (first || e > m) m = e;
+                    first = 0;
+                }
+            if (v != m) continue;
+            if (nc == capc) {
+                capc = capc ? capc * 2 : 4096;
+                c = (cand_t *)realloc(c, capc * sizeof(cand_t));
+                if (!c) return -2;
+            }
+            c[nc].v = eig[i];
+            c[nc].idx = (uint32_t)i;
+            nc++;
+        }
+    if (stats) { stats[0] = (double)nc; stats[1] = max_val; }
+    if (nc == 0) { free(c); return 0; }
+    qsort(c, nc, sizeof(cand_t), cand_cmp);
+    int ncorners = 0;
+    if (min_dist >= 1) {
+        const int cell = (int)lrint(min_dist);
+        const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+        /* per-cell singly linked lists of accepted points */
+        int *head = (int *)malloc((size_t)gw * gh * sizeof(int));
+        int *next = (int *)malloc(nc * sizeof(int));
+        float *ax = (float *)malloc(nc * sizeof(float));
+        float *ay = (float *)malloc(nc * sizeof(float));
+        if (!head || !next || !ax || !ay) { free(head); free(next); free(ax); free(ay); free(c); return -2; }
+        for (size_t i = 0; i < (size_t)gw * gh; i++) head[i] = -1;
+        const float md2 = (float)(min_dist * min_dist);
+        int nacc = 0;
+        for (size_t i = 0; i < nc; i++) {
+            int y = (int)(c[i].idx / (uint32_t)W), x = (int)(c[i].idx % (uint32_t)W);
+            int xc = x / cell, yc = y / cell;
+            int x1 = xc - 1 < 0 ? 0 : xc - 1, y1 = yc - 1 < 0 ? 0 : yc - 1;
+            int x2 = xc + 1 > gw - 1 ? gw - 1 : xc + 1, y2 = yc + 1 > gh - 1 ? gh - 1 : yc + 1;
+            int good = 1;
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (int k = head[yy * gw + xx]; k >= 0; k = next[k]) {
+                        float dx = (float)x - ax[k], dy = (float)y - ay[k];
+                        if (dx * dx + dy * dy < md2) { good = 0; break; }
+                    }
+            if (!good) continue;
+            ax[nacc] = (float)x; ay[nacc] = (float)y;
+            next[nacc] = head[yc * gw + xc];
+            head[yc * gw + xc] = nacc;
+            nacc++;
+            if (ncorners < cap) { out_xy[2 * ncorners] = (float)x; out_xy[2 * ncorners + 1] = (float)y; }
+            ncorners++;
+            if (max_corners > 0 && ncorners == max_corners) break;
+        }
+        free(head); free(next); free(ax); free(ay);
+    } else {
+        for (size_t i = 0; i < nc; i++) {
+            int y = (int)(c[i].idx / (uint32_t)W), x = (int)(c[i].idx % (uint32_t)W);
+            if (ncorners < cap) { out_xy[2 * ncorners] = (float)x; out_xy[2 * ncorners + 1] = (float)y; }
+            ncorners++;
+            if (max_corners > 0 && ncorners == max_corners) break;
+        }
+    }
+    free(c);
+    return ncorners > cap ? -3 : ncorners;
+}
+
+/* cv2.goodFeaturesToTrack(img, mask=, maxCorners, qualityLevel, minDistance,
+ * blockSize) as called at klt.py:120, 494. */
+int ko_good_features(const uint8_t *img, const uint8_t *mask, int H, int W,
+                     int max_corners, double quality, double min_dist, int block,
+                     float *out_xy, int cap, double *stats)
+{
+    float *eig = (float *)malloc((size_t)H * W * sizeof(float));
+    if (!eig) return -2;
+    int rc = ko_min_eigen(img, H, W, block, eig);
+    if (rc == 0)
+        rc = ko_select_corners(eig, mask, H, W, max_corners, quality, min_dist, out_xy, cap, stats);
+    free(eig);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* cv::pyrDown u8 (buildOpticalFlowPyramid level l -> l+1, App. A.3) */
+int ko_pyrdown_u8(const uint8_t *src, int H, int W, uint8_t *dst)
+{
+    int dh = (H + 1) / 2, dw = (W + 1) / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            static const int k[5] = {1, 4, 6, 4, 1};
+            int s = 0;
+            for (int j = 0; j < 5; j++) {
+                const uint8_t *row = src + (size_t)reflect101(2 * y + j - 2, H) * W;
+                int rs = 0;
+                for (int i = 0; i < 5; i++) rs += k[i] * row[reflect101(2 * x + i - 2, W)];
+                s += k[j] * rs;
+            }
+            dst[(size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
+        }
+    return 0;
+}
+
+typedef struct {
+    const uint8_t *img;
+    int H, W;
+} level_t;
+
+static inline int px(const level_t *L, int y, int x)
+{
+    return L->img[(size_t)reflect101(y, L->H) * L->W + reflect101(x, L->W)];
+}
+
+/* calcScharrDeriv at an in-image position; zero outside (BORDER_CONSTANT) */
+static inline void scharr(const level_t *L, int y, int x, int *ix, int *iy)
+{
+    if ((unsigned)x >= (unsigned)L->W || (unsigned)y >= (unsigned)L->H) { *ix = 0; *iy = 0; return; }
+    int a00 = px(L, y - 1, x - 1), a01 = px(L, y - 1, x), a02 = px(L, y - 1, x + 1);
+    int a10 = px(L, y, x - 1), a12 = px(L, y, x + 1);
+    int a20 = px(L, y + 1, x - 1), a21 = px(L, y + 1, x), a22 = px(L, y + 1, x + 1);
+    *ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+    *iy = ((a20 + a22) * 3 + a21 * 10) - ((a00 + a02) * 3 + a01 * 10);
+}
+
+#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+static inline void lk_weights(float a, float b, int *w00, int *w01, int *w10, int *w11)
+{
+    float oma = 1.f - a, omb = 1.f - b;
+    float t00 = oma * omb, t01 = a * omb, t10 = oma * b;
+    *w00 = (int)lrintf(t00 * 16384.f);
+    *w01 = (int)lrintf(t01 * 16384.f);
+    *w10 = (int)lrintf(t10 * 16384.f);
+    *w11 = 16384 - *w00 - *w01 - *w10;
+}
+
+/* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(w,w), maxLevel,
+ * criteria=(EPS|COUNT, max_count, eps)) with flags=0, minEigThreshold=1e-4
+ * (klt.py:128-140).  status/err are not produced: KARIOS
+ * discards them (klt.py:142-144, 153).  iters (nullable): per-point level-0
+ * iteration count, diagnostic only. */
+int ko_pyrlk(const uint8_t *prev, const uint8_t *next, int H, int W,
+             const float *pts, int n, int win, int max_level, int max_count,
+             double eps, float *out_pts, int *iters)
+{
+    if (win <= 2 || max_level < 0) return -1;
+    if (max_count < 0) max_count = 0;
+    if (max_count > 100) max_count = 100;
+    if (eps < 0) eps = 0;
+    if (eps > 10) eps = 10;
+    const double epsilon = eps * eps;
+    /* pyramids; stop when next size would be <= winSize */
+    enum { MAXL = 8 };
+    level_t P[MAXL + 1], N[MAXL + 1];
+    uint8_t *own[2 * (MAXL + 1)];
+    int nown = 0;
+    if (max_level > MAXL) max_level = MAXL;
+    P[0].img = prev; P[0].H = H; P[0].W = W;
+    N[0].img = next; N[0].H = H; N[0].W = W;
+    int levels = 0;
+    {
+        int w = W, h = H;
+        for (int l = 0; l < max_level; l++) {
+            int nw = (w + 1) / 2, nh = (h + 1) / 2;
+            if (nw <= win || nh <= win) break;
+            uint8_t *a = (uint8_t *)malloc((size_t)nw * nh), *b = (uint8_t *)malloc((size_t)nw * nh);
+            if (!a || !b) return -2;
+            ko_pyrdown_u8(P[l].img, P[l].H, P[l].W, a);
+            ko_pyrdown_u8(N[l].img, N[l].H, N[l].W, b);
+            own[nown++] = a; own[nown++] = b;
+            P[l + 1].img = a; P[l + 1].H = nh; P[l + 1].W = nw;
+            N[l + 1].img = b; N[l + 1].H = nh; N[l + 1].W = nw;
+            levels = l + 1;
+            w = nw; h = nh;
+        }
+    }
+    const float half = (float)(win - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    for (int i = 0; i < 2 * n; i++) out_pts[i] = pts[i];
+
+#pragma omp parallel
+    {
+        short *Ibuf = (short *)malloc((size_t)win * win * 3 * sizeof(short));
+        short *dIx = Ibuf + (size_t)win * win, *dIy = dIx + (size_t)win * win;
+        for (int level = levels; level >= 0; level--) {
+            const level_t *I = &P[level], *J = &N[level];
+#pragma omp for schedule(dynamic, 64)
+            for (int p = 0; p < n; p++) {
+                float sc = (float)(1. / (1 << level));
+                float prx = pts[2 * p] * sc, pry = pts[2 * p + 1] * sc;
+                float nx, ny;
+                if (level == levels) { nx = prx; ny = pry; }
+                else { nx = out_pts[2 * p] * 2.f; ny = out_pts[2 * p + 1] * 2.f; }
+                out_pts[2 * p] = nx; out_pts[2 * p + 1] = ny;
+                if (level == 0 && iters) iters[p] = 0;
+                prx -= half; pry -= half;
+                int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
+                if (ipx < -win || ipx >= I->W || ipy < -win || ipy >= I->H) continue;
+                float a = prx - (float)ipx, b = pry - (float)ipy;
+                int w00, w01, w10, w11;
+                lk_weights(a, b, &w00, &w01, &w10, &w11);
+                int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+                for (int y = 0; y < win; y++)
+                    for (int x = 0; x < win; x++) {
+                        int gy = ipy + y, gx = ipx + x;
+                        int ival = DESCALE(px(I, gy, gx) * w00 + px(I, gy, gx + 1) * w01 +
+                                           px(I, gy + 1, gx) * w10 + px(I, gy + 1, gx + 1) * w11, 14 - 5);
+                        int x00, y00, x01, y01, x10, y10, x11, y11;
+                        scharr(I, gy, gx, &x00, &y00);
+                        scharr(I, gy, gx + 1, &x01, &y01);
+                        scharr(I, gy + 1, gx, &x10, &y10);
+                        scharr(I, gy + 1, gx + 1, &x11, &y11);
+                        int ixv = DESCALE(x00 * w00 + x01 * w01 + x10 * w10 + x11 * w11, 14);
+                        int iyv = DESCALE(y00 * w00 + y01 * w01 + y10 * w10 + y11 * w11, 14);
+                        Ibuf[y * win + x] = (short)ival;
+                        dIx[y * win + x] = (short)ixv;
+                        dIy[y * win + x] = (short)iyv;
+                        iA11 += (int64_t)ixv * ixv;
+                        iA12 += (int64_t)ixv * iyv;
+                        iA22 += (int64_t)iyv * iyv;
+                    }
+                float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+                float D = A11 * A22 - A12 * A12;
+                float dA = A11 - A22;
+                float q = dA * dA + 4.f * A12 * A12;
+                float minEig = (A22 + A11 - sqrtf(q)) / (float)(2 * win * win);
+                if (minEig < 1e-4f || D < FLT_EPSILON) continue;
+                D = 1.f / D;
+                nx -= half; ny -= half;
+                float pdx = 0.f, pdy = 0.f;
+                for (int j = 0; j < max_count; j++) {
+                    int inx = (int)floorf(nx), iny = (int)floorf(ny);
+                    if (inx < -win || inx >= J->W || iny < -win || iny >= J->H) break;
+                    a = nx - (float)inx; b = ny - (float)iny;
+                    lk_weights(a, b, &w00, &w01, &w10, &w11);
+                    int64_t ib1 = 0, ib2 = 0;
+                    for (int y = 0; y < win; y++)
+                        for (int x = 0; x < win; x++) {
+                            int gy = iny + y, gx = inx + x;
+                            int diff = DESCALE(px(J, gy, gx) * w00 + px(J, gy, gx + 1) * w01 +
+                                               px(J, gy + 1, gx) * w10 + px(J, gy + 1, gx + 1) * w11, 14 - 5) -
+                                       Ibuf[y * win + x];
+                            ib1 += (int64_t)diff * dIx[y * win + x];
+                            ib2 += (int64_t)diff * dIy[y * win + x];
+                        }
+                    float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+                    float ddx = (A12 * b2 - A22 * b1) * D;
+                    float ddy = (A12 * b1 - A11 * b2) * D;
+                    nx += ddx; ny += ddy;
+                    out_pts[2 * p] = nx + half; out_pts[2 * p + 1] = ny + half;
+                    if (level == 0 && iters) iters[p] = j + 1;
+                    /* Point2f::ddot: double accumulation of the f32 deltas */
+                    if ((double)ddx * ddx + (double)ddy * ddy <= epsilon) break;
+                    if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+                        out_pts[2 * p] -= ddx * 0.5f;
+                        out_pts[2 * p + 1] -= ddy * 0.5f;
+                        break;
+                    }
+                    pdx = ddx; pdy = ddy;
+                }
+            }
+        }
+        free(Ibuf);
+    }
+    for (int i = 0; i < nown; i++) free(own[i]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* ZNCCService._compute_zncc + _zncc2 (zncc_service.py:45-126,186-238):
+ * 57x57 chips at (x0,y0) / (round(x0+dx), round(y0+dy)), ZNCC on the
+ * centre 43x43 (n=21).  NaN where the reference returns NaN. */
+int ko_zncc_batch(const void *ref, const void *mon, int dtype, int Href, int Wref,
+                  int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
+                  const float *x0, const float *y0, const float *dx, const float *dy,
+                  int n, double *out)
+{
+    const int margin = 28, hw = 21, np_ = 43 * 43;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < n; k++) {
+        out[k] = NAN;
+        int X0 = (int)x0[k], Y0 = (int)y0[k];
+        /* round(np.float32 sum): half-to-even on the f32 sum */
+        float sx = x0[k] + dx[k], sy = y0[k] + dy[k];
+        if (!isfinite(sx) || !isfinite(sy)) continue;
+        long X1 = lrintf(sx), Y1 = lrintf(sy);
+        if (X0 - margin < 0 || Y0 - margin < 0 || X1 - margin < 0 || Y1 - margin < 0) continue;
+        if (X0 >= Wref - margin || Y0 >= Href - margin || X1 >= Wmon - margin || Y1 >= Hmon - margin) continue;
+        double s1 = 0, s2 = 0;
+        for (int j = -hw; j <= hw; j++)
+            for (int i = -hw; i <= hw; i++) {
+                s1 += load_as_double(ref, dtype, (size_t)(Y0 + j) * stride_ref + X0 + i);
+                s2 += load_as_double(mon, dtype, (size_t)(Y1 + j) * stride_mon + X1 + i);
+            }
+        double m1 = s1 / np_, m2 = s2 / np_;
+        double v1 = 0, v2 = 0, cc = 0;
+        for (int j = -hw; j <= hw; j++)
+            for (int i = -hw; i <= hw; i++) {
+                double a = load_as_double(ref, dtype, (size_t)(Y0 + j) * stride_ref + X0 + i) - m1;
+                double b = load_as_double(mon, dtype, (size_t)(Y1 + j) * stride_mon + X1 + i) - m2;
+                v1 += a * a; v2 += b * b; cc += a * b;
+            }
+        double sd1 = sqrt(v1 / np_), sd2 = sqrt(v2 / np_);
+        if (sd1 == 0 || sd2 == 0) continue;
+        out[k] = cc / (sd1 * sd2) / np_;
+    }
+    return 0;
+}

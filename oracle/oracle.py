@@ -1,0 +1,313 @@
+"""CPU oracle for the KARIOS matching hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product package ``karios_amd`` never does.
+
+Thin ctypes binding over ``libkarios_oracle.so`` (karios_oracle.c, the dense
+restatement) plus numpy restatements of the reference's numpy glue.  Every
+function cites the reference file:line (relative to /root/reference) it follows.
+
+Parity status: see the header of karios_oracle.c ("parity unpinned" for the
+OpenCV-defined arithmetic; numpy-defined pieces are pinned by tests/golden).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libkarios_oracle.so")
+
+_DT = {np.dtype("uint8"): 0, np.dtype("uint16"): 1, np.dtype("int16"): 2,
+       np.dtype("float32"): 3, np.dtype("float64"): 4}
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "karios_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.ko_auto_mask.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check_img(a):
+    a = np.asarray(a)
+    if a.ndim != 2 or a.dtype not in _DT:
+        raise TypeError(f"unsupported image {a.dtype} ndim={a.ndim}")
+    if a.strides[1] != a.itemsize:
+        a = np.ascontiguousarray(a)
+    return a, _DT[a.dtype], a.strides[0] // a.itemsize
+
+
+# ----------------------------------------------------------------- numpy glue
+def minmax(arr):
+    """np.nanmin/np.nanmax as floats (klt.py:46)."""
+    a, dt, st = _check_img(arr)
+    mn, mx = C.c_double(), C.c_double()
+    lib().ko_minmax(_p(a), dt, a.shape[0], a.shape[1], C.c_ssize_t(st), C.byref(mn), C.byref(mx))
+    return mn.value, mx.value
+
+
+def to_uint8(arr, invert: bool = False):
+    """_to_uint8 (klt.py:42-49), optional 255-x (klt.py:419)."""
+    a, dt, st = _check_img(arr)
+    mn, mx = (0.0, 0.0) if dt == 0 else minmax(a)
+    out = np.empty(a.shape, np.uint8)
+    lib().ko_to_uint8(_p(a), dt, a.shape[0], a.shape[1], C.c_ssize_t(st),
+                      C.c_double(mn), C.c_double(mx), int(bool(invert)), _p(out))
+    return out
+
+
+def auto_mask(mon, ref, nodata_mon=None, nodata_ref=None):
+    """Automatic validity mask (klt.py:268-273) -> (uint8 mask, valid count)."""
+    m, dt, sm = _check_img(mon)
+    r, dt2, sr = _check_img(ref)
+    if dt != dt2 or m.shape != r.shape:
+        raise TypeError("mon/ref dtype or shape mismatch")
+    mask = np.empty(m.shape, np.uint8)
+    nm = C.byref(C.c_double(float(nodata_mon))) if nodata_mon is not None else None
+    nr = C.byref(C.c_double(float(nodata_ref))) if nodata_ref is not None else None
+    valid = lib().ko_auto_mask(_p(m), _p(r), dt, m.shape[0], m.shape[1], C.c_ssize_t(sm),
+                               C.c_ssize_t(sr), nm, nr, _p(mask))
+    return mask, int(valid)
+
+
+def sobel_kernel(ksize: int, order: int):
+    out = np.zeros(ksize, np.int32)
+    if lib().ko_sobel_kernel(ksize, order, _p(out)) != 0:
+        raise ValueError("bad ksize")
+    return out
+
+
+def laplacian_u8(img, ksize: int):
+    """cv2.Laplacian(u8, cv2.CV_8U, ksize=k) (klt.py:433-434)."""
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(a)
+    if lib().ko_laplacian_u8(_p(a), a.shape[0], a.shape[1], int(ksize), _p(out)) != 0:
+        raise ValueError(f"bad Laplacian ksize {ksize}")
+    return out
+
+
+def min_eigen(img, block: int):
+    """cornerMinEigenVal map inside goodFeaturesToTrack."""
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.empty(a.shape, np.float32)
+    if lib().ko_min_eigen(_p(a), a.shape[0], a.shape[1], int(block), _p(out)) != 0:
+        raise ValueError("min_eigen failed")
+    return out
+
+
+def good_features(img, mask=None, maxCorners=0, qualityLevel=0.1, minDistance=10, blockSize=3,
+                  return_stats=False):
+    """cv2.goodFeaturesToTrack (klt.py:120) -> (N,1,2) float32 or None."""
+    a = np.ascontiguousarray(img, np.uint8)
+    H, W = a.shape
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    cap = int(maxCorners) if maxCorners > 0 else H * W
+    out = np.empty((max(cap, 1), 2), np.float32)
+    stats = np.zeros(2, np.float64)
+    n = lib().ko_good_features(_p(a), None if m is None else _p(m), H, W, int(maxCorners),
+                               C.c_double(qualityLevel), C.c_double(minDistance), int(blockSize),
+                               _p(out), cap, _p(stats))
+    if n < 0:
+        raise RuntimeError(f"ko_good_features rc={n}")
+    res = None if n == 0 else out[:n].reshape(n, 1, 2).copy()
+    return (res, stats) if return_stats else res
+
+
+def pyrdown_u8(img):
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.empty(((a.shape[0] + 1) // 2, (a.shape[1] + 1) // 2), np.uint8)
+    lib().ko_pyrdown_u8(_p(a), a.shape[0], a.shape[1], _p(out))
+    return out
+
+
+def pyr_lk(prev, nxt, pts, win=25, max_level=1, max_count=30, eps=0.03, return_iters=False):
+    """cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(w,w), maxLevel=1,
+    criteria=(EPS|COUNT,30,0.03)) (klt.py:128-140) -> next points (N,1,2) f32."""
+    a = np.ascontiguousarray(prev, np.uint8)
+    b = np.ascontiguousarray(nxt, np.uint8)
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch")
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = p.shape[0]
+    out = np.empty_like(p)
+    it = np.zeros(max(n, 1), np.int32)
+    rc = lib().ko_pyrlk(_p(a), _p(b), a.shape[0], a.shape[1], _p(p), n, int(win), int(max_level),
+                        int(max_count), C.c_double(eps), _p(out), _p(it))
+    if rc != 0:
+        raise RuntimeError(f"ko_pyrlk rc={rc}")
+    out = out.reshape(n, 1, 2)
+    return (out, it[:n]) if return_iters else out
+
+
+def filter_outliers(x0, y0, x1, y1, score):
+    """__filter_outliers (klt.py:52-71)."""
+    dx = x1 - x0
+    dy = y1 - y0
+    while True:
+        ind = ((np.abs(dx - dx.mean()) < 3 * dx.std()) & (np.abs(dy - dy.mean()) < 3 * dy.std())
+               & (np.abs(dx - dx.mean()) < 20) & (np.abs(dy - dy.mean()) < 20))
+        if int(ind.sum()) == len(dx):
+            break
+        dx, dy, x0, x1, y0, y1, score = dx[ind], dy[ind], x0[ind], x1[ind], y0[ind], y1[ind], score[ind]
+    return x0, y0, x1, y1, score
+
+
+def klt_tracker(ref_data, image_data, mask, conf, p0=None):
+    """klt_tracker (klt.py:83-172) -> (dict of float32 columns, Ninit) | None."""
+    if p0 is None:
+        p0 = good_features(ref_data, mask, conf.maxCorners, conf.qualityLevel, conf.minDistance,
+                           conf.blocksize)
+    if p0 is None:
+        return None
+    w = conf.matching_winsize
+    p1 = pyr_lk(ref_data, image_data, p0, w)
+    p0r = pyr_lk(image_data, ref_data, p1, w)
+    d = abs(p0 - p0r).reshape(-1, 2).max(-1)
+    back_threshold = 0.1
+    st = d < back_threshold
+    ninit = len(p0)
+    p0s, p1s, d = p0[st], p1[st], d[st]
+    score = 1 - d / back_threshold
+    x0, y0 = p0s[:, 0, 0], p0s[:, 0, 1]
+    x1, y1 = p1s[:, 0, 0], p1s[:, 0, 1]
+    if getattr(conf, "outliers_filtering", False):
+        x0, y0, x1, y1, score = filter_outliers(x0, y0, x1, y1, score)
+    return {"x0": x0, "y0": y0, "dx": x1 - x0, "dy": y1 - y0, "score": score}, ninit
+
+
+def resolve_ksize(ksize):
+    """mon/ref kernel size from int | dict (klt.py:431-432)."""
+    if isinstance(ksize, dict):
+        return ksize.get("mon", ksize.get("ref", 1)), ksize.get("ref", ksize.get("mon", 1))
+    return ksize, ksize
+
+
+def klt_tile(mon_box, ref_box, conf, mask_box=None, nodata_mon=None, nodata_ref=None,
+             x_off=0, y_off=0, invert_mon=False):
+    """KLT._match_tile for fixed ksize / fixed polarity (klt.py:236-349, 407-436):
+    -> dict of float32 columns sorted by (x0, y0) plus 'Ninit', or None."""
+    if mask_box is None:
+        mask_box, valid = auto_mask(mon_box, ref_box, nodata_mon, nodata_ref)
+    else:
+        mask_box = np.asarray(mask_box)
+        valid = int((mask_box > 0).sum())
+    if valid == 0:
+        return None
+    mon_k, ref_k = resolve_ksize(conf.laplacian_kernel_size)
+    mon_u8 = to_uint8(mon_box, invert=invert_mon)
+    lap_mon = laplacian_u8(mon_u8, mon_k)
+    lap_ref = laplacian_u8(to_uint8(ref_box), ref_k)
+    res = klt_tracker(lap_ref, lap_mon, mask_box, conf)
+    if res is None:
+        return None
+    cols, ninit = res
+    cols["x0"] = cols["x0"] + x_off
+    cols["y0"] = cols["y0"] + y_off
+    order = np.lexsort((cols["y0"], cols["x0"]))
+    out = {k: v[order] for k, v in cols.items()}
+    out["Ninit"] = ninit
+    out["lap_mon"], out["lap_ref"], out["mask"] = lap_mon, lap_ref, mask_box
+    return out
+
+
+def radial_angle(dx, dy):
+    """_handle_klt_results columns (core.py:872-873), float32 in -> float32 out."""
+    return np.sqrt(dx ** 2 + dy ** 2), np.degrees(np.arctan2(dy, dx))
+
+
+def zncc_batch(ref, mon, x0, y0, dx, dy):
+    """ZNCCService.compute_zncc per keypoint (zncc_service.py:186-238) -> float64[n]."""
+    r, dt, sr = _check_img(ref)
+    m, dt2, sm = _check_img(mon)
+    if dt != dt2:
+        raise TypeError("dtype mismatch")
+    x0, y0, dx, dy = (np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy))
+    n = len(x0)
+    out = np.empty(max(n, 1), np.float64)
+    lib().ko_zncc_batch(_p(r), _p(m), dt, r.shape[0], r.shape[1], m.shape[0], m.shape[1],
+                        C.c_ssize_t(sr), C.c_ssize_t(sm), _p(x0), _p(y0), _p(dx), _p(dy), n, _p(out))
+    return out[:n]
+
+
+def shift_image(img, y_off=0, x_off=0):
+    """shift_image (image.py:70-101)."""
+    y_off, x_off = int(round(y_off)), int(round(x_off))
+    new = np.zeros(img.shape, img.dtype)
+    if x_off > 0:
+        new[:, :-x_off] = img[:, x_off:]
+    elif x_off < 0:
+        new[:, -x_off:] = img[:, :x_off]
+    if x_off != 0:
+        img, new = new, np.zeros(img.shape, img.dtype)
+    if y_off > 0:
+        new[:-y_off, :] = img[y_off:, :]
+    elif y_off < 0:
+        new[-y_off:, :] = img[:y_off, :]
+    if y_off != 0:
+        img = new
+    return img
+
+
+def phase_cross_correlation(reference_image, moving_image):
+    """skimage.registration.phase_cross_correlation (0.24 defaults:
+    upsample_factor=1, space='real', normalization='phase'), shift only
+    (large_offset.py:39).  scikit-image is a third-party
+    dependency absent from /root/reference (environment.yml:11)."""
+    import scipy.fft as sfft
+    src = sfft.fftn(np.asarray(reference_image, np.float64))
+    tgt = sfft.fftn(np.asarray(moving_image, np.float64))
+    prod = src * tgt.conj()
+    eps = np.finfo(prod.real.dtype).eps
+    prod /= np.maximum(np.abs(prod), 100 * eps)
+    cc = sfft.ifftn(prod)
+    maxima = np.unravel_index(np.argmax(np.abs(cc)), cc.shape)
+    mid = np.array([np.fix(s / 2) for s in cc.shape])
+    shift = np.stack(maxima).astype(np.float64)
+    shift[shift > mid] -= np.array(cc.shape)[shift > mid]
+    for d in range(cc.ndim):
+        if cc.shape[d] == 1:
+            shift[d] = 0
+    return shift
+
+
+def large_offset(mon, ref, min_threshold=2):
+    """LargeOffsetMatcher.match + thresholding of _detect_large_offset
+    (large_offset.py:32-41, core.py:756-769) -> [row_off, col_off]."""
+    off = phase_cross_correlation(mon, ref)
+    if abs(off[1]) < min_threshold:
+        off[1] = 0
+    if abs(off[0]) < min_threshold:
+        off[0] = 0
+    return off
+
+
+def default_conf(**kw):
+    """processing_configuration.json:8-19 defaults as a duck-typed config."""
+    d = dict(minDistance=10, blocksize=15, maxCorners=20000, matching_winsize=25, qualityLevel=0.1,
+             xStart=0, tile_size=20000, laplacian_kernel_size=7, outliers_filtering=False,
+             laplacian_invert_polarity=False)
+    d.update(kw)
+    return SimpleNamespace(**d)
