@@ -1,0 +1,172 @@
+/*
+ * karios_hip.h -- C ABI of libkarios_hip.so, the MI355X (gfx950) implementation of
+ * the KARIOS image-matching hot path.
+ *
+ * The reference (telespazio-tim/karios) has no FFI of its own: the seam is the
+ * Python module surface of `karios.matcher`.  Each entry
+ * point below replaces the third-party C++ the reference reaches through cv2 /
+ * skimage / numpy at the cited call site (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a KARIOS maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every function returns an int status: 0 = OK, <0 = error (KM_E_*);
+ *     km_last_error(ctx) gives the message.  Nothing throws across the boundary.
+ *   - "host" entry points take caller-owned host buffers (numpy) and do the
+ *     H2D/D2H copies themselves; "_dev" entry points take device pointers
+ *     (hipMalloc'ed or a torch CUDA tensor's data_ptr) and run entirely on the
+ *     context's stream.  No pointer is retained after return.
+ *   - images are row-major, `stride` is in ELEMENTS between rows.
+ *   - a context owns one HIP stream plus a grow-only device workspace; it is not
+ *     thread-safe: use one context per calling thread (the reference calls
+ *     klt_tracker from a ThreadPoolExecutor, klt.py:526-527).
+ */
+#ifndef KARIOS_HIP_H
+#define KARIOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct km_ctx km_ctx;
+
+/* pixel types accepted for raw images */
+enum { KM_U8 = 0, KM_U16 = 1, KM_I16 = 2, KM_F32 = 3 };
+
+/* status codes */
+enum {
+    KM_OK = 0,
+    KM_E_ARG = -1,      /* malformed argument (cv2.error equivalent) */
+    KM_E_HIP = -2,      /* HIP runtime failure */
+    KM_E_NOMEM = -3,
+    KM_E_UNSUPPORTED = -4,
+    KM_E_NO_DEVICE = -5,
+    KM_E_INTERNAL = -6
+};
+
+/* KLTConfiguration fields (core/configuration.py:36-50) + the fixed LK criteria of
+ * klt.py:128-132 (maxLevel 1, COUNT|EPS 30 / 0.03) + back_threshold klt.py:143. */
+typedef struct km_klt_params {
+    int32_t max_corners;      /* maxCorners */
+    int32_t block_size;       /* blocksize */
+    int32_t win_size;         /* matching_winsize */
+    int32_t max_level;        /* 1 */
+    int32_t max_count;        /* 30 */
+    int32_t ksize_mon;        /* laplacian_kernel_size (mon) */
+    int32_t ksize_ref;        /* laplacian_kernel_size (ref) */
+    int32_t invert_mon;       /* laplacian_invert_polarity */
+    double quality_level;     /* qualityLevel */
+    double min_distance;      /* minDistance */
+    double epsilon;           /* 0.03 */
+} km_klt_params;
+
+/* diagnostics of the last km_klt_* / km_good_features call on a context */
+typedef struct km_klt_stats {
+    int64_t valid_pixels;     /* mask > 0 count (klt.py:276) */
+    int64_t n_candidates;     /* local maxima above threshold */
+    int32_t n_init;           /* corners selected (Ninit, klt.py:150) */
+    int32_t n_select_batches; /* greedy-selection batches executed */
+    double min_ref, max_ref, min_mon, max_mon; /* _to_uint8 stretch bounds */
+    float max_eig;            /* maxVal of minMaxLoc */
+    float reserved;
+} km_klt_stats;
+
+/* ---- context ------------------------------------------------------------ */
+int km_version(void);
+int km_ctx_create(int device, km_ctx **out);
+int km_ctx_destroy(km_ctx *ctx);
+const char *km_last_error(km_ctx *ctx);   /* ctx may be NULL: last global error */
+int km_ctx_sync(km_ctx *ctx);
+/* enable (1) / disable (0) hipEvent stage timing; read back after a call */
+int km_set_profiling(km_ctx *ctx, int enable);
+/* stage times (ms) of the last pipeline call; names via km_stage_name(i) */
+int km_get_stage_ms(km_ctx *ctx, float *out, int cap, int *n);
+const char *km_stage_name(int i);
+int km_get_klt_stats(km_ctx *ctx, km_klt_stats *out);
+
+/* ---- device memory helpers (bench / multi-GPU plumbing) ----------------- */
+int km_dev_alloc(km_ctx *ctx, size_t bytes, void **dptr);
+int km_dev_free(km_ctx *ctx, void *dptr);
+int km_h2d(km_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int km_d2h(km_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- fine-grained mirrors (host buffers) -------------------------------- */
+/* _to_uint8 (matcher/klt.py:42-49) [+ 255-x, klt.py:419]; out_minmax[2] nullable */
+int km_to_uint8(km_ctx *ctx, const void *img, int dtype, int H, int W, ptrdiff_t stride,
+                int invert, uint8_t *out, double *out_minmax);
+/* automatic validity mask (klt.py:268-273); nodata pointers nullable */
+int km_auto_mask(km_ctx *ctx, const void *mon, const void *ref, int dtype, int H, int W,
+                 ptrdiff_t stride_mon, ptrdiff_t stride_ref, const double *nodata_mon,
+                 const double *nodata_ref, uint8_t *mask, int64_t *valid);
+/* cv2.Laplacian(u8, CV_8U, ksize) (klt.py:359-360, 427-434, 480-483) */
+int km_laplacian_u8(km_ctx *ctx, const uint8_t *src, int H, int W, int ksize, uint8_t *dst);
+/* cornerMinEigenVal inside cv2.goodFeaturesToTrack (klt.py:120) */
+int km_min_eigen(km_ctx *ctx, const uint8_t *src, int H, int W, int block_size, float *eig);
+/* cv2.goodFeaturesToTrack(img, mask=, maxCorners, qualityLevel, minDistance, blockSize)
+ * (klt.py:120, 494).  out_xy: 2*cap floats (x,y interleaved); *out_n = 0 <=> None */
+int km_good_features(km_ctx *ctx, const uint8_t *img, const uint8_t *mask, int H, int W,
+                     int max_corners, double quality_level, double min_distance,
+                     int block_size, float *out_xy, int cap, int *out_n);
+/* cv::pyrDown u8 (pyramid level of calcOpticalFlowPyrLK) */
+int km_pyrdown_u8(km_ctx *ctx, const uint8_t *src, int H, int W, uint8_t *dst);
+/* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(w,w), maxLevel, criteria)
+ * (klt.py:134-140); status/err are not produced (discarded at klt.py:142-153) */
+int km_pyrlk(km_ctx *ctx, const uint8_t *prev, const uint8_t *next, int H, int W,
+             const float *pts, int n, int win_size, int max_level, int max_count,
+             double epsilon, float *out_pts);
+/* klt_tracker body up to the forward-backward distance (klt.py:103-142):
+ * GFTT on ref (unless p0 given) + LK ref->mon + LK mon->ref.
+ * Outputs, each 2*cap floats: p0, p1, p0r; *out_n = Ninit (0 <=> "No features"). */
+int km_klt_track(km_ctx *ctx, const uint8_t *ref_lap, const uint8_t *mon_lap,
+                 const uint8_t *mask, int H, int W, const km_klt_params *prm,
+                 const float *p0_in, int n_p0, float *p0, float *p1, float *p0r, int cap,
+                 int *out_n);
+/* KLT._match_tile numeric core for one box (klt.py:252-301, 407-436): raw images ->
+ * uint8 stretch -> Laplacians -> auto mask (if mask NULL) -> klt_track.
+ * *out_n = 0 with stats.valid_pixels == 0 <=> "No valid pixels" (klt.py:276-279). */
+int km_klt_tile(km_ctx *ctx, const void *ref, const void *mon, int dtype, int H, int W,
+                ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *mask,
+                const double *nodata_ref, const double *nodata_mon,
+                const km_klt_params *prm, float *p0, float *p1, float *p0r, int cap,
+                int *out_n);
+/* ZNCCService.compute_zncc per keypoint (matcher/zncc_service.py:186-238, _zncc2 :45-126):
+ * out[k] = NaN where the reference returns NaN */
+int km_zncc_batch(km_ctx *ctx, const void *ref, const void *mon, int dtype, int Href,
+                  int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
+                  const float *x0, const float *y0, const float *dx, const float *dy, int n,
+                  double *out);
+/* skimage.registration.phase_cross_correlation(reference_image, moving_image)[0]
+ * (matcher/large_offset.py:39): out_rc = [row, col] */
+int km_phase_shift(km_ctx *ctx, const void *reference_image, const void *moving_image,
+                   int dtype, int H, int W, ptrdiff_t stride_a, ptrdiff_t stride_b,
+                   double out_rc[2]);
+/* shift_image (core/image.py:70-101); elem_size in bytes (1, 2, 4 or 8) */
+int km_shift_image(km_ctx *ctx, const void *img, int elem_size, int H, int W,
+                   ptrdiff_t stride, int y_off, int x_off, void *out);
+
+/* ---- device-resident pipeline (inputs already in HBM) -------------------- */
+/* same as km_klt_tile with d_ref/d_mon/d_mask device pointers; outputs are device
+ * pointers too (each 2*cap floats) plus a device int for the count.  Asynchronous on
+ * the context stream; call km_ctx_sync before reading results. */
+int km_klt_tile_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H,
+                    int W, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
+                    const uint8_t *d_mask, const double *nodata_ref,
+                    const double *nodata_mon, const km_klt_params *prm, float *d_p0,
+                    float *d_p1, float *d_p0r, int cap, int *d_n);
+int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype,
+                      int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
+                      ptrdiff_t stride_mon, const float *d_x0, const float *d_y0,
+                      const float *d_dx, const float *d_dy, int n, double *d_out);
+int km_phase_shift_dev(km_ctx *ctx, const void *d_reference_image,
+                       const void *d_moving_image, int dtype, int H, int W,
+                       ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);
+int km_shift_image_dev(km_ctx *ctx, const void *d_img, int elem_size, int H, int W,
+                       ptrdiff_t stride, int y_off, int x_off, void *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KARIOS_HIP_H */

@@ -1,0 +1,186 @@
+"""ctypes binding of libkarios_hip.so (C ABI: include/karios_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no
+MI355X-class HIP device is visible, every entry point raises.  Nothing in this
+package imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkarios_hip.so")
+
+KM_U8, KM_U16, KM_I16, KM_F32 = 0, 1, 2, 3
+_DTYPES = {np.dtype("uint8"): KM_U8, np.dtype("uint16"): KM_U16, np.dtype("int16"): KM_I16,
+           np.dtype("float32"): KM_F32}
+
+
+class KariosHipError(RuntimeError):
+    """A libkarios_hip call returned a negative status (cv2.error equivalent)."""
+
+
+class KltParams(C.Structure):
+    _fields_ = [("max_corners", C.c_int32), ("block_size", C.c_int32), ("win_size", C.c_int32),
+                ("max_level", C.c_int32), ("max_count", C.c_int32), ("ksize_mon", C.c_int32),
+                ("ksize_ref", C.c_int32), ("invert_mon", C.c_int32), ("quality_level", C.c_double),
+                ("min_distance", C.c_double), ("epsilon", C.c_double)]
+
+
+class KltStats(C.Structure):
+    _fields_ = [("valid_pixels", C.c_int64), ("n_candidates", C.c_int64), ("n_init", C.c_int32),
+                ("n_select_batches", C.c_int32), ("min_ref", C.c_double), ("max_ref", C.c_double),
+                ("min_mon", C.c_double), ("max_mon", C.c_double), ("max_eig", C.c_float),
+                ("reserved", C.c_float)]
+
+
+_vp, _i, _d, _sz, _pd = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/karios_hip.h one to one
+SIGNATURES = {
+    "km_version": (_i, []),
+    "km_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "km_ctx_destroy": (_i, [_vp]),
+    "km_last_error": (C.c_char_p, [_vp]),
+    "km_ctx_sync": (_i, [_vp]),
+    "km_set_profiling": (_i, [_vp, _i]),
+    "km_get_stage_ms": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
+    "km_stage_name": (C.c_char_p, [_i]),
+    "km_get_klt_stats": (_i, [_vp, C.POINTER(KltStats)]),
+    "km_dev_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "km_dev_free": (_i, [_vp, _vp]),
+    "km_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "km_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
+    "km_auto_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _vp, C.POINTER(C.c_int64)]),
+    "km_laplacian_u8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "km_min_eigen": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "km_good_features": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _i, _pi]),
+    "km_pyrdown_u8": (_i, [_vp, _vp, _i, _i, _vp]),
+    "km_pyrlk": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _d, _vp]),
+    "km_klt_track": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(KltParams), _vp, _i, _vp, _vp, _vp, _i, _pi]),
+    "km_klt_tile": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), _vp, _vp,
+                         _vp, _i, _pi]),
+    "km_zncc_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
+    "km_phase_shift": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
+    "km_shift_image": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
+    "km_klt_tile_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), _vp,
+                             _vp, _vp, _i, _vp]),
+    "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
+    "km_phase_shift_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
+    "km_shift_image_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load libkarios_hip.so (built by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise KariosHipError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(karios_amd has no CPU fallback)")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def dtype_code(arr: np.ndarray) -> int:
+    try:
+        return _DTYPES[arr.dtype]
+    except KeyError:
+        raise KariosHipError(f"unsupported pixel type {arr.dtype} (uint8, uint16, int16, float32)") from None
+
+
+def as_image(arr) -> np.ndarray:
+    """2-D array whose rows are contiguous (row stride may exceed the width)."""
+    a = np.asarray(arr)
+    if a.ndim != 2:
+        raise KariosHipError(f"expected a 2-D image, got shape {a.shape}")
+    if a.shape[1] > 1 and a.strides[1] != a.itemsize or a.strides[0] % a.itemsize or a.strides[0] < 0:
+        a = np.ascontiguousarray(a)
+    if a.shape[0] > 1 and a.strides[0] < a.shape[1] * a.itemsize:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def row_stride(a: np.ndarray) -> int:
+    return a.strides[0] // a.itemsize if a.shape[0] > 1 else a.shape[1]
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP stream + grow-only device workspace.  Not thread-safe: one per thread."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.km_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self.lib.km_last_error(None)
+            raise KariosHipError(f"km_ctx_create(device={device}) failed ({rc}): {msg.decode() if msg else ''}")
+        self.handle = h
+        self.device = device
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.km_last_error(self.handle)
+            raise KariosHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.km_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+    def sync(self):
+        self.check(self.lib.km_ctx_sync(self.handle), "km_ctx_sync")
+
+    def stats(self) -> KltStats:
+        s = KltStats()
+        self.check(self.lib.km_get_klt_stats(self.handle, C.byref(s)), "km_get_klt_stats")
+        return s
+
+    def set_profiling(self, on: bool):
+        self.check(self.lib.km_set_profiling(self.handle, int(bool(on))), "km_set_profiling")
+
+    def stage_ms(self) -> dict:
+        buf = (C.c_float * 16)()
+        n = C.c_int()
+        self.check(self.lib.km_get_stage_ms(self.handle, buf, 16, C.byref(n)), "km_get_stage_ms")
+        return {self.lib.km_stage_name(i).decode(): float(buf[i]) for i in range(n.value)}
+
+
+_tls = threading.local()
+
+
+def default_context(device: int | None = None) -> Context:
+    """Per-thread context (klt_tracker is called from a thread pool, reference klt.py:526)."""
+    if device is None:
+        device = int(os.environ.get("KARIOS_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    if device not in ctxs:
+        ctxs[device] = Context(device)
+    return ctxs[device]

@@ -1,0 +1,53 @@
+"""numpy-backed stand-in for `karios.core.image.GdalRasterImage` + `shift_image`.
+
+GDAL I/O is out of scope (KARIOS keeps it); the matcher only touches the accessor
+surface listed in SURVEY.md 8(a18): `.x_size .y_size .read() .array .no_data_value
+.clear_cache() .file_name .filepath`.  A real `GdalRasterImage` can be passed instead.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import ops
+
+
+class NumpyRasterImage:
+    """Duck type of GdalRasterImage (reference core/image.py:255-459) over an in-memory array."""
+
+    def __init__(self, array: np.ndarray, no_data_value=None, filepath: str = "memory.tif"):
+        a = np.asarray(array)
+        if a.ndim != 2:
+            raise ValueError("NumpyRasterImage expects a single-band 2-D array")
+        self._array = a
+        self.no_data_value = no_data_value
+        self.filepath = filepath
+
+    @property
+    def file_name(self) -> str:
+        return self.filepath.rsplit("/", 1)[-1]
+
+    @property
+    def x_size(self) -> int:
+        return int(self._array.shape[1])
+
+    @property
+    def y_size(self) -> int:
+        return int(self._array.shape[0])
+
+    @property
+    def array(self) -> np.ndarray:
+        return self._array
+
+    def read(self, band: int, x_off: int, y_off: int, x_size: int, y_size: int) -> np.ndarray:
+        """Same argument order as GdalRasterImage.read (image.py:351-370)."""
+        if band != 1:
+            raise ValueError("single-band image")
+        return self._array[y_off:y_off + y_size, x_off:x_off + x_size]
+
+    def clear_cache(self) -> None:
+        """GdalRasterImage drops its cached array here; the in-memory image keeps its data."""
+
+
+def shift_image(img, y_off=0, x_off=0):
+    """karios.core.image.shift_image (image.py:70-101), executed on the GPU."""
+    return ops.shift_image(img, y_off=y_off, x_off=x_off)

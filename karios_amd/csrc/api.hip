@@ -1,0 +1,684 @@
+// C ABI of libkarios_hip.so (include/karios_hip.h): context, workspace, host-buffer wrappers and
+// the device-resident KLT tile pipeline.  Nothing here computes on the CPU: every entry point
+// ends in HIP kernels on the context stream; there is no fallback path.
+#include "common.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+static thread_local std::string g_last_error;
+
+int km_fail(km_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+void *km_ws(km_ctx *c, int slot, size_t bytes)
+{
+    km_buf &b = c->ws[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return b.p;
+    if (b.p) {
+        // the stream may still use the old buffer
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 16 + 256;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        km_fail(c, KM_E_NOMEM, "hipMalloc(%zu) for workspace slot %d: %s", want, slot, hipGetErrorString(e));
+        return nullptr;
+    }
+    b.p = p; b.cap = want;
+    return p;
+}
+
+extern "C" {
+
+int km_version(void) { return 100; }
+
+const char *km_last_error(km_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int km_ctx_create(int device, km_ctx **out)
+{
+    if (!out) return km_fail(nullptr, KM_E_ARG, "km_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return km_fail(nullptr, KM_E_NO_DEVICE, "no HIP device available (%s); libkarios_hip has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return km_fail(nullptr, KM_E_ARG, "device %d out of range [0,%d)", device, ndev);
+    km_ctx *c = new (std::nothrow) km_ctx();
+    if (!c) return km_fail(nullptr, KM_E_NOMEM, "out of host memory");
+    c->device = device;
+    memset(&c->stats, 0, sizeof c->stats);
+    memset(c->ev_used, 0, sizeof c->ev_used);
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = km_fail(nullptr, KM_E_HIP, "stream creation on device %d: %s", device, hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return KM_OK;
+}
+
+int km_ctx_destroy(km_ctx *c)
+{
+    if (!c) return KM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    kp_destroy(c);
+    for (int i = 0; i < WS_COUNT; i++)
+        if (c->ws[i].p) (void)hipFree(c->ws[i].p);
+    if (c->ev_ready)
+        for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->ev[i][0]); (void)hipEventDestroy(c->ev[i][1]); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return KM_OK;
+}
+
+int km_ctx_sync(km_ctx *c)
+{
+    if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_set_profiling(km_ctx *c, int enable)
+{
+    if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    if (enable && !c->ev_ready) {
+        for (int i = 0; i < ST_COUNT; i++) { KM_HIP(c, hipEventCreate(&c->ev[i][0])); KM_HIP(c, hipEventCreate(&c->ev[i][1])); }
+        c->ev_ready = true;
+    }
+    c->profiling = enable != 0;
+    return KM_OK;
+}
+
+static const char *const kStageNames[ST_COUNT] = {"minmax", "stretch_laplacian_mask", "min_eigen", "candidates", "sort",
+                                                  "select", "pyramid", "lk_fwd_bwd", "zncc"};
+
+const char *km_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+int km_get_stage_ms(km_ctx *c, float *out, int cap, int *n)
+{
+    if (!c || !out) return km_fail(c, KM_E_ARG, "km_get_stage_ms: null argument");
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    int m = cap < ST_COUNT ? cap : ST_COUNT;
+    for (int i = 0; i < m; i++) {
+        out[i] = 0.f;
+        if (c->ev_ready && c->ev_used[i]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) out[i] = ms;
+        }
+    }
+    if (n) *n = m;
+    return KM_OK;
+}
+
+int km_get_klt_stats(km_ctx *c, km_klt_stats *out)
+{
+    if (!c || !out) return km_fail(c, KM_E_ARG, "km_get_klt_stats: null argument");
+    *out = c->stats;
+    return KM_OK;
+}
+
+int km_dev_alloc(km_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return km_fail(c, KM_E_ARG, "km_dev_alloc: null argument");
+    KM_HIP(c, hipSetDevice(c->device));
+    KM_HIP(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return KM_OK;
+}
+int km_dev_free(km_ctx *c, void *dptr)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_HIP(c, hipFree(dptr));
+    return KM_OK;
+}
+int km_h2d(km_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+int km_d2h(km_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ helpers
+static int begin_call(km_ctx *c)
+{
+    if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    KM_HIP(c, hipSetDevice(c->device));
+    memset(c->ev_used, 0, sizeof c->ev_used);
+    return KM_OK;
+}
+
+// strided host image -> dense device buffer in workspace slot
+static int upload_image(km_ctx *c, int slot, const void *host, size_t elem, int H, int W, ptrdiff_t stride, void **dptr)
+{
+    void *d = km_ws(c, slot, (size_t)H * W * elem);
+    if (!d) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpy2DAsync(d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H, hipMemcpyHostToDevice,
+                               c->stream));
+    *dptr = d;
+    return KM_OK;
+}
+
+static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride, const char *what)
+{
+    if (!p) return km_fail(c, KM_E_ARG, "%s: null image", what);
+    if (H <= 0 || W <= 0) return km_fail(c, KM_E_ARG, "%s: empty image %dx%d", what, H, W);
+    if (stride < W) return km_fail(c, KM_E_ARG, "%s: stride %td < width %d", what, stride, W);
+    return KM_OK;
+}
+
+static km_scalars *scalars(km_ctx *c) { return (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars)); }
+
+// pyramid of a dense u8 device image: level 0 = the image, levels >= 1 in workspace `slot`
+static int build_pyramid(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, int slot, km_pyr *P)
+{
+    P->img[0] = d_img; P->H[0] = H; P->W[0] = W; P->levels = 0;
+    if (max_level > 4) max_level = 4;
+    size_t total = 0;
+    int w = W, h = H, nl = 0;
+    int hs[5], wsz[5];
+    for (int l = 0; l < max_level; l++) {
+        const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+        if (nw <= win || nh <= win) break;
+        nl = l + 1; hs[nl] = nh; wsz[nl] = nw;
+        total += ((size_t)nw * nh + 255) & ~(size_t)255;
+        w = nw; h = nh;
+    }
+    if (nl == 0) return KM_OK;
+    uint8_t *base = (uint8_t *)km_ws(c, slot, total);
+    if (!base) return KM_E_NOMEM;
+    size_t off = 0;
+    for (int l = 1; l <= nl; l++) {
+        uint8_t *dst = base + off;
+        int rc = kd_pyrdown_u8(c, P->img[l - 1], P->H[l - 1], P->W[l - 1], dst);
+        if (rc) return rc;
+        P->img[l] = dst; P->H[l] = hs[l]; P->W[l] = wsz[l];
+        off += ((size_t)wsz[l] * hs[l] + 255) & ~(size_t)255;
+    }
+    P->levels = nl;
+    return KM_OK;
+}
+
+// goodFeaturesToTrack on a dense device u8 image.  Leaves the corner count in scalars->n_corners
+// (device) and the corner list in d_xy.  One host sync (candidate count).
+static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int H, int W, int max_corners, double quality,
+                    double min_distance, int block, float *d_xy, int cap, km_scalars *sc)
+{
+    int rc;
+    float *eig = (float *)km_ws(c, WS_EIG, (size_t)H * W * sizeof(float));
+    if (!eig) return KM_E_NOMEM;
+    {
+        km_stage_timer t(c, ST_EIGEN);
+        if ((rc = kd_min_eigen(c, d_img, d_mask, H, W, block, eig, &sc->max_eig_key))) return rc;
+    }
+    size_t capk = (size_t)H * W / 8 + 4096;
+    unsigned ncand = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
+        if (!keys) return KM_E_NOMEM;
+        {
+            km_stage_timer t(c, ST_CANDIDATES);
+            if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk))) return rc;
+        }
+        KM_HIP(c, hipMemcpyAsync(&ncand, &sc->n_cand, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+        if (ncand <= capk) break;
+        capk = (size_t)ncand + 4096;  // plateau-heavy image: grow and redo
+    }
+    c->stats.n_candidates = ncand;
+    unsigned long long *keys = (unsigned long long *)c->ws[WS_KEYS0].p;
+    unsigned long long *sorted = keys;
+    if (ncand > 0) {
+        km_stage_timer t(c, ST_SORT);
+        if ((rc = ks_sort_keys_desc(c, keys, ncand, &sorted))) return rc;
+    }
+    {
+        km_stage_timer t(c, ST_SELECT);
+        if ((rc = ks_select(c, sorted, ncand, H, W, max_corners, min_distance, d_xy, cap, sc))) return rc;
+    }
+    return KM_OK;
+}
+
+static int read_stats(km_ctx *c, km_scalars *sc)
+{
+    km_scalars h;
+    KM_HIP(c, hipMemcpyAsync(&h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.n_init = h.n_corners;
+    c->stats.n_select_batches = h.n_batches;
+    c->stats.max_eig = h.max_eig;
+    c->stats.min_ref = h.mm[0]; c->stats.max_ref = h.mm[1]; c->stats.min_mon = h.mm[2]; c->stats.max_mon = h.mm[3];
+    if (h.n_cand == 0xffffffffu) return km_fail(c, KM_E_INTERNAL, "corner grid cell overflow");
+    return KM_OK;
+}
+
+// klt_tracker numeric core on dense device u8 images (klt.py:103-142)
+static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_mon_lap, const uint8_t *d_mask, int H, int W,
+                         const km_klt_params *prm, const float *d_p0_in, int n_p0, float *d_p0, float *d_p1, float *d_p0r, int cap,
+                         km_scalars *sc)
+{
+    int rc;
+    if (d_p0_in) {
+        if (n_p0 > cap) return km_fail(c, KM_E_ARG, "p0 count %d exceeds capacity %d", n_p0, cap);
+        if (n_p0 > 0 && d_p0_in != d_p0)
+            KM_HIP(c, hipMemcpyAsync(d_p0, d_p0_in, (size_t)n_p0 * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        KM_HIP(c, hipMemcpyAsync(&sc->n_corners, &n_p0, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));  // n_p0 is a stack variable
+    } else {
+        if ((rc = gftt_dev(c, d_ref_lap, d_mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, d_p0,
+                           cap, sc)))
+            return rc;
+    }
+    km_pyr A, B;
+    {
+        km_stage_timer t(c, ST_PYRAMID);
+        if ((rc = build_pyramid(c, d_ref_lap, H, W, prm->win_size, prm->max_level, WS_PYR_A, &A))) return rc;
+        if ((rc = build_pyramid(c, d_mon_lap, H, W, prm->win_size, prm->max_level, WS_PYR_B, &B))) return rc;
+    }
+    const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
+    {
+        km_stage_timer t(c, ST_LK);
+        if ((rc = kl_track(c, A, B, d_p0, &sc->n_corners, n_max, prm->win_size, prm->max_count, prm->epsilon, true, d_p1, d_p0r)))
+            return rc;
+    }
+    return KM_OK;
+}
+
+static int check_params(km_ctx *c, const km_klt_params *p)
+{
+    if (!p) return km_fail(c, KM_E_ARG, "null params");
+    if (p->block_size < 1) return km_fail(c, KM_E_ARG, "blockSize %d < 1", p->block_size);
+    if (p->win_size <= 2) return km_fail(c, KM_E_ARG, "winSize %d must be > 2", p->win_size);
+    if (p->max_level < 0) return km_fail(c, KM_E_ARG, "maxLevel %d < 0", p->max_level);
+    if (!(p->quality_level > 0)) return km_fail(c, KM_E_ARG, "qualityLevel must be > 0");
+    if (p->min_distance < 0) return km_fail(c, KM_E_ARG, "minDistance must be >= 0");
+    return KM_OK;
+}
+
+static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                             const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                             float *d_p0, float *d_p1, float *d_p0r, int cap, km_scalars *sc, bool *no_valid)
+{
+    int rc;
+    const size_t n = (size_t)H * W;
+    uint8_t *lap_ref = (uint8_t *)km_ws(c, WS_U8_A, n), *lap_mon = (uint8_t *)km_ws(c, WS_U8_B, n);
+    if (!lap_ref || !lap_mon) return KM_E_NOMEM;
+    uint8_t *mask_auto = nullptr;
+    if (!d_mask) { mask_auto = (uint8_t *)km_ws(c, WS_MASK, n); if (!mask_auto) return KM_E_NOMEM; }
+    if (dtype != KM_U8) {
+        km_stage_timer t(c, ST_MINMAX);
+        if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0]))) return rc;
+        if ((rc = kd_minmax(c, d_mon, dtype, H, W, smon, &sc->mm[2]))) return rc;
+    } else {
+        KM_HIP(c, hipMemsetAsync(sc->mm, 0, sizeof sc->mm, c->stream));
+    }
+    {
+        km_stage_timer t(c, ST_LAPLACIAN);
+        if (d_mask) { if ((rc = kd_count_nonzero(c, d_mask, n, &sc->valid))) return rc; }
+        if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, sc->mm, prm->ksize_ref, prm->ksize_mon,
+                                            prm->invert_mon, nodata_ref, nodata_mon, lap_ref, lap_mon, mask_auto, &sc->valid)))
+            return rc;
+    }
+    unsigned long long valid = 0;
+    KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.valid_pixels = (int64_t)valid;
+    *no_valid = valid == 0;
+    if (valid == 0) {  // "No valid pixels, skipping this tile" (klt.py:276-279)
+        KM_HIP(c, hipMemsetAsync(&sc->n_corners, 0, 2 * sizeof(int), c->stream));
+        return KM_OK;
+    }
+    return klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ fine-grained host mirrors
+int km_to_uint8(km_ctx *c, const void *img, int dtype, int H, int W, ptrdiff_t stride, int invert, uint8_t *out, double *out_minmax)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, img, H, W, stride, "to_uint8"))) return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es || !out) return km_fail(c, KM_E_ARG, "to_uint8: bad dtype %d or null output", dtype);
+    void *d_img;
+    if ((rc = upload_image(c, WS_RAW_A, img, es, H, W, stride, &d_img))) return rc;
+    km_scalars *sc = scalars(c);
+    uint8_t *d_out = (uint8_t *)km_ws(c, WS_U8_A, (size_t)H * W);
+    if (!sc || !d_out) return KM_E_NOMEM;
+    if (dtype != KM_U8) { if ((rc = kd_minmax(c, d_img, dtype, H, W, W, sc->mm))) return rc; }
+    else KM_HIP(c, hipMemsetAsync(sc->mm, 0, sizeof sc->mm, c->stream));
+    if ((rc = kd_to_uint8(c, d_img, dtype, H, W, W, sc->mm, invert, d_out))) return rc;
+    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    double mm[2];
+    KM_HIP(c, hipMemcpyAsync(mm, sc->mm, sizeof mm, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (out_minmax) { out_minmax[0] = mm[0]; out_minmax[1] = mm[1]; }
+    return KM_OK;
+}
+
+int km_auto_mask(km_ctx *c, const void *mon, const void *ref, int dtype, int H, int W, ptrdiff_t smon, ptrdiff_t sref,
+                 const double *nodata_mon, const double *nodata_ref, uint8_t *mask, int64_t *valid)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, mon, H, W, smon, "auto_mask")) || (rc = check_image(c, ref, H, W, sref, "auto_mask")))
+        return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es || !mask) return km_fail(c, KM_E_ARG, "auto_mask: bad dtype %d or null output", dtype);
+    void *d_mon, *d_ref;
+    if ((rc = upload_image(c, WS_RAW_A, ref, es, H, W, sref, &d_ref)) || (rc = upload_image(c, WS_RAW_B, mon, es, H, W, smon, &d_mon))) return rc;
+    km_scalars *sc = scalars(c);
+    uint8_t *d_mask = (uint8_t *)km_ws(c, WS_MASK, (size_t)H * W);
+    if (!sc || !d_mask) return KM_E_NOMEM;
+    if ((rc = kd_auto_mask(c, d_mon, d_ref, dtype, H, W, W, W, nodata_mon, nodata_ref, d_mask, &sc->valid))) return rc;
+    unsigned long long v = 0;
+    KM_HIP(c, hipMemcpyAsync(mask, d_mask, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipMemcpyAsync(&v, &sc->valid, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (valid) *valid = (int64_t)v;
+    return KM_OK;
+}
+
+int km_laplacian_u8(km_ctx *c, const uint8_t *src, int H, int W, int ksize, uint8_t *dst)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, src, H, W, W, "laplacian"))) return rc;
+    if (!dst) return km_fail(c, KM_E_ARG, "laplacian: null output");
+    void *d_src;
+    if ((rc = upload_image(c, WS_RAW_A, src, 1, H, W, W, &d_src))) return rc;
+    uint8_t *d_dst = (uint8_t *)km_ws(c, WS_U8_A, (size_t)H * W);
+    if (!d_dst) return KM_E_NOMEM;
+    if ((rc = kd_laplacian_u8(c, (const uint8_t *)d_src, H, W, ksize, d_dst))) return rc;
+    KM_HIP(c, hipMemcpyAsync(dst, d_dst, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_min_eigen(km_ctx *c, const uint8_t *src, int H, int W, int block, float *eig)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, src, H, W, W, "min_eigen"))) return rc;
+    if (!eig) return km_fail(c, KM_E_ARG, "min_eigen: null output");
+    void *d_src;
+    if ((rc = upload_image(c, WS_RAW_A, src, 1, H, W, W, &d_src))) return rc;
+    km_scalars *sc = scalars(c);
+    float *d_eig = (float *)km_ws(c, WS_EIG, (size_t)H * W * sizeof(float));
+    if (!sc || !d_eig) return KM_E_NOMEM;
+    if ((rc = kd_min_eigen(c, (const uint8_t *)d_src, nullptr, H, W, block, d_eig, &sc->max_eig_key))) return rc;
+    KM_HIP(c, hipMemcpyAsync(eig, d_eig, (size_t)H * W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_good_features(km_ctx *c, const uint8_t *img, const uint8_t *mask, int H, int W, int max_corners, double quality,
+                     double min_distance, int block, float *out_xy, int cap, int *out_n)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, img, H, W, W, "good_features"))) return rc;
+    if (!out_xy || !out_n || cap < 0) return km_fail(c, KM_E_ARG, "good_features: null output");
+    if (!(quality > 0)) return km_fail(c, KM_E_ARG, "qualityLevel must be > 0");
+    if (min_distance < 0) return km_fail(c, KM_E_ARG, "minDistance must be >= 0");
+    if (max_corners > 0 && cap < max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, max_corners);
+    void *d_img, *d_mask = nullptr;
+    if ((rc = upload_image(c, WS_RAW_A, img, 1, H, W, W, &d_img))) return rc;
+    if (mask && (rc = upload_image(c, WS_MASK_IN, mask, 1, H, W, W, &d_mask))) return rc;
+    km_scalars *sc = scalars(c);
+    float *d_xy = (float *)km_ws(c, WS_PTS0, (size_t)(cap > 0 ? cap : 1) * 2 * sizeof(float));
+    if (!sc || !d_xy) return KM_E_NOMEM;
+    if ((rc = gftt_dev(c, (const uint8_t *)d_img, (const uint8_t *)d_mask, H, W, max_corners, quality, min_distance, block, d_xy, cap, sc)))
+        return rc;
+    if ((rc = read_stats(c, sc))) return rc;
+    int n = c->stats.n_init;
+    if (n > cap) return km_fail(c, KM_E_ARG, "good_features: %d corners exceed capacity %d", n, cap);
+    if (n > 0) {
+        KM_HIP(c, hipMemcpyAsync(out_xy, d_xy, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *out_n = n;
+    return KM_OK;
+}
+
+int km_pyrdown_u8(km_ctx *c, const uint8_t *src, int H, int W, uint8_t *dst)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, src, H, W, W, "pyrdown"))) return rc;
+    if (!dst) return km_fail(c, KM_E_ARG, "pyrdown: null output");
+    void *d_src;
+    if ((rc = upload_image(c, WS_RAW_A, src, 1, H, W, W, &d_src))) return rc;
+    const size_t on = (size_t)((H + 1) / 2) * ((W + 1) / 2);
+    uint8_t *d_dst = (uint8_t *)km_ws(c, WS_U8_A, on);
+    if (!d_dst) return KM_E_NOMEM;
+    if ((rc = kd_pyrdown_u8(c, (const uint8_t *)d_src, H, W, d_dst))) return rc;
+    KM_HIP(c, hipMemcpyAsync(dst, d_dst, on, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_pyrlk(km_ctx *c, const uint8_t *prev, const uint8_t *next, int H, int W, const float *pts, int n, int win, int max_level,
+             int max_count, double epsilon, float *out_pts)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, prev, H, W, W, "pyrlk")) || (rc = check_image(c, next, H, W, W, "pyrlk"))) return rc;
+    if (n < 0 || (n > 0 && (!pts || !out_pts))) return km_fail(c, KM_E_ARG, "pyrlk: bad points");
+    if (win <= 2 || max_level < 0) return km_fail(c, KM_E_ARG, "pyrlk: winSize %d / maxLevel %d", win, max_level);
+    if (n == 0) return KM_OK;
+    void *d_prev, *d_next;
+    if ((rc = upload_image(c, WS_U8_A, prev, 1, H, W, W, &d_prev)) || (rc = upload_image(c, WS_U8_B, next, 1, H, W, W, &d_next))) return rc;
+    float *d_in = (float *)km_ws(c, WS_PTS0, (size_t)n * 2 * sizeof(float));
+    float *d_out = (float *)km_ws(c, WS_PTS1, (size_t)n * 2 * sizeof(float));
+    if (!d_in || !d_out) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(d_in, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    km_pyr A, B;
+    if ((rc = build_pyramid(c, (const uint8_t *)d_prev, H, W, win, max_level, WS_PYR_A, &A)) ||
+        (rc = build_pyramid(c, (const uint8_t *)d_next, H, W, win, max_level, WS_PYR_B, &B)))
+        return rc;
+    if ((rc = kl_track(c, A, B, d_in, nullptr, n, win, max_count, epsilon, false, d_out, nullptr))) return rc;
+    KM_HIP(c, hipMemcpyAsync(out_pts, d_out, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+static int fetch_tracks(km_ctx *c, km_scalars *sc, const float *d_p0, const float *d_p1, const float *d_p0r, float *p0, float *p1,
+                        float *p0r, int cap, int *out_n)
+{
+    int rc;
+    if ((rc = read_stats(c, sc))) return rc;
+    int n = c->stats.n_init;
+    if (n > cap) return km_fail(c, KM_E_ARG, "%d corners exceed capacity %d", n, cap);
+    if (n > 0) {
+        const size_t b = (size_t)n * 2 * sizeof(float);
+        KM_HIP(c, hipMemcpyAsync(p0, d_p0, b, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipMemcpyAsync(p1, d_p1, b, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipMemcpyAsync(p0r, d_p0r, b, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *out_n = n;
+    return KM_OK;
+}
+
+int km_klt_track(km_ctx *c, const uint8_t *ref_lap, const uint8_t *mon_lap, const uint8_t *mask, int H, int W, const km_klt_params *prm,
+                 const float *p0_in, int n_p0, float *p0, float *p1, float *p0r, int cap, int *out_n)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref_lap, H, W, W, "klt_track")) ||
+        (rc = check_image(c, mon_lap, H, W, W, "klt_track")))
+        return rc;
+    if (!p0 || !p1 || !p0r || !out_n || cap <= 0) return km_fail(c, KM_E_ARG, "klt_track: null output");
+    if (!p0_in && prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
+    void *d_ref, *d_mon, *d_mask = nullptr;
+    if ((rc = upload_image(c, WS_U8_A, ref_lap, 1, H, W, W, &d_ref)) || (rc = upload_image(c, WS_U8_B, mon_lap, 1, H, W, W, &d_mon))) return rc;
+    if (mask && (rc = upload_image(c, WS_MASK_IN, mask, 1, H, W, W, &d_mask))) return rc;
+    km_scalars *sc = scalars(c);
+    const size_t pb = (size_t)cap * 2 * sizeof(float);
+    float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
+    if (!sc || !d_p0 || !d_p1 || !d_p0r) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    const float *d_p0_in = nullptr;
+    if (p0_in) {
+        if (n_p0 < 0 || n_p0 > cap) return km_fail(c, KM_E_ARG, "klt_track: p0 count %d (capacity %d)", n_p0, cap);
+        if (n_p0 > 0) KM_HIP(c, hipMemcpyAsync(d_p0, p0_in, (size_t)n_p0 * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_p0_in = d_p0;
+    }
+    if ((rc = klt_track_dev(c, (const uint8_t *)d_ref, (const uint8_t *)d_mon, (const uint8_t *)d_mask, H, W, prm, d_p0_in, n_p0, d_p0, d_p1,
+                            d_p0r, cap, sc)))
+        return rc;
+    return fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n);
+}
+
+int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon, const uint8_t *mask,
+                const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float *p0, float *p1, float *p0r, int cap,
+                int *out_n)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref, H, W, sref, "klt_tile")) ||
+        (rc = check_image(c, mon, H, W, smon, "klt_tile")))
+        return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es) return km_fail(c, KM_E_ARG, "klt_tile: bad dtype %d", dtype);
+    if (!p0 || !p1 || !p0r || !out_n || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile: null output");
+    if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
+    void *d_ref, *d_mon, *d_mask = nullptr;
+    if ((rc = upload_image(c, WS_RAW_A, ref, es, H, W, sref, &d_ref)) || (rc = upload_image(c, WS_RAW_B, mon, es, H, W, smon, &d_mon))) return rc;
+    if (mask && (rc = upload_image(c, WS_MASK_IN, mask, 1, H, W, W, &d_mask))) return rc;
+    km_scalars *sc = scalars(c);
+    const size_t pb = (size_t)cap * 2 * sizeof(float);
+    float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
+    if (!sc || !d_p0 || !d_p1 || !d_p0r) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    bool no_valid = false;
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, W, W, (const uint8_t *)d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r,
+                                cap, sc, &no_valid)))
+        return rc;
+    return fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n);
+}
+
+int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                    const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float *d_p0,
+                    float *d_p1, float *d_p0r, int cap, int *d_n)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_dev")) ||
+        (rc = check_image(c, d_mon, H, W, smon, "klt_tile_dev")))
+        return rc;
+    if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_dev: bad dtype %d", dtype);
+    if (!d_p0 || !d_p1 || !d_p0r || !d_n || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_dev: null output");
+    if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
+    km_scalars *sc = scalars(c);
+    if (!sc) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    bool no_valid = false;
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
+                                &no_valid)))
+        return rc;
+    KM_HIP(c, hipMemcpyAsync(d_n, &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    return KM_OK;
+}
+
+int km_zncc_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
+                      ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, d_ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, d_mon, Hmon, Wmon, smon, "zncc")))
+        return rc;
+    if (n < 0 || (n > 0 && (!d_x0 || !d_y0 || !d_dx || !d_dy || !d_out))) return km_fail(c, KM_E_ARG, "zncc: bad keypoint arrays");
+    km_stage_timer t(c, ST_ZNCC);
+    return kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_out);
+}
+
+int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
+                  ptrdiff_t smon, const float *x0, const float *y0, const float *dx, const float *dy, int n, double *out)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, mon, Hmon, Wmon, smon, "zncc")))
+        return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es) return km_fail(c, KM_E_ARG, "zncc: bad dtype %d", dtype);
+    if (n < 0 || (n > 0 && (!x0 || !y0 || !dx || !dy || !out))) return km_fail(c, KM_E_ARG, "zncc: bad keypoint arrays");
+    if (n == 0) return KM_OK;
+    void *d_ref, *d_mon;
+    if ((rc = upload_image(c, WS_RAW_A, ref, es, Href, Wref, sref, &d_ref)) || (rc = upload_image(c, WS_RAW_B, mon, es, Hmon, Wmon, smon, &d_mon)))
+        return rc;
+    float *kp = (float *)km_ws(c, WS_MISC0, (size_t)n * 4 * sizeof(float));
+    double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)n * sizeof(double));
+    if (!kp || !d_out) return KM_E_NOMEM;
+    const float *src[4] = {x0, y0, dx, dy};
+    for (int i = 0; i < 4; i++) KM_HIP(c, hipMemcpyAsync(kp + (size_t)i * n, src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, d_out)))
+        return rc;
+    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_phase_shift_dev(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double out_rc[2])
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, d_a, H, W, sa, "phase_shift")) || (rc = check_image(c, d_b, H, W, sb, "phase_shift"))) return rc;
+    if (!out_rc || !km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d or null output", dtype);
+    return kp_phase_shift(c, d_a, d_b, dtype, H, W, sa, sb, out_rc);
+}
+
+int km_phase_shift(km_ctx *c, const void *a, const void *b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double out_rc[2])
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, a, H, W, sa, "phase_shift")) || (rc = check_image(c, b, H, W, sb, "phase_shift"))) return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!out_rc || !es) return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d or null output", dtype);
+    void *d_a, *d_b;
+    if ((rc = upload_image(c, WS_RAW_A, a, es, H, W, sa, &d_a)) || (rc = upload_image(c, WS_RAW_B, b, es, H, W, sb, &d_b))) return rc;
+    return kp_phase_shift(c, d_a, d_b, dtype, H, W, W, W, out_rc);
+}
+
+int km_shift_image_dev(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride, int y_off, int x_off, void *d_out)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, d_img, H, W, stride, "shift_image"))) return rc;
+    if (!d_out) return km_fail(c, KM_E_ARG, "shift_image: null output");
+    return kd_shift_image(c, d_img, elem_size, H, W, stride, y_off, x_off, d_out);
+}
+
+int km_shift_image(km_ctx *c, const void *img, int elem_size, int H, int W, ptrdiff_t stride, int y_off, int x_off, void *out)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, img, H, W, stride, "shift_image"))) return rc;
+    if (!out || (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8)) return km_fail(c, KM_E_ARG, "shift_image: elem_size %d", elem_size);
+    void *d_img;
+    if ((rc = upload_image(c, WS_RAW_A, img, (size_t)elem_size, H, W, stride, &d_img))) return rc;
+    void *d_out = km_ws(c, WS_RAW_B, (size_t)H * W * elem_size);
+    if (!d_out) return KM_E_NOMEM;
+    if ((rc = kd_shift_image(c, d_img, elem_size, H, W, W, y_off, x_off, d_out))) return rc;
+    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)H * W * elem_size, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// Internal declarations shared by the HIP translation units of libkarios_hip.so.
+// gfx950 only: 64-lane wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/karios_hip.h"
+
+#define KM_WAVE 64
+
+// OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
+__host__ __device__ __forceinline__ int km_reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+enum km_stage {
+    ST_MINMAX = 0,
+    ST_LAPLACIAN,
+    ST_EIGEN,
+    ST_CANDIDATES,
+    ST_SORT,
+    ST_SELECT,
+    ST_PYRAMID,
+    ST_LK,
+    ST_ZNCC,
+    ST_COUNT
+};
+
+struct km_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Grow-only device workspace slots.
+enum km_slot {
+    WS_RAW_A = 0,   // host-API staging of raw image A (ref)
+    WS_RAW_B,       // host-API staging of raw image B (mon)
+    WS_MASK_IN,     // host-API staging of a user mask
+    WS_U8_A,        // uint8 / Laplacian of ref
+    WS_U8_B,        // uint8 / Laplacian of mon
+    WS_MASK,        // auto mask
+    WS_EIG,         // f32 min-eigenvalue map
+    WS_PYR_A,       // pyramid levels >= 1 of image A
+    WS_PYR_B,
+    WS_KEYS0,       // candidate keys
+    WS_KEYS1,       // sort double buffer
+    WS_SORT_TMP,    // rocprim temporary storage
+    WS_GRID,        // accepted-point grid of the greedy selection
+    WS_PTS0,        // p0
+    WS_PTS1,        // p1
+    WS_PTS2,        // p0r
+    WS_SCALARS,     // min/max doubles, counters, max-eig
+    WS_PARTIAL,     // reduction partials
+    WS_MISC0,
+    WS_MISC1,
+    WS_MISC2,
+    WS_MISC3,
+    WS_FFT_A,
+    WS_FFT_B,
+    WS_FFT_WORK,
+    WS_COUNT
+};
+
+// Device-side scalar block (lives in WS_SCALARS).
+struct km_scalars {
+    double mm[4];             // min_ref, max_ref, min_mon, max_mon
+    unsigned long long valid; // mask>0 count
+    unsigned int max_eig_key; // ordered-uint encoding of max eig over mask
+    unsigned int n_cand;      // candidates emitted (may exceed capacity)
+    int n_corners;            // corners selected
+    int n_batches;
+    float thr;                // maxVal * qualityLevel as f32
+    float max_eig;
+    unsigned long long argmax_key; // phase correlation arg-max
+};
+
+struct km_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    km_buf ws[WS_COUNT];
+    std::string err;
+    bool profiling = false;
+    hipEvent_t ev[ST_COUNT][2];
+    bool ev_used[ST_COUNT];
+    bool ev_ready = false;
+    km_klt_stats stats;
+    void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
+    int fft_h = 0, fft_w = 0;
+    size_t fft_work_bytes = 0;
+};
+
+int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
+void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+
+#define KM_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return km_fail((ctx), KM_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,    \
+                           hipGetErrorString(e_));                                          \
+    } while (0)
+
+#define KM_LAUNCH_CHECK(ctx) KM_HIP(ctx, hipGetLastError())
+
+struct km_stage_timer {
+    km_ctx *c;
+    int s;
+    km_stage_timer(km_ctx *ctx, int stage) : c(ctx), s(stage)
+    {
+        if (c->profiling && c->ev_ready && !c->ev_used[s]) {
+            (void)hipEventRecord(c->ev[s][0], c->stream);
+        } else if (c->profiling && c->ev_ready) {
+            s = -1;  // stage already timed in this call (only the first span is kept)
+        }
+    }
+    ~km_stage_timer()
+    {
+        if (s >= 0 && c->profiling && c->ev_ready) {
+            (void)hipEventRecord(c->ev[s][1], c->stream);
+            c->ev_used[s] = true;
+        }
+    }
+};
+
+static inline size_t km_dtype_size(int dtype)
+{
+    switch (dtype) {
+    case KM_U8: return 1;
+    case KM_U16: return 2;
+    case KM_I16: return 2;
+    case KM_F32: return 4;
+    default: return 0;
+    }
+}
+
+// ---- launchers implemented in the kernel translation units (all asynchronous) ----
+// k_dense.hip
+int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
+              double *d_mm /* [2] */);
+int kd_to_uint8(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
+                const double *d_mm, int invert, uint8_t *d_out);
+int kd_auto_mask(km_ctx *c, const void *d_mon, const void *d_ref, int dtype, int H, int W,
+                 ptrdiff_t stride_mon, ptrdiff_t stride_ref, const double *nodata_mon,
+                 const double *nodata_ref, uint8_t *d_mask, unsigned long long *d_valid);
+int kd_count_nonzero(km_ctx *c, const uint8_t *d_mask, size_t n, unsigned long long *d_valid);
+int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, uint8_t *d_dst);
+// fused: raw ref+mon -> uint8 stretch -> Laplacians (+ auto mask when d_mask_out != null)
+int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H,
+                              int W, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
+                              const double *d_mm /* [4] */, int ksize_ref, int ksize_mon,
+                              int invert_mon, const double *nodata_ref, const double *nodata_mon,
+                              uint8_t *d_lap_ref, uint8_t *d_lap_mon, uint8_t *d_mask_out,
+                              unsigned long long *d_valid);
+int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block,
+                 float *d_eig, unsigned int *d_max_key);
+int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
+                  double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap);
+int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);
+int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride,
+                   int y_off, int x_off, void *d_out);
+// k_select.hip
+int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted);
+int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W,
+              int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc);
+// k_lk.hip
+struct km_pyr {
+    const uint8_t *img[5];
+    int H[5], W[5];
+    int levels;  // highest level index actually built (<= max_level)
+};
+int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n,
+             int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
+             float *d_p0r);
+// k_zncc.hip
+int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
+            int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,
+            const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out);
+// k_phase.hip
+int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W,
+                   ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);
+void kp_destroy(km_ctx *c);

@@ -1,0 +1,760 @@
+// Dense per-pixel kernels of the KARIOS matching path (gfx950):
+//   K1  NaN-aware min/max reduction            (reference klt.py:46)
+//   K2  uint8 stretch -> Laplacian -> auto mask (klt.py:42-49, 268-273, 433-434)
+//   K3  Sobel -> structure tensor -> box sum -> min eigenvalue (+ masked max)
+//   K4  threshold + 3x3 local maxima + mask -> candidate keys
+//   K6  pyrDown 5x5
+//   K11 integer image shift                     (core/image.py:70-101)
+// All are HBM-bound stencils / reductions: LDS tiles with halo, integer-exact
+// arithmetic, no MFMA.
+#include "common.hpp"
+
+// ------------------------------------------------------------------ helpers
+template <typename T> struct px_traits;
+template <> struct px_traits<uint8_t> { using acc = int; static constexpr int code = KM_U8; };
+template <> struct px_traits<uint16_t> { using acc = int; static constexpr int code = KM_U16; };
+template <> struct px_traits<int16_t> { using acc = int; static constexpr int code = KM_I16; };
+template <> struct px_traits<float> { using acc = float; static constexpr int code = KM_F32; };
+
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// stretch one raw value to uint8 exactly like numpy does in _to_uint8 (klt.py:48):
+// integer dtypes in fp64, float32 in fp32; truncating cast; NaN -> 0.
+template <typename T>
+__device__ __forceinline__ unsigned stretch_u8(T v, double mn, double range, bool degenerate)
+{
+    if constexpr (sizeof(T) == 1) {
+        return (unsigned)v;
+    } else if constexpr (px_traits<T>::code == KM_F32) {
+        if (degenerate) return 0u;
+        float t = __fmul_rn(__fdiv_rn(__fsub_rn(v, (float)mn), (float)range), 255.0f);
+        return (t != t) ? 0u : (unsigned)(int)t;
+    } else {
+        if (degenerate) return 0u;
+        double t = __dmul_rn(__ddiv_rn(__dsub_rn((double)v, mn), range), 255.0);
+        return (unsigned)(int)t;
+    }
+}
+
+// ------------------------------------------------------------------ K1 min/max
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict__ img, int H, int W,
+                                                             ptrdiff_t stride, double *partial)
+{
+    using A = typename px_traits<T>::acc;
+    A mn, mx;
+    if constexpr (px_traits<T>::code == KM_F32) { mn = INFINITY; mx = -INFINITY; }
+    else { mn = 0x7fffffff; mx = -0x7fffffff - 1; }
+    auto upd = [&](T v) {
+        if constexpr (px_traits<T>::code == KM_F32) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        else { mn = min(mn, (A)v); mx = max(mx, (A)v); }
+    };
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nth = (size_t)gridDim.x * blockDim.x;
+    if (stride == W) {
+        // flat, 16-byte vector loads over the aligned body
+        const size_t n = (size_t)H * W;
+        constexpr int V = 16 / sizeof(T);
+        const uintptr_t base = (uintptr_t)img;
+        size_t head = ((16 - (base & 15)) & 15) / sizeof(T);
+        if (head > n) head = n;
+        const size_t nvec = (n - head) / V;
+        const uint4 *vp = (const uint4 *)(img + head);
+        for (size_t i = tid; i < nvec; i += nth) {
+            uint4 q = vp[i];
+            T e[V];
+            __builtin_memcpy(e, &q, 16);
+#pragma unroll
+            for (int k = 0; k < V; k++) upd(e[k]);
+        }
+        if (tid < head) upd(img[tid]);
+        const size_t tail0 = head + nvec * V;
+        if (tail0 + tid < n && tid < V) upd(img[tail0 + tid]);
+    } else {
+        for (int y = blockIdx.x; y < H; y += gridDim.x) {
+            const T *row = img + (size_t)y * stride;
+            for (int x = threadIdx.x; x < W; x += blockDim.x) upd(row[x]);
+        }
+    }
+    double dmn = wave_min((double)mn), dmx = wave_max((double)mx);
+    __shared__ double s[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { s[0][w] = dmn; s[1][w] = dmx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
+        partial[2 * blockIdx.x + 1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial, int nb, double *out)
+{
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        mn = fmin(mn, partial[2 * i]);
+        mx = fmax(mx, partial[2 * i + 1]);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ double s[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { s[0][w] = mn; s[1][w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
+        out[1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
+    }
+}
+
+int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, double *d_mm)
+{
+    const int nb = 2048;
+    double *partial = (double *)km_ws(c, WS_PARTIAL, 2 * nb * sizeof(double));
+    if (!partial) return KM_E_NOMEM;
+    switch (dtype) {
+    case KM_U8: minmax_partial_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_img, H, W, stride, partial); break;
+    case KM_U16: minmax_partial_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_img, H, W, stride, partial); break;
+    case KM_I16: minmax_partial_kernel<int16_t><<<nb, 256, 0, c->stream>>>((const int16_t *)d_img, H, W, stride, partial); break;
+    case KM_F32: minmax_partial_kernel<float><<<nb, 256, 0, c->stream>>>((const float *)d_img, H, W, stride, partial); break;
+    default: return km_fail(c, KM_E_ARG, "minmax: bad dtype %d", dtype);
+    }
+    KM_LAUNCH_CHECK(c);
+    minmax_final_kernel<<<1, 256, 0, c->stream>>>(partial, nb, d_mm);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ standalone stretch / mask
+template <typename T>
+__global__ __launch_bounds__(256) void to_uint8_kernel(const T *__restrict__ img, int H, int W, ptrdiff_t stride,
+                                                       const double *mm, int invert, uint8_t *out)
+{
+    const double mn = mm[0], mx = mm[1], range = mx - mn;
+    const bool deg = !(mx > mn);
+    const size_t n = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        unsigned r = stretch_u8<T>(img[(size_t)y * stride + x], mn, range, deg);
+        out[i] = (uint8_t)(invert ? 255u - r : r);
+    }
+}
+
+int kd_to_uint8(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, const double *d_mm,
+                int invert, uint8_t *d_out)
+{
+    const int nb = 4096;
+    switch (dtype) {
+    case KM_U8: to_uint8_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_img, H, W, stride, d_mm, invert, d_out); break;
+    case KM_U16: to_uint8_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_img, H, W, stride, d_mm, invert, d_out); break;
+    case KM_I16: to_uint8_kernel<int16_t><<<nb, 256, 0, c->stream>>>((const int16_t *)d_img, H, W, stride, d_mm, invert, d_out); break;
+    case KM_F32: to_uint8_kernel<float><<<nb, 256, 0, c->stream>>>((const float *)d_img, H, W, stride, d_mm, invert, d_out); break;
+    default: return km_fail(c, KM_E_ARG, "to_uint8: bad dtype %d", dtype);
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+struct nodata_t {
+    double mon, ref;
+    int has_mon, has_ref;
+};
+
+template <typename T>
+__device__ __forceinline__ bool px_valid(T a /*mon*/, T b /*ref*/, const nodata_t &nd)
+{
+    bool ok = (a != (T)0) && (b != (T)0);
+    if constexpr (px_traits<T>::code == KM_F32) ok = ok && isfinite(a) && isfinite(b);
+    if (nd.has_mon) ok = ok && ((double)a != nd.mon);
+    if (nd.has_ref) ok = ok && ((double)b != nd.ref);
+    return ok;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void auto_mask_kernel(const T *__restrict__ mon, const T *__restrict__ ref, int H, int W,
+                                                        ptrdiff_t smon, ptrdiff_t sref, nodata_t nd, uint8_t *mask,
+                                                        unsigned long long *valid)
+{
+    const size_t n = (size_t)H * W;
+    unsigned long long cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        bool ok = px_valid<T>(mon[(size_t)y * smon + x], ref[(size_t)y * sref + x], nd);
+        mask[i] = ok ? 1 : 0;
+        cnt += ok;
+    }
+    cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(valid, cnt);
+}
+
+static nodata_t make_nodata(const double *nodata_mon, const double *nodata_ref)
+{
+    nodata_t nd;
+    nd.has_mon = nodata_mon != nullptr; nd.mon = nodata_mon ? *nodata_mon : 0.0;
+    nd.has_ref = nodata_ref != nullptr; nd.ref = nodata_ref ? *nodata_ref : 0.0;
+    return nd;
+}
+
+int kd_auto_mask(km_ctx *c, const void *d_mon, const void *d_ref, int dtype, int H, int W, ptrdiff_t smon,
+                 ptrdiff_t sref, const double *nodata_mon, const double *nodata_ref, uint8_t *d_mask,
+                 unsigned long long *d_valid)
+{
+    nodata_t nd = make_nodata(nodata_mon, nodata_ref);
+    KM_HIP(c, hipMemsetAsync(d_valid, 0, sizeof(unsigned long long), c->stream));
+    const int nb = 4096;
+    switch (dtype) {
+    case KM_U8: auto_mask_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_mon, (const uint8_t *)d_ref, H, W, smon, sref, nd, d_mask, d_valid); break;
+    case KM_U16: auto_mask_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_mon, (const uint16_t *)d_ref, H, W, smon, sref, nd, d_mask, d_valid); break;
+    case KM_I16: auto_mask_kernel<int16_t><<<nb, 256, 0, c->stream>>>((const int16_t *)d_mon, (const int16_t *)d_ref, H, W, smon, sref, nd, d_mask, d_valid); break;
+    case KM_F32: auto_mask_kernel<float><<<nb, 256, 0, c->stream>>>((const float *)d_mon, (const float *)d_ref, H, W, smon, sref, nd, d_mask, d_valid); break;
+    default: return km_fail(c, KM_E_ARG, "auto_mask: bad dtype %d", dtype);
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const uint8_t *__restrict__ m, size_t n, unsigned long long *valid)
+{
+    unsigned long long cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cnt += m[i] != 0;
+    cnt = wave_sum_u64(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(valid, cnt);
+}
+
+int kd_count_nonzero(km_ctx *c, const uint8_t *d_mask, size_t n, unsigned long long *d_valid)
+{
+    KM_HIP(c, hipMemsetAsync(d_valid, 0, sizeof(unsigned long long), c->stream));
+    count_nonzero_kernel<<<2048, 256, 0, c->stream>>>(d_mask, n, d_valid);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ K2 stretch + Laplacian (+mask)
+// Output tile 64x32 per 256-thread workgroup.  The Laplacian of odd ksize k is written as
+//   sum_j ks[j] * (kd *x u8)[y+j] + kd[j] * (ks *x u8)[y+j]
+// (ksize 1 and 3 fit the same form with kd=[1,-2,1] and ks=[0,1,0] / [1,2,1]); both images use
+// radius R = max of the two, the shorter kernel zero-padded, so one launch serves mixed sizes.
+#define LAP_TW 64
+#define LAP_TH 32
+
+struct lap_coef {
+    int kd[2][11];
+    int ks[2][11];
+};
+
+template <int R, typename T, int NIMG, bool MASK>
+__global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                                  ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
+                                                  lap_coef cf, int invert1, nodata_t nd, uint8_t *__restrict__ out0,
+                                                  uint8_t *__restrict__ out1, uint8_t *__restrict__ mask_out,
+                                                  unsigned long long *valid)
+{
+    constexpr int HX = (R + 3) & ~3;          // x halo rounded to 4 for packed LDS words
+    constexpr int TWH = LAP_TW + 2 * HX;      // LDS tile row length (bytes)
+    constexpr int THH = LAP_TH + 2 * R;
+    constexpr int CPR = TWH / 4;              // 4-pixel chunks per row
+    __shared__ uint32_t tile[NIMG][THH][CPR];
+    __shared__ int hd[NIMG][THH][LAP_TW];
+    __shared__ int hs[NIMG][THH][LAP_TW];
+
+    const int X0 = blockIdx.x * LAP_TW, Y0 = blockIdx.y * LAP_TH;
+    const int tid = threadIdx.x;
+    double mn[NIMG], range[NIMG];
+    bool deg[NIMG];
+#pragma unroll
+    for (int i = 0; i < NIMG; i++) {
+        if constexpr (sizeof(T) == 1) { mn[i] = 0; range[i] = 1; deg[i] = false; }
+        else { mn[i] = mm[2 * i]; double mx = mm[2 * i + 1]; range[i] = mx - mn[i]; deg[i] = !(mx > mn[i]); }
+    }
+    const T *imgs[2] = {img0, img1};
+    const ptrdiff_t strides[2] = {stride0, stride1};
+
+    // ---- phase 1: load raw tile + halo (REFLECT_101), stretch to u8, pack into LDS
+    unsigned cnt = 0;
+    for (int ci = tid; ci < THH * CPR; ci += 256) {
+        const int row = ci / CPR, cx = ci - row * CPR;
+        const int gy = km_reflect101(Y0 - R + row, H);
+        const int gx0 = X0 - HX + cx * 4;
+        T v[NIMG][4];
+        const bool inside = gx0 >= 0 && gx0 + 3 < W;
+#pragma unroll
+        for (int i = 0; i < NIMG; i++) {
+            const T *rowp = imgs[i] + (size_t)gy * strides[i];
+            if (inside && ((((uintptr_t)(rowp + gx0)) & (4 * sizeof(T) - 1)) == 0)) {
+                if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(rowp + gx0); __builtin_memcpy(v[i], &q, 4); }
+                else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(rowp + gx0); __builtin_memcpy(v[i], &q, 8); }
+                else { uint4 q = *(const uint4 *)(rowp + gx0); __builtin_memcpy(v[i], &q, 16); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[i][k] = rowp[km_reflect101(gx0 + k, W)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIMG; i++) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned u = stretch_u8<T>(v[i][k], mn[i], range[i], deg[i]);
+                if (i == 1 && invert1) u = 255u - u;
+                packed |= u << (8 * k);
+            }
+            tile[i][row][cx] = packed;
+        }
+        if constexpr (MASK) {
+            // auto mask for interior pixels: v[0] = ref, v[1] = mon
+            const int oy = Y0 - R + row;
+            if (row >= R && row < R + LAP_TH && oy < H && gx0 >= X0 && gx0 < X0 + LAP_TW && gx0 < W) {
+                uint32_t mp = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool ok = (gx0 + k < W) && px_valid<T>(v[1][k], v[0][k], nd);
+                    mp |= (ok ? 1u : 0u) << (8 * k);
+                    cnt += ok;
+                }
+                const size_t o = (size_t)oy * W + gx0;
+                if (gx0 + 3 < W && (o & 3) == 0) *(uint32_t *)(mask_out + o) = mp;
+                else {
+                    for (int k = 0; k < 4 && gx0 + k < W; k++) mask_out[o + k] = (uint8_t)((mp >> (8 * k)) & 1u);
+                }
+            }
+        }
+    }
+    if constexpr (MASK) {
+        unsigned long long c64 = wave_sum_u64((unsigned long long)cnt);
+        if ((tid & 63) == 0 && c64) atomicAdd(valid, c64);
+    }
+    __syncthreads();
+
+    // ---- phase 2: horizontal passes (kd and ks) for 4 consecutive outputs per item
+    constexpr int NW = (2 * R + 4 + (HX - R) + 3) / 4;  // words covering [x+HX-R, x+HX+R+4)
+    for (int it = tid; it < NIMG * THH * (LAP_TW / 4); it += 256) {
+        const int i = it / (THH * (LAP_TW / 4));
+        const int rem = it - i * (THH * (LAP_TW / 4));
+        const int row = rem / (LAP_TW / 4), q = rem - row * (LAP_TW / 4);
+        // output x = 4q..4q+3 ; source bytes start at tile column 4q + HX - R
+        uint32_t w[NW + 1];
+#pragma unroll
+        for (int k = 0; k < NW + 1; k++) w[k] = (q + k < CPR) ? tile[i][row][q + k] : 0u;
+        int ad[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 2 * R + 4; t++) {
+            const int b = t + (HX - R);
+            const int pv = (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int k = t - o;  // tap index for output o
+                if (k >= 0 && k <= 2 * R) {
+                    ad[o] += cf.kd[i][k] * pv;
+                    as[o] += cf.ks[i][k] * pv;
+                }
+            }
+        }
+        *(int4 *)&hd[i][row][4 * q] = make_int4(ad[0], ad[1], ad[2], ad[3]);
+        *(int4 *)&hs[i][row][4 * q] = make_int4(as[0], as[1], as[2], as[3]);
+    }
+    __syncthreads();
+
+    // ---- phase 3: vertical combine, clip to [0,255], packed store
+    uint8_t *outs[2] = {out0, out1};
+    for (int it = tid; it < NIMG * LAP_TH * (LAP_TW / 4); it += 256) {
+        const int i = it / (LAP_TH * (LAP_TW / 4));
+        const int rem = it - i * (LAP_TH * (LAP_TW / 4));
+        const int row = rem / (LAP_TW / 4), q = rem - row * (LAP_TW / 4);
+        const int oy = Y0 + row, ox = X0 + 4 * q;
+        if (oy >= H || ox >= W) continue;
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j <= 2 * R; j++) {
+            const int4 a = *(const int4 *)&hd[i][row + j][4 * q];
+            const int4 b = *(const int4 *)&hs[i][row + j][4 * q];
+            const int ksj = cf.ks[i][j], kdj = cf.kd[i][j];
+            acc[0] += ksj * a.x + kdj * b.x;
+            acc[1] += ksj * a.y + kdj * b.y;
+            acc[2] += ksj * a.z + kdj * b.z;
+            acc[3] += ksj * a.w + kdj * b.w;
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) packed |= (uint32_t)min(max(acc[k], 0), 255) << (8 * k);
+        const size_t o = (size_t)oy * W + ox;
+        if (ox + 3 < W && (o & 3) == 0) *(uint32_t *)(outs[i] + o) = packed;
+        else {
+            for (int k = 0; k < 4 && ox + k < W; k++) outs[i][o + k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
+// OpenCV getSobelKernels recurrence (order 0 / 2), centred into an 11-tap array of radius R
+static bool fill_coef(int ksize, int R, int *kd, int *ks)
+{
+    int d[12] = {0}, s[12] = {0};
+    auto gen = [](int k, int order, int *ker) {
+        if (k == 3) {
+            static const int k0[3] = {1, 2, 1}, k2[3] = {1, -2, 1};
+            for (int i = 0; i < 3; i++) ker[i] = order == 0 ? k0[i] : k2[i];
+            return;
+        }
+        ker[0] = 1;
+        for (int i = 0; i < k; i++) ker[i + 1] = 0;
+        for (int i = 0; i < k - order - 1; i++) {
+            int oldv = ker[0];
+            for (int j = 1; j <= k; j++) { int nv = ker[j] + ker[j - 1]; ker[j - 1] = oldv; oldv = nv; }
+        }
+        for (int i = 0; i < order; i++) {
+            int oldv = -ker[0];
+            for (int j = 1; j <= k; j++) { int nv = ker[j - 1] - ker[j]; ker[j - 1] = oldv; oldv = nv; }
+        }
+    };
+    int r;
+    if (ksize == 1) { d[0] = 1; d[1] = -2; d[2] = 1; s[0] = 0; s[1] = 1; s[2] = 0; r = 1; }
+    else if (ksize == 3 || ksize == 5 || ksize == 7 || ksize == 9 || ksize == 11) { gen(ksize, 2, d); gen(ksize, 0, s); r = ksize / 2; }
+    else return false;
+    if (r > R) return false;
+    for (int i = 0; i < 11; i++) { kd[i] = 0; ks[i] = 0; }
+    for (int i = 0; i < 2 * r + 1; i++) { kd[i + (R - r)] = d[i]; ks[i + (R - r)] = s[i]; }
+    return true;
+}
+
+template <typename T, int NIMG, bool MASK>
+static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
+                      const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
+                      unsigned long long *valid)
+{
+    dim3 grid((W + LAP_TW - 1) / LAP_TW, (H + LAP_TH - 1) / LAP_TH);
+#define KM_LAP_CASE(RR)                                                                                         \
+    case RR:                                                                                                    \
+        lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, \
+                                                                   mask, valid);                               \
+        break;
+    switch (R) {
+        KM_LAP_CASE(1)
+        KM_LAP_CASE(2)
+        KM_LAP_CASE(3)
+        KM_LAP_CASE(4)
+        KM_LAP_CASE(5)
+    default: return km_fail(c, KM_E_UNSUPPORTED, "laplacian radius %d", R);
+    }
+#undef KM_LAP_CASE
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+static int lap_radius(int ksize) { return ksize == 1 ? 1 : ksize / 2; }
+
+int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, uint8_t *d_dst)
+{
+    lap_coef cf;
+    const int R = lap_radius(ksize);
+    if (ksize < 1 || ksize > 11 || !(ksize & 1) || !fill_coef(ksize, R, cf.kd[0], cf.ks[0]))
+        return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize %d (supported: 1,3,5,7,9,11)", ksize);
+    for (int i = 0; i < 11; i++) { cf.kd[1][i] = 0; cf.ks[1][i] = 0; }
+    nodata_t nd = make_nodata(nullptr, nullptr);
+    return launch_lap<uint8_t, 1, false>(c, R, d_src, d_src, H, W, W, W, nullptr, cf, 0, nd, d_dst, nullptr, nullptr, nullptr);
+}
+
+int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref,
+                              ptrdiff_t smon, const double *d_mm, int ksize_ref, int ksize_mon, int invert_mon,
+                              const double *nodata_ref, const double *nodata_mon, uint8_t *d_lap_ref, uint8_t *d_lap_mon,
+                              uint8_t *d_mask_out, unsigned long long *d_valid)
+{
+    lap_coef cf;
+    const int R = lap_radius(ksize_ref) > lap_radius(ksize_mon) ? lap_radius(ksize_ref) : lap_radius(ksize_mon);
+    auto okk = [](int k) { return k >= 1 && k <= 11 && (k & 1); };
+    if (!okk(ksize_ref) || !okk(ksize_mon) || !fill_coef(ksize_ref, R, cf.kd[0], cf.ks[0]) ||
+        !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
+        return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
+    nodata_t nd = make_nodata(nodata_mon, nodata_ref);
+    if (d_mask_out) KM_HIP(c, hipMemsetAsync(d_valid, 0, sizeof(unsigned long long), c->stream));
+#define KM_PAIR(T)                                                                                                          \
+    (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
+                                         d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                        \
+                : launch_lap<T, 2, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
+                                          d_lap_ref, d_lap_mon, nullptr, nullptr))
+    switch (dtype) {
+    case KM_U8: return KM_PAIR(uint8_t);
+    case KM_U16: return KM_PAIR(uint16_t);
+    case KM_I16: return KM_PAIR(int16_t);
+    case KM_F32: return KM_PAIR(float);
+    default: return km_fail(c, KM_E_ARG, "stretch_laplacian: bad dtype %d", dtype);
+    }
+#undef KM_PAIR
+}
+
+// ------------------------------------------------------------------ K3 min-eigenvalue map
+// Output tile 64x32.  Exact-integer Sobel products and box sums (<= 31x31 window fits int32),
+// one conversion to f32, then OpenCV's calcMinEigenVal formula with every f32 op rounded
+// separately.  cov's own REFLECT_101 border (boxFilter) is honoured by evaluating the Sobel
+// at the reflected position, NOT by reflecting the image under the window.
+#define EIG_TW 64
+#define EIG_TH 32
+#define EIG_SEG 16
+
+__device__ __forceinline__ unsigned eig_key(float f)
+{
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float eig_unkey(unsigned k)
+{
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+
+__global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H,
+                                                  int W, int block, double scale2, float *__restrict__ eig,
+                                                  unsigned int *max_key)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = block / 2, Rr = block - 1 - L;
+    const int PW = EIG_TW + L + Rr, PH = EIG_TH + L + Rr;  // product region
+    const int LW = (PW + 2 + 3) & ~3, LH = PH + 2;          // lap tile (1-px Sobel halo), row padded to 4
+    uint8_t *lap = smem;                                    // [LH][LW]
+    int *dxy = (int *)(smem + (((size_t)LH * LW + 15) & ~(size_t)15));  // [PH][PW] packed (dx | dy<<16)
+    int *hsum = dxy + (size_t)PH * PW;                      // [3][PH][EIG_TW]
+    const int X0 = blockIdx.x * EIG_TW, Y0 = blockIdx.y * EIG_TH;
+    const int tid = threadIdx.x;
+    const int lx0 = X0 - L - 1, ly0 = Y0 - L - 1;           // global coords of lap[0][0]
+
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int r = i / LW, cx = i - r * LW;
+        lap[i] = src[(size_t)km_reflect101(ly0 + r, H) * W + km_reflect101(lx0 + cx, W)];
+    }
+    __syncthreads();
+
+    const int xlim = min(X0 + EIG_TW, W) - 1 + Rr, ylim = min(Y0 + EIG_TH, H) - 1 + Rr;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int r = i / PW, cx = i - r * PW;
+        const int gx = X0 - L + cx, gy = Y0 - L + r;
+        int packed = 0;
+        if (gx <= xlim && gy <= ylim) {
+            const int qx = km_reflect101(gx, W) - lx0, qy = km_reflect101(gy, H) - ly0;
+            const uint8_t *p = lap + (size_t)qy * LW + qx;
+            const int a00 = p[-LW - 1], a01 = p[-LW], a02 = p[-LW + 1];
+            const int a10 = p[-1], a12 = p[1];
+            const int a20 = p[LW - 1], a21 = p[LW], a22 = p[LW + 1];
+            const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+            const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+            packed = (dx & 0xffff) | (dy << 16);
+        }
+        dxy[i] = packed;
+    }
+    __syncthreads();
+
+    // horizontal box sums: one row segment of EIG_SEG outputs per work item (sliding window)
+    const int nseg = EIG_TW / EIG_SEG;
+    for (int it = tid; it < PH * nseg; it += 256) {
+        const int r = it / nseg, sg = it - r * nseg;
+        const int *row = dxy + (size_t)r * PW + sg * EIG_SEG;
+        int sxx = 0, sxy = 0, syy = 0;
+        for (int k = 0; k < block; k++) {
+            const int v = row[k];
+            const int dx = (int)(short)(v & 0xffff), dy = v >> 16;
+            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+        }
+        int *o0 = hsum + (size_t)r * EIG_TW + sg * EIG_SEG;
+        int *o1 = o0 + (size_t)PH * EIG_TW, *o2 = o1 + (size_t)PH * EIG_TW;
+        o0[0] = sxx; o1[0] = sxy; o2[0] = syy;
+        for (int x = 1; x < EIG_SEG; x++) {
+            const int vo = row[x - 1], vn = row[x - 1 + block];
+            const int dxo = (int)(short)(vo & 0xffff), dyo = vo >> 16;
+            const int dxn = (int)(short)(vn & 0xffff), dyn = vn >> 16;
+            sxx += dxn * dxn - dxo * dxo; sxy += dxn * dyn - dxo * dyo; syy += dyn * dyn - dyo * dyo;
+            o0[x] = sxx; o1[x] = sxy; o2[x] = syy;
+        }
+    }
+    __syncthreads();
+
+    // vertical box sums + eigenvalue: thread = column x, 8 consecutive rows
+    const int x = tid & 63, yc = (tid >> 6) * (EIG_TH / 4);
+    const int gx = X0 + x;
+    float best = -INFINITY;
+    bool have = false;
+    if (gx < W) {
+        const int *h0 = hsum + x, *h1 = h0 + (size_t)PH * EIG_TW, *h2 = h1 + (size_t)PH * EIG_TW;
+        int sa = 0, sb = 0, sc = 0;
+        for (int k = 0; k < block; k++) {
+            sa += h0[(size_t)(yc + k) * EIG_TW]; sb += h1[(size_t)(yc + k) * EIG_TW]; sc += h2[(size_t)(yc + k) * EIG_TW];
+        }
+        for (int r = 0; r < EIG_TH / 4; r++) {
+            const int gy = Y0 + yc + r;
+            if (gy >= H) break;
+            if (r > 0) {
+                const size_t o = (size_t)(yc + r - 1) * EIG_TW, n = (size_t)(yc + r - 1 + block) * EIG_TW;
+                sa += h0[n] - h0[o]; sb += h1[n] - h1[o]; sc += h2[n] - h2[o];
+            }
+            const float cxx = (float)__dmul_rn((double)sa, scale2);
+            const float cxy = (float)__dmul_rn((double)sb, scale2);
+            const float cyy = (float)__dmul_rn((double)sc, scale2);
+            const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
+            const float t = __fsub_rn(a, cc);
+            const float s = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
+            const float e = __fsub_rn(__fadd_rn(a, cc), __fsqrt_rn(s));
+            const size_t o = (size_t)gy * W + gx;
+            eig[o] = e;
+            if (!mask || mask[o]) { best = have ? fmaxf(best, e) : e; have = true; }
+        }
+    }
+    unsigned key = have ? eig_key(best) : 0u;
+    for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
+    if ((tid & 63) == 0 && key) atomicMax(max_key, key);
+}
+
+int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig,
+                 unsigned int *d_max_key)
+{
+    if (block < 1 || block > 31) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d (supported 1..31)", block);
+    const int L = block / 2, Rr = block - 1 - L;
+    const int PW = EIG_TW + L + Rr, PH = EIG_TH + L + Rr, LW = (PW + 2 + 3) & ~3, LH = PH + 2;
+    const size_t sm = (((size_t)LH * LW + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * EIG_TW * 4;
+    if (sm > 160 * 1024) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d needs %zu B LDS", block, sm);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    KM_HIP(c, hipMemsetAsync(d_max_key, 0, sizeof(unsigned int), c->stream));
+    const double scale = 1.0 / (4.0 * (double)block * 255.0);
+    dim3 grid((W + EIG_TW - 1) / EIG_TW, (H + EIG_TH - 1) / EIG_TH);
+    eig_kernel<<<grid, 256, sm, c->stream>>>(d_src, d_mask, H, W, block, scale * scale, d_eig, d_max_key);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ K4 candidates
+// goodFeaturesToTrack steps 4-5: thr = (float)(maxVal*q); TOZERO threshold;
+// pixel is a candidate iff it is non-zero, equals the 3x3 max of the thresholded map, lies off
+// the 1-px border and passes the mask.  Key = (f32 bits << 32) | raster index, so a single
+// descending u64 sort reproduces greaterThanPtr (value desc, address desc).
+__global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig, const uint8_t *__restrict__ mask, int H, int W,
+                                                   double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
+                                                   size_t cap)
+{
+    const unsigned mk = sc->max_eig_key;
+    const float maxv = mk ? eig_unkey(mk) : 0.f;
+    const float thr = (float)__dmul_rn((double)maxv, quality);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sc->thr = thr; sc->max_eig = maxv; }
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+    if (x >= W - 1 || y >= H - 1) return;
+    const size_t i = (size_t)y * W + x;
+    const float v = eig[i];
+    if (!(v > thr) || v == 0.f) return;
+    if (mask && !mask[i]) return;
+    float m = -INFINITY;  // 3x3 dilate of the thresholded map, centre excluded
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int k = -1; k <= 1; k++) {
+            if (j == 0 && k == 0) continue;
+            const float e = eig[i + (ptrdiff_t)j * W + k];
+            m = fmaxf(m, e > thr ? e : 0.f);
+        }
+    if (v < m) return;
+    const unsigned pos = atomicAdd(&sc->n_cand, 1u);
+    if (pos < cap) keys[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(unsigned)i;
+}
+
+int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W, double quality, km_scalars *d_sc,
+                  unsigned long long *d_keys, size_t cap)
+{
+    KM_HIP(c, hipMemsetAsync(&d_sc->n_cand, 0, sizeof(unsigned int), c->stream));
+    if (H < 3 || W < 3) {
+        return KM_OK;
+    }
+    dim3 grid((W - 2 + 63) / 64, (H - 2 + 3) / 4);
+    cand_kernel<<<grid, 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ K6 pyrDown
+// cv::pyrDown u8: separable [1 4 6 4 1], (sum + 128) >> 8, REFLECT_101, dst = ((W+1)/2, (H+1)/2).
+#define PYR_TW 64
+#define PYR_TH 16
+__global__ __launch_bounds__(256) void pyrdown_kernel(const uint8_t *__restrict__ src, int H, int W, uint8_t *__restrict__ dst,
+                                                      int dh, int dw)
+{
+    // source rows needed: 2*Y0-2 .. 2*(Y0+TH-1)+2  -> 2*TH+3 rows; horizontal pass result kept in LDS
+    __shared__ unsigned short hrow[2 * PYR_TH + 3][PYR_TW];
+    const int X0 = blockIdx.x * PYR_TW, Y0 = blockIdx.y * PYR_TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (2 * PYR_TH + 3) * PYR_TW; i += 256) {
+        const int r = i / PYR_TW, cx = i - r * PYR_TW;
+        const int ox = X0 + cx;
+        unsigned short s = 0;
+        if (ox < dw) {
+            const uint8_t *row = src + (size_t)km_reflect101(2 * Y0 - 2 + r, H) * W;
+            const int sx = 2 * ox;
+            if (sx - 2 >= 0 && sx + 2 < W)
+                s = (unsigned short)(row[sx - 2] + 4 * row[sx - 1] + 6 * row[sx] + 4 * row[sx + 1] + row[sx + 2]);
+            else
+                s = (unsigned short)(row[km_reflect101(sx - 2, W)] + 4 * row[km_reflect101(sx - 1, W)] + 6 * row[km_reflect101(sx, W)] +
+                                     4 * row[km_reflect101(sx + 1, W)] + row[km_reflect101(sx + 2, W)]);
+        }
+        hrow[r][cx] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < PYR_TH * PYR_TW; i += 256) {
+        const int r = i / PYR_TW, cx = i - r * PYR_TW;
+        const int ox = X0 + cx, oy = Y0 + r;
+        if (ox >= dw || oy >= dh) continue;
+        const int s = hrow[2 * r][cx] + 4 * hrow[2 * r + 1][cx] + 6 * hrow[2 * r + 2][cx] + 4 * hrow[2 * r + 3][cx] + hrow[2 * r + 4][cx];
+        dst[(size_t)oy * dw + ox] = (uint8_t)((s + 128) >> 8);
+    }
+}
+
+int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst)
+{
+    const int dh = (H + 1) / 2, dw = (W + 1) / 2;
+    dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH);
+    pyrdown_kernel<<<grid, 256, 0, c->stream>>>(d_src, H, W, d_dst, dh, dw);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ K11 integer shift
+template <typename T>
+__global__ __launch_bounds__(256) void shift_kernel(const T *__restrict__ img, int H, int W, ptrdiff_t stride, int y_off, int x_off,
+                                                    T *__restrict__ out)
+{
+    const size_t n = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        const long sy = (long)y + y_off, sx = (long)x + x_off;
+        T v = (T)0;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = img[(size_t)sy * stride + sx];
+        out[i] = v;
+    }
+}
+
+int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride, int y_off, int x_off, void *d_out)
+{
+    const int nb = 4096;
+    switch (elem_size) {
+    case 1: shift_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_img, H, W, stride, y_off, x_off, (uint8_t *)d_out); break;
+    case 2: shift_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_img, H, W, stride, y_off, x_off, (uint16_t *)d_out); break;
+    case 4: shift_kernel<uint32_t><<<nb, 256, 0, c->stream>>>((const uint32_t *)d_img, H, W, stride, y_off, x_off, (uint32_t *)d_out); break;
+    case 8: shift_kernel<uint64_t><<<nb, 256, 0, c->stream>>>((const uint64_t *)d_img, H, W, stride, y_off, x_off, (uint64_t *)d_out); break;
+    default: return km_fail(c, KM_E_ARG, "shift_image: elem_size %d", elem_size);
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

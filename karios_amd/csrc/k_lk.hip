@@ -1,0 +1,223 @@
+// K7: pyramidal Lucas-Kanade tracker, forward and backward pass fused
+// (cv2.calcOpticalFlowPyrLK x2, reference klt.py:134-140; algorithm SURVEY App. A.3).
+//
+// One 64-lane wavefront per keypoint.  Per pyramid level the (w+3)^2 neighbourhood of the
+// template image is staged in LDS, the Scharr derivative is evaluated there (no dense
+// derivative image is ever written to HBM), and every lane keeps its <= NPL window pixels
+// (Q5 intensity, Ix, Iy) in registers for all iterations.  The normal matrix and mismatch
+// vector are exact integer sums (per-lane int32, wave-reduced in int64) converted once to
+// f32, so the result does not depend on the reduction order; all f32 steps of the 2x2
+// solve are rounded individually (this file is compiled with -ffp-contract=off).
+// The backward pass starts from the forward result of the same keypoint, so both passes run
+// back to back in the same wavefront.
+#include "common.hpp"
+
+#include <float.h>
+
+struct lk_args {
+    km_pyr A, B;
+    const float *pts_in;
+    const int *d_n;
+    int n_max, win, max_count, backward;
+    double epsilon;
+    float *p1, *p0r;
+};
+
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
+{
+    const float oma = 1.f - a, omb = 1.f - b;
+    const float t00 = oma * omb, t01 = a * omb, t10 = oma * b;
+    w00 = __float2int_rn(t00 * 16384.f);
+    w01 = __float2int_rn(t01 * 16384.f);
+    w10 = __float2int_rn(t10 * 16384.f);
+    w11 = 16384 - w00 - w01 - w10;
+}
+
+// Track one point from image pyramid I to J (all lanes hold identical scalars).
+template <int NPL>
+__device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
+                               const short (&lx)[NPL], const short (&ly)[NPL], uint8_t *raw, int *der, float &outx, float &outy)
+{
+    const int lane = threadIdx.x;
+    const float half = (float)(win - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int RW = win + 3, DW = win + 1, npx = win * win;
+    float resx = px, resy = py;
+    for (int level = I.levels; level >= 0; level--) {
+        const uint8_t *Iimg = I.img[level], *Jimg = J.img[level];
+        const int IW = I.W[level], IH = I.H[level], JW = J.W[level], JH = J.H[level];
+        const float sc = (float)(1. / (1 << level));
+        float prx = px * sc, pry = py * sc;
+        float nx, ny;
+        if (level == I.levels) { nx = prx; ny = pry; }
+        else { nx = resx * 2.f; ny = resy * 2.f; }
+        resx = nx; resy = ny;
+        prx -= half; pry -= half;
+        const int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
+        if (ipx < -win || ipx >= IW || ipy < -win || ipy >= IH) continue;
+        float a = prx - (float)ipx, b = pry - (float)ipy;
+        int w00, w01, w10, w11;
+        lk_weights(a, b, w00, w01, w10, w11);
+
+        // stage the template neighbourhood (REFLECT_101 outside the image)
+        __syncthreads();
+        const bool inside = ipx - 1 >= 0 && ipy - 1 >= 0 && ipx + win + 1 < IW && ipy + win + 1 < IH;
+        for (int i = lane; i < RW * RW; i += 64) {
+            const int r = i / RW, cx = i - r * RW;
+            int gy = ipy - 1 + r, gx = ipx - 1 + cx;
+            if (!inside) { gy = km_reflect101(gy, IH); gx = km_reflect101(gx, IW); }
+            raw[i] = Iimg[(size_t)gy * IW + gx];
+        }
+        __syncthreads();
+        // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image
+        for (int i = lane; i < DW * DW; i += 64) {
+            const int r = i / DW, cx = i - r * DW;
+            const int gy = ipy + r, gx = ipx + cx;
+            int v = 0;
+            if ((unsigned)gx < (unsigned)IW && (unsigned)gy < (unsigned)IH) {
+                const uint8_t *p = raw + (r + 1) * RW + (cx + 1);
+                const int a00 = p[-RW - 1], a01 = p[-RW], a02 = p[-RW + 1];
+                const int a10 = p[-1], a12 = p[1];
+                const int a20 = p[RW - 1], a21 = p[RW], a22 = p[RW + 1];
+                const int ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+                const int iy = ((a20 + a22) * 3 + a21 * 10) - ((a00 + a02) * 3 + a01 * 10);
+                v = (ix & 0xffff) | (iy << 16);
+            }
+            der[i] = v;
+        }
+        __syncthreads();
+        // per-lane window pixels -> registers; exact integer normal matrix
+        int Iv[NPL], Ixv[NPL], Iyv[NPL];
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums fit int32 (<= NPL * 4080^2)
+        long long lA11 = 0, lA12 = 0, lA22 = 0;
+#pragma unroll
+        for (int k = 0; k < NPL; k++) {
+            Iv[k] = 0; Ixv[k] = 0; Iyv[k] = 0;
+            if (k * 64 + lane < npx) {
+                const int y = ly[k], x = lx[k];
+                const uint8_t *p = raw + (y + 1) * RW + (x + 1);
+                Iv[k] = descale(p[0] * w00 + p[1] * w01 + p[RW] * w10 + p[RW + 1] * w11, 14 - 5);
+                const int d00 = der[y * DW + x], d01 = der[y * DW + x + 1], d10 = der[(y + 1) * DW + x], d11 = der[(y + 1) * DW + x + 1];
+                const int ixv = descale((int)(short)(d00 & 0xffff) * w00 + (int)(short)(d01 & 0xffff) * w01 + (int)(short)(d10 & 0xffff) * w10 +
+                                            (int)(short)(d11 & 0xffff) * w11, 14);
+                const int iyv = descale((d00 >> 16) * w00 + (d01 >> 16) * w01 + (d10 >> 16) * w10 + (d11 >> 16) * w11, 14);
+                Ixv[k] = ixv; Iyv[k] = iyv;
+                sA11 += ixv * ixv; sA12 += ixv * iyv; sA22 += iyv * iyv;
+                if ((k & 7) == 7) { lA11 += sA11; lA12 += sA12; lA22 += sA22; sA11 = sA12 = sA22 = 0; }
+            }
+        }
+        lA11 += sA11; lA12 += sA12; lA22 += sA22;
+        const long long iA11 = wave_sum_i64(lA11), iA12 = wave_sum_i64(lA12), iA22 = wave_sum_i64(lA22);
+        const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float dA = A11 - A22;
+        const float q = dA * dA + 4.f * A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf(q)) / (float)(2 * win * win);
+        if (minEig < 1e-4f || D < FLT_EPSILON) continue;
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= JW || iny < -win || iny >= JH) break;
+            a = nx - (float)inx; b = ny - (float)iny;
+            lk_weights(a, b, w00, w01, w10, w11);
+            const bool jin = inx >= 0 && iny >= 0 && inx + win < JW && iny + win < JH;
+            int sb1 = 0, sb2 = 0;
+            long long lb1 = 0, lb2 = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; k++) {
+                if (k * 64 + lane < npx) {
+                    int gy = iny + ly[k], gx = inx + lx[k];
+                    int j00, j01, j10, j11;
+                    if (jin) {
+                        const uint8_t *p = Jimg + (size_t)gy * JW + gx;
+                        j00 = p[0]; j01 = p[1]; j10 = p[JW]; j11 = p[JW + 1];
+                    } else {
+                        const int y0 = km_reflect101(gy, JH), y1 = km_reflect101(gy + 1, JH);
+                        const int x0 = km_reflect101(gx, JW), x1 = km_reflect101(gx + 1, JW);
+                        j00 = Jimg[(size_t)y0 * JW + x0]; j01 = Jimg[(size_t)y0 * JW + x1];
+                        j10 = Jimg[(size_t)y1 * JW + x0]; j11 = Jimg[(size_t)y1 * JW + x1];
+                    }
+                    const int diff = descale(j00 * w00 + j01 * w01 + j10 * w10 + j11 * w11, 14 - 5) - Iv[k];
+                    sb1 += diff * Ixv[k]; sb2 += diff * Iyv[k];
+                    if ((k & 7) == 7) { lb1 += sb1; lb2 += sb2; sb1 = sb2 = 0; }
+                }
+            }
+            lb1 += sb1; lb2 += sb2;
+            const long long ib1 = wave_sum_i64(lb1), ib2 = wave_sum_i64(lb2);
+            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            const float ddx = (A12 * b2 - A22 * b1) * D;
+            const float ddy = (A12 * b1 - A11 * b2) * D;
+            nx += ddx; ny += ddy;
+            resx = nx + half; resy = ny + half;
+            if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= epsilon) break;
+            if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+                resx -= ddx * 0.5f; resy -= ddy * 0.5f;
+                break;
+            }
+            pdx = ddx; pdy = ddy;
+        }
+    }
+    outx = resx; outy = resy;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void lk_kernel(lk_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int p = blockIdx.x;
+    const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
+    if (p >= n) return;
+    const int win = g.win;
+    uint8_t *raw = smem;
+    int *der = (int *)(smem + (((win + 3) * (win + 3) + 15) & ~15));
+    short lx[NPL], ly[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int idx = k * 64 + (int)threadIdx.x;
+        const int y = idx / win;
+        ly[k] = (short)y; lx[k] = (short)(idx - y * win);
+    }
+    const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
+    float fx, fy;
+    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, lx, ly, raw, der, fx, fy);
+    if (threadIdx.x == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
+    if (g.backward) {
+        float rx, ry;
+        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, lx, ly, raw, der, rx, ry);
+        if (threadIdx.x == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
+    }
+}
+
+int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
+             double epsilon, bool backward_too, float *d_p1, float *d_p0r)
+{
+    if (n_max <= 0) return KM_OK;
+    if (win <= 2) return km_fail(c, KM_E_ARG, "winSize %d must be > 2", win);
+    if (win > 40) return km_fail(c, KM_E_UNSUPPORTED, "winSize %d (supported 3..40)", win);
+    lk_args g;
+    g.A = A; g.B = B; g.pts_in = d_pts_in; g.d_n = d_n; g.n_max = n_max; g.win = win;
+    g.max_count = max_count < 0 ? 0 : max_count > 100 ? 100 : max_count;
+    g.backward = backward_too ? 1 : 0;
+    double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
+    g.epsilon = e * e;
+    g.p1 = d_p1; g.p0r = d_p0r;
+    const size_t sm = (((size_t)(win + 3) * (win + 3) + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
+    const int npl = (win * win + 63) / 64;
+    if (npl <= 4) lk_kernel<4><<<n_max, 64, sm, c->stream>>>(g);
+    else if (npl <= 10) lk_kernel<10><<<n_max, 64, sm, c->stream>>>(g);
+    else if (npl <= 16) lk_kernel<16><<<n_max, 64, sm, c->stream>>>(g);
+    else lk_kernel<25><<<n_max, 64, sm, c->stream>>>(g);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

@@ -371,7 +371,7 @@ int ko_select_corners(const float *eig, const uint8_t *mask, int H, int W,
         float *ay = (float *)malloc(nc * sizeof(float));
         if (!head || !next || !ax || !ay) { free(head); free(next); free(ax); free(ay); free(c); return -2; }
         for (size_t i = 0; i < (size_t)gw * gh; i++) head[i] = -1;
-        const float md2 = (float)(min_dist * min_dist);
+        const double md2 = min_dist * min_dist; /* OpenCV: double minDistance *= minDistance */
         int nacc = 0;
         for (size_t i = 0; i < nc; i++) {
             int y = (int)(c[i].idx / (uint32_t)W), x = (int)(c[i].idx % (uint32_t)W);
@@ -383,7 +383,7 @@ int ko_select_corners(const float *eig, const uint8_t *mask, int H, int W,
                 for (int xx = x1; xx <= x2 && good; xx++)
                     for (int k = head[yy * gw + xx]; k >= 0; k = next[k]) {
                         float dx = (float)x - ax[k], dy = (float)y - ay[k];
-                        if (dx * dx + dy * dy < md2) { good = 0; break; }
+                        if ((double)(dx * dx + dy * dy) < md2) { good = 0; break; }
                     }
             if (!good) continue;
             ax[nacc] = (float)x; ay[nacc] = (float)y;

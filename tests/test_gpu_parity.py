@@ -1,0 +1,240 @@
+"""GPU parity: every HIP operator against the CPU oracle on the same seeded inputs,
+called through the C ABI (karios_amd.ops -> libkarios_hip.so).
+
+Bars (BASELINE.json north_star / SURVEY.md 8d): integer / byte / index results bit-exact;
+sub-pixel displacements within 1e-3 px; ZNCC within 1e-9.
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_u8
+from karios_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64), (67, 93), (200, 131), (33, 257), (5, 7), (1, 40), (40, 1), (130, 64)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.int16, np.float32, np.uint8])
+@pytest.mark.parametrize("invert", [False, True])
+def test_to_uint8_bit_exact(ops, O, dtype, invert):
+    rng = np.random.default_rng(1)
+    for shape in [(67, 93), (128, 256), (5, 3)]:
+        if dtype == np.float32:
+            a = (rng.standard_normal(shape) * 1000).astype(np.float32)
+            a[0, 0] = np.nan
+        elif dtype == np.int16:
+            a = rng.integers(-3000, 9000, shape).astype(np.int16)
+        elif dtype == np.uint8:
+            a = rng.integers(0, 256, shape).astype(np.uint8)
+        else:
+            a = rng.integers(1, 16000, shape).astype(np.uint16)
+        got, mm = ops.to_uint8(a, invert=invert, return_minmax=True)
+        exp = O.to_uint8(a, invert=invert)
+        np.testing.assert_array_equal(got, exp)
+        if dtype != np.uint8:
+            assert mm == O.minmax(a)
+
+
+def test_to_uint8_constant_and_strided(ops, O):
+    a = np.full((40, 50), 1234, np.uint16)
+    np.testing.assert_array_equal(ops.to_uint8(a), np.zeros_like(a, np.uint8))
+    big = np.random.default_rng(2).integers(0, 5000, (100, 300)).astype(np.uint16)
+    view = big[10:90, 17:203]  # row stride > width, unaligned start
+    np.testing.assert_array_equal(ops.to_uint8(view), O.to_uint8(np.ascontiguousarray(view)))
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_auto_mask(ops, O, dtype):
+    rng = np.random.default_rng(3)
+    mon = rng.integers(0, 4, (70, 90)).astype(dtype)
+    ref = rng.integers(0, 4, (70, 90)).astype(dtype)
+    if dtype == np.float32:
+        mon[3, 3] = np.nan
+        ref[4, 4] = np.inf
+    for nd in [(None, None), (2, None), (None, 3), (1, 2)]:
+        got, nv = ops.auto_mask(mon, ref, *nd)
+        exp, ev = O.auto_mask(mon, ref, *nd)
+        np.testing.assert_array_equal(got, exp)
+        assert nv == ev
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7, 9, 11])
+def test_laplacian_bit_exact(ops, O, ksize):
+    for i, shape in enumerate(SHAPES):
+        img = rand_u8(shape, seed=10 + i)
+        np.testing.assert_array_equal(ops.laplacian_u8(img, ksize), O.laplacian_u8(img, ksize), err_msg=str(shape))
+    smooth = O.to_uint8(synth.make_pair(150, 170)[1])
+    np.testing.assert_array_equal(ops.laplacian_u8(smooth, ksize), O.laplacian_u8(smooth, ksize))
+
+
+def test_laplacian_rejects_bad_ksize(ops):
+    with pytest.raises(ops.KariosHipError):
+        ops.laplacian_u8(rand_u8((20, 20)), 4)
+    with pytest.raises(ops.KariosHipError):
+        ops.laplacian_u8(rand_u8((20, 20)), 13)
+
+
+@pytest.mark.parametrize("block", [3, 7, 15, 4, 1])
+def test_min_eigen_bit_exact(ops, O, block):
+    for i, shape in enumerate(SHAPES):
+        img = rand_u8(shape, seed=30 + i)
+        got, exp = ops.min_eigen(img, block), O.min_eigen(img, block)
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"{shape} block={block}")
+    lap = O.laplacian_u8(O.to_uint8(synth.make_pair(200, 260)[1]), 7)
+    np.testing.assert_array_equal(ops.min_eigen(lap, block).view(np.uint32), O.min_eigen(lap, block).view(np.uint32))
+
+
+def test_pyrdown_bit_exact(ops, O):
+    for i, shape in enumerate(SHAPES + [(255, 300)]):
+        img = rand_u8(shape, seed=50 + i)
+        np.testing.assert_array_equal(ops.pyr_down(img), O.pyrdown_u8(img), err_msg=str(shape))
+
+
+def _lap_pair(O, H, W, sx=0.5, sy=0.25, k=7, seed=20260101, **kw):
+    mon, ref = synth.make_pair(H, W, sx, sy, seed=seed, **kw)
+    return O.laplacian_u8(O.to_uint8(mon), k), O.laplacian_u8(O.to_uint8(ref), k), mon, ref
+
+
+@pytest.mark.parametrize("params", [
+    dict(maxCorners=2000, qualityLevel=0.1, minDistance=10, blockSize=15),
+    dict(maxCorners=0, qualityLevel=0.05, minDistance=5, blockSize=7),
+    dict(maxCorners=50, qualityLevel=0.01, minDistance=3.5, blockSize=3),
+    dict(maxCorners=300, qualityLevel=0.2, minDistance=0, blockSize=5),
+    dict(maxCorners=100000, qualityLevel=0.001, minDistance=1, blockSize=3),
+])
+def test_good_features_indices_bit_exact(ops, O, params):
+    lap_mon, lap_ref, mon, ref = _lap_pair(O, 300, 420)
+    mask, _ = O.auto_mask(mon, ref)
+    for m in (None, mask):
+        got = ops.good_features_to_track(lap_ref, mask=m, **params)
+        exp = O.good_features(lap_ref, mask=m, **params)
+        assert (got is None) == (exp is None)
+        if exp is not None:
+            np.testing.assert_array_equal(got, exp)  # same corners, same (strength) order
+
+
+def test_good_features_masked_wedge_and_ties(ops, O):
+    lap_mon, lap_ref, mon, ref = _lap_pair(O, 256, 256, nodata_wedge=True)
+    mask, _ = O.auto_mask(mon, ref)
+    got = ops.good_features_to_track(lap_ref, 5000, 0.1, 10, mask=mask, blockSize=15)
+    exp = O.good_features(lap_ref, mask, 5000, 0.1, 10, 15)
+    np.testing.assert_array_equal(got, exp)
+    # periodic pattern: exact ties everywhere, order decided by the raster-index rule
+    tile = np.zeros((16, 16), np.uint8)
+    tile[4:9, 4:9] = 255
+    img = np.tile(tile, (12, 14))
+    got = ops.good_features_to_track(img, 0, 0.01, 8, blockSize=5)
+    exp = O.good_features(img, None, 0, 0.01, 8, 5)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_good_features_flat_image_is_none(ops):
+    assert ops.good_features_to_track(np.full((80, 80), 17, np.uint8), 100, 0.1, 10, blockSize=15) is None
+    assert ops.good_features_to_track(np.zeros((2, 2), np.uint8), 100, 0.1, 10, blockSize=3) is None
+
+
+@pytest.mark.parametrize("win", [25, 9, 31, 15])
+def test_pyrlk_matches_oracle(ops, O, win):
+    lap_mon, lap_ref, _, _ = _lap_pair(O, 260, 330, sx=0.6, sy=-0.35)
+    p0 = O.good_features(lap_ref, None, 800, 0.05, 7, 9)
+    got = ops.calc_optical_flow_pyr_lk(lap_ref, lap_mon, p0, winSize=(win, win))
+    exp = O.pyr_lk(lap_ref, lap_mon, p0, win)
+    assert np.abs(got - exp).max() <= 1e-3
+    assert np.array_equal(got, exp), f"not bit-identical: max diff {np.abs(got - exp).max()}"
+    # backward pass from sub-pixel positions, including points near / beyond the border
+    extra = np.array([[[0.3, 0.2]], [[329.2, 259.9]], [[-5.5, 10.0]], [[100.25, -30.0]], [[400.0, 400.0]]], np.float32)
+    p1 = np.concatenate([got, extra])
+    gb = ops.calc_optical_flow_pyr_lk(lap_mon, lap_ref, p1, winSize=(win, win))
+    eb = O.pyr_lk(lap_mon, lap_ref, p1, win)
+    assert np.abs(gb - eb).max() <= 1e-3
+    assert np.array_equal(gb, eb)
+
+
+def test_pyrlk_small_image_no_pyramid_and_identity(ops, O):
+    img = rand_u8((40, 44), seed=77)  # (w+1)/2 <= winSize: level 1 is dropped
+    pts = np.array([[[10.0, 12.0]], [[30.5, 20.25]], [[0.0, 0.0]], [[43.0, 39.0]]], np.float32)
+    got = ops.calc_optical_flow_pyr_lk(img, img, pts)
+    np.testing.assert_array_equal(got, O.pyr_lk(img, img, pts))
+    np.testing.assert_array_equal(got[:2], pts[:2])  # identical images: zero flow, exactly
+
+
+def test_klt_track_and_tile_match_oracle(ops, O):
+    mon, ref = synth.make_pair(384, 448, 0.5, 0.25)
+    conf = O.default_conf(maxCorners=3000)
+    exp = O.klt_tile(mon, ref, conf)
+    # unfused: GPU tracker on the oracle's Laplacians
+    tr = ops.klt_track(exp["lap_ref"], exp["lap_mon"], exp["mask"], conf)
+    p0e = O.good_features(exp["lap_ref"], exp["mask"], conf.maxCorners, conf.qualityLevel, conf.minDistance, conf.blocksize)
+    np.testing.assert_array_equal(tr[0], p0e)
+    p1e = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0e, 25)
+    p0re = O.pyr_lk(exp["lap_mon"], exp["lap_ref"], p1e, 25)
+    assert np.abs(tr[1] - p1e).max() <= 1e-3 and np.abs(tr[2] - p0re).max() <= 1e-3
+    # fused tile pipeline from raw uint16
+    status, tracks = ops.klt_tile(ref, mon, conf, mon_ksize=7, ref_ksize=7)
+    assert status == "ok"
+    np.testing.assert_array_equal(tracks[0], p0e)
+    assert np.abs(tracks[1] - p1e).max() <= 1e-3 and np.abs(tracks[2] - p0re).max() <= 1e-3
+    st = ops._lib.default_context().stats()
+    assert st.valid_pixels == int(exp["mask"].sum()) and st.n_init == len(p0e)
+
+
+def test_klt_tile_mixed_ksize_invert_mask_nodata(ops, O):
+    mon, ref = synth.make_pair(300, 300, -0.4, 0.3, nodata_wedge=True)
+    conf = O.default_conf(maxCorners=1500, laplacian_kernel_size={"mon": 5, "ref": 9})
+    exp = O.klt_tile(mon, ref, conf, nodata_mon=1, nodata_ref=None, invert_mon=True)
+    status, tracks = ops.klt_tile(ref, mon, conf, nodata_mon=1, mon_ksize=5, ref_ksize=9, invert_mon=True)
+    assert status == "ok"
+    p0e = O.good_features(exp["lap_ref"], exp["mask"], 1500, 0.1, 10, 15)
+    np.testing.assert_array_equal(tracks[0], p0e)
+    p1e = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0e, 25)
+    assert np.abs(tracks[1] - p1e).max() <= 1e-3
+
+
+def test_klt_tile_no_valid_pixels(ops):
+    z = np.zeros((64, 64), np.uint16)
+    conf = type("C", (), dict(maxCorners=100, blocksize=15, matching_winsize=25, qualityLevel=0.1, minDistance=10))()
+    assert ops.klt_tile(z, z, conf, mon_ksize=7, ref_ksize=7)[0] == "no_valid_pixels"
+    flat = np.full((64, 64), 500, np.uint16)
+    assert ops.klt_tile(flat, flat, conf, mon_ksize=7, ref_ksize=7)[0] == "no_features"
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.int16, np.float32])
+def test_zncc_matches_oracle(ops, O, dtype):
+    mon, ref = synth.make_pair(200, 240, 1.5, -2.5)
+    mon, ref = mon.astype(dtype), ref.astype(dtype)
+    rng = np.random.default_rng(5)
+    n = 500
+    x0 = rng.integers(-5, 245, n).astype(np.float32)
+    y0 = rng.integers(-5, 205, n).astype(np.float32)
+    dx = (rng.standard_normal(n) * 3).astype(np.float32)
+    dy = (rng.standard_normal(n) * 3).astype(np.float32)
+    dx[:20] = np.array([0.5, 1.5, 2.5, -0.5, -1.5] * 4, np.float32)  # half-to-even rounding cases
+    got, exp = ops.zncc_batch(ref, mon, x0, y0, dx, dy), O.zncc_batch(ref, mon, x0, y0, dx, dy)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.nanmax(np.abs(got - exp)) <= 1e-9
+    assert np.isnan(exp).sum() > 10 and (~np.isnan(exp)).sum() > 100
+
+
+def test_zncc_zero_std_is_nan(ops):
+    flat = np.full((100, 100), 100, np.uint16)
+    z = np.array([50], np.float32)
+    assert np.isnan(ops.zncc_batch(flat, flat, z, z, z * 0, z * 0)[0])
+
+
+@pytest.mark.parametrize("shape,shift", [((64, 64), (7, -12)), ((96, 130), (-20, 31)), ((61, 45), (3, 5)), ((128, 128), (0, 0))])
+def test_phase_correlation_integer_shift(ops, O, shape, shift):
+    _, ref = synth.make_pair(shape[0], shape[1], 0, 0)
+    mon = np.roll(ref, shift, (0, 1))
+    got = ops.phase_cross_correlation(mon, ref)
+    exp = O.phase_cross_correlation(mon, ref)
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(got, np.array(shift, np.float64))
+
+
+def test_shift_image_matches_reference_semantics(ops, O):
+    rng = np.random.default_rng(9)
+    for dtype in (np.uint8, np.uint16, np.float32, np.float64):
+        img = rng.integers(0, 200, (37, 53)).astype(dtype)
+        for yo, xo in [(0, 0), (3, 0), (0, -4), (-5, 7), (2.6, -1.4), (40, 1), (1, -60)]:
+            np.testing.assert_array_equal(ops.shift_image(img, yo, xo), O.shift_image(img, yo, xo))
