@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ sr
             const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
             const float t = __fsub_rn(a, cc);
             const float s = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
-            const float e = __fsub_rn(__fadd_rn(a, cc), __fsqrt_rn(s));
+            const float e = __fsub_rn(__fadd_rn(a, cc), sqrtf(s));
             const size_t o = (size_t)gy * W + gx;
             eig[o] = e;
             if (!mask || mask[o]) { best = have ? fmaxf(best, e) : e; have = true; }
