@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the KARIOS matching hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic Sentinel-2-sized pair that is already
+resident in HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK
+forward/backward -> forward-backward score -> per-key-point ZNCC of the rows with score >= 0.4
+(BASELINE config 2: "Sentinel-2 10 m band pair (10980x10980), KLT only, 1 MI355X"; default
+processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000).
+With N > 1 every rank matches its own band pair (weak scaling; the reference's tiles / bands are
+independent) and the per-band key-point frames are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is computed from hipEvent stage times recorded on the
+library's stream during the timed steps; `cpu_baseline` times the CPU oracle (oracle/, a port of the
+reference path) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per pixel of one pair, per dense stage
+STAGE_BYTES_PER_PX = {
+    "minmax": 4.0,                   # read mon 2 + ref 2
+    "stretch_laplacian_mask": 7.0,   # read 2+2, write lap_mon 1 + lap_ref 1 + mask 1
+    "min_eigen": 5.0,                # read lap_ref 1, write eig 4
+    "candidates": 5.0,               # read eig 4 + mask 1
+    "pyramid": 2.5,                  # read 1+1, write 1/4+1/4
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (0 = half the image)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mon_t, ref_t, size, conf_kw, sample_rows):
+    """Oracle (kind 'port') on the top `rows` rows of the same pair, maxCorners scaled to keep the
+    corner density of the full tile; all host cores via OpenMP."""
+    from oracle import oracle as O
+    rows = sample_rows if sample_rows > 0 else max(64, size // 2)
+    rows = min(rows, size)
+    mon = mon_t[:rows].cpu().numpy().view(np.uint16)
+    ref = ref_t[:rows].cpu().numpy().view(np.uint16)
+    frac = rows / size
+    conf = O.default_conf(**dict(conf_kw, maxCorners=max(1, int(round(conf_kw["maxCorners"] * frac)))))
+    cores = O.max_threads()
+    O.klt_tile(mon[:256, :256], ref[:256, :256], conf)  # load / warm the library
+    t0 = time.perf_counter()
+    res = O.klt_tile(mon, ref, conf)
+    n = 0
+    if res is not None:
+        keep = res["score"] >= 0.4
+        O.zncc_batch(ref, mon, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
+        n = len(res["x0"])
+    dt = time.perf_counter() - t0
+    return {"value": rows * size / 1e6 / dt, "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": f"top {rows} rows x {size} cols of the same pair, maxCorners {conf.maxCorners} "
+                      f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points",
+            "keypoints_per_s": n / dt}, res
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: karios_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from karios_amd import synth
+    from karios_amd._lib import Context
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.parallel import gather_frames
+    from karios_amd.resident import ResidentPair
+
+    S = a.size
+    conf = KLTConfiguration()  # processing_configuration.json defaults: one tile, k=7, maxCorners 20000
+    t_gen = time.perf_counter()
+    mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * rank, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    ctx = Context(local_rank)
+    pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
+
+    def step():
+        frame = pair.match_tile(conf)
+        if frame is not None:
+            frame = pair.score_frame(frame, 0.4)
+        if world > 1:
+            frames = gather_frames({rank: frame}, world, conf.maxCorners, device=dev)
+            return frame, sum(len(f) for f in frames if f is not None)
+        return frame, (0 if frame is None else len(frame))
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.set_profiling(True)
+    stage_sum = {}
+    fence()
+    t0 = time.perf_counter()
+    n_kp_total = 0
+    for _ in range(a.steps):
+        frame, n_all = step()
+        n_kp_total += n_all
+        for k, v in ctx.stage_ms().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    mpx_per_s = world * S * S / 1e6 / (dt / a.steps)
+    stats = ctx.stats()
+
+    out = None
+    if rank == 0:
+        stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
+        dense = {k: stage_ms[k] for k in STAGE_BYTES_PER_PX if stage_ms.get(k, 0) > 0}
+        dom = max(dense, key=dense.get)
+        # minmax runs as 2 launch pairs and the pyramid as 2 launches; the stage span is the unit that is timed
+        algo_bytes = STAGE_BYTES_PER_PX[dom] * S * S
+        achieved = algo_bytes / (dense[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get(str(S))
+            except Exception:
+                traffic = None
+        dense_ms = sum(dense.values())
+        dense_bytes = sum(STAGE_BYTES_PER_PX[k] for k in dense) * S * S
+        out = {
+            "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, KLT + ZNCC",
+            "value": mpx_per_s, "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 stencils, f32 LK solve, f64 stretch+ZNCC", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: synthetic Sentinel-2 10 m band pair {S}x{S} uint16, shift (0.5, 0.25) px, "
+                                   "KLT only (Laplacian k=7, maxCorners 20000, one tile), ZNCC of rows with score>=0.4, "
+                                   "inputs resident in HBM", "pairs_per_step": world,
+                       "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
+            "matched_keypoints_per_sec": n_kp_total / dt,
+            "matched_keypoints_per_pair": (0 if frame is None else len(frame)),
+            "n_init": int(stats.n_init), "n_candidates": int(stats.n_candidates), "select_batches": int(stats.n_select_batches),
+            "median_dx_dy": (None if frame is None else [float(np.median(frame["dx"])), float(np.median(frame["dy"]))]),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dense[dom],
+                         "dense_path": {"bytes": dense_bytes, "ms": dense_ms, "achieved": dense_bytes / (dense_ms * 1e-3) / 1e9,
+                                        "frac": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "synth_seconds": round(t_gen, 2),
+        }
+    if rank == 0 and not a.no_cpu_baseline:
+        cb, _ = cpu_baseline(mon_t, ref_t, S, dict(maxCorners=conf.maxCorners), a.cpu_sample_rows)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

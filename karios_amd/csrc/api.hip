@@ -167,11 +167,16 @@ int km_d2h(km_ctx *c, void *dst, const void *src, size_t bytes)
 }  // extern "C"
 
 // ------------------------------------------------------------------ helpers
-static int begin_call(km_ctx *c)
+// stage timers are cleared per pipeline: the KLT entry points own [ST_MINMAX, ST_LK], ZNCC owns ST_ZNCC
+enum { RESET_NONE = 0, RESET_KLT = 1, RESET_ZNCC = 2 };
+static int begin_call(km_ctx *c, int reset = RESET_NONE)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
-    memset(c->ev_used, 0, sizeof c->ev_used);
+    if (reset == RESET_KLT)
+        for (int i = ST_MINMAX; i <= ST_LK; i++) c->ev_used[i] = false;
+    else if (reset == RESET_ZNCC)
+        c->ev_used[ST_ZNCC] = false;
     return KM_OK;
 }
 
@@ -440,7 +445,7 @@ int km_good_features(km_ctx *c, const uint8_t *img, const uint8_t *mask, int H, 
                      double min_distance, int block, float *out_xy, int cap, int *out_n)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_image(c, img, H, W, W, "good_features"))) return rc;
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_image(c, img, H, W, W, "good_features"))) return rc;
     if (!out_xy || !out_n || cap < 0) return km_fail(c, KM_E_ARG, "good_features: null output");
     if (!(quality > 0)) return km_fail(c, KM_E_ARG, "qualityLevel must be > 0");
     if (min_distance < 0) return km_fail(c, KM_E_ARG, "minDistance must be >= 0");
@@ -526,7 +531,7 @@ int km_klt_track(km_ctx *c, const uint8_t *ref_lap, const uint8_t *mon_lap, cons
                  const float *p0_in, int n_p0, float *p0, float *p1, float *p0r, int cap, int *out_n)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref_lap, H, W, W, "klt_track")) ||
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref_lap, H, W, W, "klt_track")) ||
         (rc = check_image(c, mon_lap, H, W, W, "klt_track")))
         return rc;
     if (!p0 || !p1 || !p0r || !out_n || cap <= 0) return km_fail(c, KM_E_ARG, "klt_track: null output");
@@ -557,7 +562,7 @@ int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, i
                 int *out_n)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref, H, W, sref, "klt_tile")) ||
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, ref, H, W, sref, "klt_tile")) ||
         (rc = check_image(c, mon, H, W, smon, "klt_tile")))
         return rc;
     const size_t es = km_dtype_size(dtype);
@@ -585,7 +590,7 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
                     float *d_p1, float *d_p0r, int cap, int *d_n)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_dev")) ||
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_dev")) ||
         (rc = check_image(c, d_mon, H, W, smon, "klt_tile_dev")))
         return rc;
     if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_dev: bad dtype %d", dtype);
@@ -607,7 +612,7 @@ int km_zncc_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype
                       ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_image(c, d_ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, d_mon, Hmon, Wmon, smon, "zncc")))
+    if ((rc = begin_call(c, RESET_ZNCC)) || (rc = check_image(c, d_ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, d_mon, Hmon, Wmon, smon, "zncc")))
         return rc;
     if (n < 0 || (n > 0 && (!d_x0 || !d_y0 || !d_dx || !d_dy || !d_out))) return km_fail(c, KM_E_ARG, "zncc: bad keypoint arrays");
     km_stage_timer t(c, ST_ZNCC);
@@ -618,7 +623,7 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
                   ptrdiff_t smon, const float *x0, const float *y0, const float *dx, const float *dy, int n, double *out)
 {
     int rc;
-    if ((rc = begin_call(c)) || (rc = check_image(c, ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, mon, Hmon, Wmon, smon, "zncc")))
+    if ((rc = begin_call(c, RESET_ZNCC)) || (rc = check_image(c, ref, Href, Wref, sref, "zncc")) || (rc = check_image(c, mon, Hmon, Wmon, smon, "zncc")))
         return rc;
     const size_t es = km_dtype_size(dtype);
     if (!es) return km_fail(c, KM_E_ARG, "zncc: bad dtype %d", dtype);
@@ -632,8 +637,11 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
     if (!kp || !d_out) return KM_E_NOMEM;
     const float *src[4] = {x0, y0, dx, dy};
     for (int i = 0; i < 4; i++) KM_HIP(c, hipMemcpyAsync(kp + (size_t)i * n, src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if ((rc = kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, d_out)))
-        return rc;
+    {
+        km_stage_timer t(c, ST_ZNCC);
+        if ((rc = kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, d_out)))
+            return rc;
+    }
     KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     return KM_OK;

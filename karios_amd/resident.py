@@ -1,0 +1,218 @@
+"""Device-resident matching: both full-resolution images stay in HBM, every tile of
+`KLT.match` and the ZNCC scoring run on them without further host<->device image traffic.
+
+This is the same computation as `karios_amd.matcher.KLT` + `ZNCCService` (reference
+`karios/matcher/klt.py:198-349`, `karios/api/core.py:871-907`); only the place where the
+pixels live differs.  Device buffers may come from `libkarios_hip` (`upload`) or be any
+device pointer, e.g. a torch CUDA tensor's `data_ptr()` (`from_device_pointers`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from pandas import DataFrame
+
+from . import _lib
+from ._lib import Context, KariosHipError, default_context, dtype_code
+from .matcher.klt import KLT, _frame_from_tracks
+from .ops import make_params
+
+
+class DeviceBuffer:
+    """hipMalloc'ed buffer owned by a context."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx.check(ctx.lib.km_dev_alloc(ctx.handle, self.nbytes, C.byref(p)), "km_dev_alloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.km_dev_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pragma: no cover
+            pass
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.km_h2d(self.ctx.handle, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes), "km_h2d")
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.km_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes), "km_d2h")
+        return out
+
+
+class ResidentPair:
+    """A monitored / reference image pair (plus optional user mask) resident in HBM."""
+
+    def __init__(self, ctx: Context | None, mon_ptr: int, ref_ptr: int, dtype, y_size: int, x_size: int,
+                 mask_ptr: int | None = None, no_data_mon=None, no_data_ref=None, owned=()):
+        self.ctx = ctx if ctx is not None else default_context()
+        self.mon_ptr, self.ref_ptr, self.mask_ptr = int(mon_ptr), int(ref_ptr), (int(mask_ptr) if mask_ptr else None)
+        self.dtype = np.dtype(dtype)
+        self.code = dtype_code(np.empty(0, self.dtype))
+        self.y_size, self.x_size = int(y_size), int(x_size)
+        self.no_data_mon, self.no_data_ref = no_data_mon, no_data_ref
+        self._owned = list(owned)
+        self._out = None
+        self._zbuf = None
+
+    @classmethod
+    def upload(cls, mon: np.ndarray, ref: np.ndarray, mask: np.ndarray | None = None, ctx: Context | None = None,
+               no_data_mon=None, no_data_ref=None) -> "ResidentPair":
+        ctx = ctx if ctx is not None else default_context()
+        mon, ref = np.ascontiguousarray(mon), np.ascontiguousarray(ref)
+        if mon.shape != ref.shape or mon.dtype != ref.dtype or mon.ndim != 2:
+            raise KariosHipError("ResidentPair: mon/ref must be 2-D arrays of equal shape and dtype")
+        bm, br = DeviceBuffer(ctx, mon.nbytes), DeviceBuffer(ctx, ref.nbytes)
+        bm.upload(mon)
+        br.upload(ref)
+        owned, mptr = [bm, br], None
+        if mask is not None:
+            mk = np.ascontiguousarray(mask, np.uint8)
+            bk = DeviceBuffer(ctx, mk.nbytes)
+            bk.upload(mk)
+            owned.append(bk)
+            mptr = bk.ptr
+        return cls(ctx, bm.ptr, br.ptr, mon.dtype, mon.shape[0], mon.shape[1], mptr, no_data_mon, no_data_ref, owned)
+
+    @classmethod
+    def from_device_pointers(cls, mon_ptr: int, ref_ptr: int, dtype, y_size: int, x_size: int, ctx: Context | None = None,
+                             mask_ptr: int | None = None, no_data_mon=None, no_data_ref=None, keepalive=()) -> "ResidentPair":
+        """Wrap existing device memory (row-major, dense rows), e.g. torch tensors' data_ptr()."""
+        return cls(ctx, mon_ptr, ref_ptr, dtype, y_size, x_size, mask_ptr, no_data_mon, no_data_ref, keepalive)
+
+    # ------------------------------------------------------------------ KLT
+    def _outputs(self, cap: int):
+        need = 3 * cap * 2 * 4 + 16
+        if self._out is None or self._out.nbytes < need:
+            self._out = DeviceBuffer(self.ctx, need)
+        base = self._out.ptr
+        return base, base + cap * 8, base + 2 * cap * 8, base + 3 * cap * 8
+
+    def track_tile(self, conf, box=None, mon_ksize=None, ref_ksize=None, invert_mon=False, out_ptrs=None):
+        """km_klt_tile_dev on one box (x_off, y_off, x_size, y_size) of the resident pair.
+        -> (status, (p0, p1, p0r) | None) like `ops.klt_tile`; with `out_ptrs` (p0, p1, p0r, n device
+        pointers, capacity) the results stay on the device and only (status, n) is returned."""
+        c = self.ctx
+        x_off, y_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
+        if x_off < 0 or y_off < 0 or x_off + bx > self.x_size or y_off + by > self.y_size or bx <= 0 or by <= 0:
+            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        if mon_ksize is None or ref_ksize is None:
+            mon_ksize, ref_ksize = KLT._resolve_ksize(conf.laplacian_kernel_size)
+        prm = make_params(conf, mon_ksize, ref_ksize, invert_mon)
+        cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
+        if out_ptrs is not None:
+            d0, d1, d2, dn, ocap = out_ptrs
+            if ocap < cap:
+                raise KariosHipError("track_tile: output capacity below maxCorners")
+        else:
+            d0, d1, d2, dn = self._outputs(cap)
+        es = self.dtype.itemsize
+        off = (y_off * self.x_size + x_off)
+        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
+        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
+        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        c.check(c.lib.km_klt_tile_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
+                                      by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), C.c_void_p(d0), C.c_void_p(d1),
+                                      C.c_void_p(d2), cap, C.c_void_p(dn)), "km_klt_tile_dev")
+        st = c.stats()  # valid_pixels is known on the host as soon as the call returns
+        if st.valid_pixels == 0:
+            return "no_valid_pixels", None
+        nbuf = np.empty(1, np.int32)
+        c.check(c.lib.km_d2h(c.handle, nbuf.ctypes.data_as(C.c_void_p), C.c_void_p(dn), 4), "km_d2h")
+        n = int(nbuf[0])
+        if n == 0:
+            return "no_features", None
+        if out_ptrs is not None:
+            return "ok", n
+        pts = np.empty((3, n, 2), np.float32)
+        for i, d in enumerate((d0, d1, d2)):
+            c.check(c.lib.km_d2h(c.handle, pts[i].ctypes.data_as(C.c_void_p), C.c_void_p(d), n * 8), "km_d2h")
+        return "ok", tuple(p.reshape(-1, 1, 2) for p in pts)
+
+    def match_tile(self, conf, box=None) -> DataFrame | None:
+        """One tile of `KLT.match` (reference klt.py:236-349) on resident data; fixed kernel size and
+        polarity (the 'auto' modes go through `karios_amd.matcher.KLT`)."""
+        if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto":
+            raise KariosHipError("ResidentPair.match_tile: 'auto' modes are handled by karios_amd.matcher.KLT")
+        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
+        status, tracks = self.track_tile(conf, box, invert_mon=bool(conf.laplacian_invert_polarity))
+        if status != "ok":
+            return None
+        points, _ = _frame_from_tracks(*tracks, conf)
+        points["x0"] = points["x0"] + x_off
+        points["y0"] = points["y0"] + y_off
+        points.sort_values(by=["x0", "y0"], inplace=True)
+        return points
+
+    def match(self, conf):
+        """All tiles in the reference order (x outer, y inner; klt.py:220-232)."""
+        for box in KLT(conf).tile_boxes(self.x_size, self.y_size):
+            frame = self.match_tile(conf, box)
+            if frame is not None:
+                yield frame
+
+    # ------------------------------------------------------------------ ZNCC
+    def zncc(self, x0, y0, dx, dy) -> np.ndarray:
+        """ZNCCService.compute_zncc values (zncc_service.py:186-238) for key points of the full image."""
+        c = self.ctx
+        cols = [np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy)]
+        n = len(cols[0])
+        out = np.empty(n, np.float64)
+        if n == 0:
+            return out
+        need = n * (4 * 4 + 8)
+        if self._zbuf is None or self._zbuf.nbytes < need:
+            self._zbuf = DeviceBuffer(c, need + need // 4)
+        base = self._zbuf.ptr
+        kp = np.concatenate(cols)
+        c.check(c.lib.km_h2d(c.handle, C.c_void_p(base + n * 8), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
+        f = base + n * 8
+        c.check(c.lib.km_zncc_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
+                                        self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
+                                        C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base)), "km_zncc_batch_dev")
+        c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), n * 8), "km_d2h")
+        return out
+
+    def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4) -> DataFrame:
+        """`_handle_klt_results` numeric columns (core.py:872-893): radial error, angle and the ZNCC of
+        the rows with score >= confidence_threshold (NaN elsewhere)."""
+        frame["radial error"] = np.sqrt(frame["dx"] ** 2 + frame["dy"] ** 2)
+        frame["angle"] = np.degrees(np.arctan2(frame["dy"], frame["dx"]))
+        cand = frame[frame["score"] >= confidence_threshold]
+        frame["zncc_score"] = np.nan
+        if len(cand):
+            z = self.zncc(cand["x0"].to_numpy(), cand["y0"].to_numpy(), cand["dx"].to_numpy(), cand["dy"].to_numpy())
+            frame.loc[cand.index, "zncc_score"] = z
+        return frame
+
+    # ------------------------------------------------------------------ large offset
+    def phase_offset(self) -> np.ndarray:
+        """LargeOffsetMatcher.match() on resident data (large_offset.py:39): [row, col]."""
+        c = self.ctx
+        out = (C.c_double * 2)()
+        c.check(c.lib.km_phase_shift_dev(c.handle, C.c_void_p(self.mon_ptr), C.c_void_p(self.ref_ptr), self.code, self.y_size, self.x_size,
+                                         self.x_size, self.x_size, out), "km_phase_shift_dev")
+        return np.array([out[0], out[1]], np.float64)
+
+    def shifted_monitored(self, y_off: int, x_off: int) -> "ResidentPair":
+        """shift_image(mon, y_off, x_off) on the device (image.py:70-101); returns a new pair sharing ref."""
+        c = self.ctx
+        buf = DeviceBuffer(c, self.y_size * self.x_size * self.dtype.itemsize)
+        c.check(c.lib.km_shift_image_dev(c.handle, C.c_void_p(self.mon_ptr), self.dtype.itemsize, self.y_size, self.x_size, self.x_size,
+                                         int(y_off), int(x_off), C.c_void_p(buf.ptr)), "km_shift_image_dev")
+        return ResidentPair(c, buf.ptr, self.ref_ptr, self.dtype, self.y_size, self.x_size, self.mask_ptr, self.no_data_mon,
+                            self.no_data_ref, owned=[buf, self])
+
+
+__all__ = ["ResidentPair", "DeviceBuffer", "_lib"]

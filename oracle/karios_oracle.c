@@ -31,12 +31,31 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define KO_U8 0
 #define KO_U16 1
 #define KO_I16 2
 #define KO_F32 3
 #define KO_F64 4
+
+/* thread control for the cpu_baseline leg of bench.py */
+int ko_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void ko_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
 
 /* OpenCV borderInterpolate(p, len, BORDER_REFLECT_101) */
 static inline int reflect101(int p, int len)

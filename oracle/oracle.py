@@ -47,6 +47,14 @@ def lib():
     return _lib
 
 
+def max_threads() -> int:
+    return int(lib().ko_max_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().ko_set_threads(int(n))
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
