@@ -241,6 +241,36 @@ int kd_count_nonzero(km_ctx *c, const uint8_t *d_mask, size_t n, unsigned long l
     return KM_OK;
 }
 
+// final reductions of per-workgroup partials (one workgroup; the partial arrays are tens of KB)
+__global__ __launch_bounds__(1024) void sum_u32_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned long long *out)
+{
+    unsigned long long s = 0;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) s += partial[i];
+    s = wave_sum_u64(s);
+    __shared__ unsigned long long sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; i++) t += sh[i];
+        *out = t;
+    }
+}
+__global__ __launch_bounds__(1024) void max_u32_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned *out)
+{
+    unsigned m = 0;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) m = max(m, partial[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int i = 0; i < 16; i++) t = max(t, sh[i]);
+        *out = t;
+    }
+}
+
 // ------------------------------------------------------------------ K2 stretch + Laplacian (+mask)
 // Output tile 64x32 per 256-thread workgroup.  The Laplacian of odd ksize k is written as
 //   sum_j ks[j] * (kd *x u8)[y+j] + kd[j] * (ks *x u8)[y+j]
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
                                                   ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
                                                   lap_coef cf, int invert1, nodata_t nd, uint8_t *__restrict__ out0,
                                                   uint8_t *__restrict__ out1, uint8_t *__restrict__ mask_out,
-                                                  unsigned long long *valid)
+                                                  unsigned *__restrict__ valid_partial)
 {
     constexpr int HX = (R + 3) & ~3;          // x halo rounded to 4 for packed LDS words
     constexpr int TWH = LAP_TW + 2 * HX;      // LDS tile row length (bytes)
@@ -332,10 +362,15 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
         }
     }
     if constexpr (MASK) {
-        unsigned long long c64 = wave_sum_u64((unsigned long long)cnt);
-        if ((tid & 63) == 0 && c64) atomicAdd(valid, c64);
+        // one partial per workgroup (a single-address atomic per wave would serialise ~10^5 updates)
+        __shared__ unsigned s_cnt[4];
+        const unsigned c64 = (unsigned)wave_sum_u64((unsigned long long)cnt);
+        if ((tid & 63) == 0) s_cnt[tid >> 6] = c64;
+        __syncthreads();
+        if (tid == 0) valid_partial[blockIdx.y * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    } else {
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- phase 2: horizontal passes (kd and ks) for 4 consecutive outputs per item
     constexpr int NW = (2 * R + 4 + (HX - R) + 3) / 4;  // words covering [x+HX-R, x+HX+R+4)
@@ -430,9 +465,14 @@ static bool fill_coef(int ksize, int R, int *kd, int *ks)
 template <typename T, int NIMG, bool MASK>
 static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
                       const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
-                      unsigned long long *valid)
+                      unsigned long long *valid_out)
 {
     dim3 grid((W + LAP_TW - 1) / LAP_TW, (H + LAP_TH - 1) / LAP_TH);
+    unsigned *valid = nullptr;
+    if (MASK) {
+        valid = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)grid.x * grid.y * sizeof(unsigned));
+        if (!valid) return KM_E_NOMEM;
+    }
 #define KM_LAP_CASE(RR)                                                                                         \
     case RR:                                                                                                    \
         lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, \
@@ -448,6 +488,10 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
     }
 #undef KM_LAP_CASE
     KM_LAUNCH_CHECK(c);
+    if (MASK) {
+        sum_u32_kernel<<<1, 1024, 0, c->stream>>>(valid, grid.x * grid.y, valid_out);
+        KM_LAUNCH_CHECK(c);
+    }
     return KM_OK;
 }
 
@@ -476,7 +520,6 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
     nodata_t nd = make_nodata(nodata_mon, nodata_ref);
-    if (d_mask_out) KM_HIP(c, hipMemsetAsync(d_valid, 0, sizeof(unsigned long long), c->stream));
 #define KM_PAIR(T)                                                                                                          \
     (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                          d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                        \
@@ -520,7 +563,7 @@ __host__ __device__ __forceinline__ float eig_unkey(unsigned k)
 
 __global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H,
                                                   int W, int block, double scale2, float *__restrict__ eig,
-                                                  unsigned int *max_key)
+                                                  unsigned int *__restrict__ max_partial)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = block / 2, Rr = block - 1 - L;
@@ -614,7 +657,10 @@ __global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ sr
     }
     unsigned key = have ? eig_key(best) : 0u;
     for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
-    if ((tid & 63) == 0 && key) atomicMax(max_key, key);
+    __shared__ unsigned s_key[4];
+    if ((tid & 63) == 0) s_key[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) max_partial[blockIdx.y * gridDim.x + blockIdx.x] = max(max(s_key[0], s_key[1]), max(s_key[2], s_key[3]));
 }
 
 int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig,
@@ -624,16 +670,19 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
     const int L = block / 2, Rr = block - 1 - L;
     const int PW = EIG_TW + L + Rr, PH = EIG_TH + L + Rr, LW = (PW + 2 + 3) & ~3, LH = PH + 2;
     const size_t sm = (((size_t)LH * LW + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * EIG_TW * 4;
-    if (sm > 160 * 1024) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d needs %zu B LDS", block, sm);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    if (sm > 160 * 1024 - 256) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d needs %zu B LDS", block, sm);
+    static size_t attr_bytes = 0;  // dynamic-LDS opt-in, raised on demand (kernel also holds a few static words)
+    if (sm > 48 * 1024 && sm > attr_bytes) {
+        KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        attr_bytes = sm;
     }
-    KM_HIP(c, hipMemsetAsync(d_max_key, 0, sizeof(unsigned int), c->stream));
     const double scale = 1.0 / (4.0 * (double)block * 255.0);
     dim3 grid((W + EIG_TW - 1) / EIG_TW, (H + EIG_TH - 1) / EIG_TH);
-    eig_kernel<<<grid, 256, sm, c->stream>>>(d_src, d_mask, H, W, block, scale * scale, d_eig, d_max_key);
+    unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)grid.x * grid.y * sizeof(unsigned));
+    if (!partial) return KM_E_NOMEM;
+    eig_kernel<<<grid, 256, sm, c->stream>>>(d_src, d_mask, H, W, block, scale * scale, d_eig, partial);
+    KM_LAUNCH_CHECK(c);
+    max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, grid.x * grid.y, d_max_key);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -643,33 +692,61 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
 // pixel is a candidate iff it is non-zero, equals the 3x3 max of the thresholded map, lies off
 // the 1-px border and passes the mask.  Key = (f32 bits << 32) | raster index, so a single
 // descending u64 sort reproduces greaterThanPtr (value desc, address desc).
+#define CAND_T 64
 __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig, const uint8_t *__restrict__ mask, int H, int W,
                                                    double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
                                                    size_t cap)
 {
+    __shared__ float tile[CAND_T + 2][CAND_T + 2];
+    __shared__ unsigned long long stage[CAND_T * CAND_T];
+    __shared__ unsigned s_n, s_base;
     const unsigned mk = sc->max_eig_key;
     const float maxv = mk ? eig_unkey(mk) : 0.f;
     const float thr = (float)__dmul_rn((double)maxv, quality);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sc->thr = thr; sc->max_eig = maxv; }
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
-    if (x >= W - 1 || y >= H - 1) return;
-    const size_t i = (size_t)y * W + x;
-    const float v = eig[i];
-    if (!(v > thr) || v == 0.f) return;
-    if (mask && !mask[i]) return;
-    float m = -INFINITY;  // 3x3 dilate of the thresholded map, centre excluded
-#pragma unroll
-    for (int j = -1; j <= 1; j++)
-#pragma unroll
-        for (int k = -1; k <= 1; k++) {
-            if (j == 0 && k == 0) continue;
-            const float e = eig[i + (ptrdiff_t)j * W + k];
-            m = fmaxf(m, e > thr ? e : 0.f);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { sc->thr = thr; sc->max_eig = maxv; }
+    if (tid == 0) s_n = 0;
+    // tile covers candidate pixels x in [X0, X0+64), y in [Y0, Y0+64) with X0,Y0 >= 1 (1-px border excluded)
+    const int X0 = blockIdx.x * CAND_T + 1, Y0 = blockIdx.y * CAND_T + 1;
+    for (int i = tid; i < (CAND_T + 2) * (CAND_T + 2); i += 256) {
+        const int r = i / (CAND_T + 2), cx = i - r * (CAND_T + 2);
+        const int gy = Y0 - 1 + r, gx = X0 - 1 + cx;
+        float e = 0.f;
+        if (gy < H && gx < W) { e = eig[(size_t)gy * W + gx]; e = e > thr ? e : 0.f; }  // THRESH_TOZERO
+        tile[r][cx] = e;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    for (int it = 0; it < CAND_T * CAND_T / 256; it++) {
+        const int p = it * 256 + tid;
+        const int r = p / CAND_T, cx = p - r * CAND_T;
+        const int gy = Y0 + r, gx = X0 + cx;
+        bool is = false;
+        float v = 0.f;
+        if (gy < H - 1 && gx < W - 1) {
+            v = tile[r + 1][cx + 1];
+            if (v != 0.f) {
+                float m = fmaxf(fmaxf(tile[r][cx], tile[r][cx + 1]), tile[r][cx + 2]);
+                m = fmaxf(m, fmaxf(tile[r + 1][cx], tile[r + 1][cx + 2]));
+                m = fmaxf(m, fmaxf(fmaxf(tile[r + 2][cx], tile[r + 2][cx + 1]), tile[r + 2][cx + 2]));
+                is = v >= m && (!mask || mask[(size_t)gy * W + gx]);
+            }
         }
-    if (v < m) return;
-    const unsigned pos = atomicAdd(&sc->n_cand, 1u);
-    if (pos < cap) keys[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(unsigned)i;
+        const unsigned long long bal = __ballot(is);
+        unsigned wbase = 0;
+        if (lane == 0 && bal) wbase = atomicAdd(&s_n, (unsigned)__popcll(bal));
+        wbase = __shfl(wbase, 0);
+        if (is) stage[wbase + __popcll(bal & ((1ull << lane) - 1ull))] =
+            ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)((unsigned)gy * (unsigned)W + (unsigned)gx);
+    }
+    __syncthreads();
+    const unsigned n = s_n;
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(&sc->n_cand, n);
+    __syncthreads();
+    const unsigned base = s_base;
+    for (unsigned i = tid; i < n; i += 256)
+        if ((size_t)base + i < cap) keys[(size_t)base + i] = stage[i];
 }
 
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W, double quality, km_scalars *d_sc,
@@ -679,7 +756,7 @@ int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, i
     if (H < 3 || W < 3) {
         return KM_OK;
     }
-    dim3 grid((W - 2 + 63) / 64, (H - 2 + 3) / 4);
+    dim3 grid((W - 2 + CAND_T - 1) / CAND_T, (H - 2 + CAND_T - 1) / CAND_T);
     cand_kernel<<<grid, 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap);
     KM_LAUNCH_CHECK(c);
     return KM_OK;

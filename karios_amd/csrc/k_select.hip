@@ -5,22 +5,23 @@
 // = OpenCV's greaterThanPtr order (value desc, address desc).
 //
 // Selection: OpenCV walks the ranked list sequentially and accepts a candidate iff no
-// already-accepted corner lies closer than minDistance.  The accepted set only depends on
-// higher-ranked accepted corners, so it is reproduced exactly by one persistent 1024-thread
-// workgroup that consumes the ranked list in batches:
-//   phase 1  every lane tests its candidate against the accepted-corner cell grid (global),
-//   phase 2  survivors of the batch are resolved against each other in LDS by rank-ordered
-//            fixed-point rounds (accept when no higher-ranked survivor within range is
-//            undecided or accepted; reject when one is accepted),
-//   phase 3  accepted corners are appended in rank order and inserted in the grid.
-// It stops as soon as maxCorners corners are out, which on dense imagery is after a few
-// percent of the candidate list.
+// already-accepted corner lies closer than minDistance, stopping at maxCorners.  A candidate's
+// fate depends only on HIGHER-ranked candidates within minDistance, so
+//   (1) the decisions on any ranked prefix [0,K) equal the sequential ones, and
+//   (2) inside the prefix they are the unique fixed point of
+//         accept  <=> every higher-ranked neighbour (< minDistance) is rejected
+//         reject  <=> some higher-ranked neighbour is accepted
+//       which is reached by data-parallel sweeps over a cell grid (cell = cvRound(minDistance),
+//       3x3 cells searched, exactly the buckets OpenCV uses).
+// The first maxCorners accepted candidates in rank order (one scan) are the result; if the prefix
+// yields fewer, it is enlarged 4x and the sweeps continue from the states already decided.
 #include <cstring>
 #include <string.h>
 
 #include "common.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted)
 {
@@ -35,120 +36,107 @@ int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned 
     return KM_OK;
 }
 
-#define SEL_T 1024
-#define SEL_SLOTS 4
-
 enum { ST_UNDECIDED = 0, ST_ACCEPT = 1, ST_REJECT = 2 };
 
-__global__ __launch_bounds__(SEL_T) void select_kernel(const unsigned long long *__restrict__ keys, unsigned n, int W, int cell,
-                                                       int gw, int gh, double md2, unsigned *grid_cnt, unsigned *grid_pts,
-                                                       int max_corners, int cap, float *__restrict__ out_xy, km_scalars *sc)
+__device__ __forceinline__ void key_xy(unsigned long long key, int W, int &x, int &y)
 {
-    __shared__ short s_x[SEL_T], s_y[SEL_T];
-    __shared__ unsigned char s_state[SEL_T];
-    __shared__ int s_wave_cnt[SEL_T / 64];
-    __shared__ int s_nacc, s_changed;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_nacc = 0;
-    __syncthreads();
-    int batches = 0;
-    for (unsigned base = 0; base < n; base += SEL_T) {
-        const int nacc0 = s_nacc;
-        if (max_corners > 0 && nacc0 >= max_corners) break;
-        batches++;
-        // ---- phase 1: test against the accepted grid
-        const unsigned i = base + tid;
-        bool alive = i < n;
-        int x = 0, y = 0;
-        if (alive) {
-            const unsigned idx = (unsigned)(keys[i] & 0xffffffffull);
-            y = (int)(idx / (unsigned)W);
-            x = (int)(idx - (unsigned)y * (unsigned)W);
-            const int xc = x / cell, yc = y / cell;
-            const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
-            for (int yy = y1; yy <= y2 && alive; yy++)
-                for (int xx = x1; xx <= x2 && alive; xx++) {
+    const unsigned idx = (unsigned)(key & 0xffffffffull);
+    y = (int)(idx / (unsigned)W);
+    x = (int)(idx - (unsigned)y * (unsigned)W);
+}
+
+// count prefix candidates [k0, k1) per cell
+__global__ __launch_bounds__(256) void sel_count_kernel(const unsigned long long *__restrict__ keys, unsigned k0, unsigned k1, int W,
+                                                        int cell, int gw, unsigned *__restrict__ cell_cnt)
+{
+    const unsigned i = k0 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= k1) return;
+    int x, y;
+    key_xy(keys[i], W, x, y);
+    atomicAdd(&cell_cnt[(y / cell) * gw + (x / cell)], 1u);
+}
+
+// scatter candidate ranks [0, k1) into their cell's slice (order inside a cell is irrelevant)
+__global__ __launch_bounds__(256) void sel_fill_kernel(const unsigned long long *__restrict__ keys, unsigned k1, int W, int cell, int gw,
+                                                       const unsigned *__restrict__ cell_off, unsigned *__restrict__ cell_fill,
+                                                       unsigned *__restrict__ items)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k1) return;
+    int x, y;
+    key_xy(keys[i], W, x, y);
+    const int g = (y / cell) * gw + (x / cell);
+    items[cell_off[g] + atomicAdd(&cell_fill[g], 1u)] = i;
+}
+
+// one launch = up to SWEEPS relaxation sweeps over the prefix; states only move UNDECIDED -> final and
+// every final state is the sequential algorithm's decision, so concurrent in-place updates are safe.
+#define SEL_SWEEPS 4
+__global__ __launch_bounds__(256) void sel_sweep_kernel(const unsigned long long *__restrict__ keys, unsigned k1, int W, int cell, int gw,
+                                                        int gh, double md2, const unsigned *__restrict__ cell_off,
+                                                        const unsigned *__restrict__ cell_cnt, const unsigned *__restrict__ items,
+                                                        unsigned *state, unsigned *n_undecided)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    bool undecided = false;
+    if (i < k1 && __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ST_UNDECIDED) {
+        int x, y;
+        key_xy(keys[i], W, x, y);
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+        undecided = true;
+        for (int sweep = 0; sweep < SEL_SWEEPS && undecided; sweep++) {
+            bool blocked = false, rejected = false;
+            for (int yy = y1; yy <= y2 && !rejected; yy++)
+                for (int xx = x1; xx <= x2 && !rejected; xx++) {
                     const int g = yy * gw + xx;
-                    const unsigned cnt = __hip_atomic_load(&grid_cnt[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (unsigned k = 0; k < min(cnt, (unsigned)SEL_SLOTS); k++) {
-                        const unsigned p = __hip_atomic_load(&grid_pts[g * SEL_SLOTS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const float dx = (float)x - (float)(p & 0xffffu), dy = (float)y - (float)(p >> 16);
-                        if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+                    const unsigned o = cell_off[g], cnt = cell_cnt[g];
+                    for (unsigned k = 0; k < cnt; k++) {
+                        const unsigned j = items[o + k];
+                        if (j >= i) continue;  // only higher-ranked candidates matter
+                        int xj, yj;
+                        key_xy(keys[j], W, xj, yj);
+                        const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
+                        if (!((double)(dx * dx + dy * dy) < md2)) continue;
+                        const unsigned sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sj == ST_ACCEPT) { rejected = true; break; }
+                        if (sj == ST_UNDECIDED) blocked = true;
                     }
                 }
-        }
-        // compact survivors in rank order
-        const unsigned long long bal = __ballot(alive);
-        if (lane == 0) s_wave_cnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = 0, tot = 0;
-        for (int k = 0; k < SEL_T / 64; k++) { const int cnt = s_wave_cnt[k]; if (k < wv) off += cnt; tot += cnt; }
-        if (alive) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            s_x[pos] = (short)x; s_y[pos] = (short)y; s_state[pos] = ST_UNDECIDED;
-        }
-        __syncthreads();
-        const int ns = tot;
-        // ---- phase 2: rank-ordered fixed point among the survivors
-        if (ns > 0) {
-            const bool mine = tid < ns;
-            const int mx = mine ? s_x[tid] : 0, my = mine ? s_y[tid] : 0;
-            int st = mine ? ST_UNDECIDED : ST_REJECT;
-            for (;;) {
-                int nst = st;
-                if (st == ST_UNDECIDED) {
-                    bool blocked = false, rejected = false;
-                    for (int t = 0; t < tid; t++) {
-                        const int o = s_state[t];
-                        if (o == ST_REJECT) continue;
-                        const float dx = (float)(mx - s_x[t]), dy = (float)(my - s_y[t]);
-                        if ((double)(dx * dx + dy * dy) < md2) {
-                            if (o == ST_ACCEPT) { rejected = true; break; }
-                            blocked = true;
-                        }
-                    }
-                    nst = rejected ? ST_REJECT : blocked ? ST_UNDECIDED : ST_ACCEPT;
-                }
-                __syncthreads();  // all reads of s_state for this round done
-                if (tid == 0) s_changed = 0;
-                __syncthreads();
-                if (nst != st) { s_state[tid] = (unsigned char)nst; st = nst; s_changed = 1; }
-                __syncthreads();
-                if (!s_changed) break;
-            }
-            // ---- phase 3: append accepted in rank order, insert in the grid
-            const bool acc = mine && st == ST_ACCEPT;
-            const unsigned long long ab = __ballot(acc);
-            if (lane == 0) s_wave_cnt[wv] = __popcll(ab);
-            __syncthreads();
-            int aoff = 0, atot = 0;
-            for (int k = 0; k < SEL_T / 64; k++) { const int cnt = s_wave_cnt[k]; if (k < wv) aoff += cnt; atot += cnt; }
-            if (acc) {
-                const int pos = nacc0 + aoff + __popcll(ab & ((1ull << lane) - 1ull));
-                if ((max_corners <= 0 || pos < max_corners) && pos < cap) {
-                    out_xy[2 * pos] = (float)mx;
-                    out_xy[2 * pos + 1] = (float)my;
-                }
-                // accepted corners in one cell are >= minDistance apart and the cell side is
-                // <= minDistance + 0.5, so a cell never holds more than SEL_SLOTS of them
-                const int g = (my / cell) * gw + (mx / cell);
-                const unsigned slot = atomicAdd(&grid_cnt[g], 1u);
-                if (slot < SEL_SLOTS)
-                    __hip_atomic_store(&grid_pts[g * SEL_SLOTS + slot], (unsigned)mx | ((unsigned)my << 16), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    sc->n_cand = 0xffffffffu;  // cannot happen (see above); poison so the host notices
-            }
-            if (tid == 0) s_nacc = nacc0 + atot;
-            __threadfence();  // grid stores visible before the next batch's loads
-            __syncthreads();
+            if (rejected) { __hip_atomic_store(&state[i], (unsigned)ST_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+            else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)ST_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
         }
     }
-    if (tid == 0) {
-        int na = s_nacc;
-        if (max_corners > 0 && na > max_corners) na = max_corners;
-        sc->n_corners = na;
-        sc->n_batches = batches;
+    const unsigned long long bal = __ballot(undecided);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_undecided, (unsigned)__popcll(bal));
+}
+
+__global__ __launch_bounds__(256) void sel_flag_kernel(const unsigned *__restrict__ state, unsigned k1, unsigned *__restrict__ flag)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < k1) flag[i] = state[i] == ST_ACCEPT ? 1u : 0u;
+}
+
+// pos = exclusive scan of the accept flags = index in OpenCV's output order
+__global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
+                                                       const unsigned *__restrict__ pos, unsigned k1, int W, int max_corners, int cap,
+                                                       float *__restrict__ out_xy, km_scalars *sc, int rounds)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k1) return;
+    const bool acc = state[i] == ST_ACCEPT;
+    const unsigned p = pos[i];
+    if (acc && (max_corners <= 0 || p < (unsigned)max_corners) && p < (unsigned)cap) {
+        int x, y;
+        key_xy(keys[i], W, x, y);
+        out_xy[2 * p] = (float)x;
+        out_xy[2 * p + 1] = (float)y;
+    }
+    if (i == k1 - 1) {
+        int total = (int)(p + (acc ? 1u : 0u));
+        if (max_corners > 0 && total > max_corners) total = max_corners;
+        sc->n_corners = total;
+        sc->n_batches = rounds;
     }
 }
 
@@ -169,8 +157,7 @@ __global__ __launch_bounds__(256) void take_first_kernel(const unsigned long lon
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W, int max_corners, double min_distance,
               float *d_xy, int cap, km_scalars *d_sc)
 {
-    if (n > 0xffffffffull) return km_fail(c, KM_E_UNSUPPORTED, "too many candidates");
-    if (W > 65535 || H > 65535) return km_fail(c, KM_E_UNSUPPORTED, "tile larger than 65535 px per side");
+    if (n > 0xfffffff0ull) return km_fail(c, KM_E_UNSUPPORTED, "too many candidates");
     if (n == 0) {
         KM_HIP(c, hipMemsetAsync(&d_sc->n_corners, 0, 2 * sizeof(int), c->stream));
         return KM_OK;
@@ -183,13 +170,62 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
     const int cell = (int)lrint(min_distance);
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
     const size_t cells = (size_t)gw * gh;
-    // layout: [cells] counts | [cells*SLOTS] packed points (x | y<<16)
-    unsigned *grid = (unsigned *)km_ws(c, WS_GRID, cells * (SEL_SLOTS + 1) * sizeof(unsigned));
-    if (!grid) return KM_E_NOMEM;
-    KM_HIP(c, hipMemsetAsync(grid, 0, cells * sizeof(unsigned), c->stream));
-    unsigned *grid_cnt = grid, *grid_pts = grid + cells;
-    select_kernel<<<1, SEL_T, 0, c->stream>>>(d_sorted, (unsigned)n, W, cell, gw, gh, min_distance * min_distance, grid_cnt, grid_pts,
-                                              max_corners, cap, d_xy, d_sc);
-    KM_LAUNCH_CHECK(c);
+    const double md2 = min_distance * min_distance;
+    const unsigned N = (unsigned)n;
+    // workspace: [cells+1] counts | [cells+1] offsets | [cells] fill cursors ; items / state / flag / pos per candidate
+    unsigned *grid = (unsigned *)km_ws(c, WS_GRID, (3 * cells + 2) * sizeof(unsigned));
+    unsigned *per = (unsigned *)km_ws(c, WS_MISC2, (size_t)N * 4 * sizeof(unsigned));
+    if (!grid || !per) return KM_E_NOMEM;
+    unsigned *cell_cnt = grid, *cell_off = grid + cells + 1, *cell_fill = grid + 2 * cells + 2;
+    unsigned *items = per, *state = per + N, *flag = per + 2 * (size_t)N, *pos = per + 3 * (size_t)N;
+    size_t scan_bytes_cells = 0, scan_bytes_k = 0;
+    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_cells, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
+    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_k, flag, pos, 0u, (size_t)N, rocprim::plus<unsigned>(), c->stream));
+    const size_t tmp_bytes = (scan_bytes_cells > scan_bytes_k ? scan_bytes_cells : scan_bytes_k) + 256;
+    void *tmp = km_ws(c, WS_SORT_TMP, tmp_bytes);
+    if (!tmp) return KM_E_NOMEM;
+    unsigned *d_und = (unsigned *)&d_sc->argmax_key;  // scratch word of the scalar block
+
+    KM_HIP(c, hipMemsetAsync(cell_cnt, 0, (cells + 1) * sizeof(unsigned), c->stream));
+    KM_HIP(c, hipMemsetAsync(state, 0, (size_t)N * sizeof(unsigned), c->stream));
+    unsigned k0 = 0, k1 = (max_corners > 0) ? (unsigned)((size_t)max_corners * 8 < n ? (size_t)max_corners * 8 : n) : N;
+    int rounds = 0;
+    for (;;) {
+        // (re)build the cell lists for the prefix [0, k1): counts only need the new part [k0, k1)
+        sel_count_kernel<<<(k1 - k0 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k0, k1, W, cell, gw, cell_cnt);
+        KM_LAUNCH_CHECK(c);
+        size_t sb = scan_bytes_cells;
+        KM_HIP(c, rocprim::exclusive_scan(tmp, sb, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
+        KM_HIP(c, hipMemsetAsync(cell_fill, 0, cells * sizeof(unsigned), c->stream));
+        sel_fill_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k1, W, cell, gw, cell_off, cell_fill, items);
+        KM_LAUNCH_CHECK(c);
+        for (;;) {
+            unsigned und = 0;
+            for (int g = 0; g < 4; g++) {  // 4 launches (16 sweeps) between host checks
+                if (g == 3) KM_HIP(c, hipMemsetAsync(d_und, 0, sizeof(unsigned), c->stream));
+                sel_sweep_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k1, W, cell, gw, gh, md2, cell_off, cell_cnt, items, state,
+                                                                          d_und);
+                KM_LAUNCH_CHECK(c);
+                rounds++;
+            }
+            KM_HIP(c, hipMemcpyAsync(&und, d_und, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            KM_HIP(c, hipStreamSynchronize(c->stream));
+            if (und == 0) break;
+            if (rounds > 100000) return km_fail(c, KM_E_INTERNAL, "corner selection did not converge");
+        }
+        sel_flag_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(state, k1, flag);
+        KM_LAUNCH_CHECK(c);
+        size_t sk = scan_bytes_k;
+        KM_HIP(c, rocprim::exclusive_scan(tmp, sk, flag, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
+        sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
+        KM_LAUNCH_CHECK(c);
+        if (k1 == N) break;
+        int got = 0;
+        KM_HIP(c, hipMemcpyAsync(&got, &d_sc->n_corners, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+        if (max_corners > 0 && got >= max_corners) break;
+        k0 = k1;
+        k1 = (unsigned)((size_t)k1 * 4 < n ? (size_t)k1 * 4 : n);
+    }
     return KM_OK;
 }
