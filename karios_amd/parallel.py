@@ -85,9 +85,10 @@ def gather_frames(local: dict[int, DataFrame | None], n_units: int, cap: int, de
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t_send = torch.from_numpy(send).to(device)
-    t_recv = torch.empty((ws,) + tuple(t_send.shape), dtype=t_send.dtype, device=device)
+    # output = rank blocks concatenated along dim 0 (the layout both RCCL and gloo accept)
+    t_recv = torch.empty((ws * per_rank, send.shape[1]), dtype=t_send.dtype, device=device)
     dist.all_gather_into_tensor(t_recv, t_send)
-    recv = t_recv.cpu().numpy()
+    recv = t_recv.cpu().numpy().reshape(ws, per_rank, send.shape[1])
     frames: list[DataFrame | None] = [None] * n_units
     for r in range(ws):
         for slot in range(per_rank):

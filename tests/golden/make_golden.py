@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python
+functions (imported from /root/reference, which exists only in the build container).
+
+Run here, never on the GPU box:   python tests/golden/make_golden.py
+
+What is pinned (reference file:line)
+  to_uint8.npz      karios/matcher/klt.py:42-49      `_to_uint8` on uint16/int16/float32/uint8/constant inputs
+  shift_image.npz   karios/core/image.py:70-101      `shift_image` for a list of (y_off, x_off)
+  outliers.npz      karios/matcher/klt.py:52-71      `__filter_outliers`
+  fb_score.npz      karios/matcher/klt.py:142-170    forward-backward test / score / DataFrame assembly of `klt_tracker`
+                                                     (cv2 stub returns prescribed p0, p1, p0r)
+  zncc.npz          karios/matcher/zncc_service.py:45-126,162-238   `ZNCCService.compute_zncc` incl. rounding / bounds / NaN rules
+  klt_match_*.npz   karios/matcher/klt.py:198-349, 407-436          `KLT.match` control flow (tiling, masks, offsets, sort,
+                                                     polarity / per-image kernel sizes) with cv2's three entry points served by
+                                                     the CPU oracle -- pins the glue, not OpenCV's arithmetic
+  phase_corr.npz    scikit-image (conda python3.9, v0.18.3) `phase_cross_correlation` on pre-normalised spectra
+                    (= the 0.24 "phase" normalisation); skipped when that interpreter is absent
+
+cv2 / osgeo / skimage / rich_click are not installed here: they are replaced by stub modules before the
+reference is imported.  Only DATA (inputs + expected outputs) is written; no reference source is copied.
+"""
+import os
+import subprocess
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present: golden vectors can only be regenerated in the build container")
+    for name in ("osgeo", "osgeo.gdal", "osgeo.osr", "osgeo.ogr", "cv2", "skimage", "skimage.io", "skimage.registration",
+                 "rich_click"):
+        sys.modules.setdefault(name, mock.MagicMock())
+    sys.path.insert(0, REF)
+    import karios.core.image as rimage  # noqa: E402
+    import karios.matcher.klt as rklt  # noqa: E402
+    import karios.matcher.zncc_service as rzncc  # noqa: E402
+    return rklt, rzncc, rimage
+
+
+def oracle_cv2():
+    """cv2 stand-in whose three entry points are the CPU oracle (karios_oracle.c)."""
+    from oracle import oracle as O
+    cv2 = types.SimpleNamespace()
+    cv2.CV_8U = 0
+    cv2.TERM_CRITERIA_EPS, cv2.TERM_CRITERIA_COUNT = 2, 1
+    cv2.Laplacian = lambda img, ddepth, ksize=1: O.laplacian_u8(img, ksize)
+    cv2.goodFeaturesToTrack = lambda img, mask=None, maxCorners=0, qualityLevel=0.1, minDistance=1, blockSize=3: \
+        O.good_features(img, mask, maxCorners, qualityLevel, minDistance, blockSize)
+
+    def lk(prev, nxt, pts, _none, winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01)):
+        out = O.pyr_lk(prev, nxt, pts, winSize[0], maxLevel, criteria[1], criteria[2])
+        n = len(out)
+        return out, np.ones((n, 1), np.uint8), np.zeros((n, 1), np.float32)
+    cv2.calcOpticalFlowPyrLK = lk
+    return cv2
+
+
+class Img:
+    """GdalRasterImage duck type over an array."""
+
+    def __init__(self, a, nodata=None):
+        self.a, self.no_data_value = a, nodata
+        self.x_size, self.y_size = a.shape[1], a.shape[0]
+        self.array = a
+
+    def read(self, band, xo, yo, xs, ys):
+        return self.a[yo:yo + ys, xo:xo + xs]
+
+    def clear_cache(self):
+        pass
+
+
+def main():
+    from karios_amd import synth
+    rklt, rzncc, rimage = import_reference()
+    rng = np.random.default_rng(20261002)
+
+    # ---- _to_uint8
+    ins = {
+        "u16": rng.integers(1, 16000, (37, 53)).astype(np.uint16),
+        "u16_wide": rng.integers(0, 65536, (40, 40)).astype(np.uint16),
+        "i16": rng.integers(-3000, 9000, (29, 31)).astype(np.int16),
+        "f32": (rng.standard_normal((33, 47)) * 1000).astype(np.float32),
+        "u8": rng.integers(0, 256, (16, 16)).astype(np.uint8),
+        "const": np.full((9, 11), 777, np.uint16),
+    }
+    ins["f32_nan"] = ins["f32"].copy()
+    ins["f32_nan"][2, 3] = np.nan
+    out = {}
+    for k, v in ins.items():
+        out["in_" + k] = v
+        with np.errstate(invalid="ignore"):
+            out["out_" + k] = rklt._to_uint8(v)
+    np.savez_compressed(os.path.join(HERE, "to_uint8.npz"), **out)
+
+    # ---- shift_image
+    img = rng.integers(0, 60000, (23, 31)).astype(np.uint16)
+    offs = [(0, 0), (3, 0), (0, -4), (-5, 7), (2.6, -1.4), (30, 1), (1, -40), (-22, 30), (0.5, 1.5)]
+    d = {"img": img, "offsets": np.array(offs, np.float64)}
+    for i, (yo, xo) in enumerate(offs):
+        d[f"out_{i}"] = rimage.shift_image(img, y_off=yo, x_off=xo)
+    np.savez_compressed(os.path.join(HERE, "shift_image.npz"), **d)
+
+    # ---- __filter_outliers
+    fo = rklt.__dict__["__filter_outliers"]
+    n = 400
+    x0 = rng.integers(0, 500, n).astype(np.float32)
+    y0 = rng.integers(0, 500, n).astype(np.float32)
+    x1 = x0 + (0.5 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    y1 = y0 + (-0.2 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    x1[:12] += 25
+    y1[20:30] -= 3
+    score = rng.random(n).astype(np.float32)
+    r = fo(x0, y0, x1, y1, score)
+    np.savez_compressed(os.path.join(HERE, "outliers.npz"), x0=x0, y0=y0, x1=x1, y1=y1, score=score,
+                        **{f"out_{i}": v for i, v in enumerate(r)})
+
+    # ---- forward-backward arithmetic of klt_tracker with prescribed LK outputs
+    n = 300
+    p0 = np.stack([rng.integers(1, 400, n), rng.integers(1, 300, n)], -1).astype(np.float32).reshape(n, 1, 2)
+    p1 = p0 + (rng.standard_normal((n, 1, 2)) * 0.7).astype(np.float32)
+    p0r = p0 + (rng.standard_normal((n, 1, 2)) * 0.06).astype(np.float32)
+    p0r[:5] = p0[:5]                                   # d == 0 -> score 1
+    p0r[5, 0, 0] = p0[5, 0, 0] + np.float32(0.1)       # d == float32(0.1): not < threshold
+    calls = iter([(p1, None, np.zeros((n, 1), np.float32)), (p0r, None, np.zeros((n, 1), np.float32))])
+    cv2 = types.SimpleNamespace(TERM_CRITERIA_EPS=2, TERM_CRITERIA_COUNT=1, calcOpticalFlowPyrLK=lambda *a, **k: next(calls))
+    conf = types.SimpleNamespace(maxCorners=1, qualityLevel=0.1, minDistance=1, blocksize=3, matching_winsize=25,
+                                 outliers_filtering=False)
+    with mock.patch.object(rklt, "cv2", cv2):
+        frame, ninit = rklt.klt_tracker(None, None, None, conf, p0=p0)
+    np.savez_compressed(os.path.join(HERE, "fb_score.npz"), p0=p0, p1=p1, p0r=p0r, ninit=ninit,
+                        **{c: frame[c].to_numpy() for c in frame.columns})
+
+    # ---- ZNCCService.compute_zncc
+    import pandas as pd
+    mon, ref = synth.make_pair(160, 200, 1.5, -2.5)
+    n = 260
+    df = pd.DataFrame({
+        "x0": rng.integers(-3, 203, n).astype(np.float32), "y0": rng.integers(-3, 163, n).astype(np.float32),
+        "dx": (rng.standard_normal(n) * 3).astype(np.float32), "dy": (rng.standard_normal(n) * 3).astype(np.float32)})
+    df.loc[:19, "dx"] = np.array([0.5, 1.5, 2.5, -0.5, -1.5] * 4, np.float32)
+    df.loc[:19, "x0"] = 100.0
+    df.loc[:19, "y0"] = 80.0
+    flat = ref.copy()
+    flat[30:100, 40:120] = 5000                        # zero-variance reference patches
+    svc = rzncc.ZNCCService()
+    z = svc.compute_zncc(df, Img(mon), Img(ref)).to_numpy()
+    zf = svc.compute_zncc(df, Img(mon), Img(flat)).to_numpy()
+    kat = rzncc._zncc2(np.full((57, 57), 100.0), np.full((57, 57), 100.0), 28, 28, 28, 28, 21)
+    np.savez_compressed(os.path.join(HERE, "zncc.npz"), mon=mon, ref=ref, ref_flat=flat, zncc=z, zncc_flat=zf,
+                        uniform_is_nan=np.array(np.isnan(kat)), **{c: df[c].to_numpy() for c in df.columns})
+
+    # ---- KLT.match control flow with the oracle behind cv2
+    cases = {
+        "tiles": dict(size=(300, 420), shift=(0.5, 0.25), conf=dict(tile_size=200, maxCorners=600, laplacian_kernel_size=7)),
+        "xstart": dict(size=(260, 520), shift=(-0.4, 0.3), conf=dict(tile_size=130, xStart=130, maxCorners=300, laplacian_kernel_size=5)),
+        "mixed_inv": dict(size=(256, 256), shift=(0.3, -0.6), wedge=True, nodata=(1, None),
+                          conf=dict(tile_size=20000, maxCorners=800, laplacian_kernel_size={"mon": 5, "ref": 9},
+                                    laplacian_invert_polarity=True, outliers_filtering=True)),
+        "usermask": dict(size=(240, 300), shift=(0.2, 0.2), usermask=True,
+                         conf=dict(tile_size=20000, maxCorners=500, laplacian_kernel_size=3)),
+    }
+    from karios_amd.core import KLTConfiguration
+    with mock.patch.object(rklt, "cv2", oracle_cv2()):
+        for name, c in cases.items():
+            H, W = c["size"]
+            mon, ref = synth.make_pair(H, W, *c["shift"], nodata_wedge=c.get("wedge", False))
+            nd = c.get("nodata", (None, None))
+            mask = None
+            if c.get("usermask"):
+                mask = np.ones((H, W), np.uint8)
+                mask[:, : W // 3] = 0
+                mask[50:90, :] = 0
+            conf = KLTConfiguration(**c["conf"])
+            frames = list(rklt.KLT(conf).match(Img(mon, nd[0]), Img(ref, nd[1]), Img(mask) if mask is not None else None))
+            d = {"mon": mon, "ref": ref, "n_frames": len(frames), "nodata": np.array([np.nan if v is None else v for v in nd])}
+            if mask is not None:
+                d["mask"] = mask
+            for i, f in enumerate(frames):
+                for col in f.columns:
+                    d[f"f{i}_{col}"] = f[col].to_numpy()
+            np.savez_compressed(os.path.join(HERE, f"klt_match_{name}.npz"), **d)
+            print(name, [len(f) for f in frames])
+
+    # ---- phase correlation vs scikit-image 0.18.3 (conda python3.9), pre-normalised spectra = 0.24 'phase' normalisation
+    conda = "/opt/conda/bin/python3.9"
+    if os.path.exists(conda):
+        _, ref = synth.make_pair(96, 130, 0, 0)
+        shifts = [(7, -12), (-20, 31), (0, 0), (3, 64)]
+        np.savez(os.path.join(HERE, "_pc_in.npz"), ref=ref, shifts=np.array(shifts))
+        code = r'''
+import numpy as np, sys
+from skimage.registration import phase_cross_correlation
+d = np.load(sys.argv[1]); ref = d["ref"].astype(np.float64); out = []
+for s in d["shifts"]:
+    mon = np.roll(ref, tuple(s), (0, 1))
+    F, G = np.fft.fftn(mon), np.fft.fftn(ref)
+    P = F * G.conj(); P /= np.maximum(np.abs(P), 100 * np.finfo(np.float64).eps)
+    out.append(phase_cross_correlation(P, np.ones_like(P), space="fourier", upsample_factor=1, return_error=False))
+np.save(sys.argv[2], np.array(out, np.float64))
+'''
+        subprocess.check_call([conda, "-c", code, os.path.join(HERE, "_pc_in.npz"), os.path.join(HERE, "_pc_out.npy")])
+        np.savez_compressed(os.path.join(HERE, "phase_corr.npz"), ref=ref, shifts=np.array(shifts),
+                            skimage_shift=np.load(os.path.join(HERE, "_pc_out.npy")))
+        os.remove(os.path.join(HERE, "_pc_in.npz"))
+        os.remove(os.path.join(HERE, "_pc_out.npy"))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""CPU suite, part 2: host-side logic of karios_amd (no GPU compute) and the C ABI surface."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    from karios_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "karios_hip.h")).read()
+    declared = set(re.findall(r"\b(km_[a-z0-9_]+)\s*\(", header))
+    declared -= {"km_ctx", "km_klt_params", "km_klt_stats"}
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in karios_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.km_version() >= 100
+    assert lib.km_stage_name(1).decode() == "stretch_laplacian_mask"
+
+
+def test_struct_layout_matches_header():
+    from karios_amd._lib import KltParams, KltStats
+    assert ctypes.sizeof(KltParams) == 8 * 4 + 3 * 8
+    assert ctypes.sizeof(KltStats) == 2 * 8 + 2 * 4 + 4 * 8 + 2 * 4
+    assert KltParams.quality_level.offset == 32 and KltStats.min_ref.offset == 24
+
+
+def test_no_device_fails_loudly_without_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from karios_amd import _lib
+    with pytest.raises(_lib.KariosHipError, match="no CPU fallback"):
+        _lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "karios_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "karios_oracle" not in src and "libkarios_oracle" not in src, f
+
+
+def test_tile_boxes_reference_order():
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.matcher.klt import KLT
+    boxes = KLT(KLTConfiguration(tile_size=6000)).tile_boxes(10980, 10980)
+    assert boxes == [(0, 0, 6000, 6000), (0, 6000, 6000, 4980), (6000, 0, 4980, 6000), (6000, 6000, 4980, 4980)]
+    assert KLT(KLTConfiguration(tile_size=20000)).tile_boxes(10980, 10980) == [(0, 0, 10980, 10980)]
+    skipped = KLT(KLTConfiguration(tile_size=100, xStart=150)).tile_boxes(300, 100)
+    assert [b[0] for b in skipped] == [200]                      # x_off 0 and 100 are < xStart
+    assert len(KLT(KLTConfiguration(tile_size=100)).tile_boxes(200, 200)) == 4   # reference test_klt_match_method
+
+
+def test_frame_from_tracks_matches_reference_fb_arithmetic():
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.matcher.klt import _frame_from_tracks
+    g = np.load(os.path.join(G, "fb_score.npz"))
+    frame, ninit = _frame_from_tracks(g["p0"], g["p1"], g["p0r"], KLTConfiguration())
+    assert ninit == int(g["ninit"])
+    assert list(frame.columns) == ["x0", "y0", "dx", "dy", "score"]
+    for c in frame.columns:
+        assert frame[c].dtype == np.float32
+        np.testing.assert_array_equal(frame[c].to_numpy(), g[c])
+    assert len(frame) < ninit and frame["score"].max() == 1.0
+
+
+def test_filter_outliers_matches_reference():
+    from karios_amd.matcher.klt import _filter_outliers
+    g = np.load(os.path.join(G, "outliers.npz"))
+    for i, v in enumerate(_filter_outliers(g["x0"], g["y0"], g["x1"], g["y1"], g["score"])):
+        np.testing.assert_array_equal(v, g[f"out_{i}"])
+
+
+def test_resolve_ksize():
+    from karios_amd.matcher.klt import KLT
+    assert KLT._resolve_ksize(7) == (7, 7)
+    assert KLT._resolve_ksize({"mon": 5, "ref": 9}) == (5, 9)
+    assert KLT._resolve_ksize({"ref": 3}) == (3, 3) and KLT._resolve_ksize({"mon": 11}) == (11, 11) and KLT._resolve_ksize({}) == (1, 1)
+
+
+def test_numpy_raster_image_duck_type():
+    from karios_amd.core import NumpyRasterImage
+    a = np.arange(60, dtype=np.uint16).reshape(6, 10)
+    im = NumpyRasterImage(a, no_data_value=0, filepath="/x/y/img.tif")
+    assert (im.x_size, im.y_size, im.file_name) == (10, 6, "img.tif")
+    np.testing.assert_array_equal(im.read(1, 2, 1, 3, 4), a[1:5, 2:5])
+    im.clear_cache()
+    assert im.array is a
+
+
+def test_zncc2_mirror_error_contract():
+    from karios_amd.matcher.zncc_service import _zncc2
+    img = np.ones((5, 5))
+    with pytest.raises(ValueError, match="must be non-negative"):
+        _zncc2(img, img, 2, 2, 2, 2, -1)
+    with pytest.raises(IndexError):
+        _zncc2(img, img, 0, 0, 0, 0, 3)
+
+
+def test_pack_unpack_and_unit_enumeration():
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.parallel import enumerate_units, pack_frame, unpack_frame, units_of_rank
+    f = pd.DataFrame(np.random.default_rng(0).random((7, 5)).astype(np.float32), columns=["x0", "y0", "dx", "dy", "score"])
+    back = unpack_frame(pack_frame(f, 10))
+    pd.testing.assert_frame_equal(back, f)
+    assert unpack_frame(pack_frame(None, 4)) is None
+    with pytest.raises(ValueError):
+        pack_frame(f, 3)
+    units = enumerate_units(4, 10980, 10980, KLTConfiguration(tile_size=5490))
+    assert len(units) == 16 and [u.index for u in units] == list(range(16))
+    assert (units[1].x_off, units[1].y_off) == (0, 5490) and (units[2].x_off, units[2].y_off) == (5490, 0)   # x outer, y inner
+    parts = [units_of_rank(units, r, 8) for r in range(8)]
+    assert all(len(p) == 2 for p in parts) and sorted(u.index for p in parts for u in p) == list(range(16))
+
+
+def test_gather_frames_world_size_2_gloo(tmp_path):
+    """N>1 path: two CPU processes (gloo) exchange their per-unit frames; both end with every frame in
+    reference order."""
+    script = tmp_path / "worker.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pandas as pd, torch.distributed as dist
+from karios_amd.parallel import gather_frames
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+def frame(u):
+    n = 3 + u
+    return pd.DataFrame(np.full((n, 5), u, np.float32) + np.arange(5, dtype=np.float32), columns=["x0", "y0", "dx", "dy", "score"])
+local = {{u: (None if u == 2 else frame(u)) for u in range(5) if u % 2 == rank}}
+out = gather_frames(local, 5, 16)
+assert [None if f is None else len(f) for f in out] == [3, 4, None, 6, 7], out
+for u, f in enumerate(out):
+    if f is not None:
+        pd.testing.assert_frame_equal(f, frame(u))
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

@@ -1,0 +1,230 @@
+"""CPU suite, part 1: pin the oracle.
+
+(a) numpy-defined pieces against golden vectors produced by the reference's own functions
+    (tests/golden/make_golden.py);
+(b) OpenCV-defined pieces ("parity unpinned": cv2 is not installable here) against known-answer tests
+    derived from the published algorithm (SURVEY.md 8c list) and against independent scipy.ndimage
+    restatements.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage as ndi
+
+from conftest import rand_u8
+from karios_amd import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+# ------------------------------------------------------------------ (a) golden vectors from the reference
+def test_to_uint8_golden(O):
+    g = load("to_uint8.npz")
+    for k in [k[3:] for k in g.files if k.startswith("in_")]:
+        np.testing.assert_array_equal(O.to_uint8(g["in_" + k]), g["out_" + k], err_msg=k)
+
+
+def test_shift_image_golden(O):
+    g = load("shift_image.npz")
+    for i, (yo, xo) in enumerate(g["offsets"]):
+        np.testing.assert_array_equal(O.shift_image(g["img"], yo, xo), g[f"out_{i}"])
+
+
+def test_filter_outliers_golden(O):
+    g = load("outliers.npz")
+    r = O.filter_outliers(g["x0"], g["y0"], g["x1"], g["y1"], g["score"])
+    for i, v in enumerate(r):
+        np.testing.assert_array_equal(v, g[f"out_{i}"])
+    assert len(r[0]) < len(g["x0"])
+
+
+def test_zncc_golden(O):
+    g = load("zncc.npz")
+    for ref_key, exp_key in (("ref", "zncc"), ("ref_flat", "zncc_flat")):
+        got = O.zncc_batch(g[ref_key], g["mon"], g["x0"], g["y0"], g["dx"], g["dy"])
+        exp = g[exp_key]
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.nanmax(np.abs(got - exp)) <= 1e-9
+    assert np.isnan(g["zncc_flat"]).sum() > np.isnan(g["zncc"]).sum() > 0
+    assert bool(g["uniform_is_nan"])
+
+
+@pytest.mark.parametrize("case", ["tiles", "xstart", "mixed_inv", "usermask"])
+def test_klt_match_glue_golden(O, case):
+    """The oracle's own tile composition (oracle.klt_tile) equals the reference's KLT.match run with the
+    oracle behind cv2: tile order / offsets / mask / sort / polarity / per-image ksize glue is pinned."""
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.matcher.klt import KLT
+    g = load(f"klt_match_{case}.npz")
+    confs = {
+        "tiles": dict(tile_size=200, maxCorners=600, laplacian_kernel_size=7),
+        "xstart": dict(tile_size=130, xStart=130, maxCorners=300, laplacian_kernel_size=5),
+        "mixed_inv": dict(tile_size=20000, maxCorners=800, laplacian_kernel_size={"mon": 5, "ref": 9},
+                          laplacian_invert_polarity=True, outliers_filtering=True),
+        "usermask": dict(tile_size=20000, maxCorners=500, laplacian_kernel_size=3),
+    }
+    conf = KLTConfiguration(**confs[case])
+    mon, ref = g["mon"], g["ref"]
+    nd = [None if np.isnan(v) else v for v in g["nodata"]]
+    mask = g["mask"] if "mask" in g.files else None
+    frames = []
+    for x_off, y_off, bx, by in KLT(conf).tile_boxes(mon.shape[1], mon.shape[0]):
+        sl = (slice(y_off, y_off + by), slice(x_off, x_off + bx))
+        r = O.klt_tile(mon[sl], ref[sl], conf, mask_box=None if mask is None else mask[sl], nodata_mon=nd[0], nodata_ref=nd[1],
+                       x_off=x_off, y_off=y_off, invert_mon=bool(conf.laplacian_invert_polarity))
+        if r is not None:
+            frames.append(r)
+    assert len(frames) == int(g["n_frames"])
+    for i, f in enumerate(frames):
+        for col in ("x0", "y0", "dx", "dy", "score"):
+            np.testing.assert_array_equal(f[col], g[f"f{i}_{col}"], err_msg=f"{case} frame {i} {col}")
+
+
+def test_phase_correlation_vs_skimage(O):
+    g = load("phase_corr.npz")
+    ref = g["ref"]
+    for s, exp in zip(g["shifts"], g["skimage_shift"]):
+        mon = np.roll(ref, tuple(s), (0, 1))
+        got = O.phase_cross_correlation(mon, ref)
+        np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(g["skimage_shift"], g["shifts"].astype(np.float64))
+
+
+# ------------------------------------------------------------------ (b) OpenCV-defined pieces: KATs
+def test_sobel_kernels():
+    from oracle import oracle as O
+    assert O.sobel_kernel(5, 2).tolist() == [1, 0, -2, 0, 1] and O.sobel_kernel(5, 0).tolist() == [1, 4, 6, 4, 1]
+    assert O.sobel_kernel(7, 2).tolist() == [1, 2, -1, -4, -1, 2, 1] and O.sobel_kernel(7, 0).tolist() == [1, 6, 15, 20, 15, 6, 1]
+    assert O.sobel_kernel(9, 2).tolist() == [1, 4, 4, -4, -10, -4, 4, 4, 1]
+    assert O.sobel_kernel(11, 0).tolist() == [1, 10, 45, 120, 210, 252, 210, 120, 45, 10, 1]
+
+
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7, 9, 11])
+def test_laplacian_vs_scipy(O, ksize):
+    img = rand_u8((67, 93), seed=ksize)
+    I = img.astype(np.int64)
+    if ksize in (1, 3):
+        K = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]]) if ksize == 1 else np.array([[2, 0, 2], [0, -8, 0], [2, 0, 2]])
+        full = ndi.correlate(I, K, mode="mirror")
+    else:
+        kd, ks = O.sobel_kernel(ksize, 2).astype(np.int64), O.sobel_kernel(ksize, 0).astype(np.int64)
+        full = (ndi.correlate1d(ndi.correlate1d(I, kd, axis=1, mode="mirror"), ks, axis=0, mode="mirror")
+                + ndi.correlate1d(ndi.correlate1d(I, ks, axis=1, mode="mirror"), kd, axis=0, mode="mirror"))
+    np.testing.assert_array_equal(O.laplacian_u8(img, ksize), np.clip(full, 0, 255).astype(np.uint8))
+
+
+def test_laplacian_kats(O):
+    ramp = np.tile(np.arange(40, dtype=np.uint8) * 3, (30, 1))
+    for k in (1, 3, 5, 7):
+        assert O.laplacian_u8(ramp, k)[8:-8, 8:-8].max() == 0          # linear ramp -> zero interior
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 1
+    assert O.laplacian_u8(imp, 3)[9:12, 9:12].tolist() == [[2, 0, 2], [0, 0, 0], [2, 0, 2]]  # -8 saturates to 0
+    imp[10, 10] = 255
+    assert O.laplacian_u8(imp, 1)[9:12, 9:12].tolist() == [[0, 255, 0], [255, 0, 255], [0, 255, 0]]
+    k7 = O.laplacian_u8((imp > 0).astype(np.uint8), 7)                 # impulse response of kd x ks + ks x kd
+    kd, ks = O.sobel_kernel(7, 2), O.sobel_kernel(7, 0)
+    exp = np.clip(np.outer(ks, kd) + np.outer(kd, ks), 0, 255)
+    np.testing.assert_array_equal(k7[7:14, 7:14], exp[::-1, ::-1])
+    with pytest.raises(ValueError):
+        O.laplacian_u8(imp, 4)
+
+
+def test_min_eigen_vs_scipy(O):
+    img = O.laplacian_u8(O.to_uint8(synth.make_pair(90, 130)[1]), 3)
+    I = img.astype(np.int64)
+    sx = ndi.correlate1d(ndi.correlate1d(I, [-1, 0, 1], axis=1, mode="mirror"), [1, 2, 1], axis=0, mode="mirror")
+    sy = ndi.correlate1d(ndi.correlate1d(I, [1, 2, 1], axis=1, mode="mirror"), [-1, 0, 1], axis=0, mode="mirror")
+    for bs in (15, 3, 4):
+        one = np.ones(bs, np.int64)
+        # scipy centres an even window at index bs//2 = OpenCV's default anchor: [x - bs//2, x + bs - 1 - bs//2]
+        box = lambda a: ndi.correlate1d(ndi.correlate1d(a, one, axis=1, mode="mirror"), one, axis=0, mode="mirror")
+        sc = (1.0 / (4 * bs * 255)) ** 2
+        cxx, cxy, cyy = ((box(p) * sc).astype(np.float32) for p in (sx * sx, sx * sy, sy * sy))
+        a, c, b = cxx * np.float32(.5), cyy * np.float32(.5), cxy
+        exp = (a + c) - np.sqrt((a - c) * (a - c) + b * b)
+        np.testing.assert_array_equal(O.min_eigen(img, bs), exp, err_msg=f"block {bs}")
+
+
+def _blob_image():
+    img = np.zeros((120, 160), np.uint8)
+    for (y, x) in [(30, 30), (30, 100), (80, 60), (90, 130)]:
+        img[y - 6:y + 7, x - 6:x + 7] = 200
+    return img
+
+
+def test_good_features_kats(O):
+    img = _blob_image()
+    pts = O.good_features(img, None, 100, 0.05, 10, 7)
+    assert pts.dtype == np.float32 and pts.shape[1:] == (1, 2)
+    xy = pts.reshape(-1, 2)
+    assert np.all(xy == np.round(xy))                                       # integer-valued
+    assert xy[:, 0].min() >= 1 and xy[:, 1].min() >= 1 and xy[:, 0].max() <= 158 and xy[:, 1].max() <= 118  # never on the border
+    d = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(-1)) + np.eye(len(xy)) * 1e9
+    assert d.min() >= 10                                                    # minDistance respected
+    corners = np.array([[y + dy, x + dx] for (y, x) in [(30, 30), (30, 100), (80, 60), (90, 130)] for dy in (-6, 6) for dx in (-6, 6)])
+    for (x, y) in xy[:16]:
+        assert np.abs(corners - [y, x]).sum(1).min() <= 6                  # strongest responses sit on the square corners
+    # strongest first; truncation keeps the strongest
+    top3 = O.good_features(img, None, 3, 0.05, 10, 7)
+    np.testing.assert_array_equal(top3, pts[:3])
+    # mask removes corners but never invents new ones
+    mask = np.ones_like(img)
+    mask[:, :80] = 0
+    m = O.good_features(img, mask, 100, 0.05, 10, 7).reshape(-1, 2)
+    assert m[:, 0].min() >= 80
+    assert O.good_features(np.full((50, 50), 9, np.uint8), None, 10, 0.1, 5, 3) is None   # flat image -> None
+
+
+def test_good_features_tie_rule_larger_raster_index_first(O):
+    # two identical isolated blobs closer than minDistance: exact eig tie, the larger raster index wins
+    img = np.zeros((60, 80), np.uint8)
+    img[20:25, 20:25] = 255
+    img[20:25, 27:32] = 255
+    eig = O.min_eigen(img, 5)
+    pts = O.good_features(img, None, 0, 0.01, 30, 5).reshape(-1, 2)
+    best = np.argwhere(eig == eig.max())
+    by, bx = best[np.argmax(best[:, 0] * 80 + best[:, 1])]
+    assert len(best) >= 2 and (pts[0] == [bx, by]).all()
+
+
+def test_pyrdown_vs_scipy(O):
+    img = rand_u8((61, 77), seed=5)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    full = ndi.correlate1d(ndi.correlate1d(img.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    np.testing.assert_array_equal(O.pyrdown_u8(img), ((full[::2, ::2] + 128) >> 8).astype(np.uint8))
+
+
+def test_lk_kats(O):
+    mon, ref = synth.make_pair(200, 240, 0.5, 0.25, noise_sigma=0)
+    lm, lr = O.laplacian_u8(O.to_uint8(mon), 7), O.laplacian_u8(O.to_uint8(ref), 7)
+    p0 = O.good_features(lr, None, 300, 0.1, 10, 15)
+    same, it = O.pyr_lk(lr, lr, p0, return_iters=True)
+    np.testing.assert_array_equal(same, p0)                                  # identical images: exactly zero flow
+    assert it.max() <= 1
+    p1 = O.pyr_lk(lr, lm, p0)
+    d = (p1 - p0).reshape(-1, 2)
+    assert abs(np.median(d[:, 0]) - 0.5) < 0.05 and abs(np.median(d[:, 1]) - 0.25) < 0.05
+    shifted = np.roll(lr, (2, 3), (0, 1))                                    # integer shift (dy=2, dx=3)
+    d2 = (O.pyr_lk(lr, shifted, p0) - p0).reshape(-1, 2)
+    inner = (p0[:, 0, 0] > 30) & (p0[:, 0, 0] < 210) & (p0[:, 0, 1] > 30) & (p0[:, 0, 1] < 170)
+    assert np.abs(np.median(d2[inner], 0) - [3, 2]).max() < 1e-2
+    # a point whose window is flat in `prev` keeps its initial guess (not dropped)
+    flat = np.zeros((100, 100), np.uint8)
+    pt = np.array([[[50.0, 50.0]]], np.float32)
+    np.testing.assert_array_equal(O.pyr_lk(flat, rand_u8((100, 100), 3), pt), pt)
+
+
+def test_config1_pipeline(O, pair512):
+    """BASELINE config 1: 512x512 synthetic pair with a known 0.5 px shift, CPU path."""
+    mon, ref = pair512
+    r = O.klt_tile(mon, ref, O.default_conf())
+    assert r["Ninit"] > 1000 and len(r["x0"]) > 0.9 * r["Ninit"]
+    assert abs(np.median(r["dx"]) - 0.5) < 0.02 and abs(np.median(r["dy"])) < 0.02
+    assert r["score"].min() >= 0 and r["score"].max() <= 1
+    assert np.all(np.diff(r["x0"]) >= 0)                                     # sorted by (x0, y0)
