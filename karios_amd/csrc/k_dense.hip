@@ -9,7 +9,13 @@
 // arithmetic, no MFMA.
 #include "common.hpp"
 
+#include <type_traits>
+
 // ------------------------------------------------------------------ helpers
+// 24-bit multiply-add: full-rate v_mad_i32_i24 (a plain int multiply is a quarter-rate v_mul_lo_u32);
+// every use below has both factors within +-2^23 and a product within int32.
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
 template <typename T> struct px_traits;
 template <> struct px_traits<uint8_t> { using acc = int; static constexpr int code = KM_U8; };
 template <> struct px_traits<uint16_t> { using acc = int; static constexpr int code = KM_U16; };
@@ -272,91 +278,168 @@ __global__ __launch_bounds__(1024) void max_u32_kernel(const unsigned *__restric
 }
 
 // ------------------------------------------------------------------ K2 stretch + Laplacian (+mask)
-// Output tile 64x32 per 256-thread workgroup.  The Laplacian of odd ksize k is written as
+// Output tile 128x16 per 256-thread workgroup.  The Laplacian of odd ksize k is written as
 //   sum_j ks[j] * (kd *x u8)[y+j] + kd[j] * (ks *x u8)[y+j]
 // (ksize 1 and 3 fit the same form with kd=[1,-2,1] and ks=[0,1,0] / [1,2,1]); both images use
 // radius R = max of the two, the shorter kernel zero-padded, so one launch serves mixed sizes.
-#define LAP_TW 64
-#define LAP_TH 32
+//
+// uint8 stretch of 16-bit integer images without a per-pixel fp64 division: numpy computes
+// trunc(fl(fl(d/r)*255)) with d = v - min, r = max - min.  For 255*d not divisible by r the exact
+// quotient is >= 1/r away from an integer, far more than the fp64 rounding error, so
+// floor(255*d / r) in integer arithmetic is the same number.  For the <= 256 values of d with
+// 255*d == k*r exactly, fp64 rounding decides between k and k-1: those answers are tabulated per
+// image by `stretch_table_kernel` with the very fp64 expression numpy uses.
+#define LAP_TW 128
+#define LAP_TH 16
 
 struct lap_coef {
     int kd[2][11];
     int ks[2][11];
 };
 
+// tab[img][k] = numpy's uint8 for the pixel value whose exact stretch is the integer k
+__global__ __launch_bounds__(256) void stretch_table_kernel(const double *__restrict__ mm, uint8_t *__restrict__ tab, int nimg)
+{
+    const int k = threadIdx.x;
+    for (int i = 0; i < nimg; i++) {
+        const double mn = mm[2 * i], mx = mm[2 * i + 1], range = mx - mn;
+        uint8_t out = (uint8_t)k;
+        if (mx > mn && range <= 65535.0 && range == floor(range)) {
+            const unsigned long long R = (unsigned long long)range, kr = (unsigned long long)k * R;
+            if (kr % 255ull == 0) {
+                const double v = mn + (double)(kr / 255ull);
+                const double t = __dmul_rn(__ddiv_rn(__dsub_rn(v, mn), range), 255.0);
+                out = (uint8_t)(int)t;
+            }
+        }
+        tab[i * 256 + k] = out;
+    }
+}
+
+template <typename T> struct stretcher {
+    // generic (f32 / u8): arithmetic path
+    double mn, range;
+    bool deg;
+    __device__ void init(const double *mm, int img, const uint8_t *) {
+        if constexpr (sizeof(T) == 1) { mn = 0; range = 1; deg = false; }
+        else { mn = mm[2 * img]; const double mx = mm[2 * img + 1]; range = mx - mn; deg = !(mx > mn); }
+    }
+    __device__ __forceinline__ unsigned operator()(T v, const uint8_t *) const { return stretch_u8<T>(v, mn, range, deg); }
+};
+template <typename T> struct stretcher_i16 {
+    int mn_i, R;
+    float rf;
+    bool deg;
+    __device__ void init(const double *mm, int img, const uint8_t *) {
+        const double mn = mm[2 * img], mx = mm[2 * img + 1];
+        deg = !(mx > mn);
+        mn_i = (int)mn; R = deg ? 1 : (int)(mx - mn);
+        rf = 1.0f / (float)R;
+    }
+    __device__ __forceinline__ unsigned operator()(T v, const uint8_t *tab) const {
+        if (deg) return 0u;
+        const int n = __mul24((int)v - mn_i, 255);           // < 2^24: exact in f32
+        int q = (int)((float)n * rf);
+        int r = n - __mul24(q, R);
+        if (r < 0) { q--; r += R; } else if (r >= R) { q++; r -= R; }
+        return r == 0 ? (unsigned)tab[q] : (unsigned)q;
+    }
+};
+template <> struct stretcher<uint16_t> : stretcher_i16<uint16_t> {};
+template <> struct stretcher<int16_t> : stretcher_i16<int16_t> {};
+
 template <int R, typename T, int NIMG, bool MASK>
 __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                   ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
-                                                  lap_coef cf, int invert1, nodata_t nd, uint8_t *__restrict__ out0,
-                                                  uint8_t *__restrict__ out1, uint8_t *__restrict__ mask_out,
-                                                  unsigned *__restrict__ valid_partial)
+                                                  const uint8_t *__restrict__ tabs, lap_coef cf, int invert1, nodata_t nd,
+                                                  uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
+                                                  uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial)
 {
+    using HT = typename std::conditional<(R <= 3), short, int>::type;  // |kd*x| <= 3060, ks*x <= 16320 for k <= 7
     constexpr int HX = (R + 3) & ~3;          // x halo rounded to 4 for packed LDS words
     constexpr int TWH = LAP_TW + 2 * HX;      // LDS tile row length (bytes)
     constexpr int THH = LAP_TH + 2 * R;
     constexpr int CPR = TWH / 4;              // 4-pixel chunks per row
+    constexpr int NQ = LAP_TW / 4;            // output quads per row
+    constexpr int NIT = (THH * CPR + 255) / 256;
     __shared__ uint32_t tile[NIMG][THH][CPR];
-    __shared__ int hd[NIMG][THH][LAP_TW];
-    __shared__ int hs[NIMG][THH][LAP_TW];
+    __shared__ __attribute__((aligned(16))) HT hbuf[2][NIMG][THH][LAP_TW];  // [0] = kd pass, [1] = ks pass
+    auto &hd = hbuf[0];
+    auto &hs = hbuf[1];
+    __shared__ uint8_t s_tab[NIMG][256];
 
     const int X0 = blockIdx.x * LAP_TW, Y0 = blockIdx.y * LAP_TH;
     const int tid = threadIdx.x;
-    double mn[NIMG], range[NIMG];
-    bool deg[NIMG];
-#pragma unroll
-    for (int i = 0; i < NIMG; i++) {
-        if constexpr (sizeof(T) == 1) { mn[i] = 0; range[i] = 1; deg[i] = false; }
-        else { mn[i] = mm[2 * i]; double mx = mm[2 * i + 1]; range[i] = mx - mn[i]; deg[i] = !(mx > mn[i]); }
+    constexpr bool kTab = (sizeof(T) == 2);
+    if constexpr (kTab) {
+        for (int i = tid; i < NIMG * 256; i += 256) (&s_tab[0][0])[i] = tabs[i];
     }
+    stretcher<T> st[NIMG];
+#pragma unroll
+    for (int i = 0; i < NIMG; i++) st[i].init(mm, i, nullptr);
     const T *imgs[2] = {img0, img1};
     const ptrdiff_t strides[2] = {stride0, stride1};
 
-    // ---- phase 1: load raw tile + halo (REFLECT_101), stretch to u8, pack into LDS
+    // ---- phase 1a: issue every global load of this thread (raw tile + halo, REFLECT_101)
+    T v[NIT][NIMG][4];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int ci = it * 256 + tid;
+        if (ci < THH * CPR) {
+            const int row = ci / CPR, cx = ci - row * CPR;
+            const int gy = km_reflect101(Y0 - R + row, H);
+            const int gx0 = X0 - HX + cx * 4;
+            const bool inside = gx0 >= 0 && gx0 + 3 < W;
+#pragma unroll
+            for (int i = 0; i < NIMG; i++) {
+                const T *rowp = imgs[i] + (size_t)gy * strides[i];
+                if (inside && ((((uintptr_t)(rowp + gx0)) & (4 * sizeof(T) - 1)) == 0)) {
+                    if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(rowp + gx0); __builtin_memcpy(v[it][i], &q, 4); }
+                    else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(rowp + gx0); __builtin_memcpy(v[it][i], &q, 8); }
+                    else { uint4 q = *(const uint4 *)(rowp + gx0); __builtin_memcpy(v[it][i], &q, 16); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[it][i][k] = rowp[km_reflect101(gx0 + k, W)];
+                }
+            }
+        }
+    }
+    if constexpr (kTab) __syncthreads();  // s_tab ready
+    // ---- phase 1b: stretch to u8, pack into LDS, emit the auto mask
     unsigned cnt = 0;
-    for (int ci = tid; ci < THH * CPR; ci += 256) {
-        const int row = ci / CPR, cx = ci - row * CPR;
-        const int gy = km_reflect101(Y0 - R + row, H);
-        const int gx0 = X0 - HX + cx * 4;
-        T v[NIMG][4];
-        const bool inside = gx0 >= 0 && gx0 + 3 < W;
 #pragma unroll
-        for (int i = 0; i < NIMG; i++) {
-            const T *rowp = imgs[i] + (size_t)gy * strides[i];
-            if (inside && ((((uintptr_t)(rowp + gx0)) & (4 * sizeof(T) - 1)) == 0)) {
-                if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(rowp + gx0); __builtin_memcpy(v[i], &q, 4); }
-                else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(rowp + gx0); __builtin_memcpy(v[i], &q, 8); }
-                else { uint4 q = *(const uint4 *)(rowp + gx0); __builtin_memcpy(v[i], &q, 16); }
-            } else {
+    for (int it = 0; it < NIT; it++) {
+        const int ci = it * 256 + tid;
+        if (ci < THH * CPR) {
+            const int row = ci / CPR, cx = ci - row * CPR;
+            const int gx0 = X0 - HX + cx * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[i][k] = rowp[km_reflect101(gx0 + k, W)];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NIMG; i++) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                unsigned u = stretch_u8<T>(v[i][k], mn[i], range[i], deg[i]);
-                if (i == 1 && invert1) u = 255u - u;
-                packed |= u << (8 * k);
-            }
-            tile[i][row][cx] = packed;
-        }
-        if constexpr (MASK) {
-            // auto mask for interior pixels: v[0] = ref, v[1] = mon
-            const int oy = Y0 - R + row;
-            if (row >= R && row < R + LAP_TH && oy < H && gx0 >= X0 && gx0 < X0 + LAP_TW && gx0 < W) {
-                uint32_t mp = 0;
+            for (int i = 0; i < NIMG; i++) {
+                uint32_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    bool ok = (gx0 + k < W) && px_valid<T>(v[1][k], v[0][k], nd);
-                    mp |= (ok ? 1u : 0u) << (8 * k);
-                    cnt += ok;
+                    unsigned u = st[i](v[it][i][k], s_tab[i]);
+                    if (i == 1 && invert1) u = 255u - u;
+                    packed |= u << (8 * k);
                 }
-                const size_t o = (size_t)oy * W + gx0;
-                if (gx0 + 3 < W && (o & 3) == 0) *(uint32_t *)(mask_out + o) = mp;
-                else {
-                    for (int k = 0; k < 4 && gx0 + k < W; k++) mask_out[o + k] = (uint8_t)((mp >> (8 * k)) & 1u);
+                tile[i][row][cx] = packed;
+            }
+            if constexpr (MASK) {
+                // auto mask for interior pixels: v[.][0] = ref, v[.][1] = mon
+                const int oy = Y0 - R + row;
+                if (row >= R && row < R + LAP_TH && oy < H && gx0 >= X0 && gx0 < X0 + LAP_TW && gx0 < W) {
+                    uint32_t mp = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool ok = (gx0 + k < W) && px_valid<T>(v[it][1][k], v[it][0][k], nd);
+                        mp |= (ok ? 1u : 0u) << (8 * k);
+                        cnt += ok;
+                    }
+                    const size_t o = (size_t)oy * W + gx0;
+                    if (gx0 + 3 < W && (o & 3) == 0) *(uint32_t *)(mask_out + o) = mp;
+                    else {
+                        for (int k = 0; k < 4 && gx0 + k < W; k++) mask_out[o + k] = (uint8_t)((mp >> (8 * k)) & 1u);
+                    }
                 }
             }
         }
@@ -372,61 +455,168 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
         __syncthreads();
     }
 
-    // ---- phase 2: horizontal passes (kd and ks) for 4 consecutive outputs per item
-    constexpr int NW = (2 * R + 4 + (HX - R) + 3) / 4;  // words covering [x+HX-R, x+HX+R+4)
-    for (int it = tid; it < NIMG * THH * (LAP_TW / 4); it += 256) {
-        const int i = it / (THH * (LAP_TW / 4));
-        const int rem = it - i * (THH * (LAP_TW / 4));
-        const int row = rem / (LAP_TW / 4), q = rem - row * (LAP_TW / 4);
-        // output x = 4q..4q+3 ; source bytes start at tile column 4q + HX - R
-        uint32_t w[NW + 1];
+    uint8_t *outs[2] = {out0, out1};
+    if constexpr (R <= 3) {
+        // ================= packed path (ksize <= 7): v_dot4 horizontally, v_dot2 vertically =================
+        // pixels are stored biased (p - 128, bit 7 flipped) so that signed 8-bit dot products apply;
+        // sum(kd) = 0 and sum(ks) = 4^R remove / restore the bias exactly.
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        int *hds = (int *)&hd[0][0][0];  // [NIMG][THH][LAP_TW] packed (hd | hs << 16); hd+hs storage is contiguous
+        int kdp[NIMG][2], ksp[NIMG][2], bias[NIMG], vk[NIMG][2 * R + 1];
 #pragma unroll
-        for (int k = 0; k < NW + 1; k++) w[k] = (q + k < CPR) ? tile[i][row][q + k] : 0u;
-        int ad[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0};
+        for (int i = 0; i < NIMG; i++) {
+            int sum = 0;
 #pragma unroll
-        for (int t = 0; t < 2 * R + 4; t++) {
-            const int b = t + (HX - R);
-            const int pv = (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            for (int h = 0; h < 2; h++) {
+                unsigned a = 0, b = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int t = 4 * h + k;
+                    const int d = t <= 2 * R ? cf.kd[i][t] : 0, sm = t <= 2 * R ? cf.ks[i][t] : 0;
+                    a |= ((unsigned)d & 0xffu) << (8 * k);
+                    b |= ((unsigned)sm & 0xffu) << (8 * k);
+                    sum += sm;
+                }
+                kdp[i][h] = (int)a; ksp[i][h] = (int)b;
+            }
+            bias[i] = 128 * sum;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; t++) vk[i][t] = (cf.ks[i][t] & 0xffff) | (cf.kd[i][t] << 16);
+        }
+        // ---- phase 2: horizontal kd / ks passes, 4 outputs per item
+        for (int it = tid; it < NIMG * THH * NQ; it += 256) {
+            const int i = it / (THH * NQ);
+            const int rem = it - i * (THH * NQ);
+            const int row = rem / NQ, q = rem - row * NQ;
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = ((q + k < CPR) ? tile[i][row][q + k] : 0u) ^ 0x80808080u;
+            int o4[4];
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                const int k = t - o;  // tap index for output o
-                if (k >= 0 && k <= 2 * R) {
-                    ad[o] += cf.kd[i][k] * pv;
-                    as[o] += cf.ks[i][k] * pv;
+                constexpr int base = HX - R;
+                const int sft = (o + base) & 3, wi = (o + base) >> 2;
+                const int g0 = (int)__builtin_amdgcn_alignbyte(w[wi + 1], w[wi], sft);
+                const int g1 = (int)__builtin_amdgcn_alignbyte(wi + 2 < 4 ? w[wi + 2] : 0u, w[wi + 1], sft);
+                const int vd = __builtin_amdgcn_sdot4(g0, kdp[i][0], __builtin_amdgcn_sdot4(g1, kdp[i][1], 0, false), false);
+                const int vs = __builtin_amdgcn_sdot4(g0, ksp[i][0], __builtin_amdgcn_sdot4(g1, ksp[i][1], bias[i], false), false);
+                o4[o] = (vd & 0xffff) | (vs << 16);
+            }
+            *(int4 *)&hds[((size_t)i * THH + row) * LAP_TW + 4 * q] = make_int4(o4[0], o4[1], o4[2], o4[3]);
+        }
+        __syncthreads();
+        // ---- phase 3: vertical combine on 4x4 micro-tiles: one v_dot2 per tap and pixel
+        for (int it = tid; it < NIMG * (LAP_TH / 4) * NQ; it += 256) {
+            const int i = it / ((LAP_TH / 4) * NQ);
+            const int rem = it - i * ((LAP_TH / 4) * NQ);
+            const int rg = rem / NQ, q = rem - rg * NQ;
+            const int ox = X0 + 4 * q;
+            if (ox >= W || Y0 + 4 * rg >= H) continue;
+            int acc[4][4];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) acc[o][c2] = 0;
+#pragma unroll
+            for (int j = 0; j < 2 * R + 4; j++) {
+                const int4 a = *(const int4 *)&hds[((size_t)i * THH + 4 * rg + j) * LAP_TW + 4 * q];
+                const int av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int tap = j - o;
+                    if (tap >= 0 && tap <= 2 * R) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; c2++)
+                            acc[o][c2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, av[c2]), __builtin_bit_cast(short2v, vk[i][tap]),
+                                                                acc[o][c2], false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int oy = Y0 + 4 * rg + o;
+                if (oy >= H) break;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) packed |= (uint32_t)min(max(acc[o][k], 0), 255) << (8 * k);
+                const size_t off = (size_t)oy * W + ox;
+                if (ox + 3 < W && (off & 3) == 0) *(uint32_t *)(outs[i] + off) = packed;
+                else {
+                    for (int k = 0; k < 4 && ox + k < W; k++) outs[i][off + k] = (uint8_t)(packed >> (8 * k));
                 }
             }
         }
-        *(int4 *)&hd[i][row][4 * q] = make_int4(ad[0], ad[1], ad[2], ad[3]);
-        *(int4 *)&hs[i][row][4 * q] = make_int4(as[0], as[1], as[2], as[3]);
-    }
-    __syncthreads();
-
-    // ---- phase 3: vertical combine, clip to [0,255], packed store
-    uint8_t *outs[2] = {out0, out1};
-    for (int it = tid; it < NIMG * LAP_TH * (LAP_TW / 4); it += 256) {
-        const int i = it / (LAP_TH * (LAP_TW / 4));
-        const int rem = it - i * (LAP_TH * (LAP_TW / 4));
-        const int row = rem / (LAP_TW / 4), q = rem - row * (LAP_TW / 4);
-        const int oy = Y0 + row, ox = X0 + 4 * q;
-        if (oy >= H || ox >= W) continue;
-        int acc[4] = {0, 0, 0, 0};
+    } else {
+        // ================= generic path (ksize 9, 11): 24-bit multiply-adds on int32 planes =================
+        // ---- phase 2: horizontal passes (kd and ks) for 4 consecutive outputs per item
+        constexpr int NW = (2 * R + 4 + (HX - R) + 3) / 4;  // words covering [x+HX-R, x+HX+R+4)
+        for (int it = tid; it < NIMG * THH * NQ; it += 256) {
+            const int i = it / (THH * NQ);
+            const int rem = it - i * (THH * NQ);
+            const int row = rem / NQ, q = rem - row * NQ;
+            uint32_t w[NW + 1];
 #pragma unroll
-        for (int j = 0; j <= 2 * R; j++) {
-            const int4 a = *(const int4 *)&hd[i][row + j][4 * q];
-            const int4 b = *(const int4 *)&hs[i][row + j][4 * q];
-            const int ksj = cf.ks[i][j], kdj = cf.kd[i][j];
-            acc[0] += ksj * a.x + kdj * b.x;
-            acc[1] += ksj * a.y + kdj * b.y;
-            acc[2] += ksj * a.z + kdj * b.z;
-            acc[3] += ksj * a.w + kdj * b.w;
+            for (int k = 0; k < NW + 1; k++) w[k] = (q + k < CPR) ? tile[i][row][q + k] : 0u;
+            int ad[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 2 * R + 4; t++) {
+                const int b = t + (HX - R);
+                const int pv = (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int k = t - o;  // tap index for output o
+                    if (k >= 0 && k <= 2 * R) {
+                        ad[o] = mad24(cf.kd[i][k], pv, ad[o]);
+                        as[o] = mad24(cf.ks[i][k], pv, as[o]);
+                    }
+                }
+            }
+            HT *pd = &hd[i][row][4 * q], *ps = &hs[i][row][4 * q];
+#pragma unroll
+            for (int o = 0; o < 4; o++) { pd[o] = (HT)ad[o]; ps[o] = (HT)as[o]; }
         }
-        uint32_t packed = 0;
+        __syncthreads();
+        // ---- phase 3: vertical combine on 4x4 micro-tiles, clip to [0,255], packed stores
+        for (int it = tid; it < NIMG * (LAP_TH / 4) * NQ; it += 256) {
+            const int i = it / ((LAP_TH / 4) * NQ);
+            const int rem = it - i * ((LAP_TH / 4) * NQ);
+            const int rg = rem / NQ, q = rem - rg * NQ;
+            const int ox = X0 + 4 * q;
+            if (ox >= W || Y0 + 4 * rg >= H) continue;
+            int acc[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) packed |= (uint32_t)min(max(acc[k], 0), 255) << (8 * k);
-        const size_t o = (size_t)oy * W + ox;
-        if (ox + 3 < W && (o & 3) == 0) *(uint32_t *)(outs[i] + o) = packed;
-        else {
-            for (int k = 0; k < 4 && ox + k < W; k++) outs[i][o + k] = (uint8_t)(packed >> (8 * k));
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) acc[o][c2] = 0;
+#pragma unroll
+            for (int j = 0; j < 2 * R + 4; j++) {
+                const HT *pa = &hd[i][4 * rg + j][4 * q], *pb = &hs[i][4 * rg + j][4 * q];
+                int a[4], b[4];
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) { a[c2] = pa[c2]; b[c2] = pb[c2]; }
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int tap = j - o;
+                    if (tap >= 0 && tap <= 2 * R) {
+                        const int ksj = cf.ks[i][tap], kdj = cf.kd[i][tap];
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; c2++) acc[o][c2] = mad24(ksj, a[c2], mad24(kdj, b[c2], acc[o][c2]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int oy = Y0 + 4 * rg + o;
+                if (oy >= H) break;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) packed |= (uint32_t)min(max(acc[o][k], 0), 255) << (8 * k);
+                const size_t off = (size_t)oy * W + ox;
+                if (ox + 3 < W && (off & 3) == 0) *(uint32_t *)(outs[i] + off) = packed;
+                else {
+                    for (int k = 0; k < 4 && ox + k < W; k++) outs[i][off + k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
         }
     }
 }
@@ -464,7 +654,7 @@ static bool fill_coef(int ksize, int R, int *kd, int *ks)
 
 template <typename T, int NIMG, bool MASK>
 static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
-                      const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
+                      const uint8_t *tabs, const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
                       unsigned long long *valid_out)
 {
     dim3 grid((W + LAP_TW - 1) / LAP_TW, (H + LAP_TH - 1) / LAP_TH);
@@ -475,7 +665,7 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
     }
 #define KM_LAP_CASE(RR)                                                                                         \
     case RR:                                                                                                    \
-        lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, \
+        lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, \
                                                                    mask, valid);                               \
         break;
     switch (R) {
@@ -505,7 +695,7 @@ int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, ui
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize %d (supported: 1,3,5,7,9,11)", ksize);
     for (int i = 0; i < 11; i++) { cf.kd[1][i] = 0; cf.ks[1][i] = 0; }
     nodata_t nd = make_nodata(nullptr, nullptr);
-    return launch_lap<uint8_t, 1, false>(c, R, d_src, d_src, H, W, W, W, nullptr, cf, 0, nd, d_dst, nullptr, nullptr, nullptr);
+    return launch_lap<uint8_t, 1, false>(c, R, d_src, d_src, H, W, W, W, nullptr, nullptr, cf, 0, nd, d_dst, nullptr, nullptr, nullptr);
 }
 
 int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref,
@@ -520,10 +710,17 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
     nodata_t nd = make_nodata(nodata_mon, nodata_ref);
+    uint8_t *tabs = nullptr;
+    if (dtype == KM_U16 || dtype == KM_I16) {
+        tabs = (uint8_t *)km_ws(c, WS_MISC3, 512);
+        if (!tabs) return KM_E_NOMEM;
+        stretch_table_kernel<<<1, 256, 0, c->stream>>>(d_mm, tabs, 2);
+        KM_LAUNCH_CHECK(c);
+    }
 #define KM_PAIR(T)                                                                                                          \
-    (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
+    (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
                                          d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                        \
-                : launch_lap<T, 2, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
+                : launch_lap<T, 2, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
                                           d_lap_ref, d_lap_mon, nullptr, nullptr))
     switch (dtype) {
     case KM_U8: return KM_PAIR(uint8_t);

@@ -71,6 +71,20 @@ def _frame_from_tracks(p0, p1, p0r, conf) -> tuple[DataFrame, int]:
     return frame, ninit
 
 
+def _sorted_tile_frame(p0, p1, p0r, conf, x_off=0, y_off=0) -> tuple[DataFrame, int]:
+    """`_frame_from_tracks` + tile offsets + `sort_values(by=["x0", "y0"])` (reference klt.py:341-348) built in
+    one go: same rows, same values, same (permuted) index labels as the reference's in-place sort, without
+    the pandas sort machinery (key pairs are unique, so the order is fully determined)."""
+    frame, ninit = _frame_from_tracks(p0, p1, p0r, conf)
+    x0 = frame["x0"].to_numpy() + x_off
+    y0 = frame["y0"].to_numpy() + y_off
+    order = np.lexsort((y0, x0))
+    cols = {"x0": x0[order], "y0": y0[order]}
+    for c in ("dx", "dy", "score"):
+        cols[c] = frame[c].to_numpy()[order]
+    return DataFrame(cols, index=order, copy=False), ninit
+
+
 def klt_tracker(ref_data, image_data, mask, conf, p0=None, ctx=None) -> tuple[DataFrame, int] | None:
     """Run KLT (reference klt.py:83-172): Shi-Tomasi corners on `ref_data` (unless `p0` is
     given), pyramidal LK ref->image and image->ref, forward-backward filtering.

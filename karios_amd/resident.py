@@ -15,7 +15,7 @@ from pandas import DataFrame
 
 from . import _lib
 from ._lib import Context, KariosHipError, default_context, dtype_code
-from .matcher.klt import KLT, _frame_from_tracks
+from .matcher.klt import KLT, _sorted_tile_frame
 from .ops import make_params
 
 
@@ -149,10 +149,7 @@ class ResidentPair:
         status, tracks = self.track_tile(conf, box, invert_mon=bool(conf.laplacian_invert_polarity))
         if status != "ok":
             return None
-        points, _ = _frame_from_tracks(*tracks, conf)
-        points["x0"] = points["x0"] + x_off
-        points["y0"] = points["y0"] + y_off
-        points.sort_values(by=["x0", "y0"], inplace=True)
+        points, _ = _sorted_tile_frame(*tracks, conf, x_off=x_off, y_off=y_off)
         return points
 
     def match(self, conf):
@@ -187,13 +184,14 @@ class ResidentPair:
     def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4) -> DataFrame:
         """`_handle_klt_results` numeric columns (core.py:872-893): radial error, angle and the ZNCC of
         the rows with score >= confidence_threshold (NaN elsewhere)."""
-        frame["radial error"] = np.sqrt(frame["dx"] ** 2 + frame["dy"] ** 2)
-        frame["angle"] = np.degrees(np.arctan2(frame["dy"], frame["dx"]))
-        cand = frame[frame["score"] >= confidence_threshold]
-        frame["zncc_score"] = np.nan
-        if len(cand):
-            z = self.zncc(cand["x0"].to_numpy(), cand["y0"].to_numpy(), cand["dx"].to_numpy(), cand["dy"].to_numpy())
-            frame.loc[cand.index, "zncc_score"] = z
+        dx, dy, score = frame["dx"].to_numpy(), frame["dy"].to_numpy(), frame["score"].to_numpy()
+        frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
+        frame["angle"] = np.degrees(np.arctan2(dy, dx))
+        keep = score >= confidence_threshold
+        z = np.full(len(frame), np.nan, np.float64)
+        if keep.any():
+            z[keep] = self.zncc(frame["x0"].to_numpy()[keep], frame["y0"].to_numpy()[keep], dx[keep], dy[keep])
+        frame["zncc_score"] = z
         return frame
 
     # ------------------------------------------------------------------ large offset

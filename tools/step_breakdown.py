@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Dev tool: wall-clock breakdown of one bench step (host glue vs device pipeline)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from karios_amd import synth
+from karios_amd._lib import Context
+from karios_amd.core import KLTConfiguration
+from karios_amd.matcher.klt import _frame_from_tracks
+from karios_amd.resident import ResidentPair
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 10980
+dev = torch.device("cuda", 0)
+mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, device=dev)
+torch.cuda.synchronize()
+ctx = Context(0)
+pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx)
+conf = KLTConfiguration()
+for it in range(6):
+    t = [time.perf_counter()]
+    status, tracks = pair.track_tile(conf); t.append(time.perf_counter())
+    frame, _ = _frame_from_tracks(*tracks, conf); t.append(time.perf_counter())
+    frame.sort_values(by=["x0", "y0"], inplace=True); t.append(time.perf_counter())
+    frame = pair.score_frame(frame, 0.4); t.append(time.perf_counter())
+    if it >= 2:
+        names = ["track_tile(device+d2h)", "frame_from_tracks", "sort_values", "score_frame(zncc)"]
+        print("  ".join(f"{n}={1e3*(b-a):.3f}ms" for n, a, b in zip(names, t, t[1:])), f"total={1e3*(t[-1]-t[0]):.3f}ms")
+ctx.set_profiling(True)
+pair.track_tile(conf)
+print({k: round(v, 3) for k, v in ctx.stage_ms().items()})
