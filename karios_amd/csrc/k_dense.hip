@@ -860,10 +860,172 @@ __global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ sr
     if (tid == 0) max_partial[blockIdx.y * gridDim.x + blockIdx.x] = max(max(s_key[0], s_key[1]), max(s_key[2], s_key[3]));
 }
 
+// ---- K3, fast path: one wavefront marches down a 64-column strip (64 - block - 1 output columns).
+// Each lane owns an image column.  Per row: 3-row register window -> Sobel with the two neighbour lanes
+// (DPP wave shifts) -> integer products -> horizontal box sum = difference of a wave prefix sum (DPP scan +
+// two ds_bpermute) -> vertical box sum = running sum over a `block`-deep register ring -> eigenvalue.
+// No LDS tiles, no barriers; exact integer arithmetic identical to the tiled kernel above.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_get0(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += dpp_get0<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_get0<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_get0<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_get0<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_get0<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_get0<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+#define EIG_RS 128  // output rows per wave segment
+
+template <int BLOCK>
+__global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W,
+                                                        double scale2, float *__restrict__ eig, unsigned int *__restrict__ max_partial,
+                                                        int nstrips)
+{
+    constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, VALID = 64 - BLOCK - 1;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
+    if (strip >= nstrips) { if (lane == 0) max_partial[wave_id] = 0u; return; }
+    const int xs = strip * VALID;
+    const int gx = xs - (L + 1) + lane;                  // image column of this lane (may be outside)
+    const int cx = km_reflect101(gx, W);                 // column the lane reads (REFLECT_101 of the image)
+    const bool xborder = (xs - (L + 1) < 0) || (xs - (L + 1) + 63 >= W);
+    // cov's own REFLECT_101 border: an outside column takes the products of the lane holding its mirror column
+    const int psrc = (cx - (xs - (L + 1))) * 4;
+    const bool out_lane = lane >= L + 1 && lane < L + 1 + VALID && gx < W;
+    const int hi_addr = min(lane + Rr, 63) * 4, lo_addr = max(lane - L - 1, 0) * 4;
+    const bool lo_zero = lane - L - 1 < 0;
+    const int y0 = blockIdx.y * EIG_RS, y1 = min(H, y0 + EIG_RS);
+    const uint8_t *col = src + cx;
+
+    int ring[BLOCK][3];
+#pragma unroll
+    for (int k = 0; k < BLOCK; k++) { ring[k][0] = 0; ring[k][1] = 0; ring[k][2] = 0; }
+    int V0 = 0, V1 = 0, V2 = 0;
+    int c1 = -1, c2 = -1;            // image rows cached in a1, a2
+    int a0 = 0, a1 = 0, a2 = 0;
+    float best = 0.f;
+    bool have = false;
+
+    for (int mbase = y0 - L; mbase < y1 + Rr; mbase += BLOCK) {
+        // steady state (no row mirrored in this group of BLOCK steps): issue all BLOCK row loads (and the mask
+        // bytes of the rows completed here) up front so their latency overlaps the arithmetic
+        const bool steady = mbase - 1 >= 0 && mbase + BLOCK <= H - 1;
+        int pre[BLOCK], pmask[BLOCK];
+        if (steady) {
+#pragma unroll
+            for (int k = 0; k < BLOCK; k++) pre[k] = col[(size_t)(mbase + k + 1) * W];
+            if (!(c1 == mbase - 1 && c2 == mbase)) {
+                a1 = col[(size_t)(mbase - 1) * W]; a2 = col[(size_t)mbase * W];
+                c1 = mbase - 1; c2 = mbase;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BLOCK; k++) {
+            pmask[k] = 1;
+            const int y = mbase + k - Rr;
+            if (mask && out_lane && y >= y0 && y < y1) pmask[k] = mask[(size_t)y * W + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < BLOCK; k++) {
+            const int m = mbase + k;                      // marching row (product row index, may be outside)
+            if (m >= y1 + Rr) continue;                   // (no break: the ring index must stay a compile-time constant)
+            if (steady) {
+                a0 = a1; a1 = a2; a2 = pre[k];
+                c1 = m; c2 = m + 1;
+            } else {
+                const int r = km_reflect101(m, H);        // product row actually evaluated
+                const int n0 = km_reflect101(r - 1, H), n2 = km_reflect101(r + 1, H);
+                if (n0 == c1 && r == c2) {               // slide the window, one new row
+                    a0 = a1; a1 = a2; a2 = col[(size_t)n2 * W];
+                } else {
+                    a0 = col[(size_t)n0 * W]; a1 = col[(size_t)r * W]; a2 = col[(size_t)n2 * W];
+                }
+                c1 = r; c2 = n2;
+            }
+            // Sobel: vertical parts in-lane, horizontal parts from the neighbour lanes
+            const int t0 = a0 + 2 * a1 + a2, t1 = a2 - a0;
+            const int t0m = dpp_get0<0x138, 0xf>(t0), t0p = dpp_get0<0x130, 0xf>(t0);   // lane-1, lane+1
+            const int t1m = dpp_get0<0x138, 0xf>(t1), t1p = dpp_get0<0x130, 0xf>(t1);
+            const int dx = t0p - t0m, dy = t1m + 2 * t1 + t1p;
+            int pxx = __mul24(dx, dx), pxy = __mul24(dx, dy), pyy = __mul24(dy, dy);
+            if (xborder) {
+                pxx = __builtin_amdgcn_ds_bpermute(psrc, pxx);
+                pxy = __builtin_amdgcn_ds_bpermute(psrc, pxy);
+                pyy = __builtin_amdgcn_ds_bpermute(psrc, pyy);
+            }
+            // horizontal window [lane-L, lane+Rr] = S[lane+Rr] - S[lane-L-1]
+            const int s0 = wave_incl_scan(pxx), s1 = wave_incl_scan(pxy), s2 = wave_incl_scan(pyy);
+            int h0 = __builtin_amdgcn_ds_bpermute(hi_addr, s0), l0 = __builtin_amdgcn_ds_bpermute(lo_addr, s0);
+            int h1 = __builtin_amdgcn_ds_bpermute(hi_addr, s1), l1 = __builtin_amdgcn_ds_bpermute(lo_addr, s1);
+            int h2 = __builtin_amdgcn_ds_bpermute(hi_addr, s2), l2 = __builtin_amdgcn_ds_bpermute(lo_addr, s2);
+            if (lo_zero) { l0 = 0; l1 = 0; l2 = 0; }
+            h0 -= l0; h1 -= l1; h2 -= l2;
+            // vertical box sum: running sum over the last BLOCK rows
+            V0 += h0 - ring[k][0]; V1 += h1 - ring[k][1]; V2 += h2 - ring[k][2];
+            ring[k][0] = h0; ring[k][1] = h1; ring[k][2] = h2;
+            const int y = m - Rr;                         // output row completed by this step
+            if (y >= y0 && out_lane) {
+                const float cxx = (float)__dmul_rn((double)V0, scale2);
+                const float cxy = (float)__dmul_rn((double)V1, scale2);
+                const float cyy = (float)__dmul_rn((double)V2, scale2);
+                const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
+                const float t = __fsub_rn(a, cc);
+                const float sq = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
+                const float e = __fsub_rn(__fadd_rn(a, cc), sqrtf(sq));
+                const size_t o = (size_t)y * W + gx;
+                eig[o] = e;
+                if (pmask[k]) { best = have ? fmaxf(best, e) : e; have = true; }
+            }
+        }
+    }
+    unsigned key = have ? eig_key(best) : 0u;
+    for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
+    if (lane == 0) max_partial[wave_id] = key;
+}
+
+template <int BLOCK>
+static int launch_eig_march(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, double scale2, float *d_eig,
+                            unsigned int *d_max_key)
+{
+    constexpr int VALID = 64 - BLOCK - 1;
+    const int nstrips = (W + VALID - 1) / VALID;
+    dim3 grid((nstrips + 3) / 4, (H + EIG_RS - 1) / EIG_RS);
+    const size_t nwaves = (size_t)grid.x * 4 * grid.y;
+    unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
+    if (!partial) return KM_E_NOMEM;
+    eig_march_kernel<BLOCK><<<grid, 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips);
+    KM_LAUNCH_CHECK(c);
+    max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, (unsigned)nwaves, d_max_key);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
 int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig,
                  unsigned int *d_max_key)
 {
     if (block < 1 || block > 31) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d (supported 1..31)", block);
+    const double scale = 1.0 / (4.0 * (double)block * 255.0);
+    if (W >= 2 * block + 4 && H >= 2 * block + 4) {   // mirror columns / rows stay inside one strip
+        switch (block) {
+        case 3: return launch_eig_march<3>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        case 5: return launch_eig_march<5>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        case 7: return launch_eig_march<7>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        case 9: return launch_eig_march<9>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        case 11: return launch_eig_march<11>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        case 15: return launch_eig_march<15>(c, d_src, d_mask, H, W, scale * scale, d_eig, d_max_key);
+        default: break;
+        }
+    }
+    // generic LDS-tiled kernel: any block size 1..31, any image size
     const int L = block / 2, Rr = block - 1 - L;
     const int PW = EIG_TW + L + Rr, PH = EIG_TH + L + Rr, LW = (PW + 2 + 3) & ~3, LH = PH + 2;
     const size_t sm = (((size_t)LH * LW + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * EIG_TW * 4;
@@ -873,7 +1035,6 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
         KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         attr_bytes = sm;
     }
-    const double scale = 1.0 / (4.0 * (double)block * 255.0);
     dim3 grid((W + EIG_TW - 1) / EIG_TW, (H + EIG_TH - 1) / EIG_TH);
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)grid.x * grid.y * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
