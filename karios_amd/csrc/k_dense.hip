@@ -1050,61 +1050,130 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
 // pixel is a candidate iff it is non-zero, equals the 3x3 max of the thresholded map, lies off
 // the 1-px border and passes the mask.  Key = (f32 bits << 32) | raster index, so a single
 // descending u64 sort reproduces greaterThanPtr (value desc, address desc).
-#define CAND_T 64
+// One wavefront marches down a 256-column strip (one float4 per lane and row), keeping the thresholded
+// rows y-1, y, y+1 in registers; the 3x3 max uses the two neighbour lanes through DPP wave shifts.
+// Candidates are compacted into a per-wave LDS stage and flushed with ONE global atomic per flush.
+#define CAND_RS 32     // output rows per wave
+#define CAND_STAGE 512 // keys per wave stage (a row step adds at most 256)
+
+struct cand_row {
+    float v[4];
+    float lft, rgt;  // thresholded neighbours x-1 (lane 0 only) and x+4 (lane 63 only) from the adjacent strips
+};
+
+__device__ __forceinline__ float dpp_shr1(float v)  // value of lane-1 (0 for lane 0)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shl1(float v)  // value of lane+1 (0 for lane 63)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig, const uint8_t *__restrict__ mask, int H, int W,
                                                    double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
-                                                   size_t cap)
+                                                   size_t cap, int nstrips)
 {
-    __shared__ float tile[CAND_T + 2][CAND_T + 2];
-    __shared__ unsigned long long stage[CAND_T * CAND_T];
-    __shared__ unsigned s_n, s_base;
+    __shared__ unsigned long long stage[4][CAND_STAGE];
     const unsigned mk = sc->max_eig_key;
     const float maxv = mk ? eig_unkey(mk) : 0.f;
     const float thr = (float)__dmul_rn((double)maxv, quality);
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { sc->thr = thr; sc->max_eig = maxv; }
-    if (tid == 0) s_n = 0;
-    // tile covers candidate pixels x in [X0, X0+64), y in [Y0, Y0+64) with X0,Y0 >= 1 (1-px border excluded)
-    const int X0 = blockIdx.x * CAND_T + 1, Y0 = blockIdx.y * CAND_T + 1;
-    for (int i = tid; i < (CAND_T + 2) * (CAND_T + 2); i += 256) {
-        const int r = i / (CAND_T + 2), cx = i - r * (CAND_T + 2);
-        const int gy = Y0 - 1 + r, gx = X0 - 1 + cx;
-        float e = 0.f;
-        if (gy < H && gx < W) { e = eig[(size_t)gy * W + gx]; e = e > thr ? e : 0.f; }  // THRESH_TOZERO
-        tile[r][cx] = e;
-    }
-    __syncthreads();
-    const int lane = tid & 63;
-    for (int it = 0; it < CAND_T * CAND_T / 256; it++) {
-        const int p = it * 256 + tid;
-        const int r = p / CAND_T, cx = p - r * CAND_T;
-        const int gy = Y0 + r, gx = X0 + cx;
-        bool is = false;
-        float v = 0.f;
-        if (gy < H - 1 && gx < W - 1) {
-            v = tile[r + 1][cx + 1];
-            if (v != 0.f) {
-                float m = fmaxf(fmaxf(tile[r][cx], tile[r][cx + 1]), tile[r][cx + 2]);
-                m = fmaxf(m, fmaxf(tile[r + 1][cx], tile[r + 1][cx + 2]));
-                m = fmaxf(m, fmaxf(fmaxf(tile[r + 2][cx], tile[r + 2][cx + 1]), tile[r + 2][cx + 2]));
-                is = v >= m && (!mask || mask[(size_t)gy * W + gx]);
-            }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sc->thr = thr; sc->max_eig = maxv; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wv;
+    if (strip >= nstrips) return;
+    unsigned long long *st = stage[wv];
+    const int x0 = strip * 256 + lane * 4;               // first of this lane's 4 columns
+    const int y0 = blockIdx.y * CAND_RS, y1 = min(H, y0 + CAND_RS);
+    const bool vec = (W % 4 == 0) && x0 + 3 < W;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // raw loads are issued a group of rows ahead (load_raw), thresholding happens when the row is consumed
+    auto load_raw = [&](int y, cand_row &r) {
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; r.lft = 0.f; r.rgt = 0.f;
+        if (y < 0 || y >= H) return;                      // outside rows never matter (border rows are excluded)
+        const float *row = eig + (size_t)y * W;
+        if (vec) {
+            const float4 q = *(const float4 *)(row + x0);
+            r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (x0 + j < W) r.v[j] = row[x0 + j];
         }
-        const unsigned long long bal = __ballot(is);
-        unsigned wbase = 0;
-        if (lane == 0 && bal) wbase = atomicAdd(&s_n, (unsigned)__popcll(bal));
-        wbase = __shfl(wbase, 0);
-        if (is) stage[wbase + __popcll(bal & ((1ull << lane) - 1ull))] =
-            ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)((unsigned)gy * (unsigned)W + (unsigned)gx);
+        if (lane == 0 && x0 - 1 >= 0) r.lft = row[x0 - 1];
+        if (lane == 63 && x0 + 4 < W) r.rgt = row[x0 + 4];
+    };
+    auto threshold = [&](cand_row &r) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = r.v[j] > thr ? r.v[j] : 0.f;   // THRESH_TOZERO
+        r.lft = r.lft > thr ? r.lft : 0.f;
+        r.rgt = r.rgt > thr ? r.rgt : 0.f;
+    };
+
+    unsigned cnt = 0;  // keys in the stage (wave-uniform)
+    auto flush = [&]() {
+        if (cnt == 0) return;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&sc->n_cand, cnt);
+        base = __shfl(base, 0);
+        for (unsigned i = lane; i < cnt; i += 64)
+            if ((size_t)base + i < cap) keys[(size_t)base + i] = st[i];
+        cnt = 0;
+    };
+
+    constexpr int PF = 4;  // rows in flight
+    cand_row up, mid, dn, pre[PF];
+    uint32_t pmask[PF];    // mask bytes of the 4 pixels of row yb+k (all-ones without a mask)
+    auto load_mask = [&](int y) -> uint32_t {
+        if (!mask || y < 0 || y >= H) return 0x01010101u;
+        const uint8_t *row = mask + (size_t)y * W;
+        if (vec) return *(const uint32_t *)(row + x0);
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (x0 + j < W) m |= (uint32_t)row[x0 + j] << (8 * j);
+        return m;
+    };
+    load_raw(y0 - 1, up); threshold(up);
+    load_raw(y0, mid); threshold(mid);
+    for (int yb = y0; yb < y1; yb += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) { load_raw(yb + k + 1, pre[k]); pmask[k] = load_mask(yb + k); }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int y = yb + k;
+            if (y >= y1) continue;
+            dn = pre[k]; threshold(dn);
+            if (y >= 1 && y < H - 1) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) any = any || (mid.v[j] != 0.f);
+                if (__ballot(any)) {
+                    // column-wise max of the three rows, then the horizontal neighbours
+                    float m3[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) m3[j] = fmaxf(fmaxf(up.v[j], mid.v[j]), dn.v[j]);
+                    float mL = dpp_shr1(m3[3]), mR = dpp_shl1(m3[0]);
+                    if (lane == 0) mL = fmaxf(fmaxf(up.lft, mid.lft), dn.lft);
+                    if (lane == 63) mR = fmaxf(fmaxf(up.rgt, mid.rgt), dn.rgt);
+                    if (cnt + 256 > CAND_STAGE) flush();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float left = j == 0 ? mL : m3[j - 1], right = j == 3 ? mR : m3[j + 1];
+                        const float nb = fmaxf(fmaxf(left, right), fmaxf(up.v[j], dn.v[j]));
+                        const float v = mid.v[j];
+                        const int x = x0 + j;
+                        const bool is = v != 0.f && v >= nb && x >= 1 && x < W - 1 && ((pmask[k] >> (8 * j)) & 0xffu) != 0;
+                        const unsigned long long bal = __ballot(is);
+                        if (is) st[cnt + __popcll(bal & lt_mask)] =
+                            ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)((unsigned)y * (unsigned)W + (unsigned)x);
+                        cnt += (unsigned)__popcll(bal);
+                    }
+                }
+            }
+            up = mid; mid = dn;
+        }
     }
-    __syncthreads();
-    const unsigned n = s_n;
-    if (n == 0) return;
-    if (tid == 0) s_base = atomicAdd(&sc->n_cand, n);
-    __syncthreads();
-    const unsigned base = s_base;
-    for (unsigned i = tid; i < n; i += 256)
-        if ((size_t)base + i < cap) keys[(size_t)base + i] = stage[i];
+    flush();
 }
 
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W, double quality, km_scalars *d_sc,
@@ -1114,8 +1183,9 @@ int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, i
     if (H < 3 || W < 3) {
         return KM_OK;
     }
-    dim3 grid((W - 2 + CAND_T - 1) / CAND_T, (H - 2 + CAND_T - 1) / CAND_T);
-    cand_kernel<<<grid, 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap);
+    const int nstrips = (W + 255) / 256;
+    dim3 grid((nstrips + 3) / 4, (H + CAND_RS - 1) / CAND_RS);
+    cand_kernel<<<grid, 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap, nstrips);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
