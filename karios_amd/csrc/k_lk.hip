@@ -42,15 +42,70 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
     w11 = 16384 - w00 - w01 - w10;
 }
 
+#define LK_M 3  // margin (px) of the cached search-image patch around the current window
+
+// Stage a rows x cols byte patch whose top-left pixel is (gx0, gy0) into LDS (row pitch `pitch`, multiple of 4).
+// Inside the image: two aligned dword loads + v_alignbyte per destination word; otherwise byte loads with
+// REFLECT_101 (OpenCV pads every pyramid level by winSize with that border).
+__device__ __forceinline__ void stage_patch(const uint8_t *__restrict__ img, int IW, int IH, int gx0, int gy0, int rows, int cols,
+                                            uint8_t *lds, int pitch)
+{
+    const int lane = threadIdx.x;
+    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + cols + 4 <= IW && gy0 + rows <= IH;
+    if (inside) {
+        const int nw = (cols + 3) >> 2;
+        for (int i = lane; i < rows * nw; i += 64) {
+            const int r = i / nw, d = i - r * nw;
+            const uint8_t *p = img + (size_t)(gy0 + r) * IW + gx0 + 4 * d;
+            const unsigned off = (unsigned)((uintptr_t)p & 3);
+            const uint32_t *q = (const uint32_t *)(p - off);
+            const uint32_t w0 = q[0], w1 = q[1];
+            uint32_t v;
+            switch (off) {   // v_alignbyte needs an immediate-like uniform shift; off is per-row uniform at most
+            case 0: v = w0; break;
+            case 1: v = __builtin_amdgcn_alignbyte(w1, w0, 1); break;
+            case 2: v = __builtin_amdgcn_alignbyte(w1, w0, 2); break;
+            default: v = __builtin_amdgcn_alignbyte(w1, w0, 3); break;
+            }
+            *(uint32_t *)(lds + r * pitch + 4 * d) = v;
+        }
+    } else {
+        for (int i = lane; i < rows * cols; i += 64) {
+            const int r = i / cols, cx = i - r * cols;
+            lds[r * pitch + cx] = img[(size_t)km_reflect101(gy0 + r, IH) * IW + km_reflect101(gx0 + cx, IW)];
+        }
+    }
+}
+
+// exact wave sum of an int64 whose per-lane magnitude is < 2^31: two int32 DPP reductions (low 16 bits / rest)
+__device__ __forceinline__ int wave_sum_i32_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ long long wave_sum_split(int v)
+{
+    const int lo = v & 0xffff, hi = v >> 16;
+    return ((long long)wave_sum_i32_dpp(hi) << 16) + (long long)wave_sum_i32_dpp(lo);
+}
+
 // Track one point from image pyramid I to J (all lanes hold identical scalars).
 template <int NPL>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
-                               const short (&lx)[NPL], const short (&ly)[NPL], uint8_t *raw, int *der, float &outx, float &outy)
+                               const short (&lx)[NPL], const short (&ly)[NPL], uint8_t *raw, int *der, uint8_t *jp, float &outx,
+                               float &outy)
 {
     const int lane = threadIdx.x;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int RW = win + 3, DW = win + 1, npx = win * win;
+    const int RP = (RW + 3 + 3) & ~3;                 // raw patch pitch
+    const int JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     float resx = px, resy = py;
     for (int level = I.levels; level >= 0; level--) {
         const uint8_t *Iimg = I.img[level], *Jimg = J.img[level];
@@ -68,15 +123,11 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         int w00, w01, w10, w11;
         lk_weights(a, b, w00, w01, w10, w11);
 
-        // stage the template neighbourhood (REFLECT_101 outside the image)
+        // stage the template neighbourhood and (speculatively) the search neighbourhood around the start position
         __syncthreads();
-        const bool inside = ipx - 1 >= 0 && ipy - 1 >= 0 && ipx + win + 1 < IW && ipy + win + 1 < IH;
-        for (int i = lane; i < RW * RW; i += 64) {
-            const int r = i / RW, cx = i - r * RW;
-            int gy = ipy - 1 + r, gx = ipx - 1 + cx;
-            if (!inside) { gy = km_reflect101(gy, IH); gx = km_reflect101(gx, IW); }
-            raw[i] = Iimg[(size_t)gy * IW + gx];
-        }
+        stage_patch(Iimg, IW, IH, ipx - 1, ipy - 1, RW, RW, raw, RP);
+        int jx0 = (int)floorf(nx - half) - LK_M, jy0 = (int)floorf(ny - half) - LK_M;
+        stage_patch(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
         __syncthreads();
         // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image
         for (int i = lane; i < DW * DW; i += 64) {
@@ -84,10 +135,10 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             const int gy = ipy + r, gx = ipx + cx;
             int v = 0;
             if ((unsigned)gx < (unsigned)IW && (unsigned)gy < (unsigned)IH) {
-                const uint8_t *p = raw + (r + 1) * RW + (cx + 1);
-                const int a00 = p[-RW - 1], a01 = p[-RW], a02 = p[-RW + 1];
+                const uint8_t *p = raw + (r + 1) * RP + (cx + 1);
+                const int a00 = p[-RP - 1], a01 = p[-RP], a02 = p[-RP + 1];
                 const int a10 = p[-1], a12 = p[1];
-                const int a20 = p[RW - 1], a21 = p[RW], a22 = p[RW + 1];
+                const int a20 = p[RP - 1], a21 = p[RP], a22 = p[RP + 1];
                 const int ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
                 const int iy = ((a20 + a22) * 3 + a21 * 10) - ((a00 + a02) * 3 + a01 * 10);
                 v = (ix & 0xffff) | (iy << 16);
@@ -97,26 +148,26 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         __syncthreads();
         // per-lane window pixels -> registers; exact integer normal matrix
         int Iv[NPL], Ixv[NPL], Iyv[NPL];
-        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums fit int32 (<= NPL * 4080^2)
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums fit int32 (<= 8 * 4080^2)
         long long lA11 = 0, lA12 = 0, lA22 = 0;
 #pragma unroll
         for (int k = 0; k < NPL; k++) {
             Iv[k] = 0; Ixv[k] = 0; Iyv[k] = 0;
             if (k * 64 + lane < npx) {
                 const int y = ly[k], x = lx[k];
-                const uint8_t *p = raw + (y + 1) * RW + (x + 1);
-                Iv[k] = descale(p[0] * w00 + p[1] * w01 + p[RW] * w10 + p[RW + 1] * w11, 14 - 5);
+                const uint8_t *p = raw + (y + 1) * RP + (x + 1);
+                Iv[k] = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[RP], w10) + __mul24(p[RP + 1], w11), 14 - 5);
                 const int d00 = der[y * DW + x], d01 = der[y * DW + x + 1], d10 = der[(y + 1) * DW + x], d11 = der[(y + 1) * DW + x + 1];
-                const int ixv = descale((int)(short)(d00 & 0xffff) * w00 + (int)(short)(d01 & 0xffff) * w01 + (int)(short)(d10 & 0xffff) * w10 +
-                                            (int)(short)(d11 & 0xffff) * w11, 14);
-                const int iyv = descale((d00 >> 16) * w00 + (d01 >> 16) * w01 + (d10 >> 16) * w10 + (d11 >> 16) * w11, 14);
+                const int ixv = descale(__mul24((int)(short)(d00 & 0xffff), w00) + __mul24((int)(short)(d01 & 0xffff), w01) +
+                                            __mul24((int)(short)(d10 & 0xffff), w10) + __mul24((int)(short)(d11 & 0xffff), w11), 14);
+                const int iyv = descale(__mul24(d00 >> 16, w00) + __mul24(d01 >> 16, w01) + __mul24(d10 >> 16, w10) + __mul24(d11 >> 16, w11), 14);
                 Ixv[k] = ixv; Iyv[k] = iyv;
-                sA11 += ixv * ixv; sA12 += ixv * iyv; sA22 += iyv * iyv;
-                if ((k & 7) == 7) { lA11 += sA11; lA12 += sA12; lA22 += sA22; sA11 = sA12 = sA22 = 0; }
+                sA11 += __mul24(ixv, ixv); sA12 += __mul24(ixv, iyv); sA22 += __mul24(iyv, iyv);
             }
+            // wave-wide reductions need every lane: keep them outside the divergent branch
+            if ((k & 7) == 7) { lA11 += wave_sum_split(sA11); lA12 += wave_sum_split(sA12); lA22 += wave_sum_split(sA22); sA11 = sA12 = sA22 = 0; }
         }
-        lA11 += sA11; lA12 += sA12; lA22 += sA22;
-        const long long iA11 = wave_sum_i64(lA11), iA12 = wave_sum_i64(lA12), iA22 = wave_sum_i64(lA22);
+        const long long iA11 = lA11 + wave_sum_split(sA11), iA12 = lA12 + wave_sum_split(sA12), iA22 = lA22 + wave_sum_split(sA22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dA = A11 - A22;
@@ -129,32 +180,28 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         for (int j = 0; j < max_count; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -win || inx >= JW || iny < -win || iny >= JH) break;
+            if (inx < jx0 || iny < jy0 || inx > jx0 + 2 * LK_M || iny > jy0 + 2 * LK_M) {
+                // the window left the cached neighbourhood: re-centre it
+                __syncthreads();
+                jx0 = inx - LK_M; jy0 = iny - LK_M;
+                stage_patch(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
+                __syncthreads();
+            }
             a = nx - (float)inx; b = ny - (float)iny;
             lk_weights(a, b, w00, w01, w10, w11);
-            const bool jin = inx >= 0 && iny >= 0 && inx + win < JW && iny + win < JH;
+            const uint8_t *jb = jp + (iny - jy0) * JP + (inx - jx0);
             int sb1 = 0, sb2 = 0;
             long long lb1 = 0, lb2 = 0;
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
                 if (k * 64 + lane < npx) {
-                    int gy = iny + ly[k], gx = inx + lx[k];
-                    int j00, j01, j10, j11;
-                    if (jin) {
-                        const uint8_t *p = Jimg + (size_t)gy * JW + gx;
-                        j00 = p[0]; j01 = p[1]; j10 = p[JW]; j11 = p[JW + 1];
-                    } else {
-                        const int y0 = km_reflect101(gy, JH), y1 = km_reflect101(gy + 1, JH);
-                        const int x0 = km_reflect101(gx, JW), x1 = km_reflect101(gx + 1, JW);
-                        j00 = Jimg[(size_t)y0 * JW + x0]; j01 = Jimg[(size_t)y0 * JW + x1];
-                        j10 = Jimg[(size_t)y1 * JW + x0]; j11 = Jimg[(size_t)y1 * JW + x1];
-                    }
-                    const int diff = descale(j00 * w00 + j01 * w01 + j10 * w10 + j11 * w11, 14 - 5) - Iv[k];
-                    sb1 += diff * Ixv[k]; sb2 += diff * Iyv[k];
-                    if ((k & 7) == 7) { lb1 += sb1; lb2 += sb2; sb1 = sb2 = 0; }
+                    const uint8_t *p = jb + ly[k] * JP + lx[k];
+                    const int diff = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[JP], w10) + __mul24(p[JP + 1], w11), 14 - 5) - Iv[k];
+                    sb1 += __mul24(diff, Ixv[k]); sb2 += __mul24(diff, Iyv[k]);
                 }
+                if ((k & 7) == 7) { lb1 += wave_sum_split(sb1); lb2 += wave_sum_split(sb2); sb1 = sb2 = 0; }
             }
-            lb1 += sb1; lb2 += sb2;
-            const long long ib1 = wave_sum_i64(lb1), ib2 = wave_sum_i64(lb2);
+            const long long ib1 = lb1 + wave_sum_split(sb1), ib2 = lb2 + wave_sum_split(sb2);
             const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
             const float ddx = (A12 * b2 - A22 * b1) * D;
             const float ddy = (A12 * b1 - A11 * b2) * D;
@@ -179,8 +226,10 @@ __global__ __launch_bounds__(64) void lk_kernel(lk_args g)
     const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
     if (p >= n) return;
     const int win = g.win;
+    const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     uint8_t *raw = smem;
-    int *der = (int *)(smem + (((win + 3) * (win + 3) + 15) & ~15));
+    uint8_t *jp = smem + (((win + 3) * RP + 15) & ~15);
+    int *der = (int *)(jp + ((JS * JP + 15) & ~15));
     short lx[NPL], ly[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) {
@@ -190,11 +239,11 @@ __global__ __launch_bounds__(64) void lk_kernel(lk_args g)
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
-    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, lx, ly, raw, der, fx, fy);
+    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, lx, ly, raw, der, jp, fx, fy);
     if (threadIdx.x == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, lx, ly, raw, der, rx, ry);
+        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, lx, ly, raw, der, jp, rx, ry);
         if (threadIdx.x == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }
@@ -212,7 +261,8 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
     g.epsilon = e * e;
     g.p1 = d_p1; g.p0r = d_p0r;
-    const size_t sm = (((size_t)(win + 3) * (win + 3) + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
+    const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
+    const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
     const int npl = (win * win + 63) / 64;
     if (npl <= 4) lk_kernel<4><<<n_max, 64, sm, c->stream>>>(g);
     else if (npl <= 10) lk_kernel<10><<<n_max, 64, sm, c->stream>>>(g);
