@@ -156,6 +156,15 @@ int km_klt_tile_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype
                     const uint8_t *d_mask, const double *nodata_ref,
                     const double *nodata_mon, const km_klt_params *prm, float *d_p0,
                     float *d_p1, float *d_p0r, int cap, int *d_n);
+/* KLT._match_tile end to end on resident data (klt.py:236-349): km_klt_tile_dev, then the forward-backward
+ * test / score of klt_tracker (klt.py:142-155) and the (x0, y0) ordering (klt.py:341-348) on the device.
+ * host_out receives, in ONE device-to-host copy, 4 int32 {n_rows, n_init, 0, 0} followed by 6*cap float32:
+ * x0 | y0 | dx | dy | score | index (int32 bit pattern: the row's label after pandas' in-place sort).
+ * The optional 3-sigma outlier filter (klt.py:161-163) is not applied here. */
+int km_klt_tile_frame_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
+                          ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
+                          const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                          float x_off, float y_off, void *host_out, int cap);
 int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype,
                       int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
                       ptrdiff_t stride_mon, const float *d_x0, const float *d_y0,

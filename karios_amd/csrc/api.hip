@@ -108,7 +108,7 @@ int km_set_profiling(km_ctx *c, int enable)
 }
 
 static const char *const kStageNames[ST_COUNT] = {"minmax", "stretch_laplacian_mask", "min_eigen", "candidates", "sort",
-                                                  "select", "pyramid", "lk_fwd_bwd", "zncc"};
+                                                  "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame"};
 
 const char *km_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 
@@ -174,7 +174,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
     if (reset == RESET_KLT)
-        for (int i = ST_MINMAX; i <= ST_LK; i++) c->ev_used[i] = false;
+        { for (int i = ST_MINMAX; i <= ST_LK; i++) c->ev_used[i] = false; c->ev_used[ST_FRAME] = false; }
     else if (reset == RESET_ZNCC)
         c->ev_used[ST_ZNCC] = false;
     return KM_OK;
@@ -252,8 +252,13 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
             km_stage_timer t(c, ST_CANDIDATES);
             if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk))) return rc;
         }
-        KM_HIP(c, hipMemcpyAsync(&ncand, &sc->n_cand, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        km_scalars hs;
+        KM_HIP(c, hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         KM_HIP(c, hipStreamSynchronize(c->stream));
+        ncand = hs.n_cand;
+        c->stats.valid_pixels = (int64_t)hs.valid;
+        c->stats.max_eig = hs.max_eig;
+        c->stats.min_ref = hs.mm[0]; c->stats.max_ref = hs.mm[1]; c->stats.min_mon = hs.mm[2]; c->stats.max_mon = hs.mm[3];
         if (ncand <= capk) break;
         capk = (size_t)ncand + 4096;  // plateau-heavy image: grow and redo
     }
@@ -351,14 +356,13 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
                                             prm->invert_mon, nodata_ref, nodata_mon, lap_ref, lap_mon, mask_auto, &sc->valid)))
             return rc;
     }
-    unsigned long long valid = 0;
-    KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
-    c->stats.valid_pixels = (int64_t)valid;
-    *no_valid = valid == 0;
-    if (valid == 0) {  // "No valid pixels, skipping this tile" (klt.py:276-279)
-        KM_HIP(c, hipMemsetAsync(&sc->n_corners, 0, 2 * sizeof(int), c->stream));
-        return KM_OK;
+    // "No valid pixels" (klt.py:276-279) needs no early exit: an all-zero mask gives max-eig 0, no candidate, no corner.
+    // The count itself reaches the host with the candidate count (gftt_dev), i.e. without an extra synchronisation.
+    *no_valid = false;
+    {
+        int rc2 = klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
+        *no_valid = c->stats.valid_pixels == 0;
+        return rc2;
     }
     return klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
 }
@@ -605,6 +609,39 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
                                 &no_valid)))
         return rc;
     KM_HIP(c, hipMemcpyAsync(d_n, &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    return KM_OK;
+}
+
+int km_klt_tile_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                          const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
+                          float y_off, void *host_out, int cap)
+{
+    int rc;
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
+        (rc = check_image(c, d_mon, H, W, smon, "klt_tile_frame_dev")))
+        return rc;
+    if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: bad dtype %d", dtype);
+    if (!host_out || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: null output");
+    if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
+    km_scalars *sc = scalars(c);
+    const size_t pb = (size_t)cap * 2 * sizeof(float), ob = 16 + (size_t)cap * 6 * sizeof(float);
+    float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
+    void *d_out = km_ws(c, WS_FRAME, ob);
+    if (!sc || !d_p0 || !d_p1 || !d_p0r || !d_out) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    bool no_valid = false;
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
+                                &no_valid)))
+        return rc;
+    {
+        km_stage_timer t(c, ST_FRAME);
+        const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
+        if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out))) return rc;
+    }
+    KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.n_init = ((const int *)host_out)[1];
     return KM_OK;
 }
 

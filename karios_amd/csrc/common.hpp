@@ -31,6 +31,7 @@ enum km_stage {
     ST_PYRAMID,
     ST_LK,
     ST_ZNCC,
+    ST_FRAME,
     ST_COUNT
 };
 
@@ -66,6 +67,7 @@ enum km_slot {
     WS_FFT_A,
     WS_FFT_B,
     WS_FFT_WORK,
+    WS_FRAME,
     WS_COUNT
 };
 
@@ -179,6 +181,9 @@ struct km_pyr {
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n,
              int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
              float *d_p0r);
+// k_frame.hip
+int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
+             float x_off, float y_off, void *d_out);
 // k_zncc.hip
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
             int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,

@@ -65,6 +65,7 @@ class ResidentPair:
         self._owned = list(owned)
         self._out = None
         self._zbuf = None
+        self._host_frame = None
 
     @classmethod
     def upload(cls, mon: np.ndarray, ref: np.ndarray, mask: np.ndarray | None = None, ctx: Context | None = None,
@@ -146,11 +147,43 @@ class ResidentPair:
         if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto":
             raise KariosHipError("ResidentPair.match_tile: 'auto' modes are handled by karios_amd.matcher.KLT")
         x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
-        status, tracks = self.track_tile(conf, box, invert_mon=bool(conf.laplacian_invert_polarity))
-        if status != "ok":
-            return None
-        points, _ = _sorted_tile_frame(*tracks, conf, x_off=x_off, y_off=y_off)
-        return points
+        if getattr(conf, "outliers_filtering", False):
+            # the iterative 3-sigma filter (klt.py:52-71) runs on the host between the FB test and the sort
+            status, tracks = self.track_tile(conf, box, invert_mon=bool(conf.laplacian_invert_polarity))
+            if status != "ok":
+                return None
+            points, _ = _sorted_tile_frame(*tracks, conf, x_off=x_off, y_off=y_off)
+            return points
+        return self._match_tile_device_frame(conf, box, x_off, y_off)
+
+    def _match_tile_device_frame(self, conf, box, x_off, y_off) -> DataFrame | None:
+        """Tile pipeline + FB test + score + (x0, y0) ordering on the device, one D2H copy of the finished frame."""
+        c = self.ctx
+        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
+        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
+            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        mon_k, ref_k = KLT._resolve_ksize(conf.laplacian_kernel_size)
+        prm = make_params(conf, mon_k, ref_k, bool(conf.laplacian_invert_polarity))
+        cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
+        if self._host_frame is None or self._host_frame.size < 4 + 6 * cap:
+            self._host_frame = np.empty(4 + 6 * cap, np.float32)
+        buf = self._host_frame
+        es = self.dtype.itemsize
+        off = by_off * self.x_size + bx_off
+        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
+        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
+        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        c.check(c.lib.km_klt_tile_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
+                                            by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off), float(y_off),
+                                            buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_dev")
+        hdr = buf[:4].view(np.int32)
+        n, n_init = int(hdr[0]), int(hdr[1])
+        if n_init == 0:
+            return None           # no valid pixels / no features (klt.py:122-124, 276-279, 329-337)
+        body = buf[4:]
+        cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
+        index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
+        return DataFrame(cols, index=index, copy=False)
 
     def match(self, conf):
         """All tiles in the reference order (x outer, y inner; klt.py:220-232)."""

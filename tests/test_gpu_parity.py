@@ -238,3 +238,32 @@ def test_shift_image_matches_reference_semantics(ops, O):
         img = rng.integers(0, 200, (37, 53)).astype(dtype)
         for yo, xo in [(0, 0), (3, 0), (0, -4), (-5, 7), (2.6, -1.4), (40, 1), (1, -60)]:
             np.testing.assert_array_equal(ops.shift_image(img, yo, xo), O.shift_image(img, yo, xo))
+
+
+def test_resident_pair_device_frame_equals_host_frame(ops, O):
+    """ResidentPair.match_tile (FB test / score / ordering on the device, K8) == the reference-style numpy/pandas
+    assembly of the same tracks, row for row including the permuted index labels; tiles of a resident image."""
+    import pandas as pd
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.matcher.klt import KLT, _sorted_tile_frame
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(420, 500, 0.5, 0.25)
+    conf = KLTConfiguration(tile_size=260, maxCorners=700)
+    pair = ResidentPair.upload(mon, ref)
+    frames = list(pair.match(conf))
+    boxes = KLT(conf).tile_boxes(500, 420)
+    assert len(frames) == len(boxes) == 4
+    for f, (xo, yo, bx, by) in zip(frames, boxes):
+        status, tracks = pair.track_tile(conf, (xo, yo, bx, by))
+        exp, _ = _sorted_tile_frame(*tracks, conf, x_off=xo, y_off=yo)
+        pd.testing.assert_frame_equal(f, exp, check_exact=True)
+        o = O.klt_tile(mon[yo:yo + by, xo:xo + bx], ref[yo:yo + by, xo:xo + bx], conf, x_off=xo, y_off=yo)
+        np.testing.assert_array_equal(f["x0"].to_numpy(), o["x0"])
+        np.testing.assert_array_equal(f["score"].to_numpy(), o["score"])
+    scored = pair.score_frame(frames[0].copy(), 0.4)
+    z = O.zncc_batch(ref, mon, scored["x0"].to_numpy(), scored["y0"].to_numpy(), scored["dx"].to_numpy(), scored["dy"].to_numpy())
+    keep = scored["score"].to_numpy() >= 0.4
+    got = scored["zncc_score"].to_numpy()
+    assert np.all(np.isnan(got[~keep])) and np.nanmax(np.abs(got[keep] - z[keep])) <= 1e-9
+    flat = ResidentPair.upload(np.full((64, 64), 7, np.uint16), np.full((64, 64), 7, np.uint16))
+    assert flat.match_tile(KLTConfiguration()) is None

@@ -19,13 +19,11 @@ pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.
 conf = KLTConfiguration()
 for it in range(6):
     t = [time.perf_counter()]
-    status, tracks = pair.track_tile(conf); t.append(time.perf_counter())
-    frame, _ = _frame_from_tracks(*tracks, conf); t.append(time.perf_counter())
-    frame.sort_values(by=["x0", "y0"], inplace=True); t.append(time.perf_counter())
+    frame = pair.match_tile(conf); t.append(time.perf_counter())
     frame = pair.score_frame(frame, 0.4); t.append(time.perf_counter())
     if it >= 2:
-        names = ["track_tile(device+d2h)", "frame_from_tracks", "sort_values", "score_frame(zncc)"]
-        print("  ".join(f"{n}={1e3*(b-a):.3f}ms" for n, a, b in zip(names, t, t[1:])), f"total={1e3*(t[-1]-t[0]):.3f}ms")
+        names = ["match_tile(device frame)", "score_frame(zncc)"]
+        print("  ".join(f"{n}={1e3*(b-a):.3f}ms" for n, a, b in zip(names, t, t[1:])), f"total={1e3*(t[-1]-t[0]):.3f}ms", len(frame))
 ctx.set_profiling(True)
-pair.track_tile(conf)
+pair.match_tile(conf)
 print({k: round(v, 3) for k, v in ctx.stage_ms().items()})
