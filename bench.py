@@ -106,9 +106,9 @@ def main():
     pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
 
     def step():
-        frame = pair.match_tile(conf)
+        frame = pair.match_tile(conf, zncc_threshold=0.4)   # KLT tile + FB score + ZNCC in one device pipeline
         if frame is not None:
-            frame = pair.score_frame(frame, 0.4)
+            frame = pair.score_frame(frame, 0.4)               # radial error / angle columns (numpy, as the reference)
         if world > 1:
             frames = gather_frames({rank: frame}, world, conf.maxCorners, device=dev)
             return frame, sum(len(f) for f in frames if f is not None)

@@ -165,6 +165,15 @@ int km_klt_tile_frame_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int
                           ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
                           const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
                           float x_off, float y_off, void *host_out, int cap);
+/* Same, plus the ZNCC column of _handle_klt_results (core.py:876-893) for the rows with score >= zncc_threshold,
+ * computed on the FULL-resolution resident images (key points carry full-image coordinates through x_off / y_off).
+ * host_out: the layout above followed by cap float64 (NaN where not scored). */
+int km_klt_tile_frame_zncc_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
+                               ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
+                               const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                               float x_off, float y_off, const void *d_ref_full, const void *d_mon_full,
+                               int H_full, int W_full, ptrdiff_t stride_ref_full, ptrdiff_t stride_mon_full,
+                               double zncc_threshold, void *host_out, int cap);
 int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype,
                       int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
                       ptrdiff_t stride_mon, const float *d_x0, const float *d_y0,

@@ -612,37 +612,68 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
     return KM_OK;
 }
 
-int km_klt_tile_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                          const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
-                          float y_off, void *host_out, int cap)
+static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                           const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
+                           float y_off, const void *d_ref_full, const void *d_mon_full, int Hf, int Wf, ptrdiff_t sref_f, ptrdiff_t smon_f,
+                           bool with_zncc, double zncc_threshold, void *host_out, int cap)
 {
     int rc;
     if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
         (rc = check_image(c, d_mon, H, W, smon, "klt_tile_frame_dev")))
         return rc;
+    if (with_zncc && ((rc = check_image(c, d_ref_full, Hf, Wf, sref_f, "klt_tile_frame_zncc_dev")) ||
+                      (rc = check_image(c, d_mon_full, Hf, Wf, smon_f, "klt_tile_frame_zncc_dev"))))
+        return rc;
     if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: bad dtype %d", dtype);
     if (!host_out || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: null output");
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
+    c->ev_used[ST_ZNCC] = false;
     km_scalars *sc = scalars(c);
-    const size_t pb = (size_t)cap * 2 * sizeof(float), ob = 16 + (size_t)cap * 6 * sizeof(float);
+    const size_t pb = (size_t)cap * 2 * sizeof(float);
+    const size_t fb = 16 + (size_t)cap * 6 * sizeof(float), ob = fb + (with_zncc ? (size_t)cap * sizeof(double) : 0);
     float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
-    void *d_out = km_ws(c, WS_FRAME, ob);
+    char *d_out = (char *)km_ws(c, WS_FRAME, ob);
     if (!sc || !d_p0 || !d_p1 || !d_p0r || !d_out) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     bool no_valid = false;
     if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
                                 &no_valid)))
         return rc;
+    const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
     {
         km_stage_timer t(c, ST_FRAME);
-        const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
         if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out))) return rc;
+    }
+    if (with_zncc) {
+        km_stage_timer t(c, ST_ZNCC);
+        const float *f = (const float *)(d_out + 16);
+        if ((rc = kz_zncc_filtered(c, d_ref_full, d_mon_full, dtype, Hf, Wf, Hf, Wf, sref_f, smon_f, f, f + cap, f + 2 * (size_t)cap,
+                                   f + 3 * (size_t)cap, n_max, (const int *)d_out, f + 4 * (size_t)cap, (float)zncc_threshold,
+                                   (double *)(d_out + fb))))
+            return rc;
     }
     KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.n_init = ((const int *)host_out)[1];
     return KM_OK;
+}
+
+int km_klt_tile_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                          const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
+                          float y_off, void *host_out, int cap)
+{
+    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, x_off, y_off, nullptr, nullptr, 0, 0,
+                           0, 0, false, 0.0, host_out, cap);
+}
+
+int km_klt_tile_frame_zncc_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                               const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                               float x_off, float y_off, const void *d_ref_full, const void *d_mon_full, int Hf, int Wf, ptrdiff_t sref_f,
+                               ptrdiff_t smon_f, double zncc_threshold, void *host_out, int cap)
+{
+    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, x_off, y_off, d_ref_full, d_mon_full,
+                           Hf, Wf, sref_f, smon_f, true, zncc_threshold, host_out, cap);
 }
 
 int km_zncc_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,

@@ -188,6 +188,9 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
             int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,
             const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out);
+int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon,
+                     ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx,
+                     const float *d_dy, int n, const int *d_n, const float *d_score, float score_thr, double *d_out);
 // k_phase.hip
 int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W,
                    ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);

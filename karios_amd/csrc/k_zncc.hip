@@ -21,12 +21,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon,
                                                    int Wmon, ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0,
                                                    const float *__restrict__ y0, const float *__restrict__ dx,
-                                                   const float *__restrict__ dy, int n, double *__restrict__ out)
+                                                   const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                                   const float *__restrict__ score, float score_thr, double *__restrict__ out)
 {
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (k >= n) return;
+    if (k >= (d_n ? min(*d_n, n) : n)) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // rows below the confidence threshold are not scored (core.py:878-893): NaN, like the reference's column
+    if (score && !(score[k] >= score_thr)) { if (lane == 0) out[k] = nan; return; }
     const float fx0 = x0[k], fy0 = y0[k];
     const int X0 = (int)fx0, Y0 = (int)fy0;  // int(series["x0"])
     // round(np.float32 + np.float32): half-to-even on the f32 sum
@@ -69,9 +72,16 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
             ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out)
 {
+    return kz_zncc_filtered(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, nullptr, nullptr, 0.f, d_out);
+}
+
+int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
+                     ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, const int *d_n,
+                     const float *d_score, float score_thr, double *d_out)
+{
     if (n <= 0) return KM_OK;
     const int nb = (n + 3) / 4;
-#define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_out)
+#define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out)
     switch (dtype) {
     case KM_U8: KM_Z(uint8_t); break;
     case KM_U16: KM_Z(uint16_t); break;

@@ -109,7 +109,8 @@ def match_distributed(pairs: dict, n_bands: int, x_size: int, y_size: int, conf,
     units = enumerate_units(n_bands, x_size, y_size, conf)
     local = {}
     for u in units_of_rank(units, rank, ws):
-        frame = pairs[u.band].match_tile(conf, (u.x_off, u.y_off, u.x_size, u.y_size))
+        frame = pairs[u.band].match_tile(conf, (u.x_off, u.y_off, u.x_size, u.y_size),
+                                         zncc_threshold=confidence_threshold if score else None)
         if frame is not None and score:
             frame = pairs[u.band].score_frame(frame, confidence_threshold)
         local[u.index] = frame

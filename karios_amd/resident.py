@@ -141,9 +141,10 @@ class ResidentPair:
             c.check(c.lib.km_d2h(c.handle, pts[i].ctypes.data_as(C.c_void_p), C.c_void_p(d), n * 8), "km_d2h")
         return "ok", tuple(p.reshape(-1, 1, 2) for p in pts)
 
-    def match_tile(self, conf, box=None) -> DataFrame | None:
+    def match_tile(self, conf, box=None, zncc_threshold=None) -> DataFrame | None:
         """One tile of `KLT.match` (reference klt.py:236-349) on resident data; fixed kernel size and
-        polarity (the 'auto' modes go through `karios_amd.matcher.KLT`)."""
+        polarity (the 'auto' modes go through `karios_amd.matcher.KLT`).  With `zncc_threshold` the frame also
+        carries the `zncc_score` column of `_handle_klt_results` (core.py:876-893) computed in the same device call."""
         if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto":
             raise KariosHipError("ResidentPair.match_tile: 'auto' modes are handled by karios_amd.matcher.KLT")
         x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
@@ -153,10 +154,16 @@ class ResidentPair:
             if status != "ok":
                 return None
             points, _ = _sorted_tile_frame(*tracks, conf, x_off=x_off, y_off=y_off)
+            if zncc_threshold is not None:
+                keep = points["score"].to_numpy() >= zncc_threshold
+                z = np.full(len(points), np.nan)
+                if keep.any():
+                    z[keep] = self.zncc(*(points[c].to_numpy()[keep] for c in ("x0", "y0", "dx", "dy")))
+                points["zncc_score"] = z
             return points
-        return self._match_tile_device_frame(conf, box, x_off, y_off)
+        return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold)
 
-    def _match_tile_device_frame(self, conf, box, x_off, y_off) -> DataFrame | None:
+    def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None) -> DataFrame | None:
         """Tile pipeline + FB test + score + (x0, y0) ordering on the device, one D2H copy of the finished frame."""
         c = self.ctx
         bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
@@ -165,17 +172,24 @@ class ResidentPair:
         mon_k, ref_k = KLT._resolve_ksize(conf.laplacian_kernel_size)
         prm = make_params(conf, mon_k, ref_k, bool(conf.laplacian_invert_polarity))
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
-        if self._host_frame is None or self._host_frame.size < 4 + 6 * cap:
-            self._host_frame = np.empty(4 + 6 * cap, np.float32)
+        if self._host_frame is None or self._host_frame.size < 4 + 8 * cap:
+            self._host_frame = np.empty(4 + 8 * cap, np.float32)
         buf = self._host_frame
         es = self.dtype.itemsize
         off = by_off * self.x_size + bx_off
         mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
         nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
         nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
-        c.check(c.lib.km_klt_tile_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                            by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off), float(y_off),
-                                            buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_dev")
+        if zncc_threshold is None:
+            c.check(c.lib.km_klt_tile_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
+                                                by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off), float(y_off),
+                                                buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_dev")
+        else:
+            c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es),
+                                                     self.code, by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off),
+                                                     float(y_off), C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.y_size,
+                                                     self.x_size, self.x_size, self.x_size, float(zncc_threshold),
+                                                     buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
         hdr = buf[:4].view(np.int32)
         n, n_init = int(hdr[0]), int(hdr[1])
         if n_init == 0:
@@ -183,6 +197,8 @@ class ResidentPair:
         body = buf[4:]
         cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
         index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
+        if zncc_threshold is not None:
+            cols["zncc_score"] = body[6 * cap:8 * cap].view(np.float64)[:n].copy()
         return DataFrame(cols, index=index, copy=False)
 
     def match(self, conf):
@@ -220,6 +236,8 @@ class ResidentPair:
         dx, dy, score = frame["dx"].to_numpy(), frame["dy"].to_numpy(), frame["score"].to_numpy()
         frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
         frame["angle"] = np.degrees(np.arctan2(dy, dx))
+        if "zncc_score" in frame.columns:   # already scored on the device (match_tile(..., zncc_threshold=...))
+            return frame
         keep = score >= confidence_threshold
         z = np.full(len(frame), np.nan, np.float64)
         if keep.any():

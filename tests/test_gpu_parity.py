@@ -260,7 +260,10 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
         o = O.klt_tile(mon[yo:yo + by, xo:xo + bx], ref[yo:yo + by, xo:xo + bx], conf, x_off=xo, y_off=yo)
         np.testing.assert_array_equal(f["x0"].to_numpy(), o["x0"])
         np.testing.assert_array_equal(f["score"].to_numpy(), o["score"])
+    fused = pair.match_tile(conf, boxes[0], zncc_threshold=0.4)
     scored = pair.score_frame(frames[0].copy(), 0.4)
+    np.testing.assert_array_equal(fused["zncc_score"].to_numpy(), scored["zncc_score"].to_numpy())
+    assert list(pair.score_frame(fused, 0.4).columns) == ["x0", "y0", "dx", "dy", "score", "zncc_score", "radial error", "angle"]
     z = O.zncc_batch(ref, mon, scored["x0"].to_numpy(), scored["y0"].to_numpy(), scored["dx"].to_numpy(), scored["dy"].to_numpy())
     keep = scored["score"].to_numpy() >= 0.4
     got = scored["zncc_score"].to_numpy()

@@ -19,7 +19,7 @@ pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.
 conf = KLTConfiguration()
 for it in range(6):
     t = [time.perf_counter()]
-    frame = pair.match_tile(conf); t.append(time.perf_counter())
+    frame = pair.match_tile(conf, zncc_threshold=0.4); t.append(time.perf_counter())
     frame = pair.score_frame(frame, 0.4); t.append(time.perf_counter())
     if it >= 2:
         names = ["match_tile(device frame)", "score_frame(zncc)"]
