@@ -201,10 +201,11 @@ static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride,
 
 static km_scalars *scalars(km_ctx *c) { return (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars)); }
 
-// pyramid of a dense u8 device image: level 0 = the image, levels >= 1 in workspace `slot`
-static int build_pyramid(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, int slot, km_pyr *P)
+// both pyramids of a pair, one launch per level
+static int build_pyramid_pair(km_ctx *c, const uint8_t *d_a, const uint8_t *d_b, int H, int W, int win, int max_level, km_pyr *A, km_pyr *B)
 {
-    P->img[0] = d_img; P->H[0] = H; P->W[0] = W; P->levels = 0;
+    A->img[0] = d_a; B->img[0] = d_b;
+    A->H[0] = B->H[0] = H; A->W[0] = B->W[0] = W; A->levels = B->levels = 0;
     if (max_level > 4) max_level = 4;
     size_t total = 0;
     int w = W, h = H, nl = 0;
@@ -217,17 +218,17 @@ static int build_pyramid(km_ctx *c, const uint8_t *d_img, int H, int W, int win,
         w = nw; h = nh;
     }
     if (nl == 0) return KM_OK;
-    uint8_t *base = (uint8_t *)km_ws(c, slot, total);
-    if (!base) return KM_E_NOMEM;
+    uint8_t *ba = (uint8_t *)km_ws(c, WS_PYR_A, total), *bb = (uint8_t *)km_ws(c, WS_PYR_B, total);
+    if (!ba || !bb) return KM_E_NOMEM;
     size_t off = 0;
     for (int l = 1; l <= nl; l++) {
-        uint8_t *dst = base + off;
-        int rc = kd_pyrdown_u8(c, P->img[l - 1], P->H[l - 1], P->W[l - 1], dst);
+        int rc = kd_pyrdown_u8_pair(c, A->img[l - 1], B->img[l - 1], A->H[l - 1], A->W[l - 1], ba + off, bb + off);
         if (rc) return rc;
-        P->img[l] = dst; P->H[l] = hs[l]; P->W[l] = wsz[l];
+        A->img[l] = ba + off; B->img[l] = bb + off;
+        A->H[l] = B->H[l] = hs[l]; A->W[l] = B->W[l] = wsz[l];
         off += ((size_t)wsz[l] * hs[l] + 255) & ~(size_t)255;
     }
-    P->levels = nl;
+    A->levels = B->levels = nl;
     return KM_OK;
 }
 
@@ -264,6 +265,25 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
     }
     c->stats.n_candidates = ncand;
     unsigned long long *keys = (unsigned long long *)c->ws[WS_KEYS0].p;
+    // Strongest-first shortcut: rank and select on the top slice only; fall back to the full list when that slice
+    // cannot supply maxCorners corners (the slice is a rank prefix, so a sufficient slice gives the exact result).
+    const size_t k_target = max_corners > 0 ? (size_t)max_corners * 8 : 0;
+    if (k_target && (size_t)ncand > 4 * k_target && min_distance >= 1) {
+        unsigned long long *kept = nullptr, *sorted_kept = nullptr;
+        size_t nkept = 0;
+        int found = -1;
+        {
+            km_stage_timer t(c, ST_SORT);
+            if ((rc = ks_topk_prefilter(c, keys, ncand, k_target, sc, &kept, &nkept))) return rc;
+            if ((rc = ks_sort_keys_desc(c, kept, nkept, &sorted_kept))) return rc;
+        }
+        {
+            km_stage_timer t(c, ST_SELECT);
+            if ((rc = ks_select(c, sorted_kept, nkept, H, W, max_corners, min_distance, d_xy, cap, sc, &found))) return rc;
+        }
+        if (found >= max_corners || nkept >= ncand) return KM_OK;
+        // not enough corners in the slice: redo on the complete list
+    }
     unsigned long long *sorted = keys;
     if (ncand > 0) {
         km_stage_timer t(c, ST_SORT);
@@ -271,7 +291,7 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
     }
     {
         km_stage_timer t(c, ST_SELECT);
-        if ((rc = ks_select(c, sorted, ncand, H, W, max_corners, min_distance, d_xy, cap, sc))) return rc;
+        if ((rc = ks_select(c, sorted, ncand, H, W, max_corners, min_distance, d_xy, cap, sc, nullptr))) return rc;
     }
     return KM_OK;
 }
@@ -309,8 +329,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     km_pyr A, B;
     {
         km_stage_timer t(c, ST_PYRAMID);
-        if ((rc = build_pyramid(c, d_ref_lap, H, W, prm->win_size, prm->max_level, WS_PYR_A, &A))) return rc;
-        if ((rc = build_pyramid(c, d_mon_lap, H, W, prm->win_size, prm->max_level, WS_PYR_B, &B))) return rc;
+        if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
     }
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
@@ -504,9 +523,7 @@ int km_pyrlk(km_ctx *c, const uint8_t *prev, const uint8_t *next, int H, int W, 
     if (!d_in || !d_out) return KM_E_NOMEM;
     KM_HIP(c, hipMemcpyAsync(d_in, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     km_pyr A, B;
-    if ((rc = build_pyramid(c, (const uint8_t *)d_prev, H, W, win, max_level, WS_PYR_A, &A)) ||
-        (rc = build_pyramid(c, (const uint8_t *)d_next, H, W, win, max_level, WS_PYR_B, &B)))
-        return rc;
+    if ((rc = build_pyramid_pair(c, (const uint8_t *)d_prev, (const uint8_t *)d_next, H, W, win, max_level, &A, &B))) return rc;
     if ((rc = kl_track(c, A, B, d_in, nullptr, n, win, max_count, epsilon, false, d_out, nullptr))) return rc;
     KM_HIP(c, hipMemcpyAsync(out_pts, d_out, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));

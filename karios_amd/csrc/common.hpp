@@ -166,12 +166,15 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
                   double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap);
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);
+int kd_pyrdown_u8_pair(km_ctx *c, const uint8_t *d_src_a, const uint8_t *d_src_b, int H, int W, uint8_t *d_dst_a, uint8_t *d_dst_b);
 int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride,
                    int y_off, int x_off, void *d_out);
 // k_select.hip
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted);
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W,
-              int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc);
+              int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found);
+int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t n, size_t k_target, const km_scalars *d_sc,
+                      unsigned long long **d_kept, size_t *n_kept);
 // k_lk.hip
 struct km_pyr {
     const uint8_t *img[5];

@@ -1192,47 +1192,107 @@ int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, i
 
 // ------------------------------------------------------------------ K6 pyrDown
 // cv::pyrDown u8: separable [1 4 6 4 1], (sum + 128) >> 8, REFLECT_101, dst = ((W+1)/2, (H+1)/2).
-#define PYR_TW 64
-#define PYR_TH 16
-__global__ __launch_bounds__(256) void pyrdown_kernel(const uint8_t *__restrict__ src, int H, int W, uint8_t *__restrict__ dst,
-                                                      int dh, int dw)
+// Each thread owns 4 adjacent output columns and marches down PYR_RS output rows with a 5-deep register ring
+// of horizontal sums (two new source rows per output row, loaded one step ahead as 4 aligned dwords each).
+// Both images of a pair are processed by one launch (blockIdx.z).
+#define PYR_RS 32
+
+struct pyr_pair {
+    const uint8_t *src[2];
+    uint8_t *dst[2];
+};
+
+// horizontal [1 4 6 4 1] sums of 4 outputs from 16 source bytes starting at source column 8q-4
+__device__ __forceinline__ void pyr_hsum(const uint32_t (&w)[4], int (&h)[4])
 {
-    // source rows needed: 2*Y0-2 .. 2*(Y0+TH-1)+2  -> 2*TH+3 rows; horizontal pass result kept in LDS
-    __shared__ unsigned short hrow[2 * PYR_TH + 3][PYR_TW];
-    const int X0 = blockIdx.x * PYR_TW, Y0 = blockIdx.y * PYR_TH;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < (2 * PYR_TH + 3) * PYR_TW; i += 256) {
-        const int r = i / PYR_TW, cx = i - r * PYR_TW;
-        const int ox = X0 + cx;
-        unsigned short s = 0;
-        if (ox < dw) {
-            const uint8_t *row = src + (size_t)km_reflect101(2 * Y0 - 2 + r, H) * W;
-            const int sx = 2 * ox;
-            if (sx - 2 >= 0 && sx + 2 < W)
-                s = (unsigned short)(row[sx - 2] + 4 * row[sx - 1] + 6 * row[sx] + 4 * row[sx + 1] + row[sx + 2]);
-            else
-                s = (unsigned short)(row[km_reflect101(sx - 2, W)] + 4 * row[km_reflect101(sx - 1, W)] + 6 * row[km_reflect101(sx, W)] +
-                                     4 * row[km_reflect101(sx + 1, W)] + row[km_reflect101(sx + 2, W)]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int b = 2 * j + i + 2;   // byte index within the 16 loaded bytes
+            const int coef = i == 0 || i == 4 ? 1 : (i == 2 ? 6 : 4);
+            s += coef * (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
         }
-        hrow[r][cx] = s;
+        h[j] = s;
     }
-    __syncthreads();
-    for (int i = tid; i < PYR_TH * PYR_TW; i += 256) {
-        const int r = i / PYR_TW, cx = i - r * PYR_TW;
-        const int ox = X0 + cx, oy = Y0 + r;
-        if (ox >= dw || oy >= dh) continue;
-        const int s = hrow[2 * r][cx] + 4 * hrow[2 * r + 1][cx] + 6 * hrow[2 * r + 2][cx] + 4 * hrow[2 * r + 3][cx] + hrow[2 * r + 4][cx];
-        dst[(size_t)oy * dw + ox] = (uint8_t)((s + 128) >> 8);
+}
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
+{
+    const uint8_t *__restrict__ src = pp.src[blockIdx.z];
+    uint8_t *__restrict__ dst = pp.dst[blockIdx.z];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const int y0 = blockIdx.y * PYR_RS, y1 = min(dh, y0 + PYR_RS);
+    const int sx0 = 8 * q - 4;                                  // first source byte loaded
+    const bool fast = (W % 4 == 0) && ((uintptr_t)src % 4 == 0) && sx0 >= 0 && sx0 + 16 <= W;
+    auto load_row = [&](int sy, uint32_t (&w)[4]) {
+        const uint8_t *row = src + (size_t)km_reflect101(sy, H) * W;
+        if (fast) {
+            const uint32_t *p = (const uint32_t *)(row + sx0);
+            w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= (uint32_t)row[km_reflect101(sx0 + 4 * k + b, W)] << (8 * b);
+                w[k] = v;
+            }
+        }
+    };
+    // ring of horizontal sums for source rows 2y-2 .. 2y+2
+    int h0[4], h1[4], h2[4], h3[4], h4[4];
+    uint32_t wa[4], wb[4];
+    load_row(2 * y0 - 2, wa); pyr_hsum(wa, h0);
+    load_row(2 * y0 - 1, wa); pyr_hsum(wa, h1);
+    load_row(2 * y0, wa); pyr_hsum(wa, h2);
+    load_row(2 * y0 + 1, wa);
+    load_row(2 * y0 + 2, wb);
+    for (int y = y0; y < y1; y++) {
+        pyr_hsum(wa, h3);
+        pyr_hsum(wb, h4);
+        if (y + 1 < y1) { load_row(2 * y + 3, wa); load_row(2 * y + 4, wb); }   // next step's rows, in flight during the math
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s = h0[j] + 4 * h1[j] + 6 * h2[j] + 4 * h3[j] + h4[j];
+            packed |= (uint32_t)((s + 128) >> 8) << (8 * j);
+        }
+        const int ox = 4 * q;
+        const size_t o = (size_t)y * dw + ox;
+        if (ox + 3 < dw && (((uintptr_t)dst + o) & 3) == 0) *(uint32_t *)(dst + o) = packed;
+        else {
+            for (int j = 0; j < 4 && ox + j < dw; j++) dst[o + j] = (uint8_t)(packed >> (8 * j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { h0[j] = h2[j]; h1[j] = h3[j]; h2[j] = h4[j]; }
     }
+}
+
+static int launch_pyrdown(km_ctx *c, const pyr_pair &pp, int nimg, int H, int W)
+{
+    const int dh = (H + 1) / 2, dw = (W + 1) / 2;
+    const int nquads = (dw + 3) / 4;
+    dim3 grid((nquads + 255) / 256, (dh + PYR_RS - 1) / PYR_RS, nimg);
+    pyrdown_kernel<<<grid, 256, 0, c->stream>>>(pp, H, W, dh, dw, nquads);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
 }
 
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst)
 {
-    const int dh = (H + 1) / 2, dw = (W + 1) / 2;
-    dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH);
-    pyrdown_kernel<<<grid, 256, 0, c->stream>>>(d_src, H, W, d_dst, dh, dw);
-    KM_LAUNCH_CHECK(c);
-    return KM_OK;
+    pyr_pair pp;
+    pp.src[0] = pp.src[1] = d_src; pp.dst[0] = pp.dst[1] = d_dst;
+    return launch_pyrdown(c, pp, 1, H, W);
+}
+
+int kd_pyrdown_u8_pair(km_ctx *c, const uint8_t *d_src_a, const uint8_t *d_src_b, int H, int W, uint8_t *d_dst_a, uint8_t *d_dst_b)
+{
+    pyr_pair pp;
+    pp.src[0] = d_src_a; pp.src[1] = d_src_b; pp.dst[0] = d_dst_a; pp.dst[1] = d_dst_b;
+    return launch_pyrdown(c, pp, 2, H, W);
 }
 
 // ------------------------------------------------------------------ K11 integer shift

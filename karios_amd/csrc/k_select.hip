@@ -140,6 +140,111 @@ __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long 
     }
 }
 
+// ---- top-K pre-filter: only the strongest candidates can reach the first maxCorners corners, so the full
+// candidate list (several 10^6 keys) is cut down before the radix sort.  Values are binned by the distance of
+// their top 18 float bits from the maximum's (bins of ~0.2 %); the smallest bin bound D with at least K_target
+// candidates above it defines the kept set, which is a rank prefix of the full list.
+#define TK_NB 2048
+#define TK_SHIFT 14
+
+__device__ __forceinline__ unsigned tk_bin(unsigned long long key, unsigned top)
+{
+    const unsigned b = (unsigned)(key >> (32 + TK_SHIFT));
+    const unsigned d = top > b ? top - b : 0u;
+    return d < TK_NB - 1 ? d : TK_NB - 1;
+}
+
+__global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long *__restrict__ keys, unsigned n, const km_scalars *sc,
+                                                       unsigned *__restrict__ hist)
+{
+    __shared__ unsigned h[TK_NB];
+    for (int i = threadIdx.x; i < TK_NB; i += 1024) h[i] = 0;
+    __syncthreads();
+    const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> TK_SHIFT;   // max eig > 0: ordered key = bits | 0x80000000
+    // the clamp bin collects the bulk of the (weak) candidates: count it per wave, not per lane
+    unsigned tail = 0;
+    for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
+        const unsigned i = b + threadIdx.x;
+        const unsigned d = i < n ? tk_bin(keys[i], top) : 0xffffffffu;
+        const bool is_tail = d == TK_NB - 1;
+        tail += (unsigned)__popcll(__ballot(is_tail));
+        if (d < TK_NB - 1) atomicAdd(&h[d], 1u);
+    }
+    if ((threadIdx.x & 63) == 0 && tail) atomicAdd(&h[TK_NB - 1], tail);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TK_NB; i += 1024)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// hist[TK_NB] -> cut[0] = D (largest kept bin), cut[1] = number of kept keys
+__global__ __launch_bounds__(1024) void tk_cut_kernel(const unsigned *__restrict__ hist, unsigned k_target, unsigned *__restrict__ cut)
+{
+    __shared__ unsigned cum[TK_NB];
+    const int t = threadIdx.x;
+    // two bins per thread, serial prefix by thread 0 over 2048 entries would do as well; keep it simple and exact
+    cum[t] = hist[t]; cum[t + 1024] = hist[t + 1024];
+    __syncthreads();
+    if (t == 0) {
+        unsigned run = 0, D = TK_NB - 1, kept = 0;
+        bool found = false;
+        for (int i = 0; i < TK_NB; i++) {
+            run += cum[i];
+            if (!found && run >= k_target) { D = i; kept = run; found = true; }
+        }
+        if (!found) kept = run;
+        cut[0] = D; cut[1] = kept; cut[2] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long long *__restrict__ keys, unsigned n, const km_scalars *sc,
+                                                          unsigned *cut, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_base;
+    const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> TK_SHIFT;
+    const unsigned D = cut[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
+        const unsigned i = b + threadIdx.x;
+        unsigned long long k = 0;
+        bool keep = false;
+        if (i < n) { k = keys[i]; keep = tk_bin(k, top) <= D; }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned off = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { const unsigned cn = s_wave[w]; if (w < wv) off += cn; tot += cn; }
+        if (threadIdx.x == 0 && tot) s_base = atomicAdd(&cut[2], tot);
+        __syncthreads();
+        if (keep) out[s_base + off + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+    }
+}
+
+// keeps (at least) the k_target strongest keys: *d_kept / *n_kept; one host synchronisation
+int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t n, size_t k_target, const km_scalars *d_sc,
+                      unsigned long long **d_kept, size_t *n_kept)
+{
+    unsigned *hist = (unsigned *)km_ws(c, WS_GRID, (TK_NB + 4) * sizeof(unsigned));
+    if (!hist) return KM_E_NOMEM;
+    unsigned *cut = hist + TK_NB;
+    KM_HIP(c, hipMemsetAsync(hist, 0, (TK_NB + 4) * sizeof(unsigned), c->stream));
+    tk_hist_kernel<<<256, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, hist);
+    KM_LAUNCH_CHECK(c);
+    tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, (unsigned)k_target, cut);
+    KM_LAUNCH_CHECK(c);
+    unsigned hc[3] = {0, 0, 0};
+    KM_HIP(c, hipMemcpyAsync(hc, cut, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t kept = hc[1];
+    unsigned long long *out = (unsigned long long *)km_ws(c, WS_MISC3, (kept + 16) * sizeof(unsigned long long));
+    if (!out) return KM_E_NOMEM;
+    tk_compact_kernel<<<256, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, cut, out);
+    KM_LAUNCH_CHECK(c);
+    *d_kept = out; *n_kept = kept;
+    return KM_OK;
+}
+
 // minDistance < 1: the first maxCorners ranked candidates (featureselect.cpp else-branch)
 __global__ __launch_bounds__(256) void take_first_kernel(const unsigned long long *__restrict__ keys, unsigned n, int W, int max_corners,
                                                          int cap, float *__restrict__ out_xy, km_scalars *sc)
@@ -155,8 +260,9 @@ __global__ __launch_bounds__(256) void take_first_kernel(const unsigned long lon
 }
 
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W, int max_corners, double min_distance,
-              float *d_xy, int cap, km_scalars *d_sc)
+              float *d_xy, int cap, km_scalars *d_sc, int *n_found)
 {
+    if (n_found) *n_found = -1;  // -1: not read back
     if (n > 0xfffffff0ull) return km_fail(c, KM_E_UNSUPPORTED, "too many candidates");
     if (n == 0) {
         KM_HIP(c, hipMemsetAsync(&d_sc->n_corners, 0, 2 * sizeof(int), c->stream));
@@ -219,10 +325,12 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
         KM_HIP(c, rocprim::exclusive_scan(tmp, sk, flag, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
         sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
         KM_LAUNCH_CHECK(c);
-        if (k1 == N) break;
+        if (k1 == N && !n_found) break;
         int got = 0;
         KM_HIP(c, hipMemcpyAsync(&got, &d_sc->n_corners, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         KM_HIP(c, hipStreamSynchronize(c->stream));
+        if (n_found) *n_found = got;
+        if (k1 == N) break;
         if (max_corners > 0 && got >= max_corners) break;
         k0 = k1;
         k1 = (unsigned)((size_t)k1 * 4 < n ? (size_t)k1 * 4 : n);
