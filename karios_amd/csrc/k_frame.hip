@@ -17,51 +17,50 @@
 
 #define FB_T 1024
 
-// stable compaction of the kept points by one workgroup (n <= a few 10^4): rank = position in p0 order
+// stable compaction of the kept points (rank = position in p0 order): pass 1 counts per workgroup, pass 2 writes
+template <bool WRITE>
 __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
                                                           const float *__restrict__ p0r, const int *__restrict__ d_n, int n_max,
                                                           float back_thr, float x_off, float y_off, unsigned long long *__restrict__ keys,
                                                           unsigned *__restrict__ ranks, float *__restrict__ tmp /* 5*cap */, int cap,
-                                                          int *__restrict__ hdr)
+                                                          int *__restrict__ hdr, unsigned *__restrict__ counts)
 {
     __shared__ int s_wave[FB_T / 64];
-    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(d_n ? *d_n : n_max, n_max);
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int b = 0; b < n; b += FB_T) {
-        const int i = b + tid;
-        bool keep = false;
-        float x0 = 0, y0 = 0, x1 = 0, y1 = 0, d = 0;
-        if (i < n) {
-            x0 = p0[2 * i]; y0 = p0[2 * i + 1]; x1 = p1[2 * i]; y1 = p1[2 * i + 1];
-            d = fmaxf(fabsf(__fsub_rn(x0, p0r[2 * i])), fabsf(__fsub_rn(y0, p0r[2 * i + 1])));
-            keep = d < back_thr;   // NaN compares false, like numpy
-        }
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_wave[wv] = __popcll(bal);
-        __syncthreads();
-        int off = 0, tot = 0;
-        for (int k = 0; k < FB_T / 64; k++) { const int cnt = s_wave[k]; if (k < wv) off += cnt; tot += cnt; }
-        const int base = s_base;
-        if (keep) {
-            const int r = base + off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (r < cap) {
-                const float gx = __fadd_rn(x0, x_off), gy = __fadd_rn(y0, y_off);
-                tmp[r] = gx; tmp[cap + r] = gy;
-                tmp[2 * cap + r] = __fsub_rn(x1, x0); tmp[3 * cap + r] = __fsub_rn(y1, y0);
-                tmp[4 * cap + r] = __fsub_rn(1.0f, d / back_thr);
-                // (x0, y0) are integer-valued and non-negative: the u64 key orders exactly like the float pair
-                keys[r] = ((unsigned long long)(unsigned)(int)gx << 32) | (unsigned long long)(unsigned)(int)gy;
-                ranks[r] = (unsigned)r;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_base = base + tot;
-        __syncthreads();
+    const int i = blockIdx.x * FB_T + tid;
+    bool keep = false;
+    float x0 = 0, y0 = 0, x1 = 0, y1 = 0, d = 0;
+    if (i < n) {
+        x0 = p0[2 * i]; y0 = p0[2 * i + 1];
+        d = fmaxf(fabsf(__fsub_rn(x0, p0r[2 * i])), fabsf(__fsub_rn(y0, p0r[2 * i + 1])));
+        keep = d < back_thr;   // NaN compares false, like numpy
+        if (WRITE) { x1 = p1[2 * i]; y1 = p1[2 * i + 1]; }
     }
-    if (tid == 0) { hdr[0] = min(s_base, cap); hdr[1] = n; }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < FB_T / 64; k++) { const int cnt = s_wave[k]; if (k < wv) off += cnt; tot += cnt; }
+    if (!WRITE) {
+        if (tid == 0) counts[blockIdx.x] = (unsigned)tot;
+        return;
+    }
+    int base = 0;
+    for (unsigned b = 0; b < blockIdx.x; b++) base += (int)counts[b];
+    if (keep) {
+        const int r = base + off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (r < cap) {
+            const float gx = __fadd_rn(x0, x_off), gy = __fadd_rn(y0, y_off);
+            tmp[r] = gx; tmp[cap + r] = gy;
+            tmp[2 * cap + r] = __fsub_rn(x1, x0); tmp[3 * cap + r] = __fsub_rn(y1, y0);
+            tmp[4 * cap + r] = __fsub_rn(1.0f, d / back_thr);
+            // (x0, y0) are integer-valued and non-negative: the u64 key orders exactly like the float pair
+            keys[r] = ((unsigned long long)(unsigned)(int)gx << 32) | (unsigned long long)(unsigned)(int)gy;
+            ranks[r] = (unsigned)r;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) { hdr[0] = min(base + tot, cap); hdr[1] = n; hdr[2] = 0; hdr[3] = 0; }
 }
 
 __global__ __launch_bounds__(256) void fb_gather_kernel(const unsigned *__restrict__ order, const float *__restrict__ tmp, int cap,
@@ -91,7 +90,12 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     unsigned *ranks_alt = ranks + cap;
     // an over-long sort is avoided by sorting `cap` slots with sentinel keys behind the kept ones
     KM_HIP(c, hipMemsetAsync(keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
-    fb_compact_kernel<<<1, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr);
+    const int nblk = (n_max + FB_T - 1) / FB_T;
+    unsigned *counts = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)nblk * sizeof(unsigned));
+    if (!counts) return KM_E_NOMEM;
+    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts);
+    KM_LAUNCH_CHECK(c);
+    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts);
     KM_LAUNCH_CHECK(c);
     size_t tmp_bytes = 0;
     const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);

@@ -179,21 +179,32 @@ __global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long 
 // hist[TK_NB] -> cut[0] = D (largest kept bin), cut[1] = number of kept keys
 __global__ __launch_bounds__(1024) void tk_cut_kernel(const unsigned *__restrict__ hist, unsigned k_target, unsigned *__restrict__ cut)
 {
-    __shared__ unsigned cum[TK_NB];
-    const int t = threadIdx.x;
-    // two bins per thread, serial prefix by thread 0 over 2048 entries would do as well; keep it simple and exact
-    cum[t] = hist[t]; cum[t + 1024] = hist[t + 1024];
-    __syncthreads();
-    if (t == 0) {
-        unsigned run = 0, D = TK_NB - 1, kept = 0;
-        bool found = false;
-        for (int i = 0; i < TK_NB; i++) {
-            run += cum[i];
-            if (!found && run >= k_target) { D = i; kept = run; found = true; }
-        }
-        if (!found) kept = run;
-        cut[0] = D; cut[1] = kept; cut[2] = 0;
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_first;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned a = hist[2 * t], b = hist[2 * t + 1];
+    // inclusive scan of the pair sums across the workgroup
+    unsigned v = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(v, o);
+        if (lane >= o) v += u;
     }
+    if (lane == 63) s_wave[wv] = v;
+    if (t == 0) s_first = 0xffffffffu;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wv) base += s_wave[w]; total += s_wave[w]; }
+    const unsigned incl_b = base + v, incl_a = incl_b - b;     // cumulative counts through bins 2t and 2t+1
+    // first bin whose cumulative count reaches k_target
+    unsigned mine = 0xffffffffu;
+    if (incl_a >= k_target) mine = 2 * t;
+    else if (incl_b >= k_target) mine = 2 * t + 1;
+    if (mine != 0xffffffffu) atomicMin(&s_first, mine);
+    __syncthreads();
+    const unsigned D = s_first == 0xffffffffu ? TK_NB - 1 : s_first;
+    if (D == (unsigned)(2 * t)) { cut[0] = D; cut[1] = incl_a; cut[2] = 0; }
+    else if (D == (unsigned)(2 * t + 1)) { cut[0] = D; cut[1] = s_first == 0xffffffffu ? total : incl_b; cut[2] = 0; }
 }
 
 __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long long *__restrict__ keys, unsigned n, const km_scalars *sc,
@@ -239,7 +250,7 @@ int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t n, siz
     const size_t kept = hc[1];
     unsigned long long *out = (unsigned long long *)km_ws(c, WS_MISC3, (kept + 16) * sizeof(unsigned long long));
     if (!out) return KM_E_NOMEM;
-    tk_compact_kernel<<<256, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, cut, out);
+    tk_compact_kernel<<<1024, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, cut, out);
     KM_LAUNCH_CHECK(c);
     *d_kept = out; *n_kept = kept;
     return KM_OK;
