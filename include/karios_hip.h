@@ -148,12 +148,13 @@ int km_shift_image(km_ctx *ctx, const void *img, int elem_size, int H, int W,
                    ptrdiff_t stride, int y_off, int x_off, void *out);
 
 /* ---- device-resident pipeline (inputs already in HBM) -------------------- */
-/* same as km_klt_tile with d_ref/d_mon/d_mask device pointers; outputs are device
+/* same as km_klt_tile with d_ref/d_mon/d_mask device pointers (the mask, if any, has its own row stride:
+ * a box of a full-resolution resident mask); outputs are device
  * pointers too (each 2*cap floats) plus a device int for the count.  Asynchronous on
  * the context stream; call km_ctx_sync before reading results. */
 int km_klt_tile_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H,
                     int W, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
-                    const uint8_t *d_mask, const double *nodata_ref,
+                    const uint8_t *d_mask, ptrdiff_t stride_mask, const double *nodata_ref,
                     const double *nodata_mon, const km_klt_params *prm, float *d_p0,
                     float *d_p1, float *d_p0r, int cap, int *d_n);
 /* KLT._match_tile end to end on resident data (klt.py:236-349): km_klt_tile_dev, then the forward-backward
@@ -163,15 +164,15 @@ int km_klt_tile_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype
  * The optional 3-sigma outlier filter (klt.py:161-163) is not applied here. */
 int km_klt_tile_frame_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
                           ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
-                          const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
-                          float x_off, float y_off, void *host_out, int cap);
+                          ptrdiff_t stride_mask, const double *nodata_ref, const double *nodata_mon,
+                          const km_klt_params *prm, float x_off, float y_off, void *host_out, int cap);
 /* Same, plus the ZNCC column of _handle_klt_results (core.py:876-893) for the rows with score >= zncc_threshold,
  * computed on the FULL-resolution resident images (key points carry full-image coordinates through x_off / y_off).
  * host_out: the layout above followed by cap float64 (NaN where not scored). */
 int km_klt_tile_frame_zncc_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
                                ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
-                               const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
-                               float x_off, float y_off, const void *d_ref_full, const void *d_mon_full,
+                               ptrdiff_t stride_mask, const double *nodata_ref, const double *nodata_mon,
+                               const km_klt_params *prm, float x_off, float y_off, const void *d_ref_full, const void *d_mon_full,
                                int H_full, int W_full, ptrdiff_t stride_ref_full, ptrdiff_t stride_mon_full,
                                double zncc_threshold, void *host_out, int cap);
 int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype,

@@ -69,11 +69,11 @@ SIGNATURES = {
     "km_zncc_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_phase_shift": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
     "km_shift_image": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
-    "km_klt_tile_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), _vp,
+    "km_klt_tile_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp,
                              _vp, _vp, _i, _vp]),
-    "km_klt_tile_frame_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), C.c_float,
+    "km_klt_tile_frame_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), C.c_float,
                                    C.c_float, _vp, _i]),
-    "km_klt_tile_frame_zncc_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), C.c_float,
+    "km_klt_tile_frame_zncc_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), C.c_float,
                                         C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _vp, _i]),
     "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_phase_shift_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
@@ -82,6 +82,29 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+def _preload_shared_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).  A process must use ONE
+    HIP runtime: if the system copy is loaded first, torch later fails with "no ROCm-capable device".  When torch
+    is installed (it is the multi-GPU plumbing of karios_amd.parallel), make its runtime the process-wide one
+    before libkarios_hip.so is mapped; without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -93,6 +116,7 @@ def load():
                 raise KariosHipError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(karios_amd has no CPU fallback)")
+            _preload_shared_hip_runtime()
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -352,7 +352,7 @@ static int check_params(km_ctx *c, const km_klt_params *p)
 }
 
 static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                             const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                             const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
                              float *d_p0, float *d_p1, float *d_p0r, int cap, km_scalars *sc, bool *no_valid)
 {
     int rc;
@@ -361,6 +361,14 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
     if (!lap_ref || !lap_mon) return KM_E_NOMEM;
     uint8_t *mask_auto = nullptr;
     if (!d_mask) { mask_auto = (uint8_t *)km_ws(c, WS_MASK, n); if (!mask_auto) return KM_E_NOMEM; }
+    else if (smask != W) {
+        // box of a larger resident mask: the kernels index masks densely, so pack the box first (1 B/px copy)
+        if (smask < W) return km_fail(c, KM_E_ARG, "mask stride %td < width %d", smask, W);
+        uint8_t *dense = (uint8_t *)km_ws(c, WS_MASK, n);
+        if (!dense) return KM_E_NOMEM;
+        KM_HIP(c, hipMemcpy2DAsync(dense, (size_t)W, d_mask, (size_t)smask, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, c->stream));
+        d_mask = dense;
+    }
     if (dtype != KM_U8) {
         km_stage_timer t(c, ST_MINMAX);
         if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0]))) return rc;
@@ -600,14 +608,14 @@ int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, i
     if (!sc || !d_p0 || !d_p1 || !d_p0r) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     bool no_valid = false;
-    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, W, W, (const uint8_t *)d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r,
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, W, W, (const uint8_t *)d_mask, W, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r,
                                 cap, sc, &no_valid)))
         return rc;
     return fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n);
 }
 
 int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                    const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float *d_p0,
+                    const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float *d_p0,
                     float *d_p1, float *d_p0r, int cap, int *d_n)
 {
     int rc;
@@ -622,7 +630,7 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
     if (!sc) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     bool no_valid = false;
-    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
                                 &no_valid)))
         return rc;
     KM_HIP(c, hipMemcpyAsync(d_n, &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
@@ -630,7 +638,7 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
 }
 
 static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                           const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
+                           const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
                            float y_off, const void *d_ref_full, const void *d_mon_full, int Hf, int Wf, ptrdiff_t sref_f, ptrdiff_t smon_f,
                            bool with_zncc, double zncc_threshold, void *host_out, int cap)
 {
@@ -654,7 +662,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if (!sc || !d_p0 || !d_p1 || !d_p0r || !d_out) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     bool no_valid = false;
-    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
+    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
                                 &no_valid)))
         return rc;
     const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
@@ -677,19 +685,19 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
 }
 
 int km_klt_tile_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                          const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
-                          float y_off, void *host_out, int cap)
+                          const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                          float x_off, float y_off, void *host_out, int cap)
 {
-    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, x_off, y_off, nullptr, nullptr, 0, 0,
+    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, x_off, y_off, nullptr, nullptr, 0, 0,
                            0, 0, false, 0.0, host_out, cap);
 }
 
 int km_klt_tile_frame_zncc_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
-                               const uint8_t *d_mask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
-                               float x_off, float y_off, const void *d_ref_full, const void *d_mon_full, int Hf, int Wf, ptrdiff_t sref_f,
-                               ptrdiff_t smon_f, double zncc_threshold, void *host_out, int cap)
+                               const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon,
+                               const km_klt_params *prm, float x_off, float y_off, const void *d_ref_full, const void *d_mon_full, int Hf,
+                               int Wf, ptrdiff_t sref_f, ptrdiff_t smon_f, double zncc_threshold, void *host_out, int cap)
 {
-    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, nodata_ref, nodata_mon, prm, x_off, y_off, d_ref_full, d_mon_full,
+    return tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, x_off, y_off, d_ref_full, d_mon_full,
                            Hf, Wf, sref_f, smon_f, true, zncc_threshold, host_out, cap);
 }
 

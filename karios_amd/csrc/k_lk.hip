@@ -164,9 +164,8 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 Ixv[k] = ixv; Iyv[k] = iyv;
                 sA11 += __mul24(ixv, ixv); sA12 += __mul24(ixv, iyv); sA22 += __mul24(iyv, iyv);
             }
-            // wave-wide reductions need every lane: keep them outside the divergent branch
-            if ((k & 7) == 7) { lA11 += wave_sum_split(sA11); lA12 += wave_sum_split(sA12); lA22 += wave_sum_split(sA22); sA11 = sA12 = sA22 = 0; }
         }
+        // per-lane partial sums stay below 2^31 for NPL <= 25 (25 * 4080^2 = 4.2e8): one exact wave reduction at the end
         const long long iA11 = lA11 + wave_sum_split(sA11), iA12 = lA12 + wave_sum_split(sA12), iA22 = lA22 + wave_sum_split(sA22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -199,7 +198,6 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                     const int diff = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[JP], w10) + __mul24(p[JP + 1], w11), 14 - 5) - Iv[k];
                     sb1 += __mul24(diff, Ixv[k]); sb2 += __mul24(diff, Iyv[k]);
                 }
-                if ((k & 7) == 7) { lb1 += wave_sum_split(sb1); lb2 += wave_sum_split(sb2); sb1 = sb2 = 0; }
             }
             const long long ib1 = lb1 + wave_sum_split(sb1), ib2 = lb2 + wave_sum_split(sb2);
             const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;

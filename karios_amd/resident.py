@@ -89,7 +89,9 @@ class ResidentPair:
     @classmethod
     def from_device_pointers(cls, mon_ptr: int, ref_ptr: int, dtype, y_size: int, x_size: int, ctx: Context | None = None,
                              mask_ptr: int | None = None, no_data_mon=None, no_data_ref=None, keepalive=()) -> "ResidentPair":
-        """Wrap existing device memory (row-major, dense rows), e.g. torch tensors' data_ptr()."""
+        """Wrap existing device memory (row-major, dense rows), e.g. torch tensors' data_ptr().
+        The library works on its own HIP stream: the producer of these buffers must have completed
+        (e.g. `torch.cuda.synchronize()`) before the first call."""
         return cls(ctx, mon_ptr, ref_ptr, dtype, y_size, x_size, mask_ptr, no_data_mon, no_data_ref, keepalive)
 
     # ------------------------------------------------------------------ KLT
@@ -124,7 +126,7 @@ class ResidentPair:
         nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
         nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
         c.check(c.lib.km_klt_tile_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                      by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), C.c_void_p(d0), C.c_void_p(d1),
+                                      by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), C.c_void_p(d0), C.c_void_p(d1),
                                       C.c_void_p(d2), cap, C.c_void_p(dn)), "km_klt_tile_dev")
         st = c.stats()  # valid_pixels is known on the host as soon as the call returns
         if st.valid_pixels == 0:
@@ -182,11 +184,11 @@ class ResidentPair:
         nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
         if zncc_threshold is None:
             c.check(c.lib.km_klt_tile_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                                by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off), float(y_off),
+                                                by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(x_off), float(y_off),
                                                 buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_dev")
         else:
             c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es),
-                                                     self.code, by, bx, self.x_size, self.x_size, mask, nr, nm, C.byref(prm), float(x_off),
+                                                     self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(x_off),
                                                      float(y_off), C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.y_size,
                                                      self.x_size, self.x_size, self.x_size, float(zncc_threshold),
                                                      buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
