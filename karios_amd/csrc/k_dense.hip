@@ -687,6 +687,226 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
     return KM_OK;
 }
 
+// ---- K2, fast path (both images, ksize <= 7): one wavefront marches down a 256-column strip, 4 columns per
+// lane (62 of the 64 lanes produce output, the outer two only feed their neighbours).  Per source row: raw
+// pixels -> exact uint8 stretch -> horizontal kd / ks passes with v_dot4 on bytes assembled from the two
+// neighbour lanes (DPP wave shifts + v_alignbyte) -> (hd | hs) pairs pushed into a (2R+1)-row register ring;
+// per output row: one v_dot2 per tap and pixel over the ring.  No LDS tiles, no barriers, no index arithmetic.
+#define LAPM_RS 64   // output rows per wave
+#define LAPM_VALID 248
+
+template <int R, typename T, bool MASK>
+__global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                                        ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
+                                                        const uint8_t *__restrict__ tabs, lap_coef cf, int invert1, nodata_t nd,
+                                                        uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
+                                                        uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips)
+{
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    constexpr int NR = 2 * R + 1;
+    __shared__ uint8_t s_tab[2][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (sizeof(T) == 2) {
+        for (int i = tid; i < 512; i += 256) (&s_tab[0][0])[i] = tabs[i];
+        __syncthreads();
+    }
+    const int strip = blockIdx.x * 4 + (tid >> 6);
+    const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
+    if (strip >= nstrips) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
+    stretcher<T> st[2];
+    st[0].init(mm, 0, nullptr); st[1].init(mm, 1, nullptr);
+    const int gx0 = strip * LAPM_VALID - 4 + 4 * lane;           // first of this lane's 4 columns
+    const bool col_inside = gx0 >= 0 && gx0 + 3 < W;
+    const bool vec0 = col_inside && (stride0 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0);
+    const bool vec1 = col_inside && (stride1 % 4 == 0) && ((uintptr_t)img1 % (4 * sizeof(T)) == 0);
+    int rc[4];                                                    // REFLECT_101 columns for lanes on the border
+#pragma unroll
+    for (int k = 0; k < 4; k++) rc[k] = km_reflect101(gx0 + k, W);
+    const bool out_lane = lane >= 1 && lane <= 62 && gx0 < W;
+    const int y0 = blockIdx.y * LAPM_RS, y1 = min(H, y0 + LAPM_RS);
+
+    // packed coefficients
+    int kdp[2][2], ksp[2][2], bias[2], vk[2][NR];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int sum = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned a = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = 4 * h + k;
+                const int d = t < NR ? cf.kd[i][t] : 0, sm = t < NR ? cf.ks[i][t] : 0;
+                a |= ((unsigned)d & 0xffu) << (8 * k);
+                b |= ((unsigned)sm & 0xffu) << (8 * k);
+                sum += sm;
+            }
+            kdp[i][h] = (int)a; ksp[i][h] = (int)b;
+        }
+        bias[i] = 128 * sum;
+#pragma unroll
+        for (int t = 0; t < NR; t++) vk[i][t] = (cf.ks[i][t] & 0xffff) | (cf.kd[i][t] << 16);
+    }
+
+    unsigned cnt = 0;
+    uint8_t *outs[2] = {out0, out1};
+    // FAST: every lane of the strip is an interior, aligned lane (wave-uniform) -> no per-lane fallbacks in the loop
+    auto march = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    auto load_raw = [&](int m, T (&v)[2][4]) {
+        const int r = km_reflect101(m, H);
+        const T *r0 = img0 + (size_t)r * stride0, *r1 = img1 + (size_t)r * stride1;
+        if (FAST || vec0) {
+            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r0 + gx0); __builtin_memcpy(v[0], &q, 4); }
+            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r0 + gx0); __builtin_memcpy(v[0], &q, 8); }
+            else { uint4 q = *(const uint4 *)(r0 + gx0); __builtin_memcpy(v[0], &q, 16); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[0][k] = r0[rc[k]];
+        }
+        if (FAST || vec1) {
+            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r1 + gx0); __builtin_memcpy(v[1], &q, 4); }
+            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r1 + gx0); __builtin_memcpy(v[1], &q, 8); }
+            else { uint4 q = *(const uint4 *)(r1 + gx0); __builtin_memcpy(v[1], &q, 16); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[1][k] = r1[rc[k]];
+        }
+    };
+
+    int ring[2][NR][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) ring[i][k][j] = 0;
+    T nxt[2][4];
+    load_raw(y0 - R, nxt);
+    for (int mbase = y0 - R; mbase < y1 + R; mbase += NR) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int m = mbase + k;                 // source row of this step (may lie outside: mirrored)
+            if (m >= y1 + R) continue;               // (no break: ring indices must stay compile-time constants)
+            T v[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[i][j] = nxt[i][j];
+            if (m + 1 < y1 + R) load_raw(m + 1, nxt);   // next row's pixels travel while this row is processed
+            // ---- auto mask of source row m (it is an output row when y0 <= m < y1)
+            if constexpr (MASK) {
+                if (m >= y0 && m < y1 && out_lane) {
+                    uint32_t mp = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool ok = (gx0 + j < W) && px_valid<T>(v[1][j], v[0][j], nd);
+                        mp |= (ok ? 1u : 0u) << (8 * j);
+                        cnt += ok;
+                    }
+                    const size_t o = (size_t)m * W + gx0;
+                    if (FAST || (gx0 + 3 < W && (o & 3) == 0)) *(uint32_t *)(mask_out + o) = mp;
+                    else {
+                        for (int j = 0; j < 4 && gx0 + j < W; j++) mask_out[o + j] = (uint8_t)((mp >> (8 * j)) & 1u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                // ---- stretch to uint8 (biased by -128 for the signed dot products)
+                uint32_t cw = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    unsigned u = st[i](v[i][j], s_tab[i]);
+                    if (i == 1 && invert1) u = 255u - u;
+                    cw |= u << (8 * j);
+                }
+                cw ^= 0x80808080u;
+                const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x138, 0xf, 0xf, false);   // lane-1
+                const uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x130, 0xf, 0xf, false);   // lane+1
+                // ---- horizontal kd / ks passes: bytes [4+o-R, 4+o-R+8) of (lw | cw | rw)
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int sft = 4 + o - R;                 // 1..4 for R = 3, 3..6 for R = 1
+                    int g0, g1;
+                    if (sft < 4) {
+                        g0 = (int)__builtin_amdgcn_alignbyte(cw, lw, sft & 3);
+                        g1 = (int)__builtin_amdgcn_alignbyte(rw, cw, sft & 3);
+                    } else if (sft == 4) {
+                        g0 = (int)cw; g1 = (int)rw;
+                    } else {
+                        g0 = (int)__builtin_amdgcn_alignbyte(rw, cw, (sft - 4) & 3);
+                        g1 = (int)__builtin_amdgcn_alignbyte(0u, rw, (sft - 4) & 3);   // taps beyond 2R are zero
+                    }
+                    const int vd = __builtin_amdgcn_sdot4(g0, kdp[i][0], __builtin_amdgcn_sdot4(g1, kdp[i][1], 0, false), false);
+                    const int vs = __builtin_amdgcn_sdot4(g0, ksp[i][0], __builtin_amdgcn_sdot4(g1, ksp[i][1], bias[i], false), false);
+                    ring[i][k][o] = (vd & 0xffff) | (vs << 16);
+                }
+            }
+            // ---- vertical combine for output row y = m - R (ring slot of source row y - R + j is (k + 1 + j) mod NR)
+            const int y = m - R;
+            if (y >= y0 && out_lane) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        int acc = 0;
+#pragma unroll
+                        for (int j = 0; j < NR; j++)
+                            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ring[i][(k + 1 + j) % NR][o]),
+                                                         __builtin_bit_cast(short2v, vk[i][j]), acc, false);
+                        packed |= (uint32_t)min(max(acc, 0), 255) << (8 * o);
+                    }
+                    const size_t off = (size_t)y * W + gx0;
+                    if (FAST || (gx0 + 3 < W && (off & 3) == 0)) *(uint32_t *)(outs[i] + off) = packed;
+                    else {
+                        for (int j = 0; j < 4 && gx0 + j < W; j++) outs[i][off + j] = (uint8_t)(packed >> (8 * j));
+                    }
+                }
+            }
+        }
+    }
+    };  // march
+    const bool lane_fast = vec0 && vec1 && (W % 4 == 0) && ((uintptr_t)out0 % 4 == 0) && ((uintptr_t)out1 % 4 == 0) &&
+                           (!MASK || (uintptr_t)mask_out % 4 == 0);
+    if (__all(lane_fast)) march(std::true_type{});
+    else march(std::false_type{});
+    if constexpr (MASK) {
+        const unsigned c64 = (unsigned)wave_sum_u64((unsigned long long)cnt);
+        if (lane == 0) valid_partial[wave_id] = c64;
+    }
+}
+
+template <typename T, bool MASK>
+static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
+                            const uint8_t *tabs, const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob,
+                            uint8_t *mask, unsigned long long *valid_out)
+{
+    const int nstrips = (W + LAPM_VALID - 1) / LAPM_VALID;
+    dim3 grid((nstrips + 3) / 4, (H + LAPM_RS - 1) / LAPM_RS);
+    const size_t nwaves = (size_t)grid.x * 4 * grid.y;
+    unsigned *valid = nullptr;
+    if (MASK) {
+        valid = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
+        if (!valid) return KM_E_NOMEM;
+    }
+    switch (R) {
+    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
+    }
+    KM_LAUNCH_CHECK(c);
+    if (MASK) {
+        KM_HIP(c, hipMemsetAsync(valid_out, 0, sizeof(unsigned long long), c->stream));
+        sum_u32_kernel<<<32, 1024, 0, c->stream>>>(valid, (unsigned)nwaves, valid_out);
+        KM_LAUNCH_CHECK(c);
+    }
+    return KM_OK;
+}
+
 static int lap_radius(int ksize) { return ksize == 1 ? 1 : ksize / 2; }
 
 int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, uint8_t *d_dst)
@@ -718,6 +938,21 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         if (!tabs) return KM_E_NOMEM;
         stretch_table_kernel<<<1, 256, 0, c->stream>>>(d_mm, tabs, 2);
         KM_LAUNCH_CHECK(c);
+    }
+    if (R <= 3 && W >= 8 && H >= 8) {
+#define KM_PAIRM(T)                                                                                                              \
+    (d_mask_out ? launch_lap_march<T, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+                                            d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                           \
+                : launch_lap_march<T, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+                                             d_lap_ref, d_lap_mon, nullptr, nullptr))
+        switch (dtype) {
+        case KM_U8: return KM_PAIRM(uint8_t);
+        case KM_U16: return KM_PAIRM(uint16_t);
+        case KM_I16: return KM_PAIRM(int16_t);
+        case KM_F32: return KM_PAIRM(float);
+        default: return km_fail(c, KM_E_ARG, "stretch_laplacian: bad dtype %d", dtype);
+        }
+#undef KM_PAIRM
     }
 #define KM_PAIR(T)                                                                                                          \
     (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
