@@ -93,7 +93,7 @@ def main():
     from karios_amd import synth
     from karios_amd._lib import Context
     from karios_amd.core import KLTConfiguration
-    from karios_amd.parallel import gather_frames
+    from karios_amd.parallel import gather_blocks
     from karios_amd.resident import ResidentPair
 
     S = a.size
@@ -110,8 +110,9 @@ def main():
         if frame is not None:
             frame = pair.score_frame(frame, 0.4)               # radial error / angle columns (numpy, as the reference)
         if world > 1:
-            frames = gather_frames({rank: frame}, world, conf.maxCorners, device=dev)
-            return frame, sum(len(f) for f in frames if f is not None)
+            # the path's only exchange step: all-gather of the per-band key-point blocks (device pipeline layout) over RCCL
+            blocks = gather_blocks({rank: pair.last_block(conf.maxCorners, True)}, world, conf.maxCorners, True, device=dev)
+            return frame, int(blocks[:, :1].view(np.int32).sum())
         return frame, (0 if frame is None else len(frame))
 
     def fence():

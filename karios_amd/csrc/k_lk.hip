@@ -13,6 +13,7 @@
 #include "common.hpp"
 
 #include <float.h>
+#include <type_traits>
 
 struct lk_args {
     km_pyr A, B;
@@ -94,16 +95,24 @@ __device__ __forceinline__ long long wave_sum_split(int v)
     return ((long long)wave_sum_i32_dpp(hi) << 16) + (long long)wave_sum_i32_dpp(lo);
 }
 
+// Per-lane window-pixel offsets, packed: raw-patch offset | derivative offset << S | search-patch offset << 2S.
+// 10-bit fields cover winSize <= 25 in one 32-bit register; larger windows use 12-bit fields in 64 bits.
+template <int NPL> struct lk_off {
+    using type = typename std::conditional<(NPL <= 10), int, long long>::type;
+    static constexpr int S = NPL <= 10 ? 10 : 12;
+    static constexpr int M = (1 << S) - 1;
+};
+
 // Track one point from image pyramid I to J (all lanes hold identical scalars).
 template <int NPL>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
-                               const short (&lx)[NPL], const short (&ly)[NPL], uint8_t *raw, int *der, uint8_t *jp, float &outx,
-                               float &outy)
+                               const typename lk_off<NPL>::type (&offp)[NPL], uint8_t *raw, int *der, uint8_t *jp, float &outx, float &outy)
 {
     const int lane = threadIdx.x;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
-    const int RW = win + 3, DW = win + 1, npx = win * win;
+    const int RW = win + 3, DW = win + 1;
+    constexpr int OS = lk_off<NPL>::S, OM = lk_off<NPL>::M;
     const int RP = (RW + 3 + 3) & ~3;                 // raw patch pitch
     const int JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     float resx = px, resy = py;
@@ -147,25 +156,25 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         }
         __syncthreads();
         // per-lane window pixels -> registers; exact integer normal matrix
-        int Iv[NPL], Ixv[NPL], Iyv[NPL];
-        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums fit int32 (<= 8 * 4080^2)
+        // offp[k] packs this lane's k-th window pixel: raw-patch offset | derivative offset << 10 | search-patch offset << 20
+        int Iv[NPL], Ixy[NPL];
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums stay below 2^31 (NPL <= 25: 25 * 4080^2 = 4.2e8)
         long long lA11 = 0, lA12 = 0, lA22 = 0;
 #pragma unroll
         for (int k = 0; k < NPL; k++) {
-            Iv[k] = 0; Ixv[k] = 0; Iyv[k] = 0;
-            if (k * 64 + lane < npx) {
-                const int y = ly[k], x = lx[k];
-                const uint8_t *p = raw + (y + 1) * RP + (x + 1);
+            Iv[k] = 0; Ixy[k] = 0;
+            if (offp[k] >= 0) {
+                const uint8_t *p = raw + (int)(offp[k] & OM);
                 Iv[k] = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[RP], w10) + __mul24(p[RP + 1], w11), 14 - 5);
-                const int d00 = der[y * DW + x], d01 = der[y * DW + x + 1], d10 = der[(y + 1) * DW + x], d11 = der[(y + 1) * DW + x + 1];
+                const int *dp = der + (int)((offp[k] >> OS) & OM);
+                const int d00 = dp[0], d01 = dp[1], d10 = dp[DW], d11 = dp[DW + 1];
                 const int ixv = descale(__mul24((int)(short)(d00 & 0xffff), w00) + __mul24((int)(short)(d01 & 0xffff), w01) +
                                             __mul24((int)(short)(d10 & 0xffff), w10) + __mul24((int)(short)(d11 & 0xffff), w11), 14);
                 const int iyv = descale(__mul24(d00 >> 16, w00) + __mul24(d01 >> 16, w01) + __mul24(d10 >> 16, w10) + __mul24(d11 >> 16, w11), 14);
-                Ixv[k] = ixv; Iyv[k] = iyv;
+                Ixy[k] = (ixv & 0xffff) | (iyv << 16);
                 sA11 += __mul24(ixv, ixv); sA12 += __mul24(ixv, iyv); sA22 += __mul24(iyv, iyv);
             }
         }
-        // per-lane partial sums stay below 2^31 for NPL <= 25 (25 * 4080^2 = 4.2e8): one exact wave reduction at the end
         const long long iA11 = lA11 + wave_sum_split(sA11), iA12 = lA12 + wave_sum_split(sA12), iA22 = lA22 + wave_sum_split(sA22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -193,10 +202,10 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             long long lb1 = 0, lb2 = 0;
 #pragma unroll
             for (int k = 0; k < NPL; k++) {
-                if (k * 64 + lane < npx) {
-                    const uint8_t *p = jb + ly[k] * JP + lx[k];
+                if (offp[k] >= 0) {
+                    const uint8_t *p = jb + (int)(offp[k] >> (2 * OS));
                     const int diff = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[JP], w10) + __mul24(p[JP + 1], w11), 14 - 5) - Iv[k];
-                    sb1 += __mul24(diff, Ixv[k]); sb2 += __mul24(diff, Iyv[k]);
+                    sb1 += __mul24(diff, (int)(short)(Ixy[k] & 0xffff)); sb2 += __mul24(diff, Ixy[k] >> 16);
                 }
             }
             const long long ib1 = lb1 + wave_sum_split(sb1), ib2 = lb2 + wave_sum_split(sb2);
@@ -228,20 +237,22 @@ __global__ __launch_bounds__(64) void lk_kernel(lk_args g)
     uint8_t *raw = smem;
     uint8_t *jp = smem + (((win + 3) * RP + 15) & ~15);
     int *der = (int *)(jp + ((JS * JP + 15) & ~15));
-    short lx[NPL], ly[NPL];
+    using off_t = typename lk_off<NPL>::type;
+    constexpr int OS = lk_off<NPL>::S;
+    off_t offp[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) {
         const int idx = k * 64 + (int)threadIdx.x;
-        const int y = idx / win;
-        ly[k] = (short)y; lx[k] = (short)(idx - y * win);
+        const int y = idx / win, x = idx - y * win;
+        offp[k] = idx < win * win ? ((off_t)((y + 1) * RP + (x + 1)) | ((off_t)(y * (win + 1) + x) << OS) | ((off_t)(y * JP + x) << (2 * OS))) : (off_t)-1;
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
-    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, lx, ly, raw, der, jp, fx, fy);
+    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, offp, raw, der, jp, fx, fy);
     if (threadIdx.x == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, lx, ly, raw, der, jp, rx, ry);
+        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, offp, raw, der, jp, rx, ry);
         if (threadIdx.x == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }

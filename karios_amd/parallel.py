@@ -98,6 +98,50 @@ def gather_frames(local: dict[int, DataFrame | None], n_units: int, cap: int, de
     return frames
 
 
+def block_len(cap: int, with_zncc: bool) -> int:
+    """float32 words of one frame block (layout of km_klt_tile_frame[_zncc]_dev, see include/karios_hip.h)."""
+    return 4 + (8 if with_zncc else 6) * cap
+
+
+def gather_blocks(local: dict[int, np.ndarray | None], n_units: int, cap: int, with_zncc: bool = False, device=None) -> np.ndarray:
+    """All-gather raw frame blocks (the device pipeline's own output layout) -- the per-step exchange of the tile-parallel
+    run.  `local`: unit index -> block (or None).  Returns a (n_units, block_len) float32 array in unit order on every
+    rank; a unit without result has an all-zero header.  One flat all-gather, sized for latency, not bandwidth."""
+    import torch
+    import torch.distributed as dist
+
+    L = block_len(cap, with_zncc)
+    out = np.zeros((n_units, L), np.float32)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        for idx, blk in local.items():
+            if blk is not None:
+                out[idx] = blk[:L]
+        return out
+    ws = dist.get_world_size()
+    per_rank = (n_units + ws - 1) // ws
+    send = np.zeros((per_rank, 1 + L), np.float32)
+    send[:, 0] = -1
+    for slot, (idx, blk) in enumerate(sorted(local.items())):
+        send[slot, 0] = idx
+        if blk is not None:
+            send[slot, 1:] = blk[:L]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t_send = torch.from_numpy(send).to(device)
+    t_recv = torch.empty((ws * per_rank, 1 + L), dtype=t_send.dtype, device=device)
+    dist.all_gather_into_tensor(t_recv, t_send)
+    recv = t_recv.cpu().numpy()
+    ids = recv[:, 0].astype(np.int64)
+    ok = ids >= 0
+    out[ids[ok]] = recv[ok, 1:]
+    return out
+
+
+def blocks_to_frames(blocks: np.ndarray, cap: int, with_zncc: bool = False):
+    from .resident import ResidentPair
+    return [ResidentPair._frame_from_block(b, cap, with_zncc) for b in blocks]
+
+
 def match_distributed(pairs: dict, n_bands: int, x_size: int, y_size: int, conf, score: bool = False,
                       confidence_threshold: float = 0.4, device=None):
     """Match `n_bands` image pairs tile-parallel.  `pairs` maps band -> ResidentPair for the bands whose

@@ -192,6 +192,11 @@ class ResidentPair:
                                                      float(y_off), C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.y_size,
                                                      self.x_size, self.x_size, self.x_size, float(zncc_threshold),
                                                      buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
+        return self._frame_from_block(buf, cap, zncc_threshold is not None)
+
+    @staticmethod
+    def _frame_from_block(buf: np.ndarray, cap: int, with_zncc: bool) -> DataFrame | None:
+        """Host view of one tile's frame block (layout of km_klt_tile_frame[_zncc]_dev) -> DataFrame."""
         hdr = buf[:4].view(np.int32)
         n, n_init = int(hdr[0]), int(hdr[1])
         if n_init == 0:
@@ -199,9 +204,14 @@ class ResidentPair:
         body = buf[4:]
         cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
         index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
-        if zncc_threshold is not None:
+        if with_zncc:
             cols["zncc_score"] = body[6 * cap:8 * cap].view(np.float64)[:n].copy()
         return DataFrame(cols, index=index, copy=False)
+
+    def last_block(self, cap: int, with_zncc: bool) -> np.ndarray:
+        """The raw frame block of the last `match_tile` call: 4 int32 header + 6*cap float32 (+ cap float64), the unit of
+        the multi-GPU gather (no pandas round trip)."""
+        return self._host_frame[:4 + (8 if with_zncc else 6) * cap]
 
     def match(self, conf):
         """All tiles in the reference order (x outer, y inner; klt.py:220-232)."""

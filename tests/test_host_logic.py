@@ -154,3 +154,39 @@ print("rank", rank, "ok")
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_gather_blocks_world_size_2_gloo(tmp_path):
+    """Raw frame blocks (the device pipeline's layout) gathered across two gloo ranks and turned into frames."""
+    script = tmp_path / "worker2.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch.distributed as dist
+from karios_amd.parallel import gather_blocks, blocks_to_frames, block_len
+rank = int(os.environ["RANK"]); cap = 8
+dist.init_process_group("gloo", rank=rank, world_size=2)
+def block(u):
+    b = np.zeros(block_len(cap, True), np.float32)
+    n = 2 + u
+    b[:4].view(np.int32)[:2] = (n, n + 1)
+    body = b[4:]
+    for c in range(5):
+        body[c * cap:c * cap + n] = 10 * u + c + np.arange(n)
+    body[5 * cap:5 * cap + n].view(np.int32)[:] = np.arange(n)[::-1]
+    body[6 * cap:8 * cap].view(np.float64)[:n] = 0.5 + u
+    return b
+local = {{u: (None if u == 1 else block(u)) for u in range(4) if u % 2 == rank}}
+out = gather_blocks(local, 4, cap, True)
+assert out.shape == (4, block_len(cap, True))
+frames = blocks_to_frames(out, cap, True)
+assert [None if f is None else len(f) for f in frames] == [2, None, 4, 5], frames
+assert list(frames[2].index) == [3, 2, 1, 0] and float(frames[3]["zncc_score"].iloc[0]) == 3.5 and float(frames[2]["dy"].iloc[1]) == 24.0
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
