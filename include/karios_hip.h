@@ -138,6 +138,14 @@ int km_zncc_batch(km_ctx *ctx, const void *ref, const void *mon, int dtype, int 
                   int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
                   const float *x0, const float *y0, const float *dx, const float *dy, int n,
                   double *out);
+/* Mutual-information scores per keypoint on the 57x57 chips (next to ZNCC in _handle_klt_results, api/core.py:894-907):
+ * out_studholme[k] = MutualInfoService._mutual_info  (matcher/mutual_info_service.py:32-63, column mutual_info_score)
+ * out_nmi[k]       = ZNCCService._mutual_information (matcher/zncc_service.py:129-151,      column mi_score)
+ * either output may be NULL; NaN where the reference returns NaN */
+int km_mi_batch(km_ctx *ctx, const void *ref, const void *mon, int dtype, int Href, int Wref,
+                int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *x0,
+                const float *y0, const float *dx, const float *dy, int n, double *out_studholme,
+                double *out_nmi);
 /* skimage.registration.phase_cross_correlation(reference_image, moving_image)[0]
  * (matcher/large_offset.py:39): out_rc = [row, col] */
 int km_phase_shift(km_ctx *ctx, const void *reference_image, const void *moving_image,
@@ -179,6 +187,10 @@ int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dty
                       int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
                       ptrdiff_t stride_mon, const float *d_x0, const float *d_y0,
                       const float *d_dx, const float *d_dy, int n, double *d_out);
+int km_mi_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
+                    int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,
+                    const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out_studholme,
+                    double *d_out_nmi);
 int km_phase_shift_dev(km_ctx *ctx, const void *d_reference_image,
                        const void *d_moving_image, int dtype, int H, int W,
                        ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);

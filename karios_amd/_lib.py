@@ -67,6 +67,7 @@ SIGNATURES = {
     "km_klt_tile": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), _vp, _vp,
                          _vp, _i, _pi]),
     "km_zncc_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
+    "km_mi_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "km_phase_shift": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
     "km_shift_image": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
     "km_klt_tile_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp,
@@ -76,6 +77,7 @@ SIGNATURES = {
     "km_klt_tile_frame_zncc_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), C.c_float,
                                         C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _vp, _i]),
     "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
+    "km_mi_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "km_phase_shift_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
     "km_shift_image_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
 }

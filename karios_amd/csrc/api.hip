@@ -108,7 +108,7 @@ int km_set_profiling(km_ctx *c, int enable)
 }
 
 static const char *const kStageNames[ST_COUNT] = {"minmax", "stretch_laplacian_mask", "min_eigen", "candidates", "sort",
-                                                  "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame"};
+                                                  "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame", "mutual_info"};
 
 const char *km_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 
@@ -736,6 +736,46 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
             return rc;
     }
     KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_mi_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
+                    ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_st,
+                    double *d_nmi)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, d_ref, Href, Wref, sref, "mi")) || (rc = check_image(c, d_mon, Hmon, Wmon, smon, "mi")))
+        return rc;
+    if (n < 0 || (n > 0 && (!d_x0 || !d_y0 || !d_dx || !d_dy || (!d_st && !d_nmi)))) return km_fail(c, KM_E_ARG, "mi: bad keypoint arrays");
+    c->ev_used[ST_MI] = false;
+    km_stage_timer t(c, ST_MI);
+    return kmi_batch(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, nullptr, nullptr, 0.f, d_st, d_nmi);
+}
+
+int km_mi_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
+                ptrdiff_t smon, const float *x0, const float *y0, const float *dx, const float *dy, int n, double *out_st, double *out_nmi)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, ref, Href, Wref, sref, "mi")) || (rc = check_image(c, mon, Hmon, Wmon, smon, "mi")))
+        return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es) return km_fail(c, KM_E_ARG, "mi: bad dtype %d", dtype);
+    if (n < 0 || (n > 0 && (!x0 || !y0 || !dx || !dy || (!out_st && !out_nmi)))) return km_fail(c, KM_E_ARG, "mi: bad keypoint arrays");
+    if (n == 0) return KM_OK;
+    void *d_ref, *d_mon;
+    if ((rc = upload_image(c, WS_RAW_A, ref, es, Href, Wref, sref, &d_ref)) || (rc = upload_image(c, WS_RAW_B, mon, es, Hmon, Wmon, smon, &d_mon)))
+        return rc;
+    float *kp = (float *)km_ws(c, WS_MISC0, (size_t)n * 4 * sizeof(float));
+    double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)n * 2 * sizeof(double));
+    if (!kp || !d_out) return KM_E_NOMEM;
+    const float *src[4] = {x0, y0, dx, dy};
+    for (int i = 0; i < 4; i++) KM_HIP(c, hipMemcpyAsync(kp + (size_t)i * n, src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = kmi_batch(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, nullptr,
+                        nullptr, 0.f, out_st ? d_out : nullptr, out_nmi ? d_out + n : nullptr)))
+        return rc;
+    if (out_st) KM_HIP(c, hipMemcpyAsync(out_st, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (out_nmi) KM_HIP(c, hipMemcpyAsync(out_nmi, d_out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     return KM_OK;
 }

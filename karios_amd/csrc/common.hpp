@@ -32,6 +32,7 @@ enum km_stage {
     ST_LK,
     ST_ZNCC,
     ST_FRAME,
+    ST_MI,
     ST_COUNT
 };
 
@@ -194,6 +195,10 @@ int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href
 int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon,
                      ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx,
                      const float *d_dy, int n, const int *d_n, const float *d_score, float score_thr, double *d_out);
+// k_mi.hip
+int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
+              ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, const int *d_n,
+              const float *d_score, float score_thr, double *d_studholme, double *d_nmi);
 // k_phase.hip
 int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W,
                    ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);

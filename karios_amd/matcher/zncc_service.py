@@ -74,6 +74,20 @@ class ZNCCService:
         logger.info("ZNCC computation finish")
         return score
 
+    def compute_mi(self, df: DataFrame, monitored, reference) -> Series:
+        """NMI (2*MI/(H(X)+H(Y)), 32 bins, 57x57 chips) for each KP (reference zncc_service.py:240-287)."""
+        logger.info("Compute NMI for %s points", len(df))
+        if len(df) == 0:
+            score = Series([], index=df.index, dtype=np.float64)
+        else:
+            cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
+            _, nmi = ops.mi_batch(reference.array, monitored.array, *cols, ctx=self._ctx)
+            score = Series(nmi, index=df.index, dtype=np.float64)
+        monitored.clear_cache()
+        reference.clear_cache()
+        logger.info("NMI computation finish")
+        return score
+
     def _extract_chip(self, x: int, y: int, image):
         """57x57 chip around (x, y) (reference zncc_service.py:289-297)."""
         m = self._chip_margin

@@ -210,6 +210,24 @@ def zncc_batch(ref, mon, x0, y0, dx, dy, ctx: Context | None = None):
     return out
 
 
+def mi_batch(ref, mon, x0, y0, dx, dy, ctx: Context | None = None):
+    """Per-keypoint mutual-information scores on the 57x57 chips -> (studholme, nmi) float64 arrays:
+    `MutualInfoService._compute_mutual_info` (mutual_info_service.py:99-130, (H(X)+H(Y))/H(X,Y) in [1,2]) and
+    `ZNCCService._compute_mi` (zncc_service.py:260-287, 2*MI/(H(X)+H(Y)) in [0,1])."""
+    c = _ctx(ctx)
+    r, m = as_image(ref), as_image(mon)
+    if r.dtype != m.dtype:
+        raise KariosHipError("mi_batch: dtype mismatch")
+    x0, y0, dx, dy = (np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy))
+    n = len(x0)
+    a, b = np.empty(n, np.float64), np.empty(n, np.float64)
+    if n == 0:
+        return a, b
+    c.check(c.lib.km_mi_batch(c.handle, ptr(r), ptr(m), dtype_code(r), r.shape[0], r.shape[1], m.shape[0], m.shape[1],
+                              row_stride(r), row_stride(m), ptr(x0), ptr(y0), ptr(dx), ptr(dy), n, ptr(a), ptr(b)), "km_mi_batch")
+    return a, b
+
+
 def phase_cross_correlation(reference_image, moving_image, ctx: Context | None = None):
     """skimage.registration.phase_cross_correlation(reference_image, moving_image)[0] with the 0.24
     defaults (large_offset.py:39) -> array([row, col]) float64 holding integers."""
@@ -238,5 +256,5 @@ def shift_image(img, y_off=0, x_off=0, ctx: Context | None = None):
 
 
 __all__ = ["Context", "KariosHipError", "to_uint8", "auto_mask", "laplacian_u8", "min_eigen", "good_features_to_track",
-           "pyr_down", "calc_optical_flow_pyr_lk", "klt_track", "klt_tile", "zncc_batch", "phase_cross_correlation",
+           "pyr_down", "calc_optical_flow_pyr_lk", "klt_track", "klt_tile", "zncc_batch", "mi_batch", "phase_cross_correlation",
            "shift_image", "make_params", "_lib"]

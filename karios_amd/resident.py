@@ -242,19 +242,49 @@ class ResidentPair:
         c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), n * 8), "km_d2h")
         return out
 
-    def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4) -> DataFrame:
-        """`_handle_klt_results` numeric columns (core.py:872-893): radial error, angle and the ZNCC of
-        the rows with score >= confidence_threshold (NaN elsewhere)."""
+    def mutual_info(self, x0, y0, dx, dy):
+        """(mutual_info_score, mi_score) per key point on the resident images: `MutualInfoService.compute_mutual_info`
+        (mutual_info_service.py:73-130) and `ZNCCService.compute_mi` (zncc_service.py:240-287)."""
+        c = self.ctx
+        cols = [np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy)]
+        n = len(cols[0])
+        out = np.empty((2, n), np.float64)
+        if n == 0:
+            return out[0], out[1]
+        need = n * (4 * 4 + 2 * 8)
+        if self._zbuf is None or self._zbuf.nbytes < need:
+            self._zbuf = DeviceBuffer(c, need + need // 4)
+        base = self._zbuf.ptr
+        kp = np.concatenate(cols)
+        f = base + 2 * n * 8
+        c.check(c.lib.km_h2d(c.handle, C.c_void_p(f), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
+        c.check(c.lib.km_mi_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
+                                      self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
+                                      C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base), C.c_void_p(base + 8 * n)),
+                "km_mi_batch_dev")
+        c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), 2 * n * 8), "km_d2h")
+        return out[0], out[1]
+
+    def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4, mutual_info: bool = False) -> DataFrame:
+        """`_handle_klt_results` numeric columns (core.py:872-907): radial error, angle, the ZNCC of the rows with
+        score >= confidence_threshold (NaN elsewhere) and, with `mutual_info`, the `mutual_info_score` / `mi_score`
+        columns of the same rows."""
         dx, dy, score = frame["dx"].to_numpy(), frame["dy"].to_numpy(), frame["score"].to_numpy()
         frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
         frame["angle"] = np.degrees(np.arctan2(dy, dx))
-        if "zncc_score" in frame.columns:   # already scored on the device (match_tile(..., zncc_threshold=...))
-            return frame
         keep = score >= confidence_threshold
-        z = np.full(len(frame), np.nan, np.float64)
-        if keep.any():
-            z[keep] = self.zncc(frame["x0"].to_numpy()[keep], frame["y0"].to_numpy()[keep], dx[keep], dy[keep])
-        frame["zncc_score"] = z
+        if "zncc_score" not in frame.columns:   # else: already scored on the device (match_tile(..., zncc_threshold=...))
+            z = np.full(len(frame), np.nan, np.float64)
+            if keep.any():
+                z[keep] = self.zncc(frame["x0"].to_numpy()[keep], frame["y0"].to_numpy()[keep], dx[keep], dy[keep])
+            frame["zncc_score"] = z
+        if mutual_info:
+            st = np.full(len(frame), np.nan, np.float64)
+            nmi = np.full(len(frame), np.nan, np.float64)
+            if keep.any():
+                st[keep], nmi[keep] = self.mutual_info(frame["x0"].to_numpy()[keep], frame["y0"].to_numpy()[keep], dx[keep], dy[keep])
+            frame["mutual_info_score"] = st
+            frame["mi_score"] = nmi
         return frame
 
     # ------------------------------------------------------------------ large offset

@@ -260,6 +260,43 @@ def zncc_batch(ref, mon, x0, y0, dx, dy):
     return out[:n]
 
 
+def _kp_chips(ref, mon, x0, y0, dx, dy):
+    """Chip extraction rules shared by _compute_zncc / _compute_mutual_info / _compute_mi
+    (zncc_service.py:186-218, mutual_info_service.py:99-123): yields (k, chip_ref, chip_mon) or (k, None, None)."""
+    m = 28
+    for k in range(len(x0)):
+        X0, Y0 = int(x0[k]), int(y0[k])
+        sx, sy = np.float32(x0[k]) + np.float32(dx[k]), np.float32(y0[k]) + np.float32(dy[k])
+        if not (np.isfinite(sx) and np.isfinite(sy)):
+            yield k, None, None
+            continue
+        X1, Y1 = round(sx), round(sy)
+        if X0 - m < 0 or Y0 - m < 0 or X1 - m < 0 or Y1 - m < 0 or X0 >= ref.shape[1] - m or Y0 >= ref.shape[0] - m \
+                or X1 >= mon.shape[1] - m or Y1 >= mon.shape[0] - m:
+            yield k, None, None
+            continue
+        yield k, ref[Y0 - m:Y0 + m + 1, X0 - m:X0 + m + 1], mon[Y1 - m:Y1 + m + 1, X1 - m:X1 + m + 1]
+
+
+def mi_batch(ref, mon, x0, y0, dx, dy):
+    """(studholme, nmi) per keypoint: `_mutual_info` (mutual_info_service.py:32-63) and `_mutual_information`
+    (zncc_service.py:129-151) on the 57x57 chips, 32-bin np.histogram2d.  Pure numpy loop: small cases only."""
+    n = len(x0)
+    st, nmi = np.full(n, np.nan), np.full(n, np.nan)
+    for k, c1, c2 in _kp_chips(np.asarray(ref), np.asarray(mon), x0, y0, dx, dy):
+        if c1 is None:
+            continue
+        h, _, _ = np.histogram2d(c1.ravel(), c2.ravel(), bins=32)
+        pxy = h / h.sum()
+        px, py = pxy.sum(axis=1), pxy.sum(axis=0)
+        ent = lambda p, lg: -np.sum(p[p > 0] * lg(p[p > 0]))
+        hx, hy, hxy = ent(px, np.log), ent(py, np.log), ent(pxy, np.log)
+        st[k] = np.nan if hxy == 0 else (hx + hy) / hxy
+        hx2, hy2, hxy2 = ent(px, np.log2), ent(py, np.log2), ent(pxy.ravel(), np.log2)
+        nmi[k] = np.nan if hx2 + hy2 == 0 else 2.0 * (hx2 + hy2 - hxy2) / (hx2 + hy2)
+    return st, nmi
+
+
 def shift_image(img, y_off=0, x_off=0):
     """shift_image (image.py:70-101)."""
     y_off, x_off = int(round(y_off)), int(round(x_off))

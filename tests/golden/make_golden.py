@@ -11,6 +11,7 @@ What is pinned (reference file:line)
   fb_score.npz      karios/matcher/klt.py:142-170    forward-backward test / score / DataFrame assembly of `klt_tracker`
                                                      (cv2 stub returns prescribed p0, p1, p0r)
   zncc.npz          karios/matcher/zncc_service.py:45-126,162-238   `ZNCCService.compute_zncc` incl. rounding / bounds / NaN rules
+  mutual_info.npz   karios/matcher/mutual_info_service.py:32-130, zncc_service.py:129-151,240-287   both MI scores
   klt_match_*.npz   karios/matcher/klt.py:198-349, 407-436          `KLT.match` control flow (tiling, masks, offsets, sort,
                                                      polarity / per-image kernel sizes) with cv2's three entry points served by
                                                      the CPU oracle -- pins the glue, not OpenCV's arithmetic
@@ -45,7 +46,8 @@ def import_reference():
     import karios.core.image as rimage  # noqa: E402
     import karios.matcher.klt as rklt  # noqa: E402
     import karios.matcher.zncc_service as rzncc  # noqa: E402
-    return rklt, rzncc, rimage
+    import karios.matcher.mutual_info_service as rmi  # noqa: E402
+    return rklt, rzncc, rimage, rmi
 
 
 def oracle_cv2():
@@ -83,7 +85,7 @@ class Img:
 
 def main():
     from karios_amd import synth
-    rklt, rzncc, rimage = import_reference()
+    rklt, rzncc, rimage, rmi = import_reference()
     rng = np.random.default_rng(20261002)
 
     # ---- _to_uint8
@@ -160,6 +162,28 @@ def main():
     kat = rzncc._zncc2(np.full((57, 57), 100.0), np.full((57, 57), 100.0), 28, 28, 28, 28, 21)
     np.savez_compressed(os.path.join(HERE, "zncc.npz"), mon=mon, ref=ref, ref_flat=flat, zncc=z, zncc_flat=zf,
                         uniform_is_nan=np.array(np.isnan(kat)), **{c: df[c].to_numpy() for c in df.columns})
+
+    # ---- mutual information (next row): MutualInfoService.compute_mutual_info + ZNCCService.compute_mi
+    n = 120
+    dfm = pd.DataFrame({
+        "x0": rng.integers(20, 185, n).astype(np.float32), "y0": rng.integers(20, 145, n).astype(np.float32),
+        "dx": (rng.standard_normal(n) * 2).astype(np.float32), "dy": (rng.standard_normal(n) * 2).astype(np.float32)})
+    dfm.loc[:4, "x0"] = 80.0                            # chips inside the constant block of `flat`: H(X) = 0
+    dfm.loc[:4, "y0"] = 65.0
+    msvc = rmi.MutualInfoService()
+    flat2 = ref.copy()
+    flat2[20:120, 30:140] = 5000
+    mon_flat = mon.copy()
+    mon_flat[20:120, 30:140] = 777
+    mi = {"mon": mon, "ref": ref, "ref_flat": flat2, "mon_flat": mon_flat, **{c: dfm[c].to_numpy() for c in dfm.columns}}
+    mi["studholme"] = msvc.compute_mutual_info(dfm, Img(mon), Img(ref)).to_numpy()
+    mi["nmi"] = svc.compute_mi(dfm, Img(mon), Img(ref)).to_numpy()
+    mi["studholme_flat"] = msvc.compute_mutual_info(dfm, Img(mon), Img(flat2)).to_numpy()
+    mi["nmi_flat"] = svc.compute_mi(dfm, Img(mon), Img(flat2)).to_numpy()
+    mi["studholme_flat2"] = msvc.compute_mutual_info(dfm, Img(mon_flat), Img(flat2)).to_numpy()
+    mi["nmi_flat2"] = svc.compute_mi(dfm, Img(mon_flat), Img(flat2)).to_numpy()
+    mi["studholme_self"] = msvc.compute_mutual_info(dfm.assign(dx=0.0, dy=0.0).astype(np.float32), Img(ref), Img(ref)).to_numpy()
+    np.savez_compressed(os.path.join(HERE, "mutual_info.npz"), **mi)
 
     # ---- KLT.match control flow with the oracle behind cv2
     cases = {

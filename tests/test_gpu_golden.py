@@ -88,3 +88,39 @@ def test_phase_correlation_golden(ops):
         mon = np.roll(ref, tuple(s), (0, 1))
         got = LargeOffsetMatcher(NumpyRasterImage(ref), NumpyRasterImage(mon)).match()
         np.testing.assert_array_equal(got, exp)
+
+
+def test_mutual_info_services_golden(ops):
+    """MutualInfoService.compute_mutual_info and ZNCCService.compute_mi on the GPU vs the reference's outputs:
+    same NaN pattern (bounds, zero entropy), values within 1e-9 (fp64; log from the device libm)."""
+    from karios_amd.core import NumpyRasterImage
+    from karios_amd.matcher import MutualInfoService, ZNCCService
+    g = load("mutual_info.npz")
+    df = pd.DataFrame({c: g[c] for c in ("x0", "y0", "dx", "dy")})
+    df.index = df.index + 100
+    for ref_key, mon_key, sfx in (("ref", "mon", ""), ("ref_flat", "mon", "_flat"), ("ref_flat", "mon_flat", "_flat2")):
+        mon, ref = NumpyRasterImage(g[mon_key]), NumpyRasterImage(g[ref_key])
+        st = MutualInfoService().compute_mutual_info(df, mon, ref)
+        nmi = ZNCCService().compute_mi(df, mon, ref)
+        for got, exp in ((st, g["studholme" + sfx]), (nmi, g["nmi" + sfx])):
+            assert got.index.equals(df.index)
+            v = got.to_numpy()
+            assert np.array_equal(np.isnan(v), np.isnan(exp)), sfx
+            assert np.nanmax(np.abs(v - exp)) <= 1e-9, sfx
+    z0 = pd.DataFrame({c: g[c] for c in ("x0", "y0")}).assign(dx=np.float32(0), dy=np.float32(0)).astype(np.float32)
+    same = MutualInfoService().compute_mutual_info(z0, NumpyRasterImage(g["ref"]), NumpyRasterImage(g["ref"])).to_numpy()
+    assert np.array_equal(np.isnan(same), np.isnan(g["studholme_self"])) and np.nanmax(np.abs(same - 2.0)) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32])
+def test_mutual_info_other_dtypes(ops, dtype):
+    from oracle import oracle as O
+    g = load("mutual_info.npz")
+    ref, mon = (g["ref"] // 48).astype(dtype), (g["mon"] // 48).astype(dtype)
+    if dtype == np.float32:
+        ref, mon = ref + np.float32(0.25), mon * np.float32(1.5)
+    kp = (g["x0"], g["y0"], g["dx"], g["dy"])
+    st, nmi = ops.mi_batch(ref, mon, *kp)
+    est, enmi = O.mi_batch(ref, mon, *kp)
+    for got, exp in ((st, est), (nmi, enmi)):
+        assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.nanmax(np.abs(got - exp)) <= 1e-9

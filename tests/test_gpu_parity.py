@@ -268,5 +268,11 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
     keep = scored["score"].to_numpy() >= 0.4
     got = scored["zncc_score"].to_numpy()
     assert np.all(np.isnan(got[~keep])) and np.nanmax(np.abs(got[keep] - z[keep])) <= 1e-9
+    full = pair.score_frame(pair.match_tile(conf, boxes[0], zncc_threshold=0.4), 0.4, mutual_info=True)
+    assert list(full.columns)[-2:] == ["mutual_info_score", "mi_score"]
+    est, enmi = O.mi_batch(ref, mon, *(full[c].to_numpy()[keep] for c in ("x0", "y0", "dx", "dy")))
+    assert np.array_equal(np.isnan(full["mi_score"].to_numpy()[keep]), np.isnan(enmi))
+    assert np.nanmax(np.abs(full["mutual_info_score"].to_numpy()[keep] - est)) <= 1e-9 and np.nanmax(np.abs(full["mi_score"].to_numpy()[keep] - enmi)) <= 1e-9
+    assert np.all(np.isnan(full["mi_score"].to_numpy()[~keep]))
     flat = ResidentPair.upload(np.full((64, 64), 7, np.uint16), np.full((64, 64), 7, np.uint16))
     assert flat.match_tile(KLTConfiguration()) is None

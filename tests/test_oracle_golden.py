@@ -228,3 +228,15 @@ def test_config1_pipeline(O, pair512):
     assert abs(np.median(r["dx"]) - 0.5) < 0.02 and abs(np.median(r["dy"])) < 0.02
     assert r["score"].min() >= 0 and r["score"].max() <= 1
     assert np.all(np.diff(r["x0"]) >= 0)                                     # sorted by (x0, y0)
+
+
+def test_mutual_info_golden(O):
+    """Both MI scores (next row) against the reference's MutualInfoService / ZNCCService.compute_mi."""
+    g = load("mutual_info.npz")
+    kp = (g["x0"], g["y0"], g["dx"], g["dy"])
+    for ref_key, mon_key, sfx in (("ref", "mon", ""), ("ref_flat", "mon", "_flat"), ("ref_flat", "mon_flat", "_flat2")):
+        st, nmi = O.mi_batch(g[ref_key], g[mon_key], *kp)
+        for got, exp in ((st, g["studholme" + sfx]), (nmi, g["nmi" + sfx])):
+            assert np.array_equal(np.isnan(got), np.isnan(exp))
+            assert np.nanmax(np.abs(got - exp)) <= 1e-12
+    assert np.nanmin(g["studholme_self"]) == 2.0 and (g["studholme_flat"] == 1.0).any() and (g["nmi_flat"] == 0.0).any()
