@@ -30,9 +30,15 @@ class LargeOffsetMatcher:
         return ops.phase_cross_correlation(self._mon.array, self._ref.array, ctx=self._ctx)
 
 
-def detect_large_offset(reference_image, monitored_image, bias_correction_min_threshold=2, ctx=None):
+def detect_large_offset(reference_image, monitored_image, bias_correction_min_threshold=2, ctx=None,
+                        emulate_gdt_byte_write=False):
     """`_detect_large_offset` numeric part (core.py:751-776): phase correlation, per-axis
     threshold, integer shift of the monitored array.
+
+    `emulate_gdt_byte_write`: the reference writes the shifted array with `to_raster(path, data)` whose band type
+    defaults to `gdal.GDT_Byte` (core.py:781, image.py:388), so a uint16 monitored image comes back clamped to
+    [0, 255] uint8 and KLT then runs on that.  Off by default (native dtype kept); switch it on to
+    reproduce the reference's files bit for bit.
 
     Returns:
         (shifted monitored array, x_offset, y_offset) or None when no axis exceeds the threshold.
@@ -47,4 +53,6 @@ def detect_large_offset(reference_image, monitored_image, bias_correction_min_th
     if offsets[0] == 0 and offsets[1] == 0:
         return None
     shifted = ops.shift_image(np.asarray(monitored_image.array), x_off=offsets[1], y_off=offsets[0], ctx=ctx)
+    if emulate_gdt_byte_write and shifted.dtype != np.uint8:
+        shifted = np.clip(np.nan_to_num(shifted), 0, 255).astype(np.uint8)
     return shifted, float(offsets[1]), float(offsets[0])

@@ -51,6 +51,8 @@ CONFS = {
     "mixed_inv": dict(tile_size=20000, maxCorners=800, laplacian_kernel_size={"mon": 5, "ref": 9},
                       laplacian_invert_polarity=True, outliers_filtering=True),
     "usermask": dict(tile_size=20000, maxCorners=500, laplacian_kernel_size=3),
+    "auto_ksize": dict(tile_size=20000, maxCorners=250, laplacian_kernel_size="auto"),
+    "auto_polarity": dict(tile_size=120, maxCorners=200, laplacian_kernel_size=5, laplacian_invert_polarity="auto"),
 }
 
 
@@ -75,6 +77,10 @@ def test_klt_match_drop_in_golden(ops, case, gen_laplacian, tmp_path):
         assert np.abs(f["dx"].to_numpy() - g[f"f{i}_dx"]).max() <= 1e-3
         assert np.abs(f["dy"].to_numpy() - g[f"f{i}_dy"]).max() <= 1e-3
         assert np.abs(f["score"].to_numpy() - g[f"f{i}_score"]).max() <= 1e-2
+    if "auto_ksize" in g.files and case == "auto_ksize":
+        assert klt.auto_selected_ksize == tuple(int(v) for v in g["auto_ksize"])
+    if case == "auto_polarity":
+        assert klt.auto_selected_polarity == str(g["auto_polarity"])
     if gen_laplacian:
         assert len(os.listdir(tmp_path)) == 2 * len(KLT(KLTConfiguration(**CONFS[case])).tile_boxes(g["mon"].shape[1], g["mon"].shape[0]))
 

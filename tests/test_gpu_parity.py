@@ -276,3 +276,54 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
     assert np.all(np.isnan(full["mi_score"].to_numpy()[~keep]))
     flat = ResidentPair.upload(np.full((64, 64), 7, np.uint16), np.full((64, 64), 7, np.uint16))
     assert flat.match_tile(KLTConfiguration()) is None
+
+
+def test_error_contract_like_cv2(ops):
+    """Malformed inputs raise (the reference gets cv2.error / ValueError), they never return garbage."""
+    img = rand_u8((40, 40))
+    E = ops.KariosHipError
+    with pytest.raises(E):
+        ops.to_uint8(np.zeros((4, 4), np.float64))                       # unsupported pixel type
+    with pytest.raises(E):
+        ops.calc_optical_flow_pyr_lk(img, img[:, :30], np.zeros((1, 1, 2), np.float32))
+    with pytest.raises(E):
+        ops.calc_optical_flow_pyr_lk(img, img, np.zeros((1, 1, 2), np.float32), winSize=(2, 2))
+    with pytest.raises(E):
+        ops.good_features_to_track(img, 10, 0.0, 5)                      # qualityLevel must be > 0
+    with pytest.raises(E):
+        ops.good_features_to_track(img, 10, 0.1, -1)
+    with pytest.raises(E):
+        ops.min_eigen(img, 0)
+    with pytest.raises(E):
+        ops.phase_cross_correlation(img, img[:20])
+    with pytest.raises(E):
+        ops.zncc_batch(img, img.astype(np.uint16), [1], [1], [0], [0])
+
+
+def test_two_threads_two_contexts(ops, O):
+    """klt_tracker is called from a ThreadPoolExecutor in the reference's auto-ksize mode (klt.py:526-527): every
+    thread gets its own context (stream + workspace) and results do not depend on the interleaving."""
+    from concurrent.futures import ThreadPoolExecutor
+    from karios_amd.matcher import klt_tracker
+    mon, ref = synth.make_pair(220, 260, 0.4, 0.1)
+    lm, lr = O.laplacian_u8(O.to_uint8(mon), 5), O.laplacian_u8(O.to_uint8(ref), 5)
+    conf = O.default_conf(maxCorners=400)
+    exp = klt_tracker(lr, lm, None, conf)[0]
+    with ThreadPoolExecutor(4) as ex:
+        outs = list(ex.map(lambda _: klt_tracker(lr, lm, None, conf)[0], range(12)))
+    assert all(o.equals(exp) for o in outs)
+
+
+def test_large_offset_flow_and_gdt_byte_quirk(ops):
+    from karios_amd.core import NumpyRasterImage
+    from karios_amd.matcher import detect_large_offset
+    _, ref = synth.make_pair(128, 160, 0, 0)
+    mon = np.roll(ref, (5, -9), (0, 1))
+    res = detect_large_offset(NumpyRasterImage(ref), NumpyRasterImage(mon))
+    shifted, x_off, y_off = res
+    assert (x_off, y_off) == (-9.0, 5.0) and shifted.dtype == np.uint16
+    np.testing.assert_array_equal(shifted[:-5, 9:], ref[:-5, 9:])   # content moved back onto the reference grid
+    q = detect_large_offset(NumpyRasterImage(ref), NumpyRasterImage(mon), emulate_gdt_byte_write=True)[0]
+    assert q.dtype == np.uint8 and q.max() == 255
+    small = np.roll(ref, (1, 1), (0, 1))                                # below bias_correction_min_threshold on both axes
+    assert detect_large_offset(NumpyRasterImage(ref), NumpyRasterImage(small)) is None
