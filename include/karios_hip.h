@@ -71,7 +71,7 @@ typedef struct km_klt_stats {
     int32_t n_select_batches; /* greedy-selection batches executed */
     double min_ref, max_ref, min_mon, max_mon; /* _to_uint8 stretch bounds */
     float max_eig;            /* maxVal of minMaxLoc */
-    float reserved;
+    float emitted_ratio;      /* candidate keys emitted by the fused eig kernel / exact candidate count */
 } km_klt_stats;
 
 /* ---- context ------------------------------------------------------------ */

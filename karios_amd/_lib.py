@@ -35,7 +35,7 @@ class KltStats(C.Structure):
     _fields_ = [("valid_pixels", C.c_int64), ("n_candidates", C.c_int64), ("n_init", C.c_int32),
                 ("n_select_batches", C.c_int32), ("min_ref", C.c_double), ("max_ref", C.c_double),
                 ("min_mon", C.c_double), ("max_mon", C.c_double), ("max_eig", C.c_float),
-                ("reserved", C.c_float)]
+                ("emitted_ratio", C.c_float)]
 
 
 _vp, _i, _d, _sz, _pd = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.POINTER(C.c_double)

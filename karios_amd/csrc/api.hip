@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -238,60 +239,69 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
                     double min_distance, int block, float *d_xy, int cap, km_scalars *sc)
 {
     int rc;
-    float *eig = (float *)km_ws(c, WS_EIG, (size_t)H * W * sizeof(float));
-    if (!eig) return KM_E_NOMEM;
-    {
-        km_stage_timer t(c, ST_EIGEN);
-        if ((rc = kd_min_eigen(c, d_img, d_mask, H, W, block, eig, &sc->max_eig_key))) return rc;
-    }
-    size_t capk = (size_t)H * W / 8 + 4096;
-    unsigned ncand = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // Strongest-first shortcut: rank and select on the top slice only (a rank prefix, so a sufficient slice gives the
+    // exact result); fall back to the complete list when that slice cannot supply maxCorners corners.
+    size_t k_target = (max_corners > 0 && min_distance >= 1) ? (size_t)max_corners * 8 : 0;
+    size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
+    unsigned long long *kept = nullptr;
+    size_t nkept = 0, ntotal = 0;
+    km_scalars hs;
+    for (int attempt = 0; attempt < 3; attempt++) {
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
         if (!keys) return KM_E_NOMEM;
-        {
-            km_stage_timer t(c, ST_CANDIDATES);
-            if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk))) return rc;
+        // K3 + K4: fused marching kernel (no eig map) when it covers the case, else eig map + candidate kernel
+        // (the fused variant is exact and saves the 5 B/px eig-map round trip, but at 126 VGPRs it runs at 4 waves/SIMD and
+        //  measures 1.07 ms against 0.51 + 0.30 ms for the two separate kernels at 10980^2: opt-in until it is tuned)
+        static const bool use_fused = getenv("KARIOS_HIP_FUSED_EIG") != nullptr;
+        bool fused = false;
+        if (use_fused && H >= 3 && W >= 3) {
+            km_stage_timer t(c, ST_EIGEN);
+            rc = kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
+            if (rc == KM_OK) fused = true;
+            else if (rc != KM_E_UNSUPPORTED) return rc;
         }
-        km_scalars hs;
-        KM_HIP(c, hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
-        ncand = hs.n_cand;
+        if (!fused) {
+            float *eig = (float *)km_ws(c, WS_EIG, (size_t)H * W * sizeof(float));
+            if (!eig) return KM_E_NOMEM;
+            {
+                km_stage_timer t(c, ST_EIGEN);
+                if ((rc = kd_min_eigen(c, d_img, d_mask, H, W, block, eig, &sc->max_eig_key))) return rc;
+            }
+            {
+                km_stage_timer t(c, ST_CANDIDATES);
+                if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk))) return rc;
+            }
+        }
+        {
+            km_stage_timer t(c, ST_SORT);
+            if ((rc = ks_topk_prefilter(c, keys, capk, k_target, sc, quality, &kept, &nkept, &ntotal, &hs))) return rc;
+        }
         c->stats.valid_pixels = (int64_t)hs.valid;
         c->stats.max_eig = hs.max_eig;
         c->stats.min_ref = hs.mm[0]; c->stats.max_ref = hs.mm[1]; c->stats.min_mon = hs.mm[2]; c->stats.max_mon = hs.mm[3];
-        if (ncand <= capk) break;
-        capk = (size_t)ncand + 4096;  // plateau-heavy image: grow and redo
+        if ((size_t)hs.n_cand <= capk) break;
+        capk = (size_t)hs.n_cand + hs.n_cand / 4 + 4096 * KM_NSHARD;   // a shard overflowed: grow the key buffer and redo
+        if (attempt == 2) return km_fail(c, KM_E_INTERNAL, "candidate buffer kept overflowing");
     }
-    c->stats.n_candidates = ncand;
+    c->stats.n_candidates = (int64_t)ntotal;
+    c->stats.emitted_ratio = ntotal ? (float)((double)hs.n_cand / (double)ntotal) : 0.f;
     unsigned long long *keys = (unsigned long long *)c->ws[WS_KEYS0].p;
-    // Strongest-first shortcut: rank and select on the top slice only; fall back to the full list when that slice
-    // cannot supply maxCorners corners (the slice is a rank prefix, so a sufficient slice gives the exact result).
-    const size_t k_target = max_corners > 0 ? (size_t)max_corners * 8 : 0;
-    if (k_target && (size_t)ncand > 4 * k_target && min_distance >= 1) {
-        unsigned long long *kept = nullptr, *sorted_kept = nullptr;
-        size_t nkept = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        unsigned long long *sorted = kept;
+        if (nkept > 0) {
+            km_stage_timer t(c, ST_SORT);
+            if ((rc = ks_sort_keys_desc(c, kept, nkept, &sorted))) return rc;
+        }
         int found = -1;
         {
-            km_stage_timer t(c, ST_SORT);
-            if ((rc = ks_topk_prefilter(c, keys, ncand, k_target, sc, &kept, &nkept))) return rc;
-            if ((rc = ks_sort_keys_desc(c, kept, nkept, &sorted_kept))) return rc;
-        }
-        {
             km_stage_timer t(c, ST_SELECT);
-            if ((rc = ks_select(c, sorted_kept, nkept, H, W, max_corners, min_distance, d_xy, cap, sc, &found))) return rc;
+            if ((rc = ks_select(c, sorted, nkept, H, W, max_corners, min_distance, d_xy, cap, sc, nkept < ntotal ? &found : nullptr))) return rc;
         }
-        if (found >= max_corners || nkept >= ncand) return KM_OK;
-        // not enough corners in the slice: redo on the complete list
-    }
-    unsigned long long *sorted = keys;
-    if (ncand > 0) {
-        km_stage_timer t(c, ST_SORT);
-        if ((rc = ks_sort_keys_desc(c, keys, ncand, &sorted))) return rc;
-    }
-    {
-        km_stage_timer t(c, ST_SELECT);
-        if ((rc = ks_select(c, sorted, ncand, H, W, max_corners, min_distance, d_xy, cap, sc, nullptr))) return rc;
+        if (nkept >= ntotal || found >= max_corners) break;
+        // the top slice did not contain maxCorners mutually distant corners: repeat on every candidate
+        k_target = 0;
+        km_scalars hs2;
+        if ((rc = ks_topk_prefilter(c, keys, capk, 0, sc, quality, &kept, &nkept, &ntotal, &hs2))) return rc;
     }
     return KM_OK;
 }

@@ -9,6 +9,9 @@
 #include "../../include/karios_hip.h"
 
 #define KM_WAVE 64
+// candidate keys are appended through KM_NSHARD independent counters (one region of the key buffer each): a single
+// counter caps the whole kernel at the ~90 atomics/us one address sustains
+#define KM_NSHARD 16
 
 // OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
 __host__ __device__ __forceinline__ int km_reflect101(int p, int len)
@@ -83,6 +86,9 @@ struct km_scalars {
     float thr;                // maxVal * qualityLevel as f32
     float max_eig;
     unsigned long long argmax_key; // phase correlation arg-max
+    unsigned int run_max_key;      // running max-eig key of the fused eig+candidate kernel
+    unsigned int pad0;
+    unsigned int shard_cnt[KM_NSHARD];  // keys appended per shard (may exceed the shard capacity: overflow)
 };
 
 struct km_ctx {
@@ -164,6 +170,8 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
                               unsigned long long *d_valid);
 int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block,
                  float *d_eig, unsigned int *d_max_key);
+int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality,
+                      km_scalars *sc, unsigned long long *d_keys, size_t cap);
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
                   double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap);
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);
@@ -174,8 +182,8 @@ int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, pt
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted);
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W,
               int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found);
-int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t n, size_t k_target, const km_scalars *d_sc,
-                      unsigned long long **d_kept, size_t *n_kept);
+int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,
+                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs);
 // k_lk.hip
 struct km_pyr {
     const uint8_t *img[5];

@@ -154,9 +154,24 @@ __device__ __forceinline__ unsigned tk_bin(unsigned long long key, unsigned top)
     return d < TK_NB - 1 ? d : TK_NB - 1;
 }
 
-__global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long *__restrict__ keys, unsigned n, const km_scalars *sc,
-                                                       unsigned *__restrict__ hist)
+// exact TOZERO threshold of goodFeaturesToTrack: thr = (float)(maxVal * qualityLevel); candidates need value > thr
+__device__ __forceinline__ float tk_threshold(const km_scalars *sc, double quality)
 {
+    const unsigned mk = sc->max_eig_key;
+    const unsigned b = (mk & 0x80000000u) ? (mk & 0x7fffffffu) : ~mk;
+    const float maxv = mk ? __uint_as_float(b) : 0.f;
+    return (float)__dmul_rn((double)maxv, quality);
+}
+__device__ __forceinline__ bool tk_above(unsigned long long key, float thr) { return __uint_as_float((unsigned)(key >> 32)) > thr; }
+
+__global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long *__restrict__ keys, unsigned cap, const km_scalars *sc,
+                                                       double quality, unsigned *__restrict__ hist)
+{
+    // the key buffer is KM_NSHARD regions of cap / KM_NSHARD slots; blockIdx.y selects the region
+    const unsigned cap_s = cap / KM_NSHARD;
+    const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
+    keys += (size_t)blockIdx.y * cap_s;
+    const float thr = tk_threshold(sc, quality);
     __shared__ unsigned h[TK_NB];
     for (int i = threadIdx.x; i < TK_NB; i += 1024) h[i] = 0;
     __syncthreads();
@@ -165,7 +180,8 @@ __global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long 
     unsigned tail = 0;
     for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
         const unsigned i = b + threadIdx.x;
-        const unsigned d = i < n ? tk_bin(keys[i], top) : 0xffffffffu;
+        unsigned d = 0xffffffffu;
+        if (i < n) { const unsigned long long kk = keys[i]; if (tk_above(kk, thr)) d = tk_bin(kk, top); }
         const bool is_tail = d == TK_NB - 1;
         tail += (unsigned)__popcll(__ballot(is_tail));
         if (d < TK_NB - 1) atomicAdd(&h[d], 1u);
@@ -177,7 +193,8 @@ __global__ __launch_bounds__(1024) void tk_hist_kernel(const unsigned long long 
 }
 
 // hist[TK_NB] -> cut[0] = D (largest kept bin), cut[1] = number of kept keys
-__global__ __launch_bounds__(1024) void tk_cut_kernel(const unsigned *__restrict__ hist, unsigned k_target, unsigned *__restrict__ cut)
+__global__ __launch_bounds__(1024) void tk_cut_kernel(const unsigned *__restrict__ hist, unsigned k_target, unsigned *__restrict__ cut,
+                                                      km_scalars *sc, double quality)
 {
     __shared__ unsigned s_wave[16];
     __shared__ unsigned s_first;
@@ -203,13 +220,24 @@ __global__ __launch_bounds__(1024) void tk_cut_kernel(const unsigned *__restrict
     if (mine != 0xffffffffu) atomicMin(&s_first, mine);
     __syncthreads();
     const unsigned D = s_first == 0xffffffffu ? TK_NB - 1 : s_first;
+    if (t == 0) {
+        cut[3] = total;                      // exact number of candidates (value > thr)
+        sc->thr = tk_threshold(sc, quality);
+        const unsigned mk = sc->max_eig_key;
+        const unsigned bb = (mk & 0x80000000u) ? (mk & 0x7fffffffu) : ~mk;
+        sc->max_eig = mk ? __uint_as_float(bb) : 0.f;
+    }
     if (D == (unsigned)(2 * t)) { cut[0] = D; cut[1] = incl_a; cut[2] = 0; }
     else if (D == (unsigned)(2 * t + 1)) { cut[0] = D; cut[1] = s_first == 0xffffffffu ? total : incl_b; cut[2] = 0; }
 }
 
-__global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long long *__restrict__ keys, unsigned n, const km_scalars *sc,
-                                                          unsigned *cut, unsigned long long *__restrict__ out)
+__global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long long *__restrict__ keys, unsigned cap, const km_scalars *sc,
+                                                          double quality, unsigned *cut, unsigned long long *__restrict__ out)
 {
+    const unsigned cap_s = cap / KM_NSHARD;
+    const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
+    keys += (size_t)blockIdx.y * cap_s;
+    const float thr = tk_threshold(sc, quality);
     __shared__ unsigned s_wave[16];
     __shared__ unsigned s_base;
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> TK_SHIFT;
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long lo
         const unsigned i = b + threadIdx.x;
         unsigned long long k = 0;
         bool keep = false;
-        if (i < n) { k = keys[i]; keep = tk_bin(k, top) <= D; }
+        if (i < n) { k = keys[i]; keep = tk_above(k, thr) && tk_bin(k, top) <= D; }
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) s_wave[wv] = (unsigned)__popcll(bal);
         __syncthreads();
@@ -232,27 +260,40 @@ __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long lo
     }
 }
 
-// keeps (at least) the k_target strongest keys: *d_kept / *n_kept; one host synchronisation
-int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t n, size_t k_target, const km_scalars *d_sc,
-                      unsigned long long **d_kept, size_t *n_kept)
+// keeps (at least) the k_target strongest keys ABOVE the exact threshold (k_target = 0: all of them).  The number of keys
+// in d_keys is read on the device (sc->n_cand, clamped to cap_keys).  One host synchronisation, which also brings the
+// scalar block to the host: *n_kept, *n_total = exact candidate count, *hs (n_cand = keys emitted, valid pixels, ...).
+int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,
+                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs)
 {
     unsigned *hist = (unsigned *)km_ws(c, WS_GRID, (TK_NB + 4) * sizeof(unsigned));
     if (!hist) return KM_E_NOMEM;
     unsigned *cut = hist + TK_NB;
     KM_HIP(c, hipMemsetAsync(hist, 0, (TK_NB + 4) * sizeof(unsigned), c->stream));
-    tk_hist_kernel<<<256, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, hist);
+    tk_hist_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, d_sc, quality, hist);
     KM_LAUNCH_CHECK(c);
-    tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, (unsigned)k_target, cut);
+    tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, k_target ? (unsigned)k_target : 0xffffffffu, cut, d_sc, quality);
     KM_LAUNCH_CHECK(c);
-    unsigned hc[3] = {0, 0, 0};
+    unsigned hc[4] = {0, 0, 0, 0};
     KM_HIP(c, hipMemcpyAsync(hc, cut, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipMemcpyAsync(hs, d_sc, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     const size_t kept = hc[1];
+    *n_total = hc[3];
+    *n_kept = kept;
+    *d_kept = nullptr;
+    // total keys emitted; an overflowing shard is reported as n_cand > cap_keys so that the caller regrows and repeats
+    size_t emitted = 0, worst = 0;
+    for (int i = 0; i < KM_NSHARD; i++) { emitted += hs->shard_cnt[i]; if (hs->shard_cnt[i] > worst) worst = hs->shard_cnt[i]; }
+    hs->n_cand = (unsigned)emitted;
+    if (worst > cap_keys / KM_NSHARD) { hs->n_cand = (unsigned)(worst * KM_NSHARD > cap_keys ? worst * KM_NSHARD : cap_keys + 1); return KM_OK; }
     unsigned long long *out = (unsigned long long *)km_ws(c, WS_MISC3, (kept + 16) * sizeof(unsigned long long));
     if (!out) return KM_E_NOMEM;
-    tk_compact_kernel<<<1024, 1024, 0, c->stream>>>(d_keys, (unsigned)n, d_sc, cut, out);
-    KM_LAUNCH_CHECK(c);
-    *d_kept = out; *n_kept = kept;
+    if (kept > 0) {
+        tk_compact_kernel<<<dim3(64, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, d_sc, quality, cut, out);
+        KM_LAUNCH_CHECK(c);
+    }
+    *d_kept = out;
     return KM_OK;
 }
 

@@ -27,3 +27,5 @@ for it in range(6):
 ctx.set_profiling(True)
 pair.match_tile(conf)
 print({k: round(v, 3) for k, v in ctx.stage_ms().items()})
+
+st = ctx.stats(); print("candidates", st.n_candidates, "emitted ratio", st.emitted_ratio, "select rounds", st.n_select_batches)
