@@ -138,21 +138,37 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         int jx0 = (int)floorf(nx - half) - LK_M, jy0 = (int)floorf(ny - half) - LK_M;
         stage_patch(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
         __syncthreads();
-        // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image
-        for (int i = lane; i < DW * DW; i += 64) {
-            const int r = i / DW, cx = i - r * DW;
-            const int gy = ipy + r, gx = ipx + cx;
-            int v = 0;
-            if ((unsigned)gx < (unsigned)IW && (unsigned)gy < (unsigned)IH) {
-                const uint8_t *p = raw + (r + 1) * RP + (cx + 1);
-                const int a00 = p[-RP - 1], a01 = p[-RP], a02 = p[-RP + 1];
-                const int a10 = p[-1], a12 = p[1];
-                const int a20 = p[RP - 1], a21 = p[RP], a22 = p[RP + 1];
-                const int ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
-                const int iy = ((a20 + a22) * 3 + a21 * 10) - ((a00 + a02) * 3 + a01 * 10);
-                v = (ix & 0xffff) | (iy << 16);
+        // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image.  Four adjacent positions per lane
+        // and step share their 3x6 neighbourhood (column sums s = 3*(a0+a2)+10*a1 and d = a2-a0 per column).
+        {
+            const int ngrp = (DW + 3) >> 2;
+            for (int i = lane; i < DW * ngrp; i += 64) {
+                const int r = i / ngrp, g = i - r * ngrp;
+                const int cx0 = 4 * g;
+                const uint8_t *p = raw + (r + 1) * RP + cx0;      // column cx0-1 of the centre row is p[0]
+                int sv[6], dv[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const int a0 = p[k - RP], a1 = p[k], a2 = p[k + RP];
+                    sv[k] = (a0 + a2) * 3 + a1 * 10;   // vertical smoothing  [3 10 3]
+                    dv[k] = a2 - a0;                   // vertical difference [-1 0 1]
+                }
+                const int gy = ipy + r;
+                const bool row_in = (unsigned)gy < (unsigned)IH;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int cx = cx0 + k;
+                    if (cx < DW) {
+                        int v = 0;
+                        if (row_in && (unsigned)(ipx + cx) < (unsigned)IW) {
+                            const int ix = sv[k + 2] - sv[k];
+                            const int iy = (dv[k] + dv[k + 2]) * 3 + dv[k + 1] * 10;
+                            v = (ix & 0xffff) | (iy << 16);
+                        }
+                        der[r * DW + cx] = v;
+                    }
+                }
             }
-            der[i] = v;
         }
         __syncthreads();
         // per-lane window pixels -> registers; exact integer normal matrix
