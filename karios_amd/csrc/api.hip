@@ -269,12 +269,12 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
             }
             {
                 km_stage_timer t(c, ST_CANDIDATES);
-                if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk))) return rc;
+                if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, capk, attempt > 0))) return rc;
             }
         }
         {
             km_stage_timer t(c, ST_SORT);
-            if ((rc = ks_topk_prefilter(c, keys, capk, k_target, sc, quality, &kept, &nkept, &ntotal, &hs))) return rc;
+            if ((rc = ks_topk_prefilter(c, keys, capk, k_target, sc, quality, &kept, &nkept, &ntotal, &hs, attempt > 0))) return rc;
         }
         c->stats.valid_pixels = (int64_t)hs.valid;
         c->stats.max_eig = hs.max_eig;
@@ -295,13 +295,13 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         int found = -1;
         {
             km_stage_timer t(c, ST_SELECT);
-            if ((rc = ks_select(c, sorted, nkept, H, W, max_corners, min_distance, d_xy, cap, sc, nkept < ntotal ? &found : nullptr))) return rc;
+            if ((rc = ks_select(c, sorted, nkept, H, W, max_corners, min_distance, d_xy, cap, sc, nkept < ntotal ? &found : nullptr, pass == 0))) return rc;
         }
         if (nkept >= ntotal || found >= max_corners) break;
         // the top slice did not contain maxCorners mutually distant corners: repeat on every candidate
         k_target = 0;
         km_scalars hs2;
-        if ((rc = ks_topk_prefilter(c, keys, capk, 0, sc, quality, &kept, &nkept, &ntotal, &hs2))) return rc;
+        if ((rc = ks_topk_prefilter(c, keys, capk, 0, sc, quality, &kept, &nkept, &ntotal, &hs2, true))) return rc;
     }
     return KM_OK;
 }
@@ -383,9 +383,7 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
         km_stage_timer t(c, ST_MINMAX);
         if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0]))) return rc;
         if ((rc = kd_minmax(c, d_mon, dtype, H, W, smon, &sc->mm[2]))) return rc;
-    } else {
-        KM_HIP(c, hipMemsetAsync(sc->mm, 0, sizeof sc->mm, c->stream));
-    }
+    }   // (u8 input: mm stays 0 from the scalar block the entry point zeroed)
     {
         km_stage_timer t(c, ST_LAPLACIAN);
         if (d_mask) { if ((rc = kd_count_nonzero(c, d_mask, n, &sc->valid))) return rc; }
@@ -497,6 +495,7 @@ int km_good_features(km_ctx *c, const uint8_t *img, const uint8_t *mask, int H, 
     km_scalars *sc = scalars(c);
     float *d_xy = (float *)km_ws(c, WS_PTS0, (size_t)(cap > 0 ? cap : 1) * 2 * sizeof(float));
     if (!sc || !d_xy) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     if ((rc = gftt_dev(c, (const uint8_t *)d_img, (const uint8_t *)d_mask, H, W, max_corners, quality, min_distance, block, d_xy, cap, sc)))
         return rc;
     if ((rc = read_stats(c, sc))) return rc;

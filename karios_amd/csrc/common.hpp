@@ -12,6 +12,7 @@
 // candidate keys are appended through KM_NSHARD independent counters (one region of the key buffer each): a single
 // counter caps the whole kernel at the ~90 atomics/us one address sustains
 #define KM_NSHARD 16
+#define KM_TK_NB 2048   // bins of the top-K pre-filter histogram
 
 // OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
 __host__ __device__ __forceinline__ int km_reflect101(int p, int len)
@@ -89,6 +90,9 @@ struct km_scalars {
     unsigned int run_max_key;      // running max-eig key of the fused eig+candidate kernel
     unsigned int pad0;
     unsigned int shard_cnt[KM_NSHARD];  // keys appended per shard (may exceed the shard capacity: overflow)
+    unsigned int cut[4];           // top-K pre-filter: D, kept, compaction cursor, exact candidate count
+    unsigned int und[8];           // undecided counters of the selection sweeps (one per launch slot)
+    unsigned int hist[KM_TK_NB];   // top-K pre-filter histogram (zeroed with the block at the start of a call)
 };
 
 struct km_ctx {
@@ -173,7 +177,7 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
 int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality,
                       km_scalars *sc, unsigned long long *d_keys, size_t cap);
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
-                  double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap);
+                  double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap, bool rezero);
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);
 int kd_pyrdown_u8_pair(km_ctx *c, const uint8_t *d_src_a, const uint8_t *d_src_b, int H, int W, uint8_t *d_dst_a, uint8_t *d_dst_b);
 int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride,
@@ -181,9 +185,9 @@ int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, pt
 // k_select.hip
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted);
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W,
-              int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found);
+              int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found, bool fresh_scalars);
 int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,
-                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs);
+                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs, bool rezero);
 // k_lk.hip
 struct km_pyr {
     const uint8_t *img[5];

@@ -250,9 +250,9 @@ int kd_count_nonzero(km_ctx *c, const uint8_t *d_mask, size_t n, unsigned long l
 // final reductions of per-workgroup partials (one workgroup; the partial arrays are tens of KB)
 __global__ __launch_bounds__(1024) void sum_u32_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned long long *out)
 {
-    // grid of workgroups, each sums a slice and adds ONE value to *out (zeroed by the launcher)
+    // ONE workgroup: writes (not accumulates) the total, so the launcher needs no memset
     unsigned long long s = 0;
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) s += partial[i];
+    for (unsigned i = threadIdx.x; i < n; i += 1024) s += partial[i];
     s = wave_sum_u64(s);
     __shared__ unsigned long long sh[16];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void sum_u32_kernel(const unsigned *__restric
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int i = 0; i < 16; i++) t += sh[i];
-        if (t) atomicAdd(out, t);
+        *out = t;
     }
 }
 __global__ __launch_bounds__(1024) void max_u32_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned *out)
@@ -680,8 +680,7 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
 #undef KM_LAP_CASE
     KM_LAUNCH_CHECK(c);
     if (MASK) {
-        KM_HIP(c, hipMemsetAsync(valid_out, 0, sizeof(unsigned long long), c->stream));
-        sum_u32_kernel<<<32, 1024, 0, c->stream>>>(valid, grid.x * grid.y, valid_out);
+        sum_u32_kernel<<<1, 1024, 0, c->stream>>>(valid, grid.x * grid.y, valid_out);
         KM_LAUNCH_CHECK(c);
     }
     return KM_OK;
@@ -900,8 +899,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     }
     KM_LAUNCH_CHECK(c);
     if (MASK) {
-        KM_HIP(c, hipMemsetAsync(valid_out, 0, sizeof(unsigned long long), c->stream));
-        sum_u32_kernel<<<32, 1024, 0, c->stream>>>(valid, (unsigned)nwaves, valid_out);
+        sum_u32_kernel<<<1, 1024, 0, c->stream>>>(valid, (unsigned)nwaves, valid_out);
         KM_LAUNCH_CHECK(c);
     }
     return KM_OK;
@@ -1518,9 +1516,9 @@ __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig
 }
 
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W, double quality, km_scalars *d_sc,
-                  unsigned long long *d_keys, size_t cap)
+                  unsigned long long *d_keys, size_t cap, bool rezero)
 {
-    KM_HIP(c, hipMemsetAsync(d_sc->shard_cnt, 0, KM_NSHARD * sizeof(unsigned int), c->stream));
+    if (rezero) KM_HIP(c, hipMemsetAsync(d_sc->shard_cnt, 0, KM_NSHARD * sizeof(unsigned int), c->stream));
     if (H < 3 || W < 3) {
         return KM_OK;
     }

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restric
                                                           const float *__restrict__ p0r, const int *__restrict__ d_n, int n_max,
                                                           float back_thr, float x_off, float y_off, unsigned long long *__restrict__ keys,
                                                           unsigned *__restrict__ ranks, float *__restrict__ tmp /* 5*cap */, int cap,
-                                                          int *__restrict__ hdr, unsigned *__restrict__ counts)
+                                                          int *__restrict__ hdr, unsigned *__restrict__ counts, int n_sort)
 {
     __shared__ int s_wave[FB_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -46,8 +46,9 @@ __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restric
         if (tid == 0) counts[blockIdx.x] = (unsigned)tot;
         return;
     }
-    int base = 0;
-    for (unsigned b = 0; b < blockIdx.x; b++) base += (int)counts[b];
+    int base = 0, total = 0;
+    for (unsigned b = 0; b < gridDim.x; b++) { const int cb = (int)counts[b]; if (b < blockIdx.x) base += cb; total += cb; }
+    if (i >= total && i < n_sort) keys[i] = ~0ull;   // sentinel keys behind the kept ones keep the sort length fixed
     if (keep) {
         const int r = base + off + __popcll(bal & ((1ull << lane) - 1ull));
         if (r < cap) {
@@ -88,17 +89,15 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     if (!keys || !ranks || !tmp) return KM_E_NOMEM;
     unsigned long long *keys_alt = keys + cap;
     unsigned *ranks_alt = ranks + cap;
-    // an over-long sort is avoided by sorting `cap` slots with sentinel keys behind the kept ones
-    KM_HIP(c, hipMemsetAsync(keys, 0xff, (size_t)cap * sizeof(unsigned long long), c->stream));
     const int nblk = (n_max + FB_T - 1) / FB_T;
+    const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);   // fixed sort length: sentinel keys behind the kept rows
     unsigned *counts = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)nblk * sizeof(unsigned));
     if (!counts) return KM_E_NOMEM;
-    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts);
+    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort);
     KM_LAUNCH_CHECK(c);
-    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts);
+    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort);
     KM_LAUNCH_CHECK(c);
     size_t tmp_bytes = 0;
-    const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);
     KM_HIP(c, rocprim::radix_sort_pairs((void *)nullptr, tmp_bytes, keys, keys_alt, ranks, ranks_alt, n_sort, 0, 64, c->stream));
     void *stmp = km_ws(c, WS_SORT_TMP, tmp_bytes ? tmp_bytes : 16);
     if (!stmp) return KM_E_NOMEM;

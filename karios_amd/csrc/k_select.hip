@@ -22,6 +22,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted)
 {
@@ -47,10 +48,11 @@ __device__ __forceinline__ void key_xy(unsigned long long key, int W, int &x, in
 
 // count prefix candidates [k0, k1) per cell
 __global__ __launch_bounds__(256) void sel_count_kernel(const unsigned long long *__restrict__ keys, unsigned k0, unsigned k1, int W,
-                                                        int cell, int gw, unsigned *__restrict__ cell_cnt)
+                                                        int cell, int gw, unsigned *__restrict__ cell_cnt, unsigned *__restrict__ state)
 {
     const unsigned i = k0 + blockIdx.x * 256 + threadIdx.x;
     if (i >= k1) return;
+    state[i] = ST_UNDECIDED;   // new prefix members start undecided (older ones keep their final state)
     int x, y;
     key_xy(keys[i], W, x, y);
     atomicAdd(&cell_cnt[(y / cell) * gw + (x / cell)], 1u);
@@ -111,11 +113,9 @@ __global__ __launch_bounds__(256) void sel_sweep_kernel(const unsigned long long
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_undecided, (unsigned)__popcll(bal));
 }
 
-__global__ __launch_bounds__(256) void sel_flag_kernel(const unsigned *__restrict__ state, unsigned k1, unsigned *__restrict__ flag)
-{
-    const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i < k1) flag[i] = state[i] == ST_ACCEPT ? 1u : 0u;
-}
+struct sel_is_accept {
+    __host__ __device__ unsigned operator()(unsigned st) const { return st == ST_ACCEPT ? 1u : 0u; }
+};
 
 // pos = exclusive scan of the accept flags = index in OpenCV's output order
 __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long 
         if (max_corners > 0 && total > max_corners) total = max_corners;
         sc->n_corners = total;
         sc->n_batches = rounds;
+        sc->und[7] = (unsigned)total;   // travels to the host together with the undecided counters
     }
 }
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long 
 // candidate list (several 10^6 keys) is cut down before the radix sort.  Values are binned by the distance of
 // their top 18 float bits from the maximum's (bins of ~0.2 %); the smallest bin bound D with at least K_target
 // candidates above it defines the kept set, which is a rank prefix of the full list.
-#define TK_NB 2048
+#define TK_NB KM_TK_NB
 #define TK_SHIFT 14
 
 __device__ __forceinline__ unsigned tk_bin(unsigned long long key, unsigned top)
@@ -261,25 +262,25 @@ __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long lo
 }
 
 // keeps (at least) the k_target strongest keys ABOVE the exact threshold (k_target = 0: all of them).  The number of keys
-// in d_keys is read on the device (sc->n_cand, clamped to cap_keys).  One host synchronisation, which also brings the
-// scalar block to the host: *n_kept, *n_total = exact candidate count, *hs (n_cand = keys emitted, valid pixels, ...).
+// in d_keys is read on the device (sc->shard_cnt, clamped to the shard capacity).  The histogram and the cut live in the
+// scalar block, which the caller zeroed at the start of the call (`rezero` for a repeated pass).  One host
+// synchronisation brings the whole block to the host: *n_kept, *n_total = exact candidate count, *hs.
 int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,
-                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs)
+                      unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs, bool rezero)
 {
-    unsigned *hist = (unsigned *)km_ws(c, WS_GRID, (TK_NB + 4) * sizeof(unsigned));
-    if (!hist) return KM_E_NOMEM;
-    unsigned *cut = hist + TK_NB;
-    KM_HIP(c, hipMemsetAsync(hist, 0, (TK_NB + 4) * sizeof(unsigned), c->stream));
+    unsigned *hist = d_sc->hist, *cut = d_sc->cut;
+    if (rezero) {
+        KM_HIP(c, hipMemsetAsync(cut, 0, sizeof d_sc->cut, c->stream));
+        KM_HIP(c, hipMemsetAsync(hist, 0, sizeof d_sc->hist, c->stream));
+    }
     tk_hist_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, d_sc, quality, hist);
     KM_LAUNCH_CHECK(c);
     tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, k_target ? (unsigned)k_target : 0xffffffffu, cut, d_sc, quality);
     KM_LAUNCH_CHECK(c);
-    unsigned hc[4] = {0, 0, 0, 0};
-    KM_HIP(c, hipMemcpyAsync(hc, cut, sizeof hc, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipMemcpyAsync(hs, d_sc, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
-    const size_t kept = hc[1];
-    *n_total = hc[3];
+    const size_t kept = hs->cut[1];
+    *n_total = hs->cut[3];
     *n_kept = kept;
     *d_kept = nullptr;
     // total keys emitted; an overflowing shard is reported as n_cand > cap_keys so that the caller regrows and repeats
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void take_first_kernel(const unsigned long lon
 }
 
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W, int max_corners, double min_distance,
-              float *d_xy, int cap, km_scalars *d_sc, int *n_found)
+              float *d_xy, int cap, km_scalars *d_sc, int *n_found, bool fresh_scalars)
 {
     if (n_found) *n_found = -1;  // -1: not read back
     if (n > 0xfffffff0ull) return km_fail(c, KM_E_UNSUPPORTED, "too many candidates");
@@ -330,57 +331,55 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
     const size_t cells = (size_t)gw * gh;
     const double md2 = min_distance * min_distance;
     const unsigned N = (unsigned)n;
-    // workspace: [cells+1] counts | [cells+1] offsets | [cells] fill cursors ; items / state / flag / pos per candidate
-    unsigned *grid = (unsigned *)km_ws(c, WS_GRID, (3 * cells + 2) * sizeof(unsigned));
-    unsigned *per = (unsigned *)km_ws(c, WS_MISC2, (size_t)N * 4 * sizeof(unsigned));
+    // workspace: [cells+1] counts | [cells] fill cursors  (zeroed by ONE memset) | [cells+1] offsets ; items / state / pos per candidate
+    unsigned *grid = (unsigned *)km_ws(c, WS_GRID, (3 * cells + 4) * sizeof(unsigned));
+    unsigned *per = (unsigned *)km_ws(c, WS_MISC2, (size_t)N * 3 * sizeof(unsigned));
     if (!grid || !per) return KM_E_NOMEM;
-    unsigned *cell_cnt = grid, *cell_off = grid + cells + 1, *cell_fill = grid + 2 * cells + 2;
-    unsigned *items = per, *state = per + N, *flag = per + 2 * (size_t)N, *pos = per + 3 * (size_t)N;
+    unsigned *cell_cnt = grid, *cell_fill = grid + cells + 1, *cell_off = grid + 2 * cells + 2;
+    unsigned *items = per, *state = per + N, *pos = per + 2 * (size_t)N;
+    auto accept_flags = rocprim::make_transform_iterator(state, sel_is_accept());
     size_t scan_bytes_cells = 0, scan_bytes_k = 0;
     KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_cells, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
-    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_k, flag, pos, 0u, (size_t)N, rocprim::plus<unsigned>(), c->stream));
+    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_k, accept_flags, pos, 0u, (size_t)N, rocprim::plus<unsigned>(), c->stream));
     const size_t tmp_bytes = (scan_bytes_cells > scan_bytes_k ? scan_bytes_cells : scan_bytes_k) + 256;
     void *tmp = km_ws(c, WS_SORT_TMP, tmp_bytes);
     if (!tmp) return KM_E_NOMEM;
-    unsigned *d_und = (unsigned *)&d_sc->argmax_key;  // scratch word of the scalar block
 
-    KM_HIP(c, hipMemsetAsync(cell_cnt, 0, (cells + 1) * sizeof(unsigned), c->stream));
-    KM_HIP(c, hipMemsetAsync(state, 0, (size_t)N * sizeof(unsigned), c->stream));
-    unsigned k0 = 0, k1 = (max_corners > 0) ? (unsigned)((size_t)max_corners * 8 < n ? (size_t)max_corners * 8 : n) : N;
+    KM_HIP(c, hipMemsetAsync(cell_cnt, 0, (2 * cells + 1) * sizeof(unsigned), c->stream));   // counts + fill cursors
+    unsigned k0 = 0, k1 = (max_corners > 0) ? (unsigned)((size_t)max_corners * 3 < n ? (size_t)max_corners * 3 : n) : N;
     int rounds = 0;
+    bool und_fresh = fresh_scalars;   // d_sc->und[] was zeroed with the scalar block at the start of the call
     for (;;) {
         // (re)build the cell lists for the prefix [0, k1): counts only need the new part [k0, k1)
-        sel_count_kernel<<<(k1 - k0 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k0, k1, W, cell, gw, cell_cnt);
+        sel_count_kernel<<<(k1 - k0 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k0, k1, W, cell, gw, cell_cnt, state);
         KM_LAUNCH_CHECK(c);
         size_t sb = scan_bytes_cells;
         KM_HIP(c, rocprim::exclusive_scan(tmp, sb, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
-        KM_HIP(c, hipMemsetAsync(cell_fill, 0, cells * sizeof(unsigned), c->stream));
+        if (k0 > 0) KM_HIP(c, hipMemsetAsync(cell_fill, 0, cells * sizeof(unsigned), c->stream));
         sel_fill_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k1, W, cell, gw, cell_off, cell_fill, items);
         KM_LAUNCH_CHECK(c);
+        int got = 0;
         for (;;) {
-            unsigned und = 0;
-            for (int g = 0; g < 4; g++) {  // 4 launches (16 sweeps) between host checks
-                if (g == 3) KM_HIP(c, hipMemsetAsync(d_und, 0, sizeof(unsigned), c->stream));
+            if (!und_fresh) KM_HIP(c, hipMemsetAsync(d_sc->und, 0, sizeof d_sc->und, c->stream));
+            und_fresh = false;
+            for (int g = 0; g < 4; g++) {  // 4 launches (16 sweeps), each with its own undecided counter
                 sel_sweep_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k1, W, cell, gw, gh, md2, cell_off, cell_cnt, items, state,
-                                                                          d_und);
+                                                                          &d_sc->und[g]);
                 KM_LAUNCH_CHECK(c);
                 rounds++;
             }
-            KM_HIP(c, hipMemcpyAsync(&und, d_und, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            // optimistic tail: rank the accepted corners right away and fetch (undecided, corner count) together
+            size_t sk = scan_bytes_k;
+            KM_HIP(c, rocprim::exclusive_scan(tmp, sk, accept_flags, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
+            sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
+            KM_LAUNCH_CHECK(c);
+            unsigned back[8];
+            KM_HIP(c, hipMemcpyAsync(back, d_sc->und, sizeof back, hipMemcpyDeviceToHost, c->stream));
             KM_HIP(c, hipStreamSynchronize(c->stream));
-            if (und == 0) break;
+            got = (int)back[7];
+            if (back[3] == 0) break;   // every prefix member decided: the emitted list is final for this prefix
             if (rounds > 100000) return km_fail(c, KM_E_INTERNAL, "corner selection did not converge");
         }
-        sel_flag_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(state, k1, flag);
-        KM_LAUNCH_CHECK(c);
-        size_t sk = scan_bytes_k;
-        KM_HIP(c, rocprim::exclusive_scan(tmp, sk, flag, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
-        sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
-        KM_LAUNCH_CHECK(c);
-        if (k1 == N && !n_found) break;
-        int got = 0;
-        KM_HIP(c, hipMemcpyAsync(&got, &d_sc->n_corners, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
         if (n_found) *n_found = got;
         if (k1 == N) break;
         if (max_corners > 0 && got >= max_corners) break;
