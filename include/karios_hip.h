@@ -132,6 +132,14 @@ int km_klt_tile(km_ctx *ctx, const void *ref, const void *mon, int dtype, int H,
                 const double *nodata_ref, const double *nodata_mon,
                 const km_klt_params *prm, float *p0, float *p1, float *p0r, int cap,
                 int *out_n);
+/* Pre-filter of KLT._match_tile on one tile (klt.py:268-273 automatic mask, :407-436 `_to_uint8` + inversion +
+ * cv2.Laplacian of both images) exactly as the tile entry points run it: ONE fused kernel for both images.
+ * out_mask may be NULL (no mask derived, *out_valid = -1), else *out_valid = count of valid pixels. */
+int km_tile_prefilter(km_ctx *ctx, const void *ref, const void *mon, int dtype, int H, int W,
+                      ptrdiff_t stride_ref, ptrdiff_t stride_mon, const double *nodata_ref,
+                      const double *nodata_mon, int ksize_ref, int ksize_mon, int invert_mon,
+                      uint8_t *out_lap_ref, uint8_t *out_lap_mon, uint8_t *out_mask,
+                      int64_t *out_valid);
 /* ZNCCService.compute_zncc per keypoint (matcher/zncc_service.py:186-238, _zncc2 :45-126):
  * out[k] = NaN where the reference returns NaN */
 int km_zncc_batch(km_ctx *ctx, const void *ref, const void *mon, int dtype, int Href,

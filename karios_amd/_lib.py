@@ -66,6 +66,7 @@ SIGNATURES = {
     "km_klt_track": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(KltParams), _vp, _i, _vp, _vp, _vp, _i, _pi]),
     "km_klt_tile": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _pd, _pd, C.POINTER(KltParams), _vp, _vp,
                          _vp, _i, _pi]),
+    "km_tile_prefilter": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "km_zncc_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_mi_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "km_phase_shift": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),

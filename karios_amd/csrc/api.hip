@@ -623,6 +623,44 @@ int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, i
     return fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n);
 }
 
+// KLT._match_tile pre-filter on host buffers: uint8 stretch + Laplacian of both images and the automatic mask in the
+// fused kernel the tile path uses (klt.py:268-273, 407-436).  out_mask may be null (then no mask is derived).
+int km_tile_prefilter(km_ctx *c, const void *ref, const void *mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                      const double *nodata_ref, const double *nodata_mon, int ksize_ref, int ksize_mon, int invert_mon, uint8_t *out_lap_ref,
+                      uint8_t *out_lap_mon, uint8_t *out_mask, int64_t *out_valid)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, ref, H, W, sref, "tile_prefilter")) || (rc = check_image(c, mon, H, W, smon, "tile_prefilter")))
+        return rc;
+    const size_t es = km_dtype_size(dtype);
+    if (!es) return km_fail(c, KM_E_ARG, "tile_prefilter: bad dtype %d", dtype);
+    if (!out_lap_ref || !out_lap_mon) return km_fail(c, KM_E_ARG, "tile_prefilter: null output");
+    void *d_ref, *d_mon;
+    if ((rc = upload_image(c, WS_RAW_A, ref, es, H, W, sref, &d_ref)) || (rc = upload_image(c, WS_RAW_B, mon, es, H, W, smon, &d_mon))) return rc;
+    const size_t n = (size_t)H * W;
+    km_scalars *sc = scalars(c);
+    uint8_t *lap_ref = (uint8_t *)km_ws(c, WS_U8_A, n), *lap_mon = (uint8_t *)km_ws(c, WS_U8_B, n);
+    uint8_t *d_mask = out_mask ? (uint8_t *)km_ws(c, WS_MASK, n) : nullptr;
+    if (!sc || !lap_ref || !lap_mon || (out_mask && !d_mask)) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    if (dtype != KM_U8) {
+        if ((rc = kd_minmax(c, d_ref, dtype, H, W, W, &sc->mm[0])) || (rc = kd_minmax(c, d_mon, dtype, H, W, W, &sc->mm[2]))) return rc;
+    }
+    if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, W, W, sc->mm, ksize_ref, ksize_mon, invert_mon, nodata_ref, nodata_mon,
+                                        lap_ref, lap_mon, d_mask, &sc->valid)))
+        return rc;
+    unsigned long long valid = 0;
+    KM_HIP(c, hipMemcpyAsync(out_lap_ref, lap_ref, n, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipMemcpyAsync(out_lap_mon, lap_mon, n, hipMemcpyDeviceToHost, c->stream));
+    if (out_mask) {
+        KM_HIP(c, hipMemcpyAsync(out_mask, d_mask, n, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
+    }
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (out_valid) *out_valid = out_mask ? (int64_t)valid : -1;
+    return KM_OK;
+}
+
 int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
                     const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float *d_p0,
                     float *d_p1, float *d_p0r, int cap, int *d_n)

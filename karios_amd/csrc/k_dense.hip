@@ -285,11 +285,14 @@ __global__ __launch_bounds__(1024) void max_u32_kernel(const unsigned *__restric
 // radius R = max of the two, the shorter kernel zero-padded, so one launch serves mixed sizes.
 //
 // uint8 stretch of 16-bit integer images without a per-pixel fp64 division: numpy computes
-// trunc(fl(fl(d/r)*255)) with d = v - min, r = max - min.  For 255*d not divisible by r the exact
-// quotient is >= 1/r away from an integer, far more than the fp64 rounding error, so
-// floor(255*d / r) in integer arithmetic is the same number.  For the <= 256 values of d with
-// 255*d == k*r exactly, fp64 rounding decides between k and k-1: those answers are tabulated per
-// image by `stretch_table_kernel` with the very fp64 expression numpy uses.
+// trunc(fl(fl(d/r)*255)) with d = v - min, r = max - min (integers).  When 255*d is not a multiple of r the exact
+// quotient 255*d/r lies >= 1/r from any integer, far more than the fp64 rounding error, so the result is
+// floor(255*d/r).  When 255*d == k*r the real quotient d/r equals k/255, the correctly rounded division gives
+// fl(k/255) whatever d and r are, and fl(fl(k/255)*255) >= k holds for every k in 0..255 (256 cases, checked by
+// tests/test_host_logic.py::test_stretch_exact_multiples) - again floor(255*d/r).  The kernels evaluate that floor as
+//   (int) fma((double)d, 255/r, 0.5/r)
+// : (255*d + 0.5)/r is never an integer, has the same floor, and stays >= 0.5/r >= 7.6e-6 away from the integers,
+// eleven orders of magnitude above the fma's rounding error - three full-rate instructions, no branch, no table.
 #define LAP_TW 128
 #define LAP_TH 16
 
@@ -297,25 +300,6 @@ struct lap_coef {
     int kd[2][11];
     int ks[2][11];
 };
-
-// tab[img][k] = numpy's uint8 for the pixel value whose exact stretch is the integer k
-__global__ __launch_bounds__(256) void stretch_table_kernel(const double *__restrict__ mm, uint8_t *__restrict__ tab, int nimg)
-{
-    const int k = threadIdx.x;
-    for (int i = 0; i < nimg; i++) {
-        const double mn = mm[2 * i], mx = mm[2 * i + 1], range = mx - mn;
-        uint8_t out = (uint8_t)k;
-        if (mx > mn && range <= 65535.0 && range == floor(range)) {
-            const unsigned long long R = (unsigned long long)range, kr = (unsigned long long)k * R;
-            if (kr % 255ull == 0) {
-                const double v = mn + (double)(kr / 255ull);
-                const double t = __dmul_rn(__ddiv_rn(__dsub_rn(v, mn), range), 255.0);
-                out = (uint8_t)(int)t;
-            }
-        }
-        tab[i * 256 + k] = out;
-    }
-}
 
 template <typename T> struct stretcher {
     // generic (f32 / u8): arithmetic path
@@ -328,22 +312,16 @@ template <typename T> struct stretcher {
     __device__ __forceinline__ unsigned operator()(T v, const uint8_t *) const { return stretch_u8<T>(v, mn, range, deg); }
 };
 template <typename T> struct stretcher_i16 {
-    int mn_i, R;
-    float rf;
-    bool deg;
+    int mn_i;
+    double c1, c0;
     __device__ void init(const double *mm, int img, const uint8_t *) {
         const double mn = mm[2 * img], mx = mm[2 * img + 1];
-        deg = !(mx > mn);
-        mn_i = (int)mn; R = deg ? 1 : (int)(mx - mn);
-        rf = 1.0f / (float)R;
+        mn_i = (int)mn;
+        if (mx > mn) { const double r = mx - mn; c1 = 255.0 / r; c0 = 0.5 / r; }
+        else { c1 = 0.0; c0 = 0.0; }                     // degenerate range: every pixel maps to 0
     }
-    __device__ __forceinline__ unsigned operator()(T v, const uint8_t *tab) const {
-        if (deg) return 0u;
-        const int n = __mul24((int)v - mn_i, 255);           // < 2^24: exact in f32
-        int q = (int)((float)n * rf);
-        int r = n - __mul24(q, R);
-        if (r < 0) { q--; r += R; } else if (r >= R) { q++; r -= R; }
-        return r == 0 ? (unsigned)tab[q] : (unsigned)q;
+    __device__ __forceinline__ unsigned operator()(T v, const uint8_t *) const {
+        return (unsigned)(int)__fma_rn((double)((int)v - mn_i), c1, c0);
     }
 };
 template <> struct stretcher<uint16_t> : stretcher_i16<uint16_t> {};
@@ -352,7 +330,7 @@ template <> struct stretcher<int16_t> : stretcher_i16<int16_t> {};
 template <int R, typename T, int NIMG, bool MASK>
 __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                   ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
-                                                  const uint8_t *__restrict__ tabs, lap_coef cf, int invert1, nodata_t nd,
+                                                  lap_coef cf, int invert1, nodata_t nd,
                                                   uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
                                                   uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial)
 {
@@ -367,14 +345,8 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
     __shared__ __attribute__((aligned(16))) HT hbuf[2][NIMG][THH][LAP_TW];  // [0] = kd pass, [1] = ks pass
     auto &hd = hbuf[0];
     auto &hs = hbuf[1];
-    __shared__ uint8_t s_tab[NIMG][256];
-
     const int X0 = blockIdx.x * LAP_TW, Y0 = blockIdx.y * LAP_TH;
     const int tid = threadIdx.x;
-    constexpr bool kTab = (sizeof(T) == 2);
-    if constexpr (kTab) {
-        for (int i = tid; i < NIMG * 256; i += 256) (&s_tab[0][0])[i] = tabs[i];
-    }
     stretcher<T> st[NIMG];
 #pragma unroll
     for (int i = 0; i < NIMG; i++) st[i].init(mm, i, nullptr);
@@ -405,7 +377,6 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
             }
         }
     }
-    if constexpr (kTab) __syncthreads();  // s_tab ready
     // ---- phase 1b: stretch to u8, pack into LDS, emit the auto mask
     unsigned cnt = 0;
 #pragma unroll
@@ -419,7 +390,7 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
                 uint32_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    unsigned u = st[i](v[it][i][k], s_tab[i]);
+                    unsigned u = st[i](v[it][i][k], nullptr);
                     if (i == 1 && invert1) u = 255u - u;
                     packed |= u << (8 * k);
                 }
@@ -655,7 +626,7 @@ static bool fill_coef(int ksize, int R, int *kd, int *ks)
 
 template <typename T, int NIMG, bool MASK>
 static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
-                      const uint8_t *tabs, const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
+                      const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob, uint8_t *mask,
                       unsigned long long *valid_out)
 {
     dim3 grid((W + LAP_TW - 1) / LAP_TW, (H + LAP_TH - 1) / LAP_TH);
@@ -666,7 +637,7 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
     }
 #define KM_LAP_CASE(RR)                                                                                         \
     case RR:                                                                                                    \
-        lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, \
+        lap_kernel<RR, T, NIMG, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, \
                                                                    mask, valid);                               \
         break;
     switch (R) {
@@ -691,30 +662,55 @@ static int launch_lap(km_ctx *c, int R, const T *a, const T *b, int H, int W, pt
 // pixels -> exact uint8 stretch -> horizontal kd / ks passes with v_dot4 on bytes assembled from the two
 // neighbour lanes (DPP wave shifts + v_alignbyte) -> (hd | hs) pairs pushed into a (2R+1)-row register ring;
 // per output row: one v_dot2 per tap and pixel over the ring.  No LDS tiles, no barriers, no index arithmetic.
+// First link of a dot-product chain in the three-address VOP3P form (accumulator = inline 0 or a VGPR): the
+// two-address v_dot4c / v_dot2c the compiler prefers needs a v_mov to seed every chain.  Coefficients are
+// wave-uniform (SGPR operand; gfx9 allows one scalar source per VALU instruction, so the bias sits in a VGPR).
+__device__ __forceinline__ int dot4_seed0(int bytes, int coef_uniform)
+{
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(bytes), "s"(coef_uniform));
+    return r;
+}
+__device__ __forceinline__ int dot4_seed(int bytes, int coef_uniform, int acc)
+{
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(bytes), "s"(coef_uniform), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ int dot2_seed0(int pair, int coef_uniform)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "s"(coef_uniform));
+    return r;
+}
+// An empty asm makes a lane offset opaque at the point of use: the compiler then cannot fold it into a hoisted
+// per-lane 64-bit pointer and addresses memory as scalar row base + 32-bit vector offset (no per-lane 64-bit arithmetic).
+__device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 #define LAPM_RS 64   // output rows per wave
 #define LAPM_VALID 248
 
 template <int R, typename T, bool MASK>
 __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                         ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
-                                                        const uint8_t *__restrict__ tabs, lap_coef cf, int invert1, nodata_t nd,
+                                                        lap_coef cf, int invert1, nodata_t nd,
                                                         uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
                                                         uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips)
 {
     typedef short short2v __attribute__((ext_vector_type(2)));
     constexpr int NR = 2 * R + 1;
-    __shared__ uint8_t s_tab[2][256];
     const int tid = threadIdx.x, lane = tid & 63;
-    if constexpr (sizeof(T) == 2) {
-        for (int i = tid; i < 512; i += 256) (&s_tab[0][0])[i] = tabs[i];
-        __syncthreads();
-    }
     const int strip = blockIdx.x * 4 + (tid >> 6);
     const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
     if (strip >= nstrips) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
     stretcher<T> st[2];
     st[0].init(mm, 0, nullptr); st[1].init(mm, 1, nullptr);
     const int gx0 = strip * LAPM_VALID - 4 + 4 * lane;           // first of this lane's 4 columns
+    const unsigned ugx = (unsigned)gx0;                           // valid on the FAST path only (gx0 >= 0 there)
     const bool col_inside = gx0 >= 0 && gx0 + 3 < W;
     const bool vec0 = col_inside && (stride0 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0);
     const bool vec1 = col_inside && (stride1 % 4 == 0) && ((uintptr_t)img1 % (4 * sizeof(T)) == 0);
@@ -747,6 +743,20 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
         for (int t = 0; t < NR; t++) vk[i][t] = (cf.ks[i][t] & 0xffff) | (cf.kd[i][t] << 16);
     }
 
+    // 16-bit dtypes: nodata as a packed pixel pair (0 = "no further condition": absent, non-integral or out of range)
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    auto nodata16 = [](int has, double v) -> uint32_t {
+        if (!has || v != floor(v)) return 0u;
+        if constexpr (std::is_signed<T>::value) { if (v < -32768.0 || v > 32767.0) return 0u; }
+        else { if (v < 0.0 || v > 65535.0) return 0u; }
+        const uint32_t x = (uint32_t)(uint16_t)(int)v;
+        return x | (x << 16);
+    };
+    const uint32_t nd16_mon = nodata16(nd.has_mon, nd.mon), nd16_ref = nodata16(nd.has_ref, nd.ref);
+    (void)nd16_mon; (void)nd16_ref;
+    int vbias[2];   // bias as vector operands (see dot4_seed); the asm keeps them out of the scalar file
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vbias[0]) : "s"(bias[0]));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vbias[1]) : "s"(bias[1]));
     unsigned cnt = 0;
     uint8_t *outs[2] = {out0, out1};
     // FAST: every lane of the strip is an interior, aligned lane (wave-uniform) -> no per-lane fallbacks in the loop
@@ -755,7 +765,12 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
     auto load_raw = [&](int m, T (&v)[2][4]) {
         const int r = km_reflect101(m, H);
         const T *r0 = img0 + (size_t)r * stride0, *r1 = img1 + (size_t)r * stride1;
-        if (FAST || vec0) {
+        const unsigned lx = opaque_lane_offset(ugx * (unsigned)sizeof(T));   // byte offset of the lane's first column
+        if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic
+            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 4); }
+            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 8); }
+            else { uint4 q = *(const uint4 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 16); }
+        } else if (vec0) {
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r0 + gx0); __builtin_memcpy(v[0], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r0 + gx0); __builtin_memcpy(v[0], &q, 8); }
             else { uint4 q = *(const uint4 *)(r0 + gx0); __builtin_memcpy(v[0], &q, 16); }
@@ -763,7 +778,11 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
 #pragma unroll
             for (int k = 0; k < 4; k++) v[0][k] = r0[rc[k]];
         }
-        if (FAST || vec1) {
+        if (FAST) {
+            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 4); }
+            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 8); }
+            else { uint4 q = *(const uint4 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 16); }
+        } else if (vec1) {
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r1 + gx0); __builtin_memcpy(v[1], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r1 + gx0); __builtin_memcpy(v[1], &q, 8); }
             else { uint4 q = *(const uint4 *)(r1 + gx0); __builtin_memcpy(v[1], &q, 16); }
@@ -794,7 +813,23 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
                 for (int j = 0; j < 4; j++) v[i][j] = nxt[i][j];
             if (m + 1 < y1 + R) load_raw(m + 1, nxt);   // next row's pixels travel while this row is processed
             // ---- auto mask of source row m (it is an output row when y0 <= m < y1)
-            if constexpr (MASK) {
+            if constexpr (MASK && FAST && sizeof(T) == 2) {
+                // packed form: a pixel pair is valid iff min(mon, ref, mon ^ nodata_mon, ref ^ nodata_ref) != 0 (unsigned)
+                if (m >= y0 && m < y1 && out_lane) {
+                    uint2 qm, qr;
+                    __builtin_memcpy(&qm, v[1], 8); __builtin_memcpy(&qr, v[0], 8);
+                    auto nz2 = [&](uint32_t a, uint32_t b) {
+                        ushort2v mn2 = __builtin_elementwise_min(
+                            __builtin_elementwise_min(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b)),
+                            __builtin_elementwise_min(__builtin_bit_cast(ushort2v, a ^ nd16_mon), __builtin_bit_cast(ushort2v, b ^ nd16_ref)));
+                        mn2 = __builtin_elementwise_min(mn2, (ushort2v)(1));
+                        return __builtin_bit_cast(uint32_t, mn2);
+                    };
+                    const uint32_t mp = __builtin_amdgcn_perm(nz2(qm.y, qr.y), nz2(qm.x, qr.x), 0x06040200u);
+                    cnt += (unsigned)__popc(mp);
+                    *(uint32_t *)((mask_out + (size_t)m * W) + opaque_lane_offset(ugx)) = mp;
+                }
+            } else if constexpr (MASK) {
                 if (m >= y0 && m < y1 && out_lane) {
                     uint32_t mp = 0;
 #pragma unroll
@@ -815,12 +850,8 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
                 // ---- stretch to uint8 (biased by -128 for the signed dot products)
                 uint32_t cw = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    unsigned u = st[i](v[i][j], s_tab[i]);
-                    if (i == 1 && invert1) u = 255u - u;
-                    cw |= u << (8 * j);
-                }
-                cw ^= 0x80808080u;
+                for (int j = 0; j < 4; j++) cw |= st[i](v[i][j], nullptr) << (8 * j);
+                cw ^= (i == 1 && invert1) ? 0x7f7f7f7fu : 0x80808080u;   // (255 - u) - 128 == u ^ 0x7f
                 const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x138, 0xf, 0xf, false);   // lane-1
                 const uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x130, 0xf, 0xf, false);   // lane+1
                 // ---- horizontal kd / ks passes: bytes [4+o-R, 4+o-R+8) of (lw | cw | rw)
@@ -838,9 +869,9 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
                         g0 = (int)__builtin_amdgcn_alignbyte(rw, cw, (sft - 4) & 3);
                         g1 = (int)__builtin_amdgcn_alignbyte(0u, rw, (sft - 4) & 3);   // taps beyond 2R are zero
                     }
-                    const int vd = __builtin_amdgcn_sdot4(g0, kdp[i][0], __builtin_amdgcn_sdot4(g1, kdp[i][1], 0, false), false);
-                    const int vs = __builtin_amdgcn_sdot4(g0, ksp[i][0], __builtin_amdgcn_sdot4(g1, ksp[i][1], bias[i], false), false);
-                    ring[i][k][o] = (vd & 0xffff) | (vs << 16);
+                    const int vd = __builtin_amdgcn_sdot4(g0, kdp[i][0], dot4_seed0(g1, kdp[i][1]), false);
+                    const int vs = __builtin_amdgcn_sdot4(g0, ksp[i][0], dot4_seed(g1, ksp[i][1], vbias[i]), false);
+                    ring[i][k][o] = (int)__builtin_amdgcn_perm((uint32_t)vs, (uint32_t)vd, 0x05040100u);   // (vd & 0xffff) | (vs << 16)
                 }
             }
             // ---- vertical combine for output row y = m - R (ring slot of source row y - R + j is (k + 1 + j) mod NR)
@@ -851,15 +882,16 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
                     uint32_t packed = 0;
 #pragma unroll
                     for (int o = 0; o < 4; o++) {
-                        int acc = 0;
+                        int acc = dot2_seed0(ring[i][(k + 1) % NR][o], vk[i][0]);
 #pragma unroll
-                        for (int j = 0; j < NR; j++)
+                        for (int j = 1; j < NR; j++)
                             acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ring[i][(k + 1 + j) % NR][o]),
                                                          __builtin_bit_cast(short2v, vk[i][j]), acc, false);
                         packed |= (uint32_t)min(max(acc, 0), 255) << (8 * o);
                     }
                     const size_t off = (size_t)y * W + gx0;
-                    if (FAST || (gx0 + 3 < W && (off & 3) == 0)) *(uint32_t *)(outs[i] + off) = packed;
+                    if (FAST) *(uint32_t *)((outs[i] + (size_t)y * W) + opaque_lane_offset(ugx)) = packed;
+                    else if (gx0 + 3 < W && (off & 3) == 0) *(uint32_t *)(outs[i] + off) = packed;
                     else {
                         for (int j = 0; j < 4 && gx0 + j < W; j++) outs[i][off + j] = (uint8_t)(packed >> (8 * j));
                     }
@@ -880,7 +912,7 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
 
 template <typename T, bool MASK>
 static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
-                            const uint8_t *tabs, const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob,
+                            const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob,
                             uint8_t *mask, unsigned long long *valid_out)
 {
     const int nstrips = (W + LAPM_VALID - 1) / LAPM_VALID;
@@ -892,9 +924,9 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
         if (!valid) return KM_E_NOMEM;
     }
     switch (R) {
-    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
-    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
-    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, tabs, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
@@ -915,7 +947,7 @@ int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, ui
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize %d (supported: 1,3,5,7,9,11)", ksize);
     for (int i = 0; i < 11; i++) { cf.kd[1][i] = 0; cf.ks[1][i] = 0; }
     nodata_t nd = make_nodata(nullptr, nullptr);
-    return launch_lap<uint8_t, 1, false>(c, R, d_src, d_src, H, W, W, W, nullptr, nullptr, cf, 0, nd, d_dst, nullptr, nullptr, nullptr);
+    return launch_lap<uint8_t, 1, false>(c, R, d_src, d_src, H, W, W, W, nullptr, cf, 0, nd, d_dst, nullptr, nullptr, nullptr);
 }
 
 int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref,
@@ -930,18 +962,11 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
     nodata_t nd = make_nodata(nodata_mon, nodata_ref);
-    uint8_t *tabs = nullptr;
-    if (dtype == KM_U16 || dtype == KM_I16) {
-        tabs = (uint8_t *)km_ws(c, WS_MISC3, 512);
-        if (!tabs) return KM_E_NOMEM;
-        stretch_table_kernel<<<1, 256, 0, c->stream>>>(d_mm, tabs, 2);
-        KM_LAUNCH_CHECK(c);
-    }
     if (R <= 3 && W >= 8 && H >= 8) {
 #define KM_PAIRM(T)                                                                                                              \
-    (d_mask_out ? launch_lap_march<T, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+    (d_mask_out ? launch_lap_march<T, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                             d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                           \
-                : launch_lap_march<T, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+                : launch_lap_march<T, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                              d_lap_ref, d_lap_mon, nullptr, nullptr))
         switch (dtype) {
         case KM_U8: return KM_PAIRM(uint8_t);
@@ -953,9 +978,9 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
 #undef KM_PAIRM
     }
 #define KM_PAIR(T)                                                                                                          \
-    (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+    (d_mask_out ? launch_lap<T, 2, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                          d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                        \
-                : launch_lap<T, 2, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, tabs, cf, invert_mon, nd, \
+                : launch_lap<T, 2, false>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                           d_lap_ref, d_lap_mon, nullptr, nullptr))
     switch (dtype) {
     case KM_U8: return KM_PAIR(uint8_t);

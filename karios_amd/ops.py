@@ -193,6 +193,25 @@ def klt_tile(ref_box, mon_box, conf, mask_box=None, nodata_ref=None, nodata_mon=
     return "ok", (o0[:k].reshape(-1, 1, 2), o1[:k].reshape(-1, 1, 2), o2[:k].reshape(-1, 1, 2))
 
 
+def tile_prefilter(ref_box, mon_box, nodata_ref=None, nodata_mon=None, ref_ksize=1, mon_ksize=1, invert_mon=False,
+                   with_mask=True, ctx: Context | None = None):
+    """Pre-filter of KLT._match_tile (klt.py:268-273, 407-436) in the fused kernel of the tile path:
+    -> (laplacian(uint8(ref)), laplacian(uint8(mon) or its inverse), auto mask | None, valid pixel count | None)."""
+    c = _ctx(ctx)
+    r, m = as_image(ref_box), as_image(mon_box)
+    if r.shape != m.shape or r.dtype != m.dtype:
+        raise KariosHipError("tile_prefilter: ref/mon shape or dtype mismatch")
+    lr, lm = np.empty(r.shape, np.uint8), np.empty(r.shape, np.uint8)
+    mk = np.empty(r.shape, np.uint8) if with_mask else None
+    nv = C.c_int64()
+    nr = C.byref(C.c_double(float(nodata_ref))) if nodata_ref is not None else None
+    nm = C.byref(C.c_double(float(nodata_mon))) if nodata_mon is not None else None
+    c.check(c.lib.km_tile_prefilter(c.handle, ptr(r), ptr(m), dtype_code(r), r.shape[0], r.shape[1], row_stride(r), row_stride(m),
+                                    nr, nm, int(ref_ksize), int(mon_ksize), int(bool(invert_mon)), ptr(lr), ptr(lm), ptr(mk),
+                                    C.byref(nv)), "km_tile_prefilter")
+    return lr, lm, mk, (int(nv.value) if with_mask else None)
+
+
 def zncc_batch(ref, mon, x0, y0, dx, dy, ctx: Context | None = None):
     """ZNCCService._compute_zncc for every keypoint (zncc_service.py:186-238) -> float64[n]."""
     c = _ctx(ctx)

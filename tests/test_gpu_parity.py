@@ -59,6 +59,51 @@ def test_auto_mask(ops, O, dtype):
         assert nv == ev
 
 
+def _prefilter_case(dtype, shape, rng_span, seed):
+    """Image pair holding every value of [mn, mn + span] (all exact multiples of the stretch included) plus zeros."""
+    rng = np.random.default_rng(seed)
+    H, W = shape
+    n = H * W
+    mn = 0 if np.dtype(dtype).kind == "u" else -min(rng_span // 2, 30000)
+    if np.dtype(dtype) == np.float32:
+        ref = (rng.random((H, W)) * rng_span).astype(np.float32)
+        mon = (rng.random((H, W)) * rng_span * 0.7 + 3).astype(np.float32)
+        ref[rng.random((H, W)) < 0.01] = np.nan
+    else:
+        ref = ((np.arange(n) % (rng_span + 1)) + mn).astype(dtype).reshape(H, W)
+        mon = ((rng.permutation(n) % (rng_span + 1)) + mn).astype(dtype).reshape(H, W)
+    ref[rng.random((H, W)) < 0.02] = 0
+    mon[rng.random((H, W)) < 0.02] = 0
+    return ref, mon
+
+
+@pytest.mark.parametrize("dtype,span", [(np.uint16, 65535), (np.uint16, 510), (np.uint16, 12345), (np.uint16, 200), (np.int16, 65535),
+                                        (np.int16, 1020), (np.uint8, 255), (np.float32, 4000)])
+@pytest.mark.parametrize("shape", [(300, 520), (203, 517), (70, 1000)])
+def test_tile_prefilter_bit_exact(ops, O, dtype, span, shape):
+    """Fused stretch + Laplacian (both images) + auto mask == the three reference steps done one by one (klt.py:268-273, 407-436)."""
+    if np.dtype(dtype) == np.uint8:
+        span = 255
+    ref, mon = _prefilter_case(dtype, shape, span, seed=span + shape[1])
+    cases = [dict(kr=7, km=7, inv=False, nr=None, nm=None), dict(kr=3, km=5, inv=True, nr=None, nm=None),
+             dict(kr=1, km=7, inv=False, nr=float(ref[5, 7]), nm=float(mon[9, 3])), dict(kr=7, km=3, inv=True, nr=0.5, nm=1e9),
+             dict(kr=9, km=11, inv=False, nr=-7.0, nm=None)]
+    for cs in cases:
+        if np.dtype(dtype) == np.float32 and cs["nr"] is not None and np.isnan(cs["nr"]):
+            continue
+        lr, lm, mk, nv = ops.tile_prefilter(ref, mon, nodata_ref=cs["nr"], nodata_mon=cs["nm"], ref_ksize=cs["kr"], mon_ksize=cs["km"],
+                                            invert_mon=cs["inv"])
+        want_r = O.laplacian_u8(O.to_uint8(ref), cs["kr"])
+        want_m = O.laplacian_u8(O.to_uint8(mon, invert=cs["inv"]), cs["km"])
+        want_mask, want_valid = O.auto_mask(mon, ref, nodata_mon=cs["nm"], nodata_ref=cs["nr"])
+        assert np.array_equal(lr, want_r), cs
+        assert np.array_equal(lm, want_m), cs
+        assert np.array_equal(mk, want_mask), cs
+        assert nv == want_valid, cs
+        lr2, lm2, mk2, nv2 = ops.tile_prefilter(ref, mon, ref_ksize=cs["kr"], mon_ksize=cs["km"], invert_mon=cs["inv"], with_mask=False)
+        assert mk2 is None and nv2 is None and np.array_equal(lr2, want_r) and np.array_equal(lm2, want_m)
+
+
 @pytest.mark.parametrize("ksize", [1, 3, 5, 7, 9, 11])
 def test_laplacian_bit_exact(ops, O, ksize):
     for i, shape in enumerate(SHAPES):

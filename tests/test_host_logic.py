@@ -190,3 +190,18 @@ print("rank", rank, "ok")
              for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_stretch_exact_multiples():
+    """The integer formulation of `_to_uint8` the HIP kernels use (k_dense.hip, "uint8 stretch of 16-bit integer images"):
+    numpy's trunc(fl(fl(d / r) * 255)) equals floor(255 * d / r) for every integer d in [0, r], r <= 65535 - in
+    particular at the exact multiples 255 * d == k * r, where only fl(k / 255) * 255 >= k keeps the truncation at k."""
+    k = np.arange(256, dtype=np.float64)
+    assert np.all((k / 255.0) * 255.0 >= k)
+    for r in (1, 2, 3, 254, 255, 256, 510, 765, 1020, 4095, 10000, 12345, 32767, 32768, 65025, 65534, 65535):
+        d = np.arange(r + 1, dtype=np.int64)
+        want = ((d.astype(np.float64) / float(r)) * 255.0).astype(np.uint8)       # numpy semantics of klt.py:42-49
+        got = (255 * d) // r
+        assert np.array_equal(want, got.astype(np.uint8)), r
+        fma_form = np.floor(d.astype(np.float64) * (255.0 / r) + 0.5 / r)          # what the kernel evaluates (one fma)
+        assert np.array_equal(fma_form.astype(np.int64), got), r
