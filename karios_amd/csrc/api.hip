@@ -71,6 +71,8 @@ int km_ctx_create(int device, km_ctx **out)
         delete c;
         return rc;
     }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
     return KM_OK;
 }

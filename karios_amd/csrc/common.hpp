@@ -97,6 +97,7 @@ struct km_scalars {
 
 struct km_ctx {
     int device = 0;
+    int n_cu = 256;            // compute units of the device (wave slots = n_cu * 4 SIMDs * waves per SIMD)
     hipStream_t stream = nullptr;
     km_buf ws[WS_COUNT];
     std::string err;
@@ -111,6 +112,24 @@ struct km_ctx {
 };
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
+
+// Rows per work item of a marching kernel (one wavefront walks `rows` output rows of one column strip, re-reading
+// `halo` rows): the value in [lo, hi] that minimises  ceil(items / wave_slots) * (rows + halo), i.e. whole rounds of
+// resident waves times the work of one item - a grid that needs 2.02 rounds costs three.
+static inline int km_pick_rows(int H, int nstrips, int halo, long wave_slots, int lo, int hi)
+{
+    int best = lo;
+    double best_cost = 1e300;
+    for (int r = lo; r <= hi; r++) {
+        const long items = (long)nstrips * ((H + r - 1) / r);
+        const long rounds = (items + wave_slots - 1) / wave_slots;
+        // a thinly filled last round still lasts about half an item (fewer waves per SIMD, each one faster)
+        const double last = (double)(items - (rounds - 1) * wave_slots) / (double)wave_slots;
+        const double cost = ((double)(rounds - 1) + 0.5 + 0.5 * last) * (double)(r + halo);
+        if (cost < best_cost) { best_cost = cost; best = r; }
+    }
+    return best;
+}
 void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
 
 #define KM_HIP(ctx, call)                                                                   \

@@ -691,26 +691,36 @@ __device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
     return x;
 }
 
-#define LAPM_RS 64   // output rows per wave
 #define LAPM_VALID 248
+#ifndef LAPM_PF
+#define LAPM_PF 3      // source rows in flight per wave
+#endif
 
 template <int R, typename T, bool MASK>
 __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                         ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
                                                         lap_coef cf, int invert1, nodata_t nd,
                                                         uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
-                                                        uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips)
+                                                        uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips,
+                                                        int rows_per_item, int nitems)
 {
     typedef short short2v __attribute__((ext_vector_type(2)));
     constexpr int NR = 2 * R + 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int strip = blockIdx.x * 4 + (tid >> 6);
-    const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
-    if (strip >= nstrips) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
+    // work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
+    const int wave_id = blockIdx.x * 4 + (tid >> 6);
+    if (wave_id >= nitems) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
+    const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
     stretcher<T> st[2];
     st[0].init(mm, 0, nullptr); st[1].init(mm, 1, nullptr);
     const int gx0 = strip * LAPM_VALID - 4 + 4 * lane;           // first of this lane's 4 columns
-    const unsigned ugx = (unsigned)gx0;                           // valid on the FAST path only (gx0 >= 0 there)
+    const unsigned ugx = (unsigned)gx0;                           // used by output lanes only (gx0 >= 0 there)
+    // FAST path (W % 4 == 0, aligned rows): a lane left of the image or right of it loads the 4 columns of its
+    // in-image neighbour (clamped address) and mirrors the stretched bytes (REFLECT_101) with one byte permute:
+    //   left  [c0 c1 c2 c3] -> [ . c3 c2 c1]   (columns -4..-1; -4 is never a tap for R <= 3)
+    //   right [c0 c1 c2 c3] -> [c2 c1 c0  . ]  (columns W..W+3)
+    const unsigned ugx_load = (unsigned)min(max(gx0, 0), W - 4);
+    const unsigned edge_sel = gx0 < 0 ? 0x01020300u : gx0 >= W ? 0x03000102u : 0x03020100u;
     const bool col_inside = gx0 >= 0 && gx0 + 3 < W;
     const bool vec0 = col_inside && (stride0 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0);
     const bool vec1 = col_inside && (stride1 % 4 == 0) && ((uintptr_t)img1 % (4 * sizeof(T)) == 0);
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
 #pragma unroll
     for (int k = 0; k < 4; k++) rc[k] = km_reflect101(gx0 + k, W);
     const bool out_lane = lane >= 1 && lane <= 62 && gx0 < W;
-    const int y0 = blockIdx.y * LAPM_RS, y1 = min(H, y0 + LAPM_RS);
+    const int y0 = rowblock * rows_per_item, y1 = min(H, y0 + rows_per_item);
 
     // packed coefficients
     int kdp[2][2], ksp[2][2], bias[2], vk[2][NR];
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
     auto load_raw = [&](int m, T (&v)[2][4]) {
         const int r = km_reflect101(m, H);
         const T *r0 = img0 + (size_t)r * stride0, *r1 = img1 + (size_t)r * stride1;
-        const unsigned lx = opaque_lane_offset(ugx * (unsigned)sizeof(T));   // byte offset of the lane's first column
+        const unsigned lx = opaque_lane_offset(ugx_load * (unsigned)sizeof(T));   // byte offset of the lane's first column
         if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 8); }
@@ -799,8 +809,10 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
         for (int k = 0; k < NR; k++)
 #pragma unroll
             for (int j = 0; j < 4; j++) ring[i][k][j] = 0;
-    T nxt[2][4];
-    load_raw(y0 - R, nxt);
+    // raw rows travel LAPM_PF rows ahead of their use (a short register FIFO; the copies disappear in the unrolled body)
+    T nxt[LAPM_PF][2][4];
+#pragma unroll
+    for (int f = 0; f < LAPM_PF; f++) load_raw(min(y0 - R + f, y1 + R - 1), nxt[f]);
     for (int mbase = y0 - R; mbase < y1 + R; mbase += NR) {
 #pragma unroll
         for (int k = 0; k < NR; k++) {
@@ -810,8 +822,12 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[i][j] = nxt[i][j];
-            if (m + 1 < y1 + R) load_raw(m + 1, nxt);   // next row's pixels travel while this row is processed
+                for (int j = 0; j < 4; j++) {
+                    v[i][j] = nxt[0][i][j];
+#pragma unroll
+                    for (int f = 0; f + 1 < LAPM_PF; f++) nxt[f][i][j] = nxt[f + 1][i][j];
+                }
+            if (m + LAPM_PF < y1 + R) load_raw(m + LAPM_PF, nxt[LAPM_PF - 1]);
             // ---- auto mask of source row m (it is an output row when y0 <= m < y1)
             if constexpr (MASK && FAST && sizeof(T) == 2) {
                 // packed form: a pixel pair is valid iff min(mon, ref, mon ^ nodata_mon, ref ^ nodata_ref) != 0 (unsigned)
@@ -852,6 +868,7 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
 #pragma unroll
                 for (int j = 0; j < 4; j++) cw |= st[i](v[i][j], nullptr) << (8 * j);
                 cw ^= (i == 1 && invert1) ? 0x7f7f7f7fu : 0x80808080u;   // (255 - u) - 128 == u ^ 0x7f
+                if constexpr (FAST) cw = __builtin_amdgcn_perm(cw, cw, edge_sel);                    // border lanes: mirrored columns
                 const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x138, 0xf, 0xf, false);   // lane-1
                 const uint32_t rw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cw, 0x130, 0xf, 0xf, false);   // lane+1
                 // ---- horizontal kd / ks passes: bytes [4+o-R, 4+o-R+8) of (lw | cw | rw)
@@ -900,9 +917,10 @@ __global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ im
         }
     }
     };  // march
-    const bool lane_fast = vec0 && vec1 && (W % 4 == 0) && ((uintptr_t)out0 % 4 == 0) && ((uintptr_t)out1 % 4 == 0) &&
-                           (!MASK || (uintptr_t)mask_out % 4 == 0);
-    if (__all(lane_fast)) march(std::true_type{});
+    const bool fast = (W % 4 == 0) && (stride0 % 4 == 0) && (stride1 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0) &&
+                      ((uintptr_t)img1 % (4 * sizeof(T)) == 0) && ((uintptr_t)out0 % 4 == 0) && ((uintptr_t)out1 % 4 == 0) &&
+                      (!MASK || (uintptr_t)mask_out % 4 == 0);   // wave-uniform
+    if (fast) march(std::true_type{});
     else march(std::false_type{});
     if constexpr (MASK) {
         const unsigned c64 = (unsigned)wave_sum_u64((unsigned long long)cnt);
@@ -916,17 +934,28 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
                             uint8_t *mask, unsigned long long *valid_out)
 {
     const int nstrips = (W + LAPM_VALID - 1) / LAPM_VALID;
-    dim3 grid((nstrips + 3) / 4, (H + LAPM_RS - 1) / LAPM_RS);
-    const size_t nwaves = (size_t)grid.x * 4 * grid.y;
+    // resident waves: 4 SIMDs per CU x the waves per SIMD the register budget of this instantiation allows
+    auto slots_of = [&](const void *fn) -> long {
+        int wg_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, fn, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 4;
+        return (long)c->n_cu * 4 * wg_per_cu;
+    };
+    const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK>
+                                                                                  : (const void *)lap_march_kernel<3, T, MASK>;
+    int rows = km_pick_rows(H, nstrips, 2 * R, slots_of(fn), 32, 160);
+    if (const char *e = getenv("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
+    const int nitems = nstrips * ((H + rows - 1) / rows);
+    dim3 grid((nitems + 3) / 4);
+    const size_t nwaves = (size_t)grid.x * 4;
     unsigned *valid = nullptr;
     if (MASK) {
         valid = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
         if (!valid) return KM_E_NOMEM;
     }
     switch (R) {
-    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
-    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
-    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips); break;
+    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
