@@ -82,6 +82,11 @@ const char *km_last_error(km_ctx *ctx);   /* ctx may be NULL: last global error 
 int km_ctx_sync(km_ctx *ctx);
 /* enable (1) / disable (0) hipEvent stage timing; read back after a call */
 int km_set_profiling(km_ctx *ctx, int enable);
+/* Tuning knobs (no counterpart in the reference; results never depend on them):
+ *   "fused_eig" 0|1  GFTT: experimental single-pass minimum-eigenvalue + candidate kernel instead of eig map + candidate
+ *                    scan (default 0; initial value from the environment variable KARIOS_HIP_FUSED_EIG).
+ * Returns KM_E_ARG for an unknown name. */
+int km_set_option(km_ctx *ctx, const char *name, int value);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */
 int km_get_stage_ms(km_ctx *ctx, float *out, int cap, int *n);
 const char *km_stage_name(int i);

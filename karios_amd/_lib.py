@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkarios_hip.so")
+LIB_PATH = os.environ.get("KARIOS_HIP_LIB") or os.path.join(_HERE, "libkarios_hip.so")   # (override: development builds)
 
 KM_U8, KM_U16, KM_I16, KM_F32 = 0, 1, 2, 3
 _DTYPES = {np.dtype("uint8"): KM_U8, np.dtype("uint16"): KM_U16, np.dtype("int16"): KM_I16,
@@ -49,6 +49,7 @@ SIGNATURES = {
     "km_last_error": (C.c_char_p, [_vp]),
     "km_ctx_sync": (_i, [_vp]),
     "km_set_profiling": (_i, [_vp, _i]),
+    "km_set_option": (_i, [_vp, C.c_char_p, _i]),
     "km_get_stage_ms": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
     "km_stage_name": (C.c_char_p, [_i]),
     "km_get_klt_stats": (_i, [_vp, C.POINTER(KltStats)]),
@@ -194,6 +195,10 @@ class Context:
 
     def set_profiling(self, on: bool):
         self.check(self.lib.km_set_profiling(self.handle, int(bool(on))), "km_set_profiling")
+
+    def set_option(self, name: str, value: int):
+        """Tuning knob (include/karios_hip.h km_set_option), e.g. set_option("fused_eig", 1)."""
+        self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
 
     def stage_ms(self) -> dict:
         buf = (C.c_float * 16)()

@@ -71,6 +71,7 @@ int km_ctx_create(int device, km_ctx **out)
         delete c;
         return rc;
     }
+    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -97,6 +98,13 @@ int km_ctx_sync(km_ctx *c)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipStreamSynchronize(c->stream));
     return KM_OK;
+}
+
+int km_set_option(km_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return km_fail(c, KM_E_ARG, "km_set_option: null argument");
+    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value != 0; return KM_OK; }
+    return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
 int km_set_profiling(km_ctx *c, int enable)
@@ -248,17 +256,16 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
     unsigned long long *kept = nullptr;
     size_t nkept = 0, ntotal = 0;
     km_scalars hs;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    bool fused_overflow = false;   // a row group overflowed the fused kernel's candidate stage (plateau image): use the two-kernel path
+    for (int attempt = 0; attempt < 4; attempt++) {
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
         if (!keys) return KM_E_NOMEM;
-        // K3 + K4: fused marching kernel (no eig map) when it covers the case, else eig map + candidate kernel
-        // (the fused variant is exact and saves the 5 B/px eig-map round trip, but at 126 VGPRs it runs at 4 waves/SIMD and
-        //  measures 1.07 ms against 0.51 + 0.30 ms for the two separate kernels at 10980^2: opt-in until it is tuned)
-        static const bool use_fused = getenv("KARIOS_HIP_FUSED_EIG") != nullptr;
+        // K3 + K4: eig map + candidate kernel; the fused 4-pixel-per-lane kernel (no eig map, k_eigc.hip) is exact but at
+        // 120+ VGPRs it runs 4 waves per SIMD and is latency-bound (1.1 ms against 0.52 + 0.26 ms at 10980^2): opt-in
         bool fused = false;
-        if (use_fused && H >= 3 && W >= 3) {
+        if (c->fused_eig && !fused_overflow) {
             km_stage_timer t(c, ST_EIGEN);
-            rc = kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
+            rc = ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0);
             if (rc == KM_OK) fused = true;
             else if (rc != KM_E_UNSUPPORTED) return rc;
         }
@@ -281,9 +288,14 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         c->stats.valid_pixels = (int64_t)hs.valid;
         c->stats.max_eig = hs.max_eig;
         c->stats.min_ref = hs.mm[0]; c->stats.max_ref = hs.mm[1]; c->stats.min_mon = hs.mm[2]; c->stats.max_mon = hs.mm[3];
+        if (fused && hs.pad0 != 0u) {   // candidates were dropped: repeat with the eig-map + candidate kernels
+            fused_overflow = true;
+            KM_HIP(c, hipMemsetAsync(&sc->run_max_key, 0, (2 + KM_NSHARD) * sizeof(unsigned), c->stream));
+            continue;
+        }
         if ((size_t)hs.n_cand <= capk) break;
         capk = (size_t)hs.n_cand + hs.n_cand / 4 + 4096 * KM_NSHARD;   // a shard overflowed: grow the key buffer and redo
-        if (attempt == 2) return km_fail(c, KM_E_INTERNAL, "candidate buffer kept overflowing");
+        if (attempt == 3) return km_fail(c, KM_E_INTERNAL, "candidate buffer kept overflowing");
     }
     c->stats.n_candidates = (int64_t)ntotal;
     c->stats.emitted_ratio = ntotal ? (float)((double)hs.n_cand / (double)ntotal) : 0.f;

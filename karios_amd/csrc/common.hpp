@@ -102,6 +102,7 @@ struct km_ctx {
     km_buf ws[WS_COUNT];
     std::string err;
     bool profiling = false;
+    bool fused_eig = false;    // km_set_option("fused_eig"): experimental fused eig + candidate kernel (k_eigc.hip)
     hipEvent_t ev[ST_COUNT][2];
     bool ev_used[ST_COUNT];
     bool ev_ready = false;
@@ -195,6 +196,9 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
                  float *d_eig, unsigned int *d_max_key);
 int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality,
                       km_scalars *sc, unsigned long long *d_keys, size_t cap);
+// k_eigc.hip: fused minimum-eigenvalue + candidate pass, 4 pixels per lane (no eig map)
+int ke_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
+                      unsigned long long *d_keys, size_t cap, bool rezero);
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
                   double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap, bool rezero);
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);

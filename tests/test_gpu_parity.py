@@ -174,6 +174,51 @@ def test_good_features_masked_wedge_and_ties(ops, O):
     np.testing.assert_array_equal(got, exp)
 
 
+@pytest.mark.parametrize("block", [3, 15])
+def test_good_features_plateau_falls_back_from_fused_kernel(ops, O, block):
+    """img = g(x) + h(y) with periods dividing blockSize: the box sums of dx^2 and dy^2 cover whole periods (constant), the
+    one of dx*dy vanishes, so lambda is one constant over the whole interior and EVERY pixel ties as a 3x3 maximum.  A row
+    group then overflows the candidate stage of the fused eig+candidate kernel; the library must notice and repeat the
+    pass with the eig-map + candidate kernels (same result as the oracle: ties resolved by the raster-index rule)."""
+    from karios_amd._lib import default_context
+    g = np.array([0, 60, 200, 90, 30] if block == 15 else [0, 90, 200])
+    h = np.array([0, 50, 20])
+    img = (g[np.arange(700) % len(g)][None, :] + h[np.arange(330) % 3][:, None]).astype(np.uint8)
+    exp = O.good_features(img, None, 2000, 0.01, 4, block)
+    ctx = default_context()
+    for fused in (1, 0):
+        ctx.set_option("fused_eig", fused)
+        try:
+            got = ops.good_features_to_track(img, 2000, 0.01, 4, blockSize=block)
+        finally:
+            ctx.set_option("fused_eig", 0)
+        np.testing.assert_array_equal(got, exp)
+        assert ctx.stats().n_candidates > img.size // 2
+
+
+@pytest.mark.parametrize("params", [dict(maxCorners=1500, q=0.05, md=7, bs=15), dict(maxCorners=0, q=0.2, md=3, bs=3),
+                                    dict(maxCorners=400, q=0.01, md=12.5, bs=7), dict(maxCorners=300, q=0.1, md=5, bs=4)])
+@pytest.mark.parametrize("shape", [(300, 700), (131, 267)])
+def test_good_features_fused_kernel_bit_exact(ops, O, params, shape):
+    """The optional fused eig+candidate kernel (km_set_option "fused_eig") gives the oracle's corners too: border strips
+    (image narrower than one strip / W % 4 != 0), masks, even block sizes (those fall back to the two-kernel path)."""
+    from karios_amd._lib import default_context
+    lap_mon, lap_ref, mon, ref = _lap_pair(O, shape[0], shape[1], nodata_wedge=True)
+    mask, _ = O.auto_mask(mon, ref)
+    ctx = default_context()
+    ctx.set_option("fused_eig", 1)
+    try:
+        for mk in (None, mask):
+            got = ops.good_features_to_track(lap_ref, params["maxCorners"], params["q"], params["md"], mask=mk, blockSize=params["bs"])
+            exp = O.good_features(lap_ref, mk, params["maxCorners"], params["q"], params["md"], params["bs"])
+            if exp is None:
+                assert got is None
+            else:
+                np.testing.assert_array_equal(got, exp)
+    finally:
+        ctx.set_option("fused_eig", 0)
+
+
 def test_good_features_flat_image_is_none(ops):
     assert ops.good_features_to_track(np.full((80, 80), 17, np.uint8), 100, 0.1, 10, blockSize=15) is None
     assert ops.good_features_to_track(np.zeros((2, 2), np.uint8), 100, 0.1, 10, blockSize=3) is None
