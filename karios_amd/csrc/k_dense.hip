@@ -9,6 +9,24 @@
 // arithmetic, no MFMA.
 #include "common.hpp"
 
+// occupancy targets of the marching kernels (waves per SIMD; 0 = leave it to the register allocator)
+#ifndef KM_EIGM_WAVES
+#define KM_EIGM_WAVES 0
+#endif
+#ifndef KM_LAPM_WAVES
+#define KM_LAPM_WAVES 0
+#endif
+#if KM_EIGM_WAVES
+#define KM_EIGM_OCC __attribute__((amdgpu_waves_per_eu(KM_EIGM_WAVES, KM_EIGM_WAVES)))
+#else
+#define KM_EIGM_OCC
+#endif
+#if KM_LAPM_WAVES
+#define KM_LAPM_OCC __attribute__((amdgpu_waves_per_eu(KM_LAPM_WAVES, KM_LAPM_WAVES)))
+#else
+#define KM_LAPM_OCC
+#endif
+
 #include <type_traits>
 
 // ------------------------------------------------------------------ helpers
@@ -697,7 +715,7 @@ __device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
 #endif
 
 template <int R, typename T, bool MASK>
-__global__ __launch_bounds__(256) void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+__global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                         ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
                                                         lap_coef cf, int invert1, nodata_t nd,
                                                         uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
@@ -1172,6 +1190,9 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 }
 
 #define EIG_RS 128  // output rows per wave segment
+#ifndef EIGM_CH
+#define EIGM_CH 3     // rows fetched ahead per batch (3: 78 VGPRs = 6 waves per SIMD at blockSize 15; 15: 104 VGPRs = 4 waves)
+#endif
 
 __device__ __forceinline__ float dpp_shr1(float v)  // value of lane-1 (0 for lane 0)
 {
@@ -1188,7 +1209,7 @@ __device__ __forceinline__ float dpp_shl1(float v)  // value of lane+1 (0 for la
 //   mask / border rules and exceeds a RUNNING lower bound of the final threshold (quality * max seen so far) is emitted
 //   as a candidate key.  The exact threshold is applied afterwards, when the global maximum is known (tk_* kernels).
 template <int BLOCK, bool EMIT>
-__global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W,
+__global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W,
                                                         double scale2, float *__restrict__ eig, unsigned int *__restrict__ max_partial,
                                                         int nstrips, double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
                                                         size_t cap)
@@ -1247,7 +1268,10 @@ __global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restric
         // steady state (no row mirrored in this group of BLOCK steps): issue all BLOCK row loads (and the mask
         // bytes of the rows completed here) up front so their latency overlaps the arithmetic
         const bool steady = mbase - 1 >= 0 && mbase + BLOCK <= H - 1;
-        int pre[BLOCK], pmask[BLOCK];
+        // rows are fetched EIGM_CH at a time (source byte + mask byte of the row completed then): a deeper prefetch costs
+        // registers, i.e. resident waves, and the resident waves are what hides the latency of this kernel
+        constexpr int CH = BLOCK < EIGM_CH ? BLOCK : EIGM_CH;
+        int pre[CH], pmask[CH];
         if constexpr (EMIT) {
             // the stage is only flushed here, between row groups: the row loop itself never touches global memory for
             // the keys (a group adds at most BLOCK * 48 of them)
@@ -1262,8 +1286,6 @@ __global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restric
             thr_run = mk ? (float)__dmul_rn((double)eig_unkey(mk), quality) : 0.f;
         }
         if (steady) {
-#pragma unroll
-            for (int k = 0; k < BLOCK; k++) pre[k] = col[(size_t)(mbase + k + 1) * W];
             if (!(c1 == mbase - 1 && c2 == mbase)) {
                 a1 = col[(size_t)(mbase - 1) * W]; a2 = col[(size_t)mbase * W];
                 c1 = mbase - 1; c2 = mbase;
@@ -1271,16 +1293,21 @@ __global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restric
         }
 #pragma unroll
         for (int k = 0; k < BLOCK; k++) {
-            pmask[k] = 1;
-            const int y = mbase + k - Rr;
-            if (mask && out_lane && y >= y0 && y < y1) pmask[k] = mask[(size_t)y * W + gx];
-        }
+            if (k % CH == 0) {
 #pragma unroll
-        for (int k = 0; k < BLOCK; k++) {
+                for (int j = 0; j < CH; j++) {
+                    if (k + j < BLOCK) {
+                        if (steady) pre[j] = col[(size_t)(mbase + k + j + 1) * W];
+                        pmask[j] = 1;
+                        const int yq = mbase + k + j - Rr;
+                        if (mask && out_lane && yq >= y0 && yq < y1) pmask[j] = mask[(size_t)yq * W + gx];
+                    }
+                }
+            }
             const int m = mbase + k;                      // marching row (product row index, may be outside)
             if (m >= y1 + Rr) continue;                   // (no break: the ring index must stay a compile-time constant)
             if (steady) {
-                a0 = a1; a1 = a2; a2 = pre[k];
+                a0 = a1; a1 = a2; a2 = pre[k % CH];
                 c1 = m; c2 = m + 1;
             } else {
                 const int r = km_reflect101(m, H);        // product row actually evaluated
@@ -1325,7 +1352,7 @@ __global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restric
                 const float e = __fsub_rn(__fadd_rn(a, cc), sqrtf(sq));
                 if constexpr (!EMIT) eig[(size_t)y * W + gx] = e;
                 e_cur = e;
-                if (pmask[k]) { best = have ? fmaxf(best, e) : e; have = true; }
+                if (pmask[k % CH]) { best = have ? fmaxf(best, e) : e; have = true; }
             }
             if constexpr (EMIT) {
                 if (y >= y0 + 2) {
@@ -1339,7 +1366,7 @@ __global__ __launch_bounds__(256) void eig_march_kernel(const uint8_t *__restric
                                                                (unsigned long long)((unsigned)(y - 1) * (unsigned)W + (unsigned)gx);
                     cnt += (unsigned)__popcll(bal);
                 }
-                if (y >= y0) { e_m2 = e_m1; e_m1 = e_cur; pm_m1 = pmask[k]; }
+                if (y >= y0) { e_m2 = e_m1; e_m1 = e_cur; pm_m1 = pmask[k % CH]; }
             }
         }
     }

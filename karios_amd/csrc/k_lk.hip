@@ -12,6 +12,15 @@
 // back to back in the same wavefront.
 #include "common.hpp"
 
+#ifndef KM_LK_WAVES
+#define KM_LK_WAVES 0   // occupancy target (waves per SIMD); 0 = leave it to the register allocator
+#endif
+#if KM_LK_WAVES
+#define KM_LK_OCC __attribute__((amdgpu_waves_per_eu(KM_LK_WAVES, KM_LK_WAVES)))
+#else
+#define KM_LK_OCC
+#endif
+
 #include <float.h>
 #include <type_traits>
 
@@ -242,7 +251,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
 }
 
 template <int NPL>
-__global__ __launch_bounds__(64) void lk_kernel(lk_args g)
+__global__ __launch_bounds__(64) KM_LK_OCC void lk_kernel(lk_args g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int p = blockIdx.x;
