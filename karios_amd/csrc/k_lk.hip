@@ -104,24 +104,27 @@ __device__ __forceinline__ long long wave_sum_split(int v)
     return ((long long)wave_sum_i32_dpp(hi) << 16) + (long long)wave_sum_i32_dpp(lo);
 }
 
-// Per-lane window-pixel offsets, packed: raw-patch offset | derivative offset << S | search-patch offset << 2S.
-// 10-bit fields cover winSize <= 25 in one 32-bit register; larger windows use 12-bit fields in 64 bits.
-template <int NPL> struct lk_off {
-    using type = typename std::conditional<(NPL <= 10), int, long long>::type;
-    static constexpr int S = NPL <= 10 ? 10 : 12;
-    static constexpr int M = (1 << S) - 1;
-};
+// Window pixels are dealt to the lanes as horizontal RUNS of LK_RUN pixels (run r = t * 64 + lane covers columns
+// [x0, x0 + n) of window row y).  A run needs LK_RUN + 1 consecutive bytes from each of two rows of the search patch:
+// two (unaligned) 8-byte LDS reads per run and iteration instead of four byte reads per pixel, the byte pairs are cut out
+// with v_perm and the bilinear interpolation is two v_dot2_i32_i16 per pixel; the mismatch vector is accumulated with
+// v_dot2_i32_i16 over pixel pairs as well.  All arithmetic is the exact integer arithmetic of cv::calcOpticalFlowPyrLK.
+#define LK_RUN 5
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lk_s2 lk_as_s2(uint32_t v) { return __builtin_bit_cast(lk_s2, v); }
+__device__ __forceinline__ uint32_t lk_as_u(lk_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t lk_pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
 // Track one point from image pyramid I to J (all lanes hold identical scalars).
-template <int NPL>
+// run_desc[t] = y | x0 << 8 | n << 16 (n = 0: the lane has no t-th run).
+template <int NR>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
-                               const typename lk_off<NPL>::type (&offp)[NPL], uint8_t *raw, int *der, uint8_t *jp, float &outx, float &outy)
+                               const int (&run_desc)[NR], uint8_t *raw, int *der, uint8_t *jp, float &outx, float &outy)
 {
     const int lane = threadIdx.x;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int RW = win + 3, DW = win + 1;
-    constexpr int OS = lk_off<NPL>::S, OM = lk_off<NPL>::M;
     const int RP = (RW + 3 + 3) & ~3;                 // raw patch pitch
     const int JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     float resx = px, resy = py;
@@ -180,27 +183,36 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             }
         }
         __syncthreads();
-        // per-lane window pixels -> registers; exact integer normal matrix
-        // offp[k] packs this lane's k-th window pixel: raw-patch offset | derivative offset << 10 | search-patch offset << 20
-        int Iv[NPL], Ixy[NPL];
-        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums stay below 2^31 (NPL <= 25: 25 * 4080^2 = 4.2e8)
-        long long lA11 = 0, lA12 = 0, lA22 = 0;
+        // per-lane window pixels -> registers (16-bit pairs along the run: Q5 intensity, Ix, Iy); exact integer normal matrix
+        uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums stay below 2^31 (<= 25 pixels per lane: 25 * 4080^2 = 4.2e8)
 #pragma unroll
-        for (int k = 0; k < NPL; k++) {
-            Iv[k] = 0; Ixy[k] = 0;
-            if (offp[k] >= 0) {
-                const uint8_t *p = raw + (int)(offp[k] & OM);
-                Iv[k] = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[RP], w10) + __mul24(p[RP + 1], w11), 14 - 5);
-                const int *dp = der + (int)((offp[k] >> OS) & OM);
-                const int d00 = dp[0], d01 = dp[1], d10 = dp[DW], d11 = dp[DW + 1];
-                const int ixv = descale(__mul24((int)(short)(d00 & 0xffff), w00) + __mul24((int)(short)(d01 & 0xffff), w01) +
-                                            __mul24((int)(short)(d10 & 0xffff), w10) + __mul24((int)(short)(d11 & 0xffff), w11), 14);
-                const int iyv = descale(__mul24(d00 >> 16, w00) + __mul24(d01 >> 16, w01) + __mul24(d10 >> 16, w10) + __mul24(d11 >> 16, w11), 14);
-                Ixy[k] = (ixv & 0xffff) | (iyv << 16);
-                sA11 += __mul24(ixv, ixv); sA12 += __mul24(ixv, iyv); sA22 += __mul24(iyv, iyv);
+        for (int t = 0; t < NR; t++) {
+            const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff, n = run_desc[t] >> 16;
+            int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
+#pragma unroll
+            for (int j = 0; j <= LK_RUN; j++) { iv[j] = 0; ixv[j] = 0; iyv[j] = 0; }
+#pragma unroll
+            for (int j = 0; j < LK_RUN; j++) {
+                if (j < n) {
+                    const uint8_t *p = raw + (y + 1) * RP + (x0 + j + 1);
+                    iv[j] = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[RP], w10) + __mul24(p[RP + 1], w11), 14 - 5);
+                    const int *dp = der + y * DW + (x0 + j);
+                    const int d00 = dp[0], d01 = dp[1], d10 = dp[DW], d11 = dp[DW + 1];
+                    ixv[j] = descale(__mul24((int)(short)(d00 & 0xffff), w00) + __mul24((int)(short)(d01 & 0xffff), w01) +
+                                         __mul24((int)(short)(d10 & 0xffff), w10) + __mul24((int)(short)(d11 & 0xffff), w11), 14);
+                    iyv[j] = descale(__mul24(d00 >> 16, w00) + __mul24(d01 >> 16, w01) + __mul24(d10 >> 16, w10) + __mul24(d11 >> 16, w11), 14);
+                    sA11 += __mul24(ixv[j], ixv[j]); sA12 += __mul24(ixv[j], iyv[j]); sA22 += __mul24(iyv[j], iyv[j]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                IvP[t][q] = lk_pack16(iv[2 * q], iv[2 * q + 1]);
+                IxP[t][q] = lk_pack16(ixv[2 * q], ixv[2 * q + 1]);
+                IyP[t][q] = lk_pack16(iyv[2 * q], iyv[2 * q + 1]);
             }
         }
-        const long long iA11 = lA11 + wave_sum_split(sA11), iA12 = lA12 + wave_sum_split(sA12), iA22 = lA22 + wave_sum_split(sA22);
+        const long long iA11 = wave_sum_split(sA11), iA12 = wave_sum_split(sA12), iA22 = wave_sum_split(sA22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dA = A11 - A22;
@@ -222,18 +234,32 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             }
             a = nx - (float)inx; b = ny - (float)iny;
             lk_weights(a, b, w00, w01, w10, w11);
+            const lk_s2 wr0 = lk_as_s2(lk_pack16(w00, w01)), wr1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
             const uint8_t *jb = jp + (iny - jy0) * JP + (inx - jx0);
             int sb1 = 0, sb2 = 0;
-            long long lb1 = 0, lb2 = 0;
 #pragma unroll
-            for (int k = 0; k < NPL; k++) {
-                if (offp[k] >= 0) {
-                    const uint8_t *p = jb + (int)(offp[k] >> (2 * OS));
-                    const int diff = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[JP], w10) + __mul24(p[JP + 1], w11), 14 - 5) - Iv[k];
-                    sb1 += __mul24(diff, (int)(short)(Ixy[k] & 0xffff)); sb2 += __mul24(diff, Ixy[k] >> 16);
+            for (int t = 0; t < NR; t++) {
+                const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
+                const uint8_t *p0 = jb + y * JP + x0;
+                uint2 r0, r1;                         // bytes x0 .. x0+7 of the two patch rows (unaligned LDS reads)
+                __builtin_memcpy(&r0, p0, 8);
+                __builtin_memcpy(&r1, p0 + JP, 8);
+                int val[LK_RUN + 1];
+                val[LK_RUN] = 0;
+#pragma unroll
+                for (int k = 0; k < LK_RUN; k++) {
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);   // (byte k, byte k+1) as 16-bit values
+                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
+                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, __builtin_amdgcn_sdot2(c1, wr1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 3; q2++) {
+                    const lk_s2 diff = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1])) - lk_as_s2(IvP[t][q2]);
+                    sb1 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IxP[t][q2]), sb1, false);
+                    sb2 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IyP[t][q2]), sb2, false);
                 }
             }
-            const long long ib1 = lb1 + wave_sum_split(sb1), ib2 = lb2 + wave_sum_split(sb2);
+            const long long ib1 = wave_sum_split(sb1), ib2 = wave_sum_split(sb2);
             const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
             const float ddx = (A12 * b2 - A22 * b1) * D;
             const float ddy = (A12 * b1 - A11 * b2) * D;
@@ -250,7 +276,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
     outx = resx; outy = resy;
 }
 
-template <int NPL>
+template <int NR>
 __global__ __launch_bounds__(64) KM_LK_OCC void lk_kernel(lk_args g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -262,22 +288,21 @@ __global__ __launch_bounds__(64) KM_LK_OCC void lk_kernel(lk_args g)
     uint8_t *raw = smem;
     uint8_t *jp = smem + (((win + 3) * RP + 15) & ~15);
     int *der = (int *)(jp + ((JS * JP + 15) & ~15));
-    using off_t = typename lk_off<NPL>::type;
-    constexpr int OS = lk_off<NPL>::S;
-    off_t offp[NPL];
+    const int rpr = (win + LK_RUN - 1) / LK_RUN, total = win * rpr;
+    int run_desc[NR];
 #pragma unroll
-    for (int k = 0; k < NPL; k++) {
-        const int idx = k * 64 + (int)threadIdx.x;
-        const int y = idx / win, x = idx - y * win;
-        offp[k] = idx < win * win ? ((off_t)((y + 1) * RP + (x + 1)) | ((off_t)(y * (win + 1) + x) << OS) | ((off_t)(y * JP + x) << (2 * OS))) : (off_t)-1;
+    for (int t = 0; t < NR; t++) {
+        const int r = t * 64 + (int)threadIdx.x;
+        const int y = r / rpr, x0 = (r - y * rpr) * LK_RUN;
+        run_desc[t] = r < total ? (y | (x0 << 8) | (min(LK_RUN, win - x0) << 16)) : 0;
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
-    lk_track_point<NPL>(g.A, g.B, px, py, win, g.max_count, g.epsilon, offp, raw, der, jp, fx, fy);
+    lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, der, jp, fx, fy);
     if (threadIdx.x == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk_track_point<NPL>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, offp, raw, der, jp, rx, ry);
+        lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, der, jp, rx, ry);
         if (threadIdx.x == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }
@@ -297,11 +322,14 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     g.p1 = d_p1; g.p0r = d_p0r;
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
-    const int npl = (win * win + 63) / 64;
-    if (npl <= 4) lk_kernel<4><<<n_max, 64, sm, c->stream>>>(g);
-    else if (npl <= 10) lk_kernel<10><<<n_max, 64, sm, c->stream>>>(g);
-    else if (npl <= 16) lk_kernel<16><<<n_max, 64, sm, c->stream>>>(g);
-    else lk_kernel<25><<<n_max, 64, sm, c->stream>>>(g);
+    const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;   // runs per lane (win <= 40: <= 5)
+    switch (nr) {
+    case 1: lk_kernel<1><<<n_max, 64, sm, c->stream>>>(g); break;
+    case 2: lk_kernel<2><<<n_max, 64, sm, c->stream>>>(g); break;
+    case 3: lk_kernel<3><<<n_max, 64, sm, c->stream>>>(g); break;
+    case 4: lk_kernel<4><<<n_max, 64, sm, c->stream>>>(g); break;
+    default: lk_kernel<5><<<n_max, 64, sm, c->stream>>>(g); break;
+    }
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
