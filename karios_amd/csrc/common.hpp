@@ -114,6 +114,21 @@ struct km_ctx {
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
 
+// MI355X dispatches workgroup w of a grid to XCD w % 8, and every XCD has its own L2.  The marching kernels therefore
+// launch km_xcd_grid(ntiles) workgroups and let workgroup w process tile (w % 8) * ceil(ntiles / 8) + w / 8: each XCD
+// then owns one contiguous range of tiles (neighbouring column strips and row blocks share their halo in ONE L2 instead of
+// being fetched from HBM once per XCD).  Returns false for the padding workgroups.
+#define KM_XCDS 8u
+static inline unsigned km_xcd_grid(unsigned ntiles) { return ((ntiles + KM_XCDS - 1) / KM_XCDS) * KM_XCDS; }
+#ifdef __HIPCC__
+__device__ __forceinline__ bool km_xcd_tile(unsigned ntiles, unsigned &tile)
+{
+    const unsigned per = (ntiles + KM_XCDS - 1) / KM_XCDS, w = blockIdx.x;
+    tile = (w % KM_XCDS) * per + w / KM_XCDS;
+    return tile < ntiles;
+}
+#endif
+
 // Rows per work item of a marching kernel (one wavefront walks `rows` output rows of one column strip, re-reading
 // `halo` rows): the value in [lo, hi] that minimises  ceil(items / wave_slots) * (rows + halo), i.e. whole rounds of
 // resident waves times the work of one item - a grid that needs 2.02 rounds costs three.

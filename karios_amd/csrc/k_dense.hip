@@ -726,7 +726,9 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     constexpr int NR = 2 * R + 1;
     const int tid = threadIdx.x, lane = tid & 63;
     // work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
-    const int wave_id = blockIdx.x * 4 + (tid >> 6);
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(nitems + 3) / 4u, tile)) return;
+    const int wave_id = (int)tile * 4 + (tid >> 6);
     if (wave_id >= nitems) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
     const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
     stretcher<T> st[2];
@@ -963,8 +965,9 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     int rows = km_pick_rows(H, nstrips, 2 * R, slots_of(fn), 32, 160);
     if (const char *e = getenv("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
-    dim3 grid((nitems + 3) / 4);
-    const size_t nwaves = (size_t)grid.x * 4;
+    const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
+    dim3 grid(km_xcd_grid(ntiles));
+    const size_t nwaves = (size_t)ntiles * 4;
     unsigned *valid = nullptr;
     if (MASK) {
         valid = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
@@ -1212,15 +1215,19 @@ template <int BLOCK, bool EMIT>
 __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W,
                                                         double scale2, float *__restrict__ eig, unsigned int *__restrict__ max_partial,
                                                         int nstrips, double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
-                                                        size_t cap)
+                                                        size_t cap, int gyw)
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, VALID = 64 - BLOCK - 1;
     constexpr int STRIDE = EMIT ? VALID - 2 : VALID;     // EMIT: the outer two computed columns only serve as neighbours
     constexpr int STAGE = 1024;                          // >= (keys already staged at a group start) + BLOCK rows * 48 lanes
     __shared__ unsigned long long stage[EMIT ? 4 : 1][EMIT ? STAGE : 1];
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
+    const int gxw = (nstrips + 3) / 4;                  // workgroups per row block (logical grid gxw x gyw, XCD-swizzled)
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(gxw * gyw), tile)) return;
+    const int bx = (int)tile % gxw, by = (int)tile / gxw;
+    const int strip = bx * 4 + (threadIdx.x >> 6);
+    const int wave_id = by * (gxw * 4) + strip;
     if (strip >= nstrips) { if (lane == 0) max_partial[wave_id] = 0u; return; }
     const int xs = strip * STRIDE;
     const int gx = xs - (L + 1) + lane;                  // image column of this lane (may be outside)
@@ -1232,8 +1239,8 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
     const int hi_addr = min(lane + Rr, 63) * 4, lo_addr = max(lane - L - 1, 0) * 4;
     const bool lo_zero = lane - L - 1 < 0;
     // EMIT: candidate rows [ya, yb) need the eig rows ya-1 .. yb
-    const int ya = 1 + blockIdx.y * EIG_RS, yb = min(H - 1, ya + EIG_RS);
-    const int y0 = EMIT ? ya - 1 : blockIdx.y * EIG_RS, y1 = EMIT ? yb + 1 : min(H, y0 + EIG_RS);
+    const int ya = 1 + by * EIG_RS, yb = min(H - 1, ya + EIG_RS);
+    const int y0 = EMIT ? ya - 1 : by * EIG_RS, y1 = EMIT ? yb + 1 : min(H, y0 + EIG_RS);
     const uint8_t *col = src + cx;
     const bool cand_lane = lane >= L + 2 && lane <= L + VALID - 1 && gx >= 1 && gx <= W - 2;
     unsigned long long *st = stage[EMIT ? (threadIdx.x >> 6) : 0];
@@ -1391,7 +1398,8 @@ static int launch_eig_march(km_ctx *c, const uint8_t *d_src, const uint8_t *d_ma
     const size_t nwaves = (size_t)grid.x * 4 * grid.y;
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
-    eig_march_kernel<BLOCK, false><<<grid, 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, 0.0, nullptr, nullptr, 0);
+    eig_march_kernel<BLOCK, false><<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, 0.0, nullptr,
+                                                                                          nullptr, 0, (int)grid.y);
     KM_LAUNCH_CHECK(c);
     max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, (unsigned)nwaves, d_max_key);
     KM_LAUNCH_CHECK(c);
@@ -1410,7 +1418,8 @@ static int launch_eig_emit(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mas
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(&sc->run_max_key, 0, (2 + KM_NSHARD) * sizeof(unsigned), c->stream));   // run_max_key, pad, shard counters
-    eig_march_kernel<BLOCK, true><<<grid, 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, nullptr, partial, nstrips, quality, sc, d_keys, cap);
+    eig_march_kernel<BLOCK, true><<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, nullptr, partial, nstrips, quality, sc,
+                                                                                         d_keys, cap, (int)grid.y);
     KM_LAUNCH_CHECK(c);
     max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, (unsigned)nwaves, &sc->max_eig_key);
     KM_LAUNCH_CHECK(c);
@@ -1489,19 +1498,23 @@ struct cand_row {
 
 __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig, const uint8_t *__restrict__ mask, int H, int W,
                                                    double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
-                                                   size_t cap, int nstrips)
+                                                   size_t cap, int nstrips, int gyw)
 {
     __shared__ unsigned long long stage[4][CAND_STAGE];
     const unsigned mk = sc->max_eig_key;
     const float maxv = mk ? eig_unkey(mk) : 0.f;
     const float thr = (float)__dmul_rn((double)maxv, quality);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sc->thr = thr; sc->max_eig = maxv; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->thr = thr; sc->max_eig = maxv; }
+    const int gxw = (nstrips + 3) / 4;                  // logical grid gxw x gyw, XCD-swizzled
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(gxw * gyw), tile)) return;
+    const int bx = (int)tile % gxw, by = (int)tile / gxw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + wv;
+    const int strip = bx * 4 + wv;
     if (strip >= nstrips) return;
     unsigned long long *st = stage[wv];
     const int x0 = strip * 256 + lane * 4;               // first of this lane's 4 columns
-    const int y0 = blockIdx.y * CAND_RS, y1 = min(H, y0 + CAND_RS);
+    const int y0 = by * CAND_RS, y1 = min(H, y0 + CAND_RS);
     const bool vec = (W % 4 == 0) && x0 + 3 < W;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -1528,7 +1541,7 @@ __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig
     };
 
     unsigned cnt = 0;  // keys in the stage (wave-uniform)
-    const int wave_id = blockIdx.y * (gridDim.x * 4) + strip;
+    const int wave_id = by * (gxw * 4) + strip;
     const unsigned shard = (unsigned)wave_id % KM_NSHARD;
     const size_t cap_s = cap / KM_NSHARD;
     auto flush = [&]() {
@@ -1605,7 +1618,7 @@ int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, i
     }
     const int nstrips = (W + 255) / 256;
     dim3 grid((nstrips + 3) / 4, (H + CAND_RS - 1) / CAND_RS);
-    cand_kernel<<<grid, 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap, nstrips);
+    cand_kernel<<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_eig, d_mask, H, W, quality, d_sc, d_keys, cap, nstrips, (int)grid.y);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
