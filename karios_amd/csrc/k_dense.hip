@@ -1178,7 +1178,23 @@ __global__ __launch_bounds__(256) void eig_kernel(const uint8_t *__restrict__ sr
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_get0(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+    // full row mask: bound_ctrl makes the lanes without a source read 0, no register has to be cleared first
+    if constexpr (ROW_MASK == 0xf) return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+    else return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Correctly rounded float32 square root for x == 0 or x >= 2^-96 (the structure-tensor discriminant is 0 or >= 1e-18):
+// the hardware estimate (<= 1 ulp) corrected with two fused residuals - the sequence the compiler emits for sqrtf under
+// -fhip-fp32-correctly-rounded-divide-sqrt, without its rescaling of tiny arguments and its inf/zero special case
+// (for x == 0 the estimate is 0, both residual tests fail on NaN / 0 and 0 is returned).
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float r_dn = __int_as_float(__float_as_int(r) - 1), r_up = __int_as_float(__float_as_int(r) + 1);
+    const float e_dn = __builtin_fmaf(-r_dn, r, x), e_up = __builtin_fmaf(-r_up, r, x);
+    float res = e_dn <= 0.f ? r_dn : r;
+    res = e_up > 0.f ? r_up : res;
+    return res;
 }
 
 __device__ __forceinline__ int wave_incl_scan(int v)
@@ -1356,7 +1372,7 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
                 const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
                 const float t = __fsub_rn(a, cc);
                 const float sq = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
-                const float e = __fsub_rn(__fadd_rn(a, cc), sqrtf(sq));
+                const float e = __fsub_rn(__fadd_rn(a, cc), sqrt_rn_normal(sq));
                 if constexpr (!EMIT) eig[(size_t)y * W + gx] = e;
                 e_cur = e;
                 if (pmask[k % CH]) { best = have ? fmaxf(best, e) : e; have = true; }

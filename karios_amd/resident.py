@@ -51,6 +51,22 @@ class DeviceBuffer:
         return out
 
 
+class RawFrame:
+    """One tile's frame block as the device pipeline delivers it (layout of km_klt_tile_frame[_zncc]_dev): 4 int32
+    {n_rows, n_init, 0, 0} + 6*cap float32 (x0 | y0 | dx | dy | score | index bits) (+ cap float64 zncc)."""
+    __slots__ = ("block", "cap", "with_zncc")
+
+    def __init__(self, block: np.ndarray, cap: int, with_zncc: bool):
+        self.block, self.cap, self.with_zncc = block, cap, with_zncc
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.block[:1].view(np.int32)[0])
+
+    def to_frame(self) -> DataFrame | None:
+        return ResidentPair._frame_from_block(self.block, self.cap, self.with_zncc)
+
+
 class ResidentPair:
     """A monitored / reference image pair (plus optional user mask) resident in HBM."""
 
@@ -165,7 +181,7 @@ class ResidentPair:
             return points
         return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold)
 
-    def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None) -> DataFrame | None:
+    def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None, build_frame=True) -> DataFrame | None:
         """Tile pipeline + FB test + score + (x0, y0) ordering on the device, one D2H copy of the finished frame."""
         c = self.ctx
         bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
@@ -192,7 +208,54 @@ class ResidentPair:
                                                      float(y_off), C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.y_size,
                                                      self.x_size, self.x_size, self.x_size, float(zncc_threshold),
                                                      buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
-        return self._frame_from_block(buf, cap, zncc_threshold is not None)
+        return self._frame_from_block(buf, cap, zncc_threshold is not None) if build_frame else None
+
+    def match_tile_raw(self, conf, box=None, zncc_threshold=None) -> "RawFrame":
+        """GPU half of `match_tile`: runs the device pipeline and returns the raw frame block (a private copy), leaving
+        the pandas half to `RawFrame.to_frame()` - which may run in another thread while this thread already drives the
+        next tile (ctypes releases the GIL inside the library).  Fixed kernel size / polarity, no outlier filtering."""
+        if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
+            raise KariosHipError("ResidentPair.match_tile_raw: 'auto' modes and outlier filtering need ResidentPair.match_tile / matcher.KLT")
+        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
+        with_zncc = zncc_threshold is not None
+        # host blocks rotate through a ring of three: the previous block may still be read by the host half of the pipeline
+        ring = self.__dict__.setdefault("_raw_ring", [None, None, None])
+        slot = self.__dict__.get("_raw_slot", 0)
+        self._raw_slot = (slot + 1) % len(ring)
+        self._host_frame = ring[slot]
+        self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, build_frame=False)
+        bx, by = (box[2], box[3]) if box is not None else (self.x_size, self.y_size)
+        cap = conf.maxCorners if conf.maxCorners > 0 else max(1, (bx * by) // 4)
+        block, ring[slot], self._host_frame = self._host_frame, self._host_frame, None
+        return RawFrame(block[:4 + (8 if with_zncc else 6) * cap], cap, with_zncc)
+
+    def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
+        """`match` with the host half of tile i (DataFrame construction, optional `host_stage(frame)` such as
+        `score_frame`) overlapped with the device half of tile i+1.  Yields the frames in tile order, like `KLT.match`."""
+        from concurrent.futures import ThreadPoolExecutor
+        if boxes is None:
+            boxes = KLT(conf).tile_boxes(self.x_size, self.y_size)
+
+        def host_half(raw):
+            frame = raw.to_frame()
+            if frame is not None and host_stage is not None:
+                frame = host_stage(frame)
+            return frame
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = None
+            for box in boxes:
+                raw = self.match_tile_raw(conf, box, zncc_threshold)
+                nxt = pool.submit(host_half, raw)
+                if pending is not None:
+                    frame = pending.result()
+                    if frame is not None:
+                        yield frame
+                pending = nxt
+            if pending is not None:
+                frame = pending.result()
+                if frame is not None:
+                    yield frame
 
     @staticmethod
     def _frame_from_block(buf: np.ndarray, cap: int, with_zncc: bool) -> DataFrame | None:

@@ -368,6 +368,25 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
     assert flat.match_tile(KLTConfiguration()) is None
 
 
+def test_resident_pair_pipelined_match_equals_tile_by_tile(ops, O):
+    """`match_pipelined` (host half of tile i overlapped with the device half of tile i+1) yields the frames of `match`."""
+    import pandas as pd
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(400, 620, 0.4, -0.3, seed=5)
+    conf = KLTConfiguration(maxCorners=600, tile_size=200, xStart=10)
+    pair = ResidentPair.upload(mon, ref)
+    want = list(pair.match(conf))
+    got = list(pair.match_pipelined(conf))
+    assert len(want) == len(got) > 2
+    for a, b in zip(want, got):
+        pd.testing.assert_frame_equal(a, b)
+    scored = list(pair.match_pipelined(conf, zncc_threshold=0.4, host_stage=lambda f: pair.score_frame(f, 0.4)))
+    for a, b in zip(want, scored):
+        ref_frame = pair.score_frame(a.copy(), 0.4)
+        pd.testing.assert_frame_equal(ref_frame[sorted(ref_frame.columns)], b[sorted(b.columns)])
+
+
 def test_error_contract_like_cv2(ops):
     """Malformed inputs raise (the reference gets cv2.error / ValueError), they never return garbage."""
     img = rand_u8((40, 40))
