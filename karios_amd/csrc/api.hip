@@ -71,7 +71,7 @@ int km_ctx_create(int device, km_ctx **out)
         delete c;
         return rc;
     }
-    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
+    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -103,7 +103,7 @@ int km_ctx_sync(km_ctx *c)
 int km_set_option(km_ctx *c, const char *name, int value)
 {
     if (!c || !name) return km_fail(c, KM_E_ARG, "km_set_option: null argument");
-    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value != 0; return KM_OK; }
+    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value < 0 ? 0 : value > 2 ? 2 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
@@ -265,7 +265,8 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         bool fused = false;
         if (c->fused_eig && !fused_overflow) {
             km_stage_timer t(c, ST_EIGEN);
-            rc = ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0);
+            rc = c->fused_eig == 2 ? ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
+                                   : kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
             if (rc == KM_OK) fused = true;
             else if (rc != KM_E_UNSUPPORTED) return rc;
         }

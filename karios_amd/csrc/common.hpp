@@ -102,7 +102,7 @@ struct km_ctx {
     km_buf ws[WS_COUNT];
     std::string err;
     bool profiling = false;
-    bool fused_eig = false;    // km_set_option("fused_eig"): experimental fused eig + candidate kernel (k_eigc.hip)
+    int fused_eig = 0;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip)
     hipEvent_t ev[ST_COUNT][2];
     bool ev_used[ST_COUNT];
     bool ev_ready = false;

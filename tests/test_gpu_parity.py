@@ -186,7 +186,7 @@ def test_good_features_plateau_falls_back_from_fused_kernel(ops, O, block):
     img = (g[np.arange(700) % len(g)][None, :] + h[np.arange(330) % 3][:, None]).astype(np.uint8)
     exp = O.good_features(img, None, 2000, 0.01, 4, block)
     ctx = default_context()
-    for fused in (1, 0):
+    for fused in (2, 1, 0):
         ctx.set_option("fused_eig", fused)
         try:
             got = ops.good_features_to_track(img, 2000, 0.01, 4, blockSize=block)
@@ -206,15 +206,16 @@ def test_good_features_fused_kernel_bit_exact(ops, O, params, shape):
     lap_mon, lap_ref, mon, ref = _lap_pair(O, shape[0], shape[1], nodata_wedge=True)
     mask, _ = O.auto_mask(mon, ref)
     ctx = default_context()
-    ctx.set_option("fused_eig", 1)
     try:
-        for mk in (None, mask):
-            got = ops.good_features_to_track(lap_ref, params["maxCorners"], params["q"], params["md"], mask=mk, blockSize=params["bs"])
-            exp = O.good_features(lap_ref, mk, params["maxCorners"], params["q"], params["md"], params["bs"])
-            if exp is None:
-                assert got is None
-            else:
-                np.testing.assert_array_equal(got, exp)
+        for fused in (1, 2):
+            ctx.set_option("fused_eig", fused)
+            for mk in (None, mask):
+                got = ops.good_features_to_track(lap_ref, params["maxCorners"], params["q"], params["md"], mask=mk, blockSize=params["bs"])
+                exp = O.good_features(lap_ref, mk, params["maxCorners"], params["q"], params["md"], params["bs"])
+                if exp is None:
+                    assert got is None
+                else:
+                    np.testing.assert_array_equal(got, exp)
     finally:
         ctx.set_option("fused_eig", 0)
 
