@@ -204,6 +204,14 @@ int km_mi_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype
                     int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,
                     const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out_studholme,
                     double *d_out_nmi);
+/* KariosAPI._filter_by_dn_values (api/core.py:650-737) on resident images: key point i (x = int(x0[i]), y = int(y0[i]))
+ * is dropped (keep[i] = 0) when the reference OR the monitored pixel equals one of `no_values`, or when a pixel equals
+ * its own image's no-data value (nodata_* nullable).  x0 / y0 / no_values / keep are host arrays; a key point outside
+ * the image is an error. */
+int km_dn_keep_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
+                   ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *x0, const float *y0,
+                   int n, const double *no_values, int n_no, const double *nodata_ref,
+                   const double *nodata_mon, uint8_t *keep);
 int km_phase_shift_dev(km_ctx *ctx, const void *d_reference_image,
                        const void *d_moving_image, int dtype, int H, int W,
                        ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);

@@ -861,6 +861,32 @@ int km_phase_shift(km_ctx *c, const void *a, const void *b, int dtype, int H, in
     return kp_phase_shift(c, d_a, d_b, dtype, H, W, W, W, out_rc);
 }
 
+// KariosAPI._filter_by_dn_values (core.py:650-737) on resident images: x0 / y0 / no_values / keep are HOST arrays
+// (n key points, n_no values), the images stay on the device.  keep[i] = 1 keep, 0 drop; a key point outside the image
+// is an error (numpy's fancy indexing would raise or wrap).
+int km_dn_keep_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon, const float *x0,
+                   const float *y0, int n, const double *no_values, int n_no, const double *nodata_ref, const double *nodata_mon, uint8_t *keep)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, d_ref, H, W, sref, "dn_keep")) || (rc = check_image(c, d_mon, H, W, smon, "dn_keep"))) return rc;
+    if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "dn_keep: bad dtype %d", dtype);
+    if (n < 0 || n_no < 0 || (n > 0 && (!x0 || !y0 || !keep)) || (n_no > 0 && !no_values)) return km_fail(c, KM_E_ARG, "dn_keep: bad arrays");
+    if (n == 0) return KM_OK;
+    float *d_xy = (float *)km_ws(c, WS_MISC0, (size_t)n * 2 * sizeof(float));
+    double *d_nv = (double *)km_ws(c, WS_MISC1, (size_t)(n_no > 0 ? n_no : 1) * sizeof(double));
+    uint8_t *d_keep = (uint8_t *)km_ws(c, WS_MISC2, (size_t)n);
+    if (!d_xy || !d_nv || !d_keep) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(d_xy, x0, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    KM_HIP(c, hipMemcpyAsync(d_xy + n, y0, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (n_no > 0) KM_HIP(c, hipMemcpyAsync(d_nv, no_values, (size_t)n_no * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = kf_dn_keep(c, d_ref, d_mon, dtype, H, W, sref, smon, d_xy, d_xy + n, n, d_nv, n_no, nodata_ref, nodata_mon, d_keep))) return rc;
+    KM_HIP(c, hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++)
+        if (keep[i] > 1) return km_fail(c, KM_E_ARG, "dn_keep: key point %d (%g, %g) lies outside the %dx%d image", i, (double)x0[i], (double)y0[i], W, H);
+    return KM_OK;
+}
+
 int km_shift_image_dev(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride, int y_off, int x_off, void *d_out)
 {
     int rc;

@@ -106,3 +106,44 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
+
+// ---- K13: DN-value filter of KariosAPI._filter_by_dn_values (reference karios/api/core.py:650-737): a key point is
+// dropped when the reference OR monitored pixel under it (x = int(x0), y = int(y0), truncation) equals one of the
+// user's `no_values`, or when a pixel equals its own image's no-data value.  One thread per key point; comparisons in
+// fp64 like numpy's (`array == value` with the value promoted).  keep[i] = 2 flags a key point outside the image
+// (numpy would raise IndexError / wrap a negative index: the caller turns it into an error).
+template <typename T>
+__global__ __launch_bounds__(256) void dn_keep_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int H, int W, ptrdiff_t sref,
+                                                      ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0, int n,
+                                                      const double *__restrict__ no_values, int n_no, int has_ref_nd, double ref_nd,
+                                                      int has_mon_nd, double mon_nd, uint8_t *__restrict__ keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)x0[i], y = (int)y0[i];
+    if (x < 0 || x >= W || y < 0 || y >= H) { keep[i] = 2; return; }
+    const double r = (double)ref[(size_t)y * sref + x], m = (double)mon[(size_t)y * smon + x];
+    bool k = true;
+    for (int j = 0; j < n_no; j++) k = k && !(r == no_values[j] || m == no_values[j]);
+    if (has_ref_nd) k = k && !(r == ref_nd);
+    if (has_mon_nd) k = k && !(m == mon_nd);
+    keep[i] = k ? 1 : 0;
+}
+
+int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon, const float *d_x0,
+               const float *d_y0, int n, const double *d_no_values, int n_no, const double *ref_nd, const double *mon_nd, uint8_t *d_keep)
+{
+    if (n <= 0) return KM_OK;
+    const int nb = (n + 255) / 256;
+    const int hr = ref_nd != nullptr, hm = mon_nd != nullptr;
+    const double rv = ref_nd ? *ref_nd : 0.0, mv = mon_nd ? *mon_nd : 0.0;
+    switch (dtype) {
+#define KM_DN_CASE(CODE, T) \
+    case CODE: dn_keep_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_x0, d_y0, n, d_no_values, n_no, hr, rv, hm, mv, d_keep); break;
+        KM_DN_CASE(KM_U8, uint8_t) KM_DN_CASE(KM_U16, uint16_t) KM_DN_CASE(KM_I16, int16_t) KM_DN_CASE(KM_F32, float)
+#undef KM_DN_CASE
+    default: return km_fail(c, KM_E_ARG, "dn filter: bad dtype %d", dtype);
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

@@ -356,3 +356,39 @@ def default_conf(**kw):
              laplacian_invert_polarity=False)
     d.update(kw)
     return SimpleNamespace(**d)
+
+
+def filter_by_dn_values(x0, y0, ref, mon, no_values=None, ref_nd=None, mon_nd=None):
+    """Keep mask of `KariosAPI._filter_by_dn_values` (api/core.py:650-737): pixel under (int(x0), int(y0)) of either image
+    equal to one of `no_values`, or equal to its own image's no-data value -> drop."""
+    x = np.asarray(x0).astype(int)
+    y = np.asarray(y0).astype(int)
+    rv, mv = np.asarray(ref)[y, x], np.asarray(mon)[y, x]
+    keep = np.ones(len(x), bool)
+    for v in no_values or []:
+        keep &= ~((rv == v) | (mv == v))
+    if ref_nd is not None:
+        keep &= ~(rv == ref_nd)
+    if mon_nd is not None:
+        keep &= ~(mv == mon_nd)
+    return keep
+
+
+def handle_klt_results_columns(frame, ref, mon, confidence_threshold=0.4, large_shift_applied=False):
+    """Columns `_handle_klt_results` adds to one tile frame (api/core.py:872-907): dict of numpy arrays in CSV order.
+    `frame`: dict with float32 x0, y0, dx, dy, score."""
+    dx, dy = np.asarray(frame["dx"], np.float32), np.asarray(frame["dy"], np.float32)
+    out = {k: np.asarray(frame[k]) for k in ("x0", "y0", "dx", "dy", "score")}
+    out["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
+    out["angle"] = np.degrees(np.arctan2(dy, dx))
+    if large_shift_applied:
+        return out
+    n = len(dx)
+    keep = np.asarray(frame["score"]) >= confidence_threshold
+    z, st, nmi = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+    if keep.any():
+        sel = [np.asarray(frame[k])[keep] for k in ("x0", "y0", "dx", "dy")]
+        z[keep] = zncc_batch(ref, mon, *sel)
+        st[keep], nmi[keep] = mi_batch(ref, mon, *sel)
+    out["zncc_score"], out["mutual_info_score"], out["mi_score"] = z, st, nmi
+    return out

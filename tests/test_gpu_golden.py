@@ -130,3 +130,55 @@ def test_mutual_info_other_dtypes(ops, dtype):
     est, enmi = O.mi_batch(ref, mon, *kp)
     for got, exp in ((st, est), (nmi, enmi)):
         assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.nanmax(np.abs(got - exp)) <= 1e-9
+
+
+def test_results_step_matches_reference_golden(tmp_path):
+    """SURVEY 8(f)-2 on the device: `karios_amd.results.handle_klt_results` / `filter_by_dn_values` against the vectors the
+    reference's `_handle_klt_results` / `_filter_by_dn_values` produced (CSV structure, column order and dtypes, float32
+    columns bit-exact, scores to 1e-9)."""
+    import io
+    import pandas as pd
+    from karios_amd.resident import ResidentPair
+    from karios_amd.results import filter_by_dn_values, handle_klt_results
+    g = load("results.npz")
+    ref, mon = g["ref"], g["mon"]
+    pair = ResidentPair.upload(mon, ref)
+
+    def frames():
+        return [pd.DataFrame({c: g[f"frame{i}_{c}"] for c in ("x0", "y0", "dx", "dy", "score")}, index=g[f"frame{i}_index"]) for i in range(3)]
+
+    for tag, large in (("scored", False), ("large_shift", True)):
+        csv = tmp_path / f"{tag}.csv"
+        res = handle_klt_results(iter(frames()), csv, pair, 0.4, large_shift_applied=large)
+        names = list(g[f"{tag}_columns"])
+        assert list(res.columns) == names
+        assert np.array_equal(res.index.to_numpy(), g[f"{tag}_index"])
+        for name in names:
+            got, want = res[name].to_numpy(), g[f"{tag}_col_{name}"]
+            if name in ("zncc_score", "mutual_info_score", "mi_score"):
+                assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(want)), name
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True)
+            else:
+                assert got.dtype == want.dtype and np.array_equal(got, want), name
+        want_csv = pd.read_csv(io.BytesIO(g[f"{tag}_csv"].tobytes()), sep=";")
+        got_csv = pd.read_csv(csv, sep=";")
+        assert list(got_csv.columns) == list(want_csv.columns) and len(got_csv) == len(want_csv)
+        text_got, text_want = csv.read_text().splitlines(), g[f"{tag}_csv"].tobytes().decode().splitlines()
+        assert text_got[0] == text_want[0] and len(text_got) == len(text_want)      # header once, one line per key point
+        for a, b in zip(text_got[1:], text_want[1:]):
+            assert a.split(";")[:7] == b.split(";")[:7]                                # float32 columns: identical text
+            assert [v == "" for v in a.split(";")] == [v == "" for v in b.split(";")]  # NaN cells are empty in both
+        pd.testing.assert_frame_equal(got_csv, want_csv, rtol=0, atol=1e-9)
+
+    pts = pd.DataFrame({"x0": g["dn_points_x0"], "y0": g["dn_points_y0"]}, index=g["dn_points_index"])
+    for k in range(int(g["dn_ncases"])):
+        nd = g[f"dn_case{k}_nd"]
+        pair.no_data_ref = None if np.isnan(nd[0]) else float(nd[0])
+        pair.no_data_mon = None if np.isnan(nd[1]) else float(nd[1])
+        got = filter_by_dn_values(pts, pair, list(g[f"dn_case{k}_no_values"]))
+        assert np.array_equal(got.index.to_numpy(), g[f"dn_case{k}_kept_index"]), k
+        assert np.array_equal(got["x0"].to_numpy(), g[f"dn_case{k}_kept_x0"]), k
+    bad = pd.DataFrame({"x0": np.float32([5, 999]), "y0": np.float32([5, 5])})
+    pair.no_data_ref = 0.0
+    with pytest.raises(IndexError):
+        filter_by_dn_values(bad, pair, [1])

@@ -240,3 +240,31 @@ def test_mutual_info_golden(O):
             assert np.array_equal(np.isnan(got), np.isnan(exp))
             assert np.nanmax(np.abs(got - exp)) <= 1e-12
     assert np.nanmin(g["studholme_self"]) == 2.0 and (g["studholme_flat"] == 1.0).any() and (g["nmi_flat"] == 0.0).any()
+
+
+def test_results_step_oracle_matches_reference_golden():
+    """`_handle_klt_results` columns and `_filter_by_dn_values` (api/core.py:650-737, 848-921): the oracle restatement
+    against vectors produced by the reference's own methods (tests/golden/make_golden_results.py)."""
+    from oracle import oracle as O
+    g = load("results.npz")
+    ref, mon = g["ref"], g["mon"]
+    frames = [{c: g[f"frame{i}_{c}"] for c in ("x0", "y0", "dx", "dy", "score")} for i in range(3)]
+    for tag, large in (("scored", False), ("large_shift", True)):
+        cols = [O.handle_klt_results_columns(f, ref, mon, 0.4, large) for f in frames]
+        names = list(g[f"{tag}_columns"])
+        assert names == list(cols[0].keys())
+        for name in names:
+            got = np.concatenate([c[name] for c in cols])
+            want = g[f"{tag}_col_{name}"]
+            if name in ("zncc_score", "mutual_info_score", "mi_score"):
+                assert np.array_equal(np.isnan(got), np.isnan(want)), name
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True)
+            else:
+                assert got.dtype == want.dtype and np.array_equal(got, want), name
+    x0, y0, idx = g["dn_points_x0"], g["dn_points_y0"], g["dn_points_index"]
+    for k in range(int(g["dn_ncases"])):
+        nd = g[f"dn_case{k}_nd"]
+        keep = O.filter_by_dn_values(x0, y0, ref, mon, list(g[f"dn_case{k}_no_values"]), None if np.isnan(nd[0]) else nd[0],
+                                     None if np.isnan(nd[1]) else nd[1])
+        assert np.array_equal(idx[keep], g[f"dn_case{k}_kept_index"]), k
+        assert np.array_equal(x0[keep], g[f"dn_case{k}_kept_x0"]), k
