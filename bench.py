@@ -68,10 +68,42 @@ def cpu_baseline(mon_t, ref_t, size, conf_kw, sample_rows):
         O.zncc_batch(ref, mon, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
         n = len(res["x0"])
     dt = time.perf_counter() - t0
-    return {"value": rows * size / 1e6 / dt, "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": f"top {rows} rows x {size} cols of the same pair, maxCorners {conf.maxCorners} "
-                      f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points",
-            "keypoints_per_s": n / dt}, res
+    out = {"value": rows * size / 1e6 / dt, "unit": "Mpx/s", "cores": cores, "kind": "port",
+           "sample": f"top {rows} rows x {size} cols of the same pair, maxCorners {conf.maxCorners} "
+                     f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points",
+           "keypoints_per_s": n / dt}
+    live = cv2_live(mon, ref, dict(maxCorners=conf.maxCorners), res)
+    if live is not None:
+        out["opencv_live"] = live
+    return out, res
+
+
+def cv2_live(mon, ref, conf_kw, oracle_res):
+    """Only if OpenCV happens to be importable on the box (it is not part of the image): time the reference-equivalent
+    sequence (`_to_uint8` -> cv2.Laplacian -> goodFeaturesToTrack -> 2x calcOpticalFlowPyrLK -> FB test, klt.py:83-172,
+    407-436) on the CPU sample and report how the oracle's key points compare - the true reference arithmetic."""
+    try:
+        import cv2
+    except Exception:
+        return None
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    lap = [cv2.Laplacian(O.to_uint8(x), cv2.CV_8U, ksize=7) for x in (ref, mon)]
+    mask = ((mon != 0) & (ref != 0)).astype(np.uint8)
+    p0 = cv2.goodFeaturesToTrack(lap[0], mask=mask, maxCorners=conf_kw["maxCorners"], qualityLevel=0.1, minDistance=10, blockSize=15)
+    lk = dict(winSize=(25, 25), maxLevel=1, criteria=(cv2.TERM_CRITERIA_EPS | cv2.TERM_CRITERIA_COUNT, 30, 0.03))
+    p1, _, _ = cv2.calcOpticalFlowPyrLK(lap[0], lap[1], p0, None, **lk)
+    p0r, _, _ = cv2.calcOpticalFlowPyrLK(lap[1], lap[0], p1, None, **lk)
+    d = np.abs(p0 - p0r).reshape(-1, 2).max(-1)
+    keep = d < np.float32(0.1)
+    dt = time.perf_counter() - t0
+    out = {"opencv": cv2.__version__, "threads": cv2.getNumThreads(), "seconds": dt, "Mpx_per_s": mon.size / 1e6 / dt, "matched": int(keep.sum())}
+    if oracle_res is not None:
+        mine = set(zip(oracle_res["x0"].astype(int).tolist(), oracle_res["y0"].astype(int).tolist()))
+        theirs = set(map(tuple, p0.reshape(-1, 2)[keep].astype(int).tolist()))
+        out["keypoints_in_common"] = len(mine & theirs)
+        out["oracle_keypoints"] = len(mine)
+    return out
 
 
 def main():
