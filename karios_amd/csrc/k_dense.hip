@@ -1651,20 +1651,17 @@ struct pyr_pair {
     uint8_t *dst[2];
 };
 
-// horizontal [1 4 6 4 1] sums of 4 outputs from 16 source bytes starting at source column 8q-4
+// horizontal [1 4 6 4 1] sums of 4 outputs from 16 source bytes starting at source column 8q-4: output j covers the
+// bytes 2j+2 .. 2j+6 - four of them through one v_dot4_u32_u8 with the coefficients (1,4,6,4), the fifth added on top
 __device__ __forceinline__ void pyr_hsum(const uint32_t (&w)[4], int (&h)[4])
 {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int s = 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const int b = 2 * j + i + 2;   // byte index within the 16 loaded bytes
-            const int coef = i == 0 || i == 4 ? 1 : (i == 2 ? 6 : 4);
-            s += coef * (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
-        }
-        h[j] = s;
-    }
+    const unsigned coef = 0x04060401u;                                   // bytes (1, 4, 6, 4)
+    const uint32_t q0 = __builtin_amdgcn_alignbyte(w[1], w[0], 2);       // bytes 2..5
+    const uint32_t q2 = __builtin_amdgcn_alignbyte(w[2], w[1], 2);       // bytes 6..9
+    h[0] = (int)__builtin_amdgcn_udot4(q0, coef, (w[1] >> 16) & 0xffu, false);    // + byte 6
+    h[1] = (int)__builtin_amdgcn_udot4(w[1], coef, w[2] & 0xffu, false);          // bytes 4..7 + byte 8
+    h[2] = (int)__builtin_amdgcn_udot4(q2, coef, (w[2] >> 16) & 0xffu, false);    // + byte 10
+    h[3] = (int)__builtin_amdgcn_udot4(w[2], coef, w[3] & 0xffu, false);          // bytes 8..11 + byte 12
 }
 
 __global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
