@@ -204,6 +204,20 @@ int km_mi_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype
                     int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,
                     const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out_studholme,
                     double *d_out_nmi);
+/* KLT._match_tile_auto_ksize (klt.py:465-545) on resident data: the nk Laplacians of each image, their
+ * pyramids and the nk corner lists (goodFeaturesToTrack of every reference Laplacian) are built once and stay on the
+ * device; the nk*nk tracker runs (mon kernel outer, ref kernel inner = itertools.product order) reuse them.
+ * out_ratios[im*nk + ir] = inlier ratio len(points)/Ninit of (ksizes[im], ksizes[ir]) (0 where the reference's
+ * klt_tracker returns None); the best pair is the first maximum; out_best = {mon_ksize, ref_ksize} or {-1,-1}.
+ * host_out: frame block of the best pair (layout of km_klt_tile_frame_dev).  prm->ksize_* are ignored, prm->invert_mon
+ * applies (255 - uint8(mon) before the Laplacians, klt.py:419); outlier filtering is not part of this entry point. */
+int km_klt_auto_ksize_frame_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H,
+                                int W, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
+                                const uint8_t *d_mask, ptrdiff_t stride_mask,
+                                const double *nodata_ref, const double *nodata_mon,
+                                const km_klt_params *prm, const int *ksizes, int nk, float x_off,
+                                float y_off, void *host_out, int cap, double *out_ratios,
+                                int *out_best);
 /* KariosAPI._filter_by_dn_values (api/core.py:650-737) on resident images: key point i (x = int(x0[i]), y = int(y0[i]))
  * is dropped (keep[i] = 0) when the reference OR the monitored pixel equals one of `no_values`, or when a pixel equals
  * its own image's no-data value (nodata_* nullable).  x0 / y0 / no_values / keep are host arrays; a key point outside

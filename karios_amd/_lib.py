@@ -80,6 +80,8 @@ SIGNATURES = {
                                         C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _vp, _i]),
     "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_mi_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "km_klt_auto_ksize_frame_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp, _i, C.c_float,
+                                         C.c_float, _vp, _i, _vp, _vp]),
     "km_dn_keep_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _vp, _i, _vp, _i, _pd, _pd, _vp]),
     "km_phase_shift_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
     "km_shift_image_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),

@@ -746,6 +746,163 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     return KM_OK;
 }
 
+// pyramid of one image into caller-provided storage (levels >= 1 packed from `store`); returns the bytes used
+static int build_pyramid_single(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, uint8_t *store, km_pyr *P, size_t *used)
+{
+    P->img[0] = d_img; P->H[0] = H; P->W[0] = W; P->levels = 0;
+    if (max_level > 4) max_level = 4;
+    size_t off = 0;
+    int w = W, h = H;
+    for (int l = 1; l <= max_level; l++) {
+        const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+        if (nw <= win || nh <= win) break;
+        if (store) {
+            int rc = kd_pyrdown_u8(c, P->img[l - 1], h, w, store + off);
+            if (rc) return rc;
+            P->img[l] = store + off;
+        }
+        P->H[l] = nh; P->W[l] = nw; P->levels = l;
+        off += ((size_t)nw * nh + 255) & ~(size_t)255;
+        w = nw; h = nh;
+    }
+    if (used) *used = off;
+    return KM_OK;
+}
+
+// KLT._match_tile_auto_ksize (klt.py:465-545) on resident data: every Laplacian, pyramid and corner list is built ONCE
+// and stays on the device; the nk*nk tracker runs reuse them.  Best pair = highest inlier ratio, first wins ties, in
+// itertools.product order (mon outer, ref inner).
+int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                                const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
+                                const int *ksizes, int nk, float x_off, float y_off, void *host_out, int cap, double *out_ratios, int *out_best)
+{
+    int rc;
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_auto_ksize")) ||
+        (rc = check_image(c, d_mon, H, W, smon, "klt_auto_ksize")))
+        return rc;
+    if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_auto_ksize: bad dtype %d", dtype);
+    if (!ksizes || nk < 1 || nk > 8 || !host_out || !out_ratios || !out_best || cap <= 0) return km_fail(c, KM_E_ARG, "klt_auto_ksize: bad arguments");
+    if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
+    const size_t n = (size_t)H * W, na = (n + 255) & ~(size_t)255;
+    km_scalars *sc = scalars(c);
+    uint8_t *u8_ref = (uint8_t *)km_ws(c, WS_U8_A, n), *u8_mon = (uint8_t *)km_ws(c, WS_U8_B, n);
+    if (!sc || !u8_ref || !u8_mon) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+    // ---- mask (user mask packed to the box, or the automatic one) and uint8 stretch
+    const uint8_t *mask = d_mask;
+    if (!d_mask) {
+        uint8_t *m = (uint8_t *)km_ws(c, WS_MASK, n);
+        if (!m) return KM_E_NOMEM;
+        if ((rc = kd_auto_mask(c, d_mon, d_ref, dtype, H, W, smon, sref, nodata_mon, nodata_ref, m, &sc->valid))) return rc;
+        mask = m;
+    } else {
+        if (smask < W) return km_fail(c, KM_E_ARG, "mask stride %td < width %d", smask, W);
+        if (smask != W) {
+            uint8_t *dense = (uint8_t *)km_ws(c, WS_MASK, n);
+            if (!dense) return KM_E_NOMEM;
+            KM_HIP(c, hipMemcpy2DAsync(dense, (size_t)W, d_mask, (size_t)smask, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, c->stream));
+            mask = dense;
+        }
+        if ((rc = kd_count_nonzero(c, mask, n, &sc->valid))) return rc;
+    }
+    if (dtype != KM_U8) {
+        if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0])) || (rc = kd_minmax(c, d_mon, dtype, H, W, smon, &sc->mm[2]))) return rc;
+    }
+    if ((rc = kd_to_uint8(c, d_ref, dtype, H, W, sref, &sc->mm[0], 0, u8_ref)) || (rc = kd_to_uint8(c, d_mon, dtype, H, W, smon, &sc->mm[2], prm->invert_mon, u8_mon)))
+        return rc;
+    // ---- arena: 2*nk Laplacians, 2*nk pyramids, nk corner lists, nk*nk track pairs, counters
+    km_pyr probe;
+    size_t pyr_bytes = 0;
+    build_pyramid_single(c, u8_ref, H, W, prm->win_size, prm->max_level, nullptr, &probe, &pyr_bytes);
+    const size_t pts = ((size_t)cap * 2 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t total = (size_t)2 * nk * (na + pyr_bytes) + (size_t)nk * pts + (size_t)2 * nk * nk * pts + 4096;
+    uint8_t *arena = (uint8_t *)km_ws(c, WS_AUTO, total);
+    if (!arena) return KM_E_NOMEM;
+    uint8_t *lap_ref = arena, *lap_mon = lap_ref + (size_t)nk * na, *pyr_store = lap_mon + (size_t)nk * na;
+    uint8_t *p0_store = pyr_store + (size_t)2 * nk * pyr_bytes, *trk_store = p0_store + (size_t)nk * pts;
+    int *d_counts = (int *)(trk_store + (size_t)2 * nk * nk * pts);      // [nk] corners per ref kernel, [nk*nk] kept tracks
+    KM_HIP(c, hipMemsetAsync(d_counts, 0, (size_t)(nk + nk * nk) * sizeof(int), c->stream));
+    km_pyr PR[8], PM[8];
+    {
+        km_stage_timer t(c, ST_LAPLACIAN);
+        for (int k = 0; k < nk; k++)
+            if ((rc = kd_laplacian_u8(c, u8_ref, H, W, ksizes[k], lap_ref + (size_t)k * na)) ||
+                (rc = kd_laplacian_u8(c, u8_mon, H, W, ksizes[k], lap_mon + (size_t)k * na)))
+                return rc;
+    }
+    {
+        km_stage_timer t(c, ST_PYRAMID);
+        for (int k = 0; k < nk; k++)
+            if ((rc = build_pyramid_single(c, lap_ref + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k) * pyr_bytes, &PR[k], nullptr)) ||
+                (rc = build_pyramid_single(c, lap_mon + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k + 1) * pyr_bytes, &PM[k], nullptr)))
+                return rc;
+    }
+    // ---- corners of every reference Laplacian (klt.py:494)
+    int n_p0[8];
+    for (int k = 0; k < nk; k++) {
+        float *p0 = (float *)(p0_store + (size_t)k * pts);
+        // gftt_dev starts from a clean scalar block; the min/max and the valid-pixel count gathered above stay
+        KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
+        if ((rc = gftt_dev(c, lap_ref + (size_t)k * na, mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, p0, cap, sc)))
+            return rc;
+        KM_HIP(c, hipMemcpyAsync(&d_counts[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        KM_HIP(c, hipMemcpyAsync(&n_p0[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    // ---- nk*nk tracker runs (mon kernel outer, ref kernel inner), all queued before one synchronisation
+    const int n_lim = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
+    {
+        km_stage_timer t(c, ST_LK);
+        for (int im = 0; im < nk; im++)
+            for (int ir = 0; ir < nk; ir++) {
+                if (n_p0[ir] <= 0) continue;
+                const int combo = im * nk + ir;
+                float *p0 = (float *)(p0_store + (size_t)ir * pts);
+                float *p1 = (float *)(trk_store + (size_t)(2 * combo) * pts), *p0r = (float *)(trk_store + (size_t)(2 * combo + 1) * pts);
+                if ((rc = kl_track(c, PR[ir], PM[im], p0, &d_counts[ir], n_lim, prm->win_size, prm->max_count, prm->epsilon, true, p1, p0r)) ||
+                    (rc = kf_count_kept(c, p0, p0r, &d_counts[ir], n_lim, 0.1f, &d_counts[nk + combo])))
+                    return rc;
+            }
+    }
+    int kept[64];
+    KM_HIP(c, hipMemcpyAsync(kept, d_counts + nk, (size_t)nk * nk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long valid = 0;
+    KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.valid_pixels = (int64_t)valid;
+    double best_ratio = -1.0;
+    int best = -1;
+    for (int im = 0; im < nk; im++)
+        for (int ir = 0; ir < nk; ir++) {
+            const int combo = im * nk + ir;
+            if (n_p0[ir] <= 0) { out_ratios[combo] = 0.0; continue; }          // klt_tracker returned None: score 0, never the best
+            const double ratio = (double)kept[combo] / (double)n_p0[ir];
+            out_ratios[combo] = ratio;
+            if (ratio > best_ratio) { best_ratio = ratio; best = combo; }
+        }
+    const size_t fb = 16 + (size_t)cap * 6 * sizeof(float);
+    char *d_out = (char *)km_ws(c, WS_FRAME, fb);
+    if (!d_out) return KM_E_NOMEM;
+    out_best[0] = out_best[1] = -1;
+    if (best < 0) {
+        memset(host_out, 0, 16);
+        return KM_OK;
+    }
+    const int bm = best / nk, br = best % nk;
+    out_best[0] = ksizes[bm]; out_best[1] = ksizes[br];
+    {
+        km_stage_timer t(c, ST_FRAME);
+        if ((rc = kf_frame(c, (const float *)(p0_store + (size_t)br * pts), (const float *)(trk_store + (size_t)(2 * best) * pts),
+                           (const float *)(trk_store + (size_t)(2 * best + 1) * pts), &d_counts[br], n_lim, cap, 0.1f, x_off, y_off, d_out)))
+            return rc;
+    }
+    KM_HIP(c, hipMemcpyAsync(host_out, d_out, fb, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.n_init = ((const int *)host_out)[1];
+    return KM_OK;
+}
+
 int km_klt_tile_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
                           const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm,
                           float x_off, float y_off, void *host_out, int cap)

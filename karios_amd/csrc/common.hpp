@@ -73,6 +73,7 @@ enum km_slot {
     WS_FFT_B,
     WS_FFT_WORK,
     WS_FRAME,
+    WS_AUTO,        // batched auto-ksize search: all Laplacians, pyramids, tracks
     WS_COUNT
 };
 
@@ -212,6 +213,8 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
 int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality,
                       km_scalars *sc, unsigned long long *d_keys, size_t cap);
 // k_frame.hip: DN-value filter of the key points (core.py:650-737)
+// count of tracks passing the forward-backward test (max |p0 - p0r| < thr) among the first min(*d_n, n_max) points
+int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d_n, int n_max, float back_thr, int *d_count);
 int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon, const float *d_x0,
                const float *d_y0, int n, const double *d_no_values, int n_no, const double *ref_nd, const double *mon_nd, uint8_t *d_keep);
 // k_eigc.hip: fused minimum-eigenvalue + candidate pass, 4 pixels per lane (no eig map)

@@ -147,3 +147,25 @@ int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
+
+// ---- forward-backward inlier count of one tracker run (klt.py:142-144), for the auto-ksize search
+__global__ __launch_bounds__(256) void fb_count_kernel(const float *__restrict__ p0, const float *__restrict__ p0r, const int *__restrict__ d_n,
+                                                       int n_max, float back_thr, int *__restrict__ count)
+{
+    const int n = min(d_n ? *d_n : n_max, n_max);
+    int local = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float d = fmaxf(fabsf(__fsub_rn(p0[2 * i], p0r[2 * i])), fabsf(__fsub_rn(p0[2 * i + 1], p0r[2 * i + 1])));
+        local += d < back_thr ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d_n, int n_max, float back_thr, int *d_count)
+{
+    if (n_max <= 0) return KM_OK;
+    fb_count_kernel<<<32, 256, 0, c->stream>>>(d_p0, d_p0r, d_n, n_max, back_thr, d_count);   // *d_count zeroed by the caller
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

@@ -283,6 +283,16 @@ class KLT:
         """Try the 25 (mon_ksize, ref_ksize) pairs, keep the highest inlier ratio, first wins
         ties (klt.py:465-545).  Returns (best result | None, {pair: ratio}, best pair | None)."""
         combinations = list(itertools.product(LAPLACIAN_AUTO_CANDIDATES, repeat=2))
+        if not getattr(self._conf, "outliers_filtering", False):
+            # batched search on the device (km_klt_auto_ksize_frame_dev): the tile is uploaded once, the 10 Laplacians,
+            # their pyramids and the 5 corner lists are shared by the 25 tracker runs
+            from ..resident import ResidentPair
+            pair = ResidentPair.upload(np.ascontiguousarray(img_box), np.ascontiguousarray(ref_box), mask_box, ctx=self._ctx)
+            frame, scores, best_ksize, ninit = pair.match_tile_auto_ksize(self._conf, candidates=LAPLACIAN_AUTO_CANDIDATES)
+            for (mk, rk) in combinations:
+                logger.info("Auto laplacian: mon_ksize=%s ref_ksize=%s inlier ratio=%.3f", mk, rk, scores[(mk, rk)])
+            logger.info("Auto laplacian selected: mon_ksize=%s ref_ksize=%s", *(best_ksize if best_ksize else (None, None)))
+            return (None if frame is None else (frame, ninit)), scores, best_ksize
         img_uint8 = _to_uint8(img_box)
         ref_uint8 = _to_uint8(ref_box)
         mon_laplacians = {k: ops.laplacian_u8(img_uint8, k, ctx=self._ctx) for k in LAPLACIAN_AUTO_CANDIDATES}

@@ -210,6 +210,44 @@ class ResidentPair:
                                                      buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
         return self._frame_from_block(buf, cap, zncc_threshold is not None) if build_frame else None
 
+    def match_tile_auto_ksize(self, conf, box=None, invert_mon: bool = False, candidates=(3, 5, 7, 9, 11)):
+        """`KLT._match_tile_auto_ksize` (klt.py:465-545) for one tile of the resident pair in ONE device call: all
+        Laplacians, pyramids and corner lists are built once on the device and shared by the 25 tracker runs.
+        -> (frame | None, {(mon_k, ref_k): inlier ratio}, (mon_k, ref_k) | None, Ninit).  No outlier filtering."""
+        if getattr(conf, "outliers_filtering", False):
+            raise KariosHipError("match_tile_auto_ksize: outlier filtering runs through karios_amd.matcher.KLT")
+        c = self.ctx
+        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
+        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
+            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        prm = make_params(conf, 1, 1, bool(invert_mon))
+        cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
+        buf = np.empty(4 + 6 * cap, np.float32)
+        ks = np.ascontiguousarray(candidates, np.int32)
+        nk = len(ks)
+        ratios = np.zeros(nk * nk, np.float64)
+        best = np.zeros(2, np.int32)
+        es = self.dtype.itemsize
+        off = by_off * self.x_size + bx_off
+        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
+        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
+        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
+        c.check(c.lib.km_klt_auto_ksize_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
+                                                  by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm),
+                                                  ks.ctypes.data_as(C.c_void_p), nk, float(x_off), float(y_off),
+                                                  buf.ctypes.data_as(C.c_void_p), cap, ratios.ctypes.data_as(C.c_void_p),
+                                                  best.ctypes.data_as(C.c_void_p)), "km_klt_auto_ksize_frame_dev")
+        scores = {(int(ks[i]), int(ks[j])): float(ratios[i * nk + j]) for i in range(nk) for j in range(nk)}
+        if best[0] < 0:
+            return None, scores, None, 0
+        hdr = buf[:4].view(np.int32)
+        n, n_init = int(hdr[0]), int(hdr[1])
+        body = buf[4:]
+        cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
+        index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
+        return DataFrame(cols, index=index, copy=False), scores, (int(best[0]), int(best[1])), n_init
+
     def match_tile_raw(self, conf, box=None, zncc_threshold=None) -> "RawFrame":
         """GPU half of `match_tile`: runs the device pipeline and returns the raw frame block (a private copy), leaving
         the pandas half to `RawFrame.to_frame()` - which may run in another thread while this thread already drives the

@@ -388,6 +388,39 @@ def test_resident_pair_pipelined_match_equals_tile_by_tile(ops, O):
         pd.testing.assert_frame_equal(ref_frame[sorted(ref_frame.columns)], b[sorted(b.columns)])
 
 
+def test_auto_ksize_batched_search_matches_oracle_loop(ops, O):
+    """km_klt_auto_ksize_frame_dev == the reference's 5x5 loop (klt.py:465-545) done with the oracle:
+    every inlier ratio, the winning pair (first maximum in itertools.product order) and the winner's frame."""
+    import itertools
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_cross_sensor_pair(236, 300, seed=9)[:2]
+    mask = np.ones(ref.shape, np.uint8)
+    mask[:40, :50] = 0
+    conf = KLTConfiguration(maxCorners=500, minDistance=6, blocksize=7, laplacian_kernel_size="auto")
+    cands = [3, 5, 7, 9, 11]
+    laps_m = {k: O.laplacian_u8(O.to_uint8(mon), k) for k in cands}
+    laps_r = {k: O.laplacian_u8(O.to_uint8(ref), k) for k in cands}
+    p0s = {k: O.good_features(laps_r[k], mask, conf.maxCorners, conf.qualityLevel, conf.minDistance, conf.blocksize) for k in cands}
+    want, best, best_ratio, best_res = {}, None, -1.0, None
+    for mk, rk in itertools.product(cands, repeat=2):
+        res = None if p0s[rk] is None else O.klt_tracker(laps_r[rk], laps_m[mk], mask, conf, p0=p0s[rk])
+        if res is None:
+            want[(mk, rk)] = 0.0
+            continue
+        pts, ninit = res
+        want[(mk, rk)] = len(pts["x0"]) / ninit if ninit else 0.0
+        if want[(mk, rk)] > best_ratio:
+            best_ratio, best, best_res = want[(mk, rk)], (mk, rk), res
+    pair = ResidentPair.upload(mon, ref, mask)
+    frame, scores, got_best, ninit = pair.match_tile_auto_ksize(conf, candidates=cands)
+    assert scores == pytest.approx(want, abs=0) and got_best == best and ninit == best_res[1]
+    pts = best_res[0]
+    order = np.lexsort((pts["y0"], pts["x0"]))
+    for col in ("x0", "y0", "dx", "dy", "score"):
+        assert np.array_equal(frame[col].to_numpy(), np.asarray(pts[col], np.float32)[order]), col
+
+
 def test_error_contract_like_cv2(ops):
     """Malformed inputs raise (the reference gets cv2.error / ValueError), they never return garbage."""
     img = rand_u8((40, 40))
