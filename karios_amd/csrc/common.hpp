@@ -217,6 +217,8 @@ int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, in
 int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d_n, int n_max, float back_thr, int *d_count);
 int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon, const float *d_x0,
                const float *d_y0, int n, const double *d_no_values, int n_no, const double *ref_nd, const double *mon_nd, uint8_t *d_keep);
+// k_eig2.hip: minimum-eigenvalue map + masked maximum, 2 pixels per lane (KM_E_UNSUPPORTED when the case is not covered)
+int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig, unsigned *d_max_key);
 // k_eigc.hip: fused minimum-eigenvalue + candidate pass, 4 pixels per lane (no eig map)
 int ke_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
                       unsigned long long *d_keys, size_t cap, bool rezero);

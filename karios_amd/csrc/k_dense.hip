@@ -1463,6 +1463,11 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
                  unsigned int *d_max_key)
 {
     if (block < 1 || block > 31) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d (supported 1..31)", block);
+    static const int eig_mode = getenv("KARIOS_HIP_EIG_KERNEL") ? atoi(getenv("KARIOS_HIP_EIG_KERNEL")) : 2;   // 2: two pixels per lane, 1: one
+    if (eig_mode == 2) {
+        const int rc2 = k2_min_eigen(c, d_src, d_mask, H, W, block, d_eig, d_max_key);
+        if (rc2 != KM_E_UNSUPPORTED) return rc2;
+    }
     const double scale = 1.0 / (4.0 * (double)block * 255.0);
     if (W >= 2 * block + 4 && H >= 2 * block + 4) {   // mirror columns / rows stay inside one strip
         switch (block) {

@@ -1,0 +1,341 @@
+// K3, two pixels per lane: minimum-eigenvalue map of cv2.goodFeaturesToTrack (reference call site
+// karios/matcher/klt.py:120, 494; algorithm SURVEY.md App. A.2: Sobel 3x3 REFLECT_101 -> products -> box filter
+// blockSize x blockSize with its own REFLECT_101 border on the product images -> lambda_min) + its maximum over the mask.
+//
+// Same arithmetic as eig_march_kernel (k_dense.hip) - exact integer sums, fp64 scaling, individually rounded float32
+// operations, correctly rounded sqrt - in the register-light formulation found with the fused experiment (k_eigc.hip):
+//   * one wavefront owns 128 columns (2 per lane, one 16-bit load per row) and marches down its rows;
+//   * vertical box sum  V += P(row entering) - P(row leaving): the products of BOTH rows are recomputed from the source
+//     (two 3-row windows in registers; the trailing rows come from L2), so there is no blockSize-deep ring - six
+//     accumulators per lane whatever the block size, ~60 VGPRs, 8 waves per SIMD;
+//   * derivatives in packed 16-bit arithmetic on the pixel pair, products accumulated with v_mad_i32_i24;
+//   * horizontal box sum = difference of two pixel-prefix sums: one DPP wave scan per product + 4 ds_bpermute;
+//   * the source / mask rows travel through register FIFOs with static slots (unrolled by the FIFO depth).
+// Image borders: lanes (partly) outside load their nearest in-image pixels and a byte permute supplies the Sobel's
+// REFLECT_101 values; the products of outside columns are zeroed and the box filter's own REFLECT_101 terms are added from
+// the pixel-prefix sums through an LDS scratch (border strips only); mirrored rows are handled by the window stepping.
+#include <cstring>
+#include <string.h>
+
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace {
+
+typedef short e2_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ e2_s2 e2s(uint32_t v) { return __builtin_bit_cast(e2_s2, v); }
+__device__ __forceinline__ uint32_t e2u(e2_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ unsigned e2_key(float f)
+{
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int e2_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int e2_lane_m1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane-1, 0 at lane 0
+__device__ __forceinline__ int e2_lane_p1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }   // lane+1, 0 at lane 63
+__device__ __forceinline__ int e2_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += e2_dpp<0x142, 0xa>(v);                                       // row_bcast:15 -> rows 1,3
+    v += e2_dpp<0x143, 0xc>(v);                                       // row_bcast:31 -> rows 2,3
+    return v;
+}
+// correctly rounded float32 square root for x == 0 or x >= 2^-96 (see sqrt_rn_normal in k_dense.hip)
+__device__ __forceinline__ float e2_sqrt(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float r_dn = __int_as_float(__float_as_int(r) - 1), r_up = __int_as_float(__float_as_int(r) + 1);
+    const float e_dn = __builtin_fmaf(-r_dn, r, x), e_up = __builtin_fmaf(-r_up, r, x);
+    float res = e_dn <= 0.f ? r_dn : r;
+    res = e_up > 0.f ? r_up : res;
+    return res;
+}
+
+#define EIG2_PF 3   // rows in flight per stream
+
+template <int BLOCK>
+__global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, double scale2,
+                                                   float *__restrict__ eig, unsigned *__restrict__ max_partial, int nstrips, int rows_per_item,
+                                                   int nitems)
+{
+    constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L;
+    constexpr int ML = (L + 1 + 1) & ~1, STRIDE = (128 - ML - (Rr + 1)) & ~1;   // even margins / stride: 2-byte aligned loads when W is even
+    constexpr int PF = EIG2_PF;
+    __shared__ int xs_scratch[4][3][128];            // border strips only: pixel-prefix sums of the three products
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(nitems + 3) / 4u, tile)) return;
+    const int wave_id = (int)tile * 4 + wv;
+    if (wave_id >= nitems) { if (lane == 0) max_partial[wave_id] = 0u; return; }
+    const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
+    const int xs = strip * STRIDE - ML;              // image column of strip pixel 0
+    const int c0 = xs + 2 * lane;                    // image column of this lane's pixel 0
+    const bool border = xs < 0 || xs + 127 > W - 1;  // wave-uniform: some strip pixel lies outside the image
+    const int ye0 = rowblock * rows_per_item, ye1 = min(H, ye0 + rows_per_item) - 1;   // lambda rows of this item
+    const int m_first = ye0 - L, m_last = ye1 + Rr;  // product rows marched (may lie outside: mirrored)
+
+    uint32_t inimg_pair = 0;                         // 0xffff per pixel whose column lies inside the image
+    bool out_px[2];                                  // pixel is an output of this strip and inside the image
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int i = 2 * lane + p, c = c0 + p;
+        const bool in = c >= 0 && c <= W - 1;
+        inimg_pair |= in ? (p ? 0xffff0000u : 0x0000ffffu) : 0u;
+        out_px[p] = in && i >= ML && i < ML + STRIDE;
+    }
+    // lanes (partly) outside the image load the nearest two in-image columns; a byte permute puts REFLECT_101 values where
+    // the Sobel needs them (columns -1 and W; other outside columns never matter)
+    const int c_load = min(max(c0, 0), W - 2);
+    uint32_t load_sel = 0x0c0c0000u;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int idx = km_reflect101(c0 + p, W) - c_load;
+        load_sel |= (uint32_t)((idx >= 0 && idx <= 1) ? idx : 0) << (8 * p);
+    }
+    const uint8_t *mptr = mask ? mask : src;         // no mask: the loads still happen (fixed set of memory operations per row)
+    const uint32_t mask_or = mask ? 0u : 0x0101u;
+    const bool w_even = (W & 1) == 0 && ((uintptr_t)eig % 8 == 0);   // 8-byte aligned float2 stores
+    auto clamp_row = [&](int r) { return min(max(r, 0), H - 1); };
+
+    auto run = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;   // interior strip: no column border handling at all
+    auto load_raw = [&](const uint8_t *base, int r) -> uint32_t {   // two bytes of row r (inside the image)
+        const uint8_t *rowp = base + (size_t)r * W;
+        unsigned short v;
+        __builtin_memcpy(&v, rowp + (unsigned)(FAST ? c0 : c_load), 2);
+        return (uint32_t)v;
+    };
+    auto unpack_src = [&](uint32_t w) -> uint32_t {      // bytes (b0, b1) -> 16-bit pair
+        if (!FAST) w = __builtin_amdgcn_perm(w, w, load_sel) & 0xffffu;
+        return __builtin_amdgcn_perm(0u, w, 0x0c010c00u);
+    };
+    struct win3 { uint32_t a0, a1, a2; };
+    auto window_reload = [&](int m, win3 &w) {
+        const int r = km_reflect101(m, H);
+        w.a0 = unpack_src(load_raw(src, km_reflect101(r - 1, H)));
+        w.a1 = unpack_src(load_raw(src, r));
+        w.a2 = unpack_src(load_raw(src, km_reflect101(r + 1, H)));
+    };
+    // marching from product row m - 1 to m changes the window by at most one source row (see k_eigc.hip)
+    auto entering_row = [&](int m) -> int {
+        if (m >= 1 && m <= H - 2) return m + 1;
+        if (m < 0) return -m - 1;
+        if (m >= H) return 2 * (H - 1) - m - 1;
+        return -1;
+    };
+    auto window_step = [&](int m, win3 &w, uint32_t entering) {
+        const uint32_t e = unpack_src(entering);
+        if (m >= 1 && m <= H - 2) { w.a0 = w.a1; w.a1 = w.a2; w.a2 = e; }
+        else if (m == 0) { const uint32_t t = w.a0; w.a0 = w.a1; w.a2 = w.a1; w.a1 = t; }
+        else if (m == H - 1) { w.a0 = w.a1; w.a1 = w.a2; w.a2 = w.a0; }
+        else { w.a2 = w.a1; w.a1 = w.a0; w.a0 = e; }
+    };
+    auto derivs = [&](const win3 &w, uint32_t &dx, uint32_t &dy) {
+        const e2_s2 t0 = e2s(w.a0) + e2s(w.a2) + e2s(w.a1) + e2s(w.a1);      // column sums (for dx)
+        const e2_s2 t1 = e2s(w.a2) - e2s(w.a0);                              // column differences (for dy)
+        const uint32_t t0u = e2u(t0), t1u = e2u(t1);
+        const uint32_t l0 = (uint32_t)e2_lane_m1((int)t0u), r0 = (uint32_t)e2_lane_p1((int)t0u);
+        const uint32_t l1 = (uint32_t)e2_lane_m1((int)t1u), r1 = (uint32_t)e2_lane_p1((int)t1u);
+        const uint32_t t0_m = __builtin_amdgcn_alignbyte(t0u, l0, 2), t0_p = __builtin_amdgcn_alignbyte(r0, t0u, 2);   // (x-1, x), (x+1, x+2)
+        const uint32_t t1_m = __builtin_amdgcn_alignbyte(t1u, l1, 2), t1_p = __builtin_amdgcn_alignbyte(r1, t1u, 2);
+        dx = e2u(e2s(t0_p) - e2s(t0_m));
+        dy = e2u(e2s(t1_m) + t1 + t1 + e2s(t1_p));
+        if (!FAST) { dx &= inimg_pair; dy &= inimg_pair; }   // products of outside columns are 0
+    };
+    int V[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    auto accumulate = [&](uint32_t dx, uint32_t dy, bool subtract) {
+        const e2_s2 x = e2s(dx), y = e2s(dy);
+        const e2_s2 sx = subtract ? -x : x, sy = subtract ? -y : y;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            V[0][k] += (int)x[k] * (int)sx[k];
+            V[1][k] += (int)x[k] * (int)sy[k];
+            V[2][k] += (int)y[k] * (int)sy[k];
+        }
+    };
+    // horizontal window W(i) = S(i + Rr) - S(i - L - 1), S = inclusive pixel prefix over the strip (i = 2*lane + p)
+    constexpr int UO[2] = {(0 + Rr) / 2, (1 + Rr) / 2}, UJ[2] = {(0 + Rr) % 2, (1 + Rr) % 2};
+    constexpr int LO[2] = {-((L + 1 - 0 + 1) / 2), -((L + 1 - 1 + 1) / 2)};
+    constexpr int LJ[2] = {((0 - L - 1) % 2 + 2) % 2, ((1 - L - 1) % 2 + 2) % 2};
+    auto bperm_from = [&](int lane_off, int v) { return __builtin_amdgcn_ds_bpermute(((lane + lane_off) & 63) * 4, v); };
+    int *xsw = &xs_scratch[wv][0][0];
+    auto windows = [&](int (&Wd)[3][2]) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int A = e2_scan(V[q][0] + V[q][1]), Ap = e2_lane_m1(A);
+            const int X[2] = {Ap + V[q][0], A};
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int up = UO[p] == 0 ? X[UJ[p]] : bperm_from(UO[p], X[UJ[p]]);
+                const int lw = LO[p] == 0 ? X[LJ[p]] : bperm_from(LO[p], X[LJ[p]]);
+                Wd[q][p] = up - lw;
+            }
+            if (!FAST) {
+                // box filter's REFLECT_101 on the product images: add the products mirrored in from outside
+                *(int2 *)(xsw + q * 128 + 2 * lane) = make_int2(X[0], X[1]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int c = c0 + p;
+                    int ia = -1, ib = -1;
+                    if (c >= 0 && c < L) { ia = (L - c) - xs; ib = 0 - xs; }                                  // S'(L - c) - S'(0)
+                    else if (c <= W - 1 && c + Rr > W - 1) { ia = (W - 2) - xs; ib = (2 * W - 3 - c - Rr) - xs; }  // S'(W-2) - S'(2(W-1) - c - Rr - 1)
+                    if (ia >= 0) Wd[q][p] += xsw[q * 128 + ia] - xsw[q * 128 + ib];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    auto lambda_min = [&](int sxx, int sxy, int syy) {
+        const float cxx = (float)__dmul_rn((double)sxx, scale2);
+        const float cxy = (float)__dmul_rn((double)sxy, scale2);
+        const float cyy = (float)__dmul_rn((double)syy, scale2);
+        const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
+        const float t = __fsub_rn(a, cc);
+        const float sq = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
+        return __fsub_rn(__fadd_rn(a, cc), e2_sqrt(sq));
+    };
+
+    float best = -INFINITY;
+    win3 lead, trail;
+    // one marching step = product row m; nl / nt = source rows entering the lead / trail windows, mkraw = mask bytes of row m - Rr
+    auto row_step = [&](int m, uint32_t nl, uint32_t nt, uint32_t mkraw, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        const int step = m - m_first;
+        uint32_t dx, dy;
+        if (INTERIOR) {
+            lead.a0 = lead.a1; lead.a1 = lead.a2; lead.a2 = unpack_src(nl);
+            trail.a0 = trail.a1; trail.a1 = trail.a2; trail.a2 = unpack_src(nt);
+        } else if (step > 0) {
+            window_step(m, lead, nl);
+            window_step(m - BLOCK, trail, nt);
+        }
+        derivs(lead, dx, dy);
+        accumulate(dx, dy, false);
+        if (INTERIOR || step >= BLOCK) {
+            derivs(trail, dx, dy);
+            accumulate(dx, dy, true);
+        }
+        if (!INTERIOR && step < BLOCK - 1) return;
+        const int y = m - Rr;                            // lambda row completed by this step (ye0 <= y <= ye1)
+        const uint32_t mk = (FAST ? mkraw : (__builtin_amdgcn_perm(mkraw, mkraw, load_sel) & 0xffffu)) | mask_or;
+        int Wd[3][2];
+        windows(Wd);
+        float e[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            e[p] = lambda_min(Wd[0][p], Wd[1][p], Wd[2][p]);
+            const bool counts = out_px[p] && ((mk >> (8 * p)) & 0xffu) != 0u;
+            best = fmaxf(best, counts ? e[p] : -INFINITY);
+        }
+        float *orow = eig + (size_t)y * W;
+        if (out_px[0] || out_px[1]) {                  // margins and stride are even: the two pixels of a FAST lane go together
+            if (FAST && w_even) {
+                *(float2 *)(orow + (unsigned)c0) = make_float2(e[0], e[1]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; p++) if (out_px[p]) orow[c0 + p] = e[p];
+            }
+        }
+    };
+
+    window_reload(m_first, lead);
+    window_reload(m_first - BLOCK, trail);
+    const int mi_lo = max(m_first + BLOCK, BLOCK + 1), mi_hi = min(m_last, H - 2 - PF);
+    int m = m_first;
+    auto general_until = [&](int m_end) {
+        for (; m <= m_end; m++) {
+            const uint32_t nl = load_raw(src, max(entering_row(m), 0)), nt = load_raw(src, max(entering_row(m - BLOCK), 0));
+            const uint32_t mkraw = load_raw(mptr, clamp_row(m - Rr));
+            row_step(m, nl, nt, mkraw, std::false_type{});
+        }
+    };
+    general_until(min(mi_lo - 1, m_last));
+    if (m <= mi_hi) {
+        uint32_t ql[PF], qt[PF], qm[PF];             // static FIFO slots: slot k serves step m + k, refilled for m + k + PF
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            ql[k] = load_raw(src, m + k + 1);
+            qt[k] = load_raw(src, m + k - BLOCK + 1);
+            qm[k] = load_raw(mptr, m + k - Rr);
+        }
+        for (; m + PF - 1 <= mi_hi; m += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                row_step(m + k, ql[k], qt[k], qm[k], std::true_type{});
+                ql[k] = load_raw(src, m + k + PF + 1);
+                qt[k] = load_raw(src, m + k + PF - BLOCK + 1);
+                qm[k] = load_raw(mptr, m + k + PF - Rr);
+            }
+        }
+    }
+    general_until(m_last);
+    unsigned key = best > -INFINITY ? e2_key(best) : 0u;
+    for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
+    if (lane == 0) max_partial[wave_id] = key;
+    };  // run
+    if (!border) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+__global__ __launch_bounds__(1024) void eig2_max_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned *out)
+{
+    unsigned m = 0;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) m = max(m, partial[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int i = 0; i < 16; i++) t = max(t, sh[i]);
+        *out = t;
+    }
+}
+
+template <int BLOCK>
+int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, double scale2, float *d_eig, unsigned *d_max_key)
+{
+    constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, ML = (L + 1 + 1) & ~1, STRIDE = (128 - ML - (Rr + 1)) & ~1;
+    const int nstrips = (W + STRIDE - 1) / STRIDE;
+    int wg_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void *)eig2_kernel<BLOCK>, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 6;
+    int rows = km_pick_rows(H, nstrips, BLOCK, (long)c->n_cu * 4 * wg_per_cu, 64, 384);
+    if (const char *e = getenv("KARIOS_HIP_EIG2_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows = v; }   // tuning override
+    const int nitems = nstrips * ((H + rows - 1) / rows);
+    const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
+    unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)ntiles * 4 * sizeof(unsigned));
+    if (!partial) return KM_E_NOMEM;
+    eig2_kernel<BLOCK><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, rows, nitems);
+    KM_LAUNCH_CHECK(c);
+    eig2_max_kernel<<<1, 1024, 0, c->stream>>>(partial, ntiles * 4, d_max_key);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+}  // namespace
+
+// Minimum-eigenvalue map + masked maximum, 2 pixels per lane.  KM_E_UNSUPPORTED (no message) when the case is not covered.
+int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig, unsigned *d_max_key)
+{
+    if (block < 1 || block > 15) return KM_E_UNSUPPORTED;
+    if (!(W >= 2 * block + 8 && H >= 2 * block + 8)) return KM_E_UNSUPPORTED;   // mirrored columns / rows stay near their border
+    const double scale = 1.0 / (4.0 * (double)block * 255.0), s2 = scale * scale;
+    switch (block) {
+#define KM_EIG2_CASE(B) case B: return launch_eig2<B>(c, d_src, d_mask, H, W, s2, d_eig, d_max_key);
+        KM_EIG2_CASE(1) KM_EIG2_CASE(2) KM_EIG2_CASE(3) KM_EIG2_CASE(4) KM_EIG2_CASE(5) KM_EIG2_CASE(7) KM_EIG2_CASE(9) KM_EIG2_CASE(11)
+        KM_EIG2_CASE(13) KM_EIG2_CASE(15)
+#undef KM_EIG2_CASE
+    default: return KM_E_UNSUPPORTED;
+    }
+}
