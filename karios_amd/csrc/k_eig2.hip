@@ -308,9 +308,7 @@ int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, ML = (L + 1 + 1) & ~1, STRIDE = (128 - ML - (Rr + 1)) & ~1;
     const int nstrips = (W + STRIDE - 1) / STRIDE;
-    int wg_per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void *)eig2_kernel<BLOCK>, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 6;
-    int rows = km_pick_rows(H, nstrips, BLOCK, (long)c->n_cu * 4 * wg_per_cu, 64, 384);
+    int rows = 48;   // short items (several rounds of resident waves) balance best: 0.352 ms at 48 rows, 0.38 at 128, 0.49 at 384 (10980^2)
     if (const char *e = getenv("KARIOS_HIP_EIG2_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
     const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
