@@ -83,8 +83,9 @@ int km_ctx_sync(km_ctx *ctx);
 /* enable (1) / disable (0) hipEvent stage timing; read back after a call */
 int km_set_profiling(km_ctx *ctx, int enable);
 /* Tuning knobs (no counterpart in the reference; results never depend on them):
- *   "fused_eig" 0|1  GFTT: experimental single-pass minimum-eigenvalue + candidate kernel instead of eig map + candidate
- *                    scan (default 0; initial value from the environment variable KARIOS_HIP_FUSED_EIG).
+ *   "fused_eig" 0..3  GFTT: 3 (default) = minimum-eigenvalue + candidate detection fused in one pass, 2 pixels per lane
+ *                     (no eig map); 0 = eig map + candidate scan; 1, 2 = earlier fused kernels kept for comparison.
+ *                     Initial value from the environment variable KARIOS_HIP_FUSED_EIG.
  * Returns KM_E_ARG for an unknown name. */
 int km_set_option(km_ctx *ctx, const char *name, int value);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */

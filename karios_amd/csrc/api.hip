@@ -71,7 +71,7 @@ int km_ctx_create(int device, km_ctx **out)
         delete c;
         return rc;
     }
-    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) < 0 ? 0 : atoi(e) > 2 ? 2 : atoi(e);
+    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) < 0 ? 0 : atoi(e) > 3 ? 3 : atoi(e);
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -103,7 +103,7 @@ int km_ctx_sync(km_ctx *c)
 int km_set_option(km_ctx *c, const char *name, int value)
 {
     if (!c || !name) return km_fail(c, KM_E_ARG, "km_set_option: null argument");
-    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value < 0 ? 0 : value > 2 ? 2 : value; return KM_OK; }
+    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value < 0 ? 0 : value > 3 ? 3 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
@@ -260,13 +260,14 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
     for (int attempt = 0; attempt < 4; attempt++) {
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
         if (!keys) return KM_E_NOMEM;
-        // K3 + K4: eig map + candidate kernel; the fused 4-pixel-per-lane kernel (no eig map, k_eigc.hip) is exact but at
-        // 120+ VGPRs it runs 4 waves per SIMD and is latency-bound (1.1 ms against 0.52 + 0.26 ms at 10980^2): opt-in
+        // K3 + K4 fused (2 pixels per lane, no eig map: k_eig2.hip) when it covers the case, else eig map + candidate kernel.
+        // km_set_option("fused_eig") selects 0 = two kernels, 1 / 2 = the earlier fused experiments, 3 = default.
         bool fused = false;
         if (c->fused_eig && !fused_overflow) {
             km_stage_timer t(c, ST_EIGEN);
-            rc = c->fused_eig == 2 ? ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
-                                   : kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
+            rc = c->fused_eig == 3   ? k2_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
+                 : c->fused_eig == 2 ? ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
+                                     : kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
             if (rc == KM_OK) fused = true;
             else if (rc != KM_E_UNSUPPORTED) return rc;
         }

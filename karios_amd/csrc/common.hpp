@@ -94,6 +94,7 @@ struct km_scalars {
     unsigned int cut[4];           // top-K pre-filter: D, kept, compaction cursor, exact candidate count
     unsigned int und[8];           // undecided counters of the selection sweeps (one per launch slot)
     unsigned int hist[KM_TK_NB];   // top-K pre-filter histogram (zeroed with the block at the start of a call)
+    unsigned int run_max_shard[64]; // sharded running max-eig keys of the 2-px fused kernel (same-address device-scope traffic serialises)
 };
 
 struct km_ctx {
@@ -103,7 +104,7 @@ struct km_ctx {
     km_buf ws[WS_COUNT];
     std::string err;
     bool profiling = false;
-    int fused_eig = 0;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip)
+    int fused_eig = 3;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip), 3 fused 2-px/lane kernel (k_eig2.hip)
     hipEvent_t ev[ST_COUNT][2];
     bool ev_used[ST_COUNT];
     bool ev_ready = false;
@@ -219,6 +220,8 @@ int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H
                const float *d_y0, int n, const double *d_no_values, int n_no, const double *ref_nd, const double *mon_nd, uint8_t *d_keep);
 // k_eig2.hip: minimum-eigenvalue map + masked maximum, 2 pixels per lane (KM_E_UNSUPPORTED when the case is not covered)
 int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig, unsigned *d_max_key);
+int k2_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
+                      unsigned long long *d_keys, size_t cap, bool rezero);
 // k_eigc.hip: fused minimum-eigenvalue + candidate pass, 4 pixels per lane (no eig map)
 int ke_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
                       unsigned long long *d_keys, size_t cap, bool rezero);

@@ -31,6 +31,7 @@ __device__ __forceinline__ unsigned e2_key(float f)
     unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+__device__ __forceinline__ float e2_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ int e2_dpp(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
@@ -60,15 +61,26 @@ __device__ __forceinline__ float e2_sqrt(float x)
 
 #define EIG2_PF 3   // rows in flight per stream
 
-template <int BLOCK>
+#define EIG2_STAGE 512     // EMIT: candidate keys per wave in LDS (+ one dummy slot per lane behind them)
+#define EIG2_FLUSH_AT 128  // EMIT: flush between row segments once this many keys are staged
+#define EIG2_SEG 3         // EMIT: row groups (of EIG2_PF rows) between two looks at the stage / the running threshold
+
+// EMIT = false: writes the eig map.  EMIT = true: K3 + K4 fused - the map is never written; three lambda rows stay in
+// registers and every pixel that is a 3x3 local maximum, lies off the image border, passes the mask and exceeds a RUNNING
+// lower bound of the final threshold is appended to a per-wave LDS stage (flushed between row segments to the sharded key
+// buffer; a segment that would overflow the stage raises sc->pad0 and the caller falls back to map + candidate kernel).
+// The exact threshold is applied afterwards by the top-K pre-filter (k_select.hip tk_*).
+template <int BLOCK, bool EMIT>
 __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, double scale2,
                                                    float *__restrict__ eig, unsigned *__restrict__ max_partial, int nstrips, int rows_per_item,
-                                                   int nitems)
+                                                   int nitems, double quality, km_scalars *sc, unsigned long long *__restrict__ keys, size_t cap)
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L;
-    constexpr int ML = (L + 1 + 1) & ~1, STRIDE = (128 - ML - (Rr + 1)) & ~1;   // even margins / stride: 2-byte aligned loads when W is even
+    constexpr int XM = EMIT ? 1 : 0;                 // EMIT: one more margin pixel per side (the candidates' neighbours)
+    constexpr int ML = (L + 1 + XM + 1) & ~1, STRIDE = (128 - ML - (Rr + 1 + XM)) & ~1;   // even margins / stride: 2-byte aligned loads when W is even
     constexpr int PF = EIG2_PF;
     __shared__ int xs_scratch[4][3][128];            // border strips only: pixel-prefix sums of the three products
+    __shared__ unsigned long long stage[EMIT ? 4 : 1][EMIT ? EIG2_STAGE + 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned tile;
@@ -79,17 +91,19 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     const int xs = strip * STRIDE - ML;              // image column of strip pixel 0
     const int c0 = xs + 2 * lane;                    // image column of this lane's pixel 0
     const bool border = xs < 0 || xs + 127 > W - 1;  // wave-uniform: some strip pixel lies outside the image
-    const int ye0 = rowblock * rows_per_item, ye1 = min(H, ye0 + rows_per_item) - 1;   // lambda rows of this item
+    // map: lambda rows [ye0, ye1] = the item's rows; EMIT: candidate rows [ye0 + 1, ye1 - 1] inside 1 .. H-2
+    const int ye0 = rowblock * rows_per_item, ye1 = EMIT ? min(H - 1, ye0 + rows_per_item + 1) : min(H, ye0 + rows_per_item) - 1;
     const int m_first = ye0 - L, m_last = ye1 + Rr;  // product rows marched (may lie outside: mirrored)
 
     uint32_t inimg_pair = 0;                         // 0xffff per pixel whose column lies inside the image
-    bool out_px[2];                                  // pixel is an output of this strip and inside the image
+    bool out_px[2], cand_px[2];                      // pixel is an output of this strip and inside the image / may emit a candidate
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const int i = 2 * lane + p, c = c0 + p;
         const bool in = c >= 0 && c <= W - 1;
         inimg_pair |= in ? (p ? 0xffff0000u : 0x0000ffffu) : 0u;
-        out_px[p] = in && i >= ML && i < ML + STRIDE;
+        out_px[p] = in && i >= ML - XM && i < ML + STRIDE + XM;       // lambda is meaningful here (EMIT: the candidates' neighbours too)
+        cand_px[p] = i >= ML && i < ML + STRIDE && c >= 1 && c <= W - 2;
     }
     // lanes (partly) outside the image load the nearest two in-image columns; a byte permute puts REFLECT_101 values where
     // the Sobel needs them (columns -1 and W; other outside columns never matter)
@@ -207,6 +221,44 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     };
 
     float best = -INFINITY;
+    // ---- EMIT: candidate staging and the running threshold (see k_eigc.hip for the derivation)
+    unsigned long long *st = stage[EMIT ? wv : 0];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned cnt = 0;
+    const unsigned shard = (unsigned)wave_id % KM_NSHARD;
+    const size_t cap_s = cap / KM_NSHARD;
+    auto flush_if = [&](unsigned threshold) {
+        if (cnt <= threshold) return;
+        if (cnt > EIG2_STAGE) { if (lane == 0) atomicOr(&sc->pad0, 1u); cnt = EIG2_STAGE; }
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&sc->shard_cnt[shard], cnt);
+        base = __shfl(base, 0);
+        for (unsigned i = lane; i < cnt; i += 64)
+            if ((size_t)base + i < cap_s) keys[shard * cap_s + base + i] = st[i];
+        cnt = 0;
+    };
+    float thr_run = 0.f;
+    unsigned published = 0u;
+    // running lower bound of the final threshold: quality * max(own wave so far, global running maximum).  The global
+    // words live at device scope (all XCDs): every access costs microseconds and same-address accesses serialise (158 000
+    // loads of ONE word once cost 1.6 ms), so there are 64 of them (any subset maximum is a valid lower bound), each is read
+    // ONCE per item and written only on a clear improvement;
+    // between segments only the wave's own maximum is refreshed (register shuffles).
+    unsigned gk_seen = 0u;
+    auto refresh_threshold = [&](bool global) {
+        unsigned wk = best > -INFINITY ? e2_key(best) : 0u;
+        for (int o = 32; o > 0; o >>= 1) wk = max(wk, (unsigned)__shfl_xor((int)wk, o));
+        if (global) {
+            gk_seen = __hip_atomic_load(&sc->run_max_shard[wave_id & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (published == 0u && wk > gk_seen && (gk_seen == 0u || e2_unkey(wk) > e2_unkey(gk_seen) * 1.0625f)) {
+            if (lane == 0) atomicMax(&sc->run_max_shard[wave_id & 63], wk);   // at most one publication per item, only >= 1/16 above what was seen
+            published = 1u;
+        }
+        const unsigned mk2 = max(wk, gk_seen);
+        thr_run = mk2 ? (float)__dmul_rn((double)e2_unkey(mk2), quality) : 0.f;
+    };
+    float e2r[2] = {0.f, 0.f}, e1r[2] = {0.f, 0.f};   // lambda rows y-2, y-1
+    uint32_t mk1 = 0;                                  // mask bytes of row y-1
     win3 lead, trail;
     // one marching step = product row m; nl / nt = source rows entering the lead / trail windows, mkraw = mask bytes of row m - Rr
     auto row_step = [&](int m, uint32_t nl, uint32_t nt, uint32_t mkraw, auto interior_tag) {
@@ -238,26 +290,50 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
             const bool counts = out_px[p] && ((mk >> (8 * p)) & 0xffu) != 0u;
             best = fmaxf(best, counts ? e[p] : -INFINITY);
         }
-        float *orow = eig + (size_t)y * W;
-        if (out_px[0] || out_px[1]) {                  // margins and stride are even: the two pixels of a FAST lane go together
-            if (FAST && w_even) {
-                *(float2 *)(orow + (unsigned)c0) = make_float2(e[0], e[1]);
-            } else {
+        if constexpr (!EMIT) {
+            float *orow = eig + (size_t)y * W;
+            if (out_px[0] || out_px[1]) {              // margins and stride are even: the two pixels of a FAST lane go together
+                if (FAST && w_even) {
+                    *(float2 *)(orow + (unsigned)c0) = make_float2(e[0], e[1]);
+                } else {
 #pragma unroll
-                for (int p = 0; p < 2; p++) if (out_px[p]) orow[c0 + p] = e[p];
+                    for (int p = 0; p < 2; p++) if (out_px[p]) orow[c0 + p] = e[p];
+                }
             }
+        } else {
+            if (INTERIOR || y >= ye0 + 2) {
+                // candidate test of row y-1 against lambda rows y-2, y-1, y
+                const float m3[2] = {fmaxf(fmaxf(e2r[0], e1r[0]), e[0]), fmaxf(fmaxf(e2r[1], e1r[1]), e[1])};
+                const float m3l = __int_as_float(e2_lane_m1(__float_as_int(m3[1]))), m3r = __int_as_float(e2_lane_p1(__float_as_int(m3[0])));
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const float left = p == 0 ? m3l : m3[0], right = p == 1 ? m3r : m3[1];
+                    const float nb = fmaxf(fmaxf(left, right), fmaxf(e2r[p], e[p]));
+                    const bool is = cand_px[p] && e1r[p] > thr_run && e1r[p] != 0.f && e1r[p] >= nb && ((mk1 >> (8 * p)) & 0xffu) != 0u;
+                    const unsigned long long bal = __ballot(is);
+                    const unsigned slot = cnt + (unsigned)__popcll(bal & lt_mask);
+                    // unconditional store (no branch in the row body): non-candidates and overflow go to the lane's dummy slot
+                    st[(is && slot < EIG2_STAGE) ? slot : EIG2_STAGE + (unsigned)lane] =
+                        ((unsigned long long)__float_as_uint(e1r[p]) << 32) | (unsigned long long)((unsigned)(y - 1) * (unsigned)W + (unsigned)(c0 + p));
+                    cnt += (unsigned)__popcll(bal);
+                }
+            }
+            e2r[0] = e1r[0]; e2r[1] = e1r[1]; e1r[0] = e[0]; e1r[1] = e[1];
+            mk1 = mk;
         }
     };
 
     window_reload(m_first, lead);
     window_reload(m_first - BLOCK, trail);
-    const int mi_lo = max(m_first + BLOCK, BLOCK + 1), mi_hi = min(m_last, H - 2 - PF);
+    const int mi_lo = max(m_first + BLOCK + (EMIT ? 1 : 0), BLOCK + 1), mi_hi = min(m_last, H - 2 - PF);
     int m = m_first;
     auto general_until = [&](int m_end) {
         for (; m <= m_end; m++) {
             const uint32_t nl = load_raw(src, max(entering_row(m), 0)), nt = load_raw(src, max(entering_row(m - BLOCK), 0));
             const uint32_t mkraw = load_raw(mptr, clamp_row(m - Rr));
+            if (EMIT && ((m - m_first) & 7) == 0) refresh_threshold(m == m_first);
             row_step(m, nl, nt, mkraw, std::false_type{});
+            if (EMIT) flush_if(EIG2_FLUSH_AT);
         }
     };
     general_until(min(mi_lo - 1, m_last));
@@ -269,20 +345,29 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
             qt[k] = load_raw(src, m + k - BLOCK + 1);
             qm[k] = load_raw(mptr, m + k - Rr);
         }
-        for (; m + PF - 1 <= mi_hi; m += PF) {
+        while (m + PF - 1 <= mi_hi) {
+            // between segments: the only places of the interior march with conditional global memory traffic
+            if (EMIT) { flush_if(EIG2_FLUSH_AT); refresh_threshold(false); }
+            const int seg_end = EMIT ? min(mi_hi, m + EIG2_SEG * PF - 1) : mi_hi;
+            for (; m + PF - 1 <= seg_end; m += PF) {
 #pragma unroll
-            for (int k = 0; k < PF; k++) {
-                row_step(m + k, ql[k], qt[k], qm[k], std::true_type{});
-                ql[k] = load_raw(src, m + k + PF + 1);
-                qt[k] = load_raw(src, m + k + PF - BLOCK + 1);
-                qm[k] = load_raw(mptr, m + k + PF - Rr);
+                for (int k = 0; k < PF; k++) {
+                    row_step(m + k, ql[k], qt[k], qm[k], std::true_type{});
+                    ql[k] = load_raw(src, m + k + PF + 1);
+                    qt[k] = load_raw(src, m + k + PF - BLOCK + 1);
+                    qm[k] = load_raw(mptr, m + k + PF - Rr);
+                }
             }
         }
     }
     general_until(m_last);
+    if (EMIT) flush_if(0u);
     unsigned key = best > -INFINITY ? e2_key(best) : 0u;
     for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
-    if (lane == 0) max_partial[wave_id] = key;
+    if (lane == 0) {
+        max_partial[wave_id] = key;
+        // (no final publication: the exact maximum comes from max_partial; the running key only has to be a lower bound)
+    }
     };  // run
     if (!border) run(std::true_type{});
     else run(std::false_type{});
@@ -303,18 +388,23 @@ __global__ __launch_bounds__(1024) void eig2_max_kernel(const unsigned *__restri
     }
 }
 
-template <int BLOCK>
-int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, double scale2, float *d_eig, unsigned *d_max_key)
+template <int BLOCK, bool EMIT>
+int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, double scale2, float *d_eig, unsigned *d_max_key,
+                double quality, km_scalars *sc, unsigned long long *d_keys, size_t cap)
 {
-    constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, ML = (L + 1 + 1) & ~1, STRIDE = (128 - ML - (Rr + 1)) & ~1;
-    const int nstrips = (W + STRIDE - 1) / STRIDE;
-    int rows = 48;   // short items (several rounds of resident waves) balance best: 0.352 ms at 48 rows, 0.38 at 128, 0.49 at 384 (10980^2)
+    constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, XM = EMIT ? 1 : 0, ML = (L + 1 + XM + 1) & ~1, STRIDE = (128 - ML - (Rr + 1 + XM)) & ~1;
+    // map: strips tile the columns 0 .. W-1, items the rows 0 .. H-1; EMIT: candidate columns / rows 1 .. W-2 / 1 .. H-2
+    const int nstrips = EMIT ? (W - 1 + STRIDE - 1) / STRIDE : (W + STRIDE - 1) / STRIDE;
+    // short items (several rounds of resident waves) balance best: map 0.352 ms at 48 rows, 0.38 at 128, 0.49 at 384; fused 0.464 at 64
+    int rows = EMIT ? 64 : 48;
     if (const char *e = getenv("KARIOS_HIP_EIG2_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows = v; }   // tuning override
-    const int nitems = nstrips * ((H + rows - 1) / rows);
+    const int nrowblocks = EMIT ? (H - 2 + rows - 1) / rows : (H + rows - 1) / rows;
+    const int nitems = nstrips * nrowblocks;
     const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)ntiles * 4 * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
-    eig2_kernel<BLOCK><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, rows, nitems);
+    eig2_kernel<BLOCK, EMIT><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, rows, nitems, quality, sc,
+                                                                         d_keys, cap);
     KM_LAUNCH_CHECK(c);
     eig2_max_kernel<<<1, 1024, 0, c->stream>>>(partial, ntiles * 4, d_max_key);
     KM_LAUNCH_CHECK(c);
@@ -330,9 +420,29 @@ int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
     if (!(W >= 2 * block + 8 && H >= 2 * block + 8)) return KM_E_UNSUPPORTED;   // mirrored columns / rows stay near their border
     const double scale = 1.0 / (4.0 * (double)block * 255.0), s2 = scale * scale;
     switch (block) {
-#define KM_EIG2_CASE(B) case B: return launch_eig2<B>(c, d_src, d_mask, H, W, s2, d_eig, d_max_key);
+#define KM_EIG2_CASE(B) case B: return launch_eig2<B, false>(c, d_src, d_mask, H, W, s2, d_eig, d_max_key, 0.0, nullptr, nullptr, 0);
         KM_EIG2_CASE(1) KM_EIG2_CASE(2) KM_EIG2_CASE(3) KM_EIG2_CASE(4) KM_EIG2_CASE(5) KM_EIG2_CASE(7) KM_EIG2_CASE(9) KM_EIG2_CASE(11)
         KM_EIG2_CASE(13) KM_EIG2_CASE(15)
+#undef KM_EIG2_CASE
+    default: return KM_E_UNSUPPORTED;
+    }
+}
+
+// Fused minimum-eigenvalue + candidate pass, 2 pixels per lane (no eig map).  Expects sc->run_max_key, sc->pad0 and
+// sc->shard_cnt[] zeroed (`rezero` does it).  KM_E_UNSUPPORTED (no message) when the case is not covered.
+int k2_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
+                      unsigned long long *d_keys, size_t cap, bool rezero)
+{
+    if (block < 1 || block > 15) return KM_E_UNSUPPORTED;
+    if (!(W >= 2 * block + 8 && H >= 2 * block + 8)) return KM_E_UNSUPPORTED;
+    if (rezero) {
+        KM_HIP(c, hipMemsetAsync(&sc->run_max_key, 0, (2 + KM_NSHARD) * sizeof(unsigned), c->stream));   // run_max_key, pad, shard counters
+        KM_HIP(c, hipMemsetAsync(sc->run_max_shard, 0, sizeof sc->run_max_shard, c->stream));
+    }
+    const double scale = 1.0 / (4.0 * (double)block * 255.0), s2 = scale * scale;
+    switch (block) {
+#define KM_EIG2_CASE(B) case B: return launch_eig2<B, true>(c, d_src, d_mask, H, W, s2, nullptr, &sc->max_eig_key, quality, sc, d_keys, cap);
+        KM_EIG2_CASE(1) KM_EIG2_CASE(3) KM_EIG2_CASE(5) KM_EIG2_CASE(7) KM_EIG2_CASE(9) KM_EIG2_CASE(11) KM_EIG2_CASE(13) KM_EIG2_CASE(15)
 #undef KM_EIG2_CASE
     default: return KM_E_UNSUPPORTED;
     }

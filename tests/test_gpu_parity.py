@@ -186,7 +186,7 @@ def test_good_features_plateau_falls_back_from_fused_kernel(ops, O, block):
     img = (g[np.arange(700) % len(g)][None, :] + h[np.arange(330) % 3][:, None]).astype(np.uint8)
     exp = O.good_features(img, None, 2000, 0.01, 4, block)
     ctx = default_context()
-    for fused in (2, 1, 0):
+    for fused in (3, 2, 1, 0):
         ctx.set_option("fused_eig", fused)
         try:
             got = ops.good_features_to_track(img, 2000, 0.01, 4, blockSize=block)
@@ -207,7 +207,7 @@ def test_good_features_fused_kernel_bit_exact(ops, O, params, shape):
     mask, _ = O.auto_mask(mon, ref)
     ctx = default_context()
     try:
-        for fused in (1, 2):
+        for fused in (1, 2, 3):
             ctx.set_option("fused_eig", fused)
             for mk in (None, mask):
                 got = ops.good_features_to_track(lap_ref, params["maxCorners"], params["q"], params["md"], mask=mk, blockSize=params["bs"])
