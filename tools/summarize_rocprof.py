@@ -8,7 +8,7 @@ import csv
 import re
 import sys
 
-OURS = ("lap_kernel", "lap_march", "eig_kernel", "eig_march", "tk_", "fb_", "pyr_", "cand_kernel", "lk_kernel", "pyrdown_kernel", "minmax_", "zncc_kernel", "sel_", "select_kernel",
+OURS = ("eig2_", "eigc_", "dn_keep", "fb_count", "mi_kernel", "lap_kernel", "lap_march", "eig_kernel", "eig_march", "tk_", "fb_", "pyr_", "cand_kernel", "lk_kernel", "pyrdown_kernel", "minmax_", "zncc_kernel", "sel_", "select_kernel",
         "take_first", "sum_u32", "max_u32", "to_uint8", "auto_mask", "count_nonzero", "shift_kernel", "rocprim", "cross_power",
         "absmax", "first_index", "to_f64", "rocfft", "fft", "stretch", "lut_")
 
@@ -17,7 +17,7 @@ def short(name: str) -> str:
     if "rocprim" in name:
         m = re.search(r"(radix_sort_\w+|scan_\w+|lookback_scan\w*|init_lookback\w*|onesweep\w*|histogram\w*)", name)
         return "rocprim::" + (m.group(1) if m else "kernel")
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return name.split("(")[0][:70]
 
 
