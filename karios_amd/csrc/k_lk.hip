@@ -55,35 +55,73 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
 #define LK_M 3  // margin (px) of the cached search-image patch around the current window
 
 // Stage a rows x cols byte patch whose top-left pixel is (gx0, gy0) into LDS (row pitch `pitch`, multiple of 4).
-// Inside the image: two aligned dword loads + v_alignbyte per destination word; otherwise byte loads with
-// REFLECT_101 (OpenCV pads every pyramid level by winSize with that border).
+// Inside the image: (unaligned) dword loads, ALL issued before the first one is consumed - a loop that loads and stores
+// per trip exposes the memory latency once per trip (9 trips per level and pass at winSize 25).  Addresses are a uniform
+// base + 32-bit lane offset, so a slot in flight costs one register.  Otherwise byte loads with REFLECT_101 (OpenCV pads
+// every pyramid level by winSize with that border).
+template <int MAXIT> struct lk_patch_regs {
+    uint32_t v[MAXIT];
+};
+
+__device__ __forceinline__ bool lk_patch_inside(int IW, int IH, int gx0, int gy0, int rows, int cols, int maxit)
+{
+    return gx0 >= 0 && gy0 >= 0 && gx0 + cols + 4 <= IW && gy0 + rows <= IH && rows * ((cols + 3) >> 2) <= 64 * maxit && rows * ((cols + 3) >> 2) < 1024 &&
+           cols <= 64;
+}
+
+template <int MAXIT>
+__device__ __forceinline__ void stage_patch_issue(const uint8_t *__restrict__ img, int IW, int gx0, int gy0, int rows, int cols, lk_patch_regs<MAXIT> &rg)
+{
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));   // opaque: keeps the per-slot index arithmetic local (hoisted out of the level loop it costs ~30 VGPRs)
+    const int nw = (cols + 3) >> 2, total = rows * nw;
+    const unsigned inv_nw = 65536u / (unsigned)nw + 1u;   // i / nw == (i * inv_nw) >> 16 for i < 1024, nw <= 16 (a runtime division costs ~25 instructions)
+    const unsigned base = (unsigned)gy0 * (unsigned)IW + (unsigned)gx0;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int i = min(lane + 64 * it, total - 1);     // surplus trips re-read the last word (never stored)
+        const int r = (int)(((unsigned)i * inv_nw) >> 16), d = i - r * nw;
+        const unsigned off = base + (unsigned)r * (unsigned)IW + 4u * (unsigned)d;
+        __builtin_memcpy(&rg.v[it], img + off, 4);
+    }
+}
+
+template <int MAXIT>
+__device__ __forceinline__ void stage_patch_commit(int rows, int cols, uint8_t *lds, int pitch, const lk_patch_regs<MAXIT> &rg)
+{
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int nw = (cols + 3) >> 2, total = rows * nw;
+    const unsigned inv_nw = 65536u / (unsigned)nw + 1u;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int i = lane + 64 * it;
+        if (i < total) {
+            const int r = (int)(((unsigned)i * inv_nw) >> 16), d = i - r * nw;
+            *(uint32_t *)(lds + r * pitch + 4 * d) = rg.v[it];
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_patch_border(const uint8_t *__restrict__ img, int IW, int IH, int gx0, int gy0, int rows, int cols,
+                                                   uint8_t *lds, int pitch)
+{
+    for (int i = threadIdx.x; i < rows * cols; i += 64) {
+        const int r = i / cols, cx = i - r * cols;
+        lds[r * pitch + cx] = img[(size_t)km_reflect101(gy0 + r, IH) * IW + km_reflect101(gx0 + cx, IW)];
+    }
+}
+
+template <int MAXIT>
 __device__ __forceinline__ void stage_patch(const uint8_t *__restrict__ img, int IW, int IH, int gx0, int gy0, int rows, int cols,
                                             uint8_t *lds, int pitch)
 {
-    const int lane = threadIdx.x;
-    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + cols + 4 <= IW && gy0 + rows <= IH;
-    if (inside) {
-        const int nw = (cols + 3) >> 2;
-        for (int i = lane; i < rows * nw; i += 64) {
-            const int r = i / nw, d = i - r * nw;
-            const uint8_t *p = img + (size_t)(gy0 + r) * IW + gx0 + 4 * d;
-            const unsigned off = (unsigned)((uintptr_t)p & 3);
-            const uint32_t *q = (const uint32_t *)(p - off);
-            const uint32_t w0 = q[0], w1 = q[1];
-            uint32_t v;
-            switch (off) {   // v_alignbyte needs an immediate-like uniform shift; off is per-row uniform at most
-            case 0: v = w0; break;
-            case 1: v = __builtin_amdgcn_alignbyte(w1, w0, 1); break;
-            case 2: v = __builtin_amdgcn_alignbyte(w1, w0, 2); break;
-            default: v = __builtin_amdgcn_alignbyte(w1, w0, 3); break;
-            }
-            *(uint32_t *)(lds + r * pitch + 4 * d) = v;
-        }
+    if (lk_patch_inside(IW, IH, gx0, gy0, rows, cols, MAXIT)) {
+        lk_patch_regs<MAXIT> rg;
+        stage_patch_issue<MAXIT>(img, IW, gx0, gy0, rows, cols, rg);
+        stage_patch_commit<MAXIT>(rows, cols, lds, pitch, rg);
     } else {
-        for (int i = lane; i < rows * cols; i += 64) {
-            const int r = i / cols, cx = i - r * cols;
-            lds[r * pitch + cx] = img[(size_t)km_reflect101(gy0 + r, IH) * IW + km_reflect101(gx0 + cx, IW)];
-        }
+        stage_patch_border(img, IW, IH, gx0, gy0, rows, cols, lds, pitch);
     }
 }
 
@@ -146,16 +184,29 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
 
         // stage the template neighbourhood and (speculatively) the search neighbourhood around the start position
         __syncthreads();
-        stage_patch(Iimg, IW, IH, ipx - 1, ipy - 1, RW, RW, raw, RP);
         int jx0 = (int)floorf(nx - half) - LK_M, jy0 = (int)floorf(ny - half) - LK_M;
-        stage_patch(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
+        {
+            constexpr int MAXIT = 2 * NR;                 // covers (win + 7)^2 / 4 words for every winSize served by NR runs per lane
+            const bool in_i = lk_patch_inside(IW, IH, ipx - 1, ipy - 1, RW, RW, MAXIT), in_j = lk_patch_inside(JW, JH, jx0, jy0, JS, JS, MAXIT);
+            if (in_i && in_j) {                           // template and search patch travel together
+                lk_patch_regs<MAXIT> ri, rj;
+                stage_patch_issue<MAXIT>(Iimg, IW, ipx - 1, ipy - 1, RW, RW, ri);
+                stage_patch_issue<MAXIT>(Jimg, JW, jx0, jy0, JS, JS, rj);
+                stage_patch_commit<MAXIT>(RW, RW, raw, RP, ri);
+                stage_patch_commit<MAXIT>(JS, JS, jp, JP, rj);
+            } else {
+                stage_patch<MAXIT>(Iimg, IW, IH, ipx - 1, ipy - 1, RW, RW, raw, RP);
+                stage_patch<MAXIT>(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
+            }
+        }
         __syncthreads();
         // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image.  Four adjacent positions per lane
         // and step share their 3x6 neighbourhood (column sums s = 3*(a0+a2)+10*a1 and d = a2-a0 per column).
         {
             const int ngrp = (DW + 3) >> 2;
+            const unsigned inv_ngrp = 65536u / (unsigned)ngrp + 1u;   // exact quotient for i < 1024, ngrp <= 16
             for (int i = lane; i < DW * ngrp; i += 64) {
-                const int r = i / ngrp, g = i - r * ngrp;
+                const int r = (int)(((unsigned)i * inv_ngrp) >> 16), g = i - r * ngrp;
                 const int cx0 = 4 * g;
                 const uint8_t *p = raw + (r + 1) * RP + cx0;      // column cx0-1 of the centre row is p[0]
                 int sv[6], dv[6];
@@ -229,7 +280,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 // the window left the cached neighbourhood: re-centre it
                 __syncthreads();
                 jx0 = inx - LK_M; jy0 = iny - LK_M;
-                stage_patch(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
+                stage_patch<2 * NR>(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
                 __syncthreads();
             }
             a = nx - (float)inx; b = ny - (float)iny;
