@@ -72,7 +72,7 @@ __device__ __forceinline__ bool lk_patch_inside(int IW, int IH, int gx0, int gy0
 template <int MAXIT>
 __device__ __forceinline__ void stage_patch_issue(const uint8_t *__restrict__ img, int IW, int gx0, int gy0, int rows, int cols, lk_patch_regs<MAXIT> &rg)
 {
-    int lane = threadIdx.x;
+    int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));   // opaque: keeps the per-slot index arithmetic local (hoisted out of the level loop it costs ~30 VGPRs)
     const int nw = (cols + 3) >> 2, total = rows * nw;
     const unsigned inv_nw = 65536u / (unsigned)nw + 1u;   // i / nw == (i * inv_nw) >> 16 for i < 1024, nw <= 16 (a runtime division costs ~25 instructions)
@@ -89,7 +89,7 @@ __device__ __forceinline__ void stage_patch_issue(const uint8_t *__restrict__ im
 template <int MAXIT>
 __device__ __forceinline__ void stage_patch_commit(int rows, int cols, uint8_t *lds, int pitch, const lk_patch_regs<MAXIT> &rg)
 {
-    int lane = threadIdx.x;
+    int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int nw = (cols + 3) >> 2, total = rows * nw;
     const unsigned inv_nw = 65536u / (unsigned)nw + 1u;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void stage_patch_commit(int rows, int cols, uint8_t *
 __device__ __forceinline__ void stage_patch_border(const uint8_t *__restrict__ img, int IW, int IH, int gx0, int gy0, int rows, int cols,
                                                    uint8_t *lds, int pitch)
 {
-    for (int i = threadIdx.x; i < rows * cols; i += 64) {
+    for (int i = threadIdx.x & 63; i < rows * cols; i += 64) {
         const int r = i / cols, cx = i - r * cols;
         lds[r * pitch + cx] = img[(size_t)km_reflect101(gy0 + r, IH) * IW + km_reflect101(gx0 + cx, IW)];
     }
@@ -148,6 +148,9 @@ __device__ __forceinline__ long long wave_sum_split(int v)
 // with v_perm and the bilinear interpolation is two v_dot2_i32_i16 per pixel; the mismatch vector is accumulated with
 // v_dot2_i32_i16 over pixel pairs as well.  All arithmetic is the exact integer arithmetic of cv::calcOpticalFlowPyrLK.
 #define LK_RUN 5
+#define LK_WPB 1   // key points (= wavefronts) per workgroup (4 measured slower: 0.363 vs 0.328 ms - a workgroup only retires with its slowest wave)
+// every wavefront works on its own LDS region: only the compiler must be kept from reordering LDS traffic across the phases
+#define LK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lk_s2 lk_as_s2(uint32_t v) { return __builtin_bit_cast(lk_s2, v); }
 __device__ __forceinline__ uint32_t lk_as_u(lk_s2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -159,7 +162,7 @@ template <int NR>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
                                const int (&run_desc)[NR], uint8_t *raw, int *der, uint8_t *jp, float &outx, float &outy)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int RW = win + 3, DW = win + 1;
@@ -183,7 +186,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         lk_weights(a, b, w00, w01, w10, w11);
 
         // stage the template neighbourhood and (speculatively) the search neighbourhood around the start position
-        __syncthreads();
+        LK_WAVE_SYNC();
         int jx0 = (int)floorf(nx - half) - LK_M, jy0 = (int)floorf(ny - half) - LK_M;
         {
             constexpr int MAXIT = 2 * NR;                 // covers (win + 7)^2 / 4 words for every winSize served by NR runs per lane
@@ -199,7 +202,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 stage_patch<MAXIT>(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
             }
         }
-        __syncthreads();
+        LK_WAVE_SYNC();
         // Scharr derivative on the (w+1)^2 bilinear support; zero outside the image.  Four adjacent positions per lane
         // and step share their 3x6 neighbourhood (column sums s = 3*(a0+a2)+10*a1 and d = a2-a0 per column).
         {
@@ -233,7 +236,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 }
             }
         }
-        __syncthreads();
+        LK_WAVE_SYNC();
         // per-lane window pixels -> registers (16-bit pairs along the run: Q5 intensity, Ix, Iy); exact integer normal matrix
         uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
         int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums stay below 2^31 (<= 25 pixels per lane: 25 * 4080^2 = 4.2e8)
@@ -278,10 +281,10 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             if (inx < -win || inx >= JW || iny < -win || iny >= JH) break;
             if (inx < jx0 || iny < jy0 || inx > jx0 + 2 * LK_M || iny > jy0 + 2 * LK_M) {
                 // the window left the cached neighbourhood: re-centre it
-                __syncthreads();
+                LK_WAVE_SYNC();
                 jx0 = inx - LK_M; jy0 = iny - LK_M;
                 stage_patch<2 * NR>(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
-                __syncthreads();
+                LK_WAVE_SYNC();
             }
             a = nx - (float)inx; b = ny - (float)iny;
             lk_weights(a, b, w00, w01, w10, w11);
@@ -328,12 +331,14 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
 }
 
 template <int NR>
-__global__ __launch_bounds__(64) KM_LK_OCC void lk_kernel(lk_args g)
+__global__ __launch_bounds__(64 * LK_WPB) KM_LK_OCC void lk_kernel(lk_args g, int sm_per_wave)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int p = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * LK_WPB + wv;
     const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
-    if (p >= n) return;
+    if (p >= n) return;                                  // (no workgroup barrier anywhere: waves are independent)
+    unsigned char *smem = smem_all + (size_t)wv * sm_per_wave;
     const int win = g.win;
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     uint8_t *raw = smem;
@@ -343,18 +348,18 @@ __global__ __launch_bounds__(64) KM_LK_OCC void lk_kernel(lk_args g)
     int run_desc[NR];
 #pragma unroll
     for (int t = 0; t < NR; t++) {
-        const int r = t * 64 + (int)threadIdx.x;
+        const int r = t * 64 + (int)(threadIdx.x & 63);
         const int y = r / rpr, x0 = (r - y * rpr) * LK_RUN;
         run_desc[t] = r < total ? (y | (x0 << 8) | (min(LK_RUN, win - x0) << 16)) : 0;
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
     lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, der, jp, fx, fy);
-    if (threadIdx.x == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
+    if ((threadIdx.x & 63) == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
         lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, der, jp, rx, ry);
-        if (threadIdx.x == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
+        if ((threadIdx.x & 63) == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }
 
@@ -373,13 +378,15 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     g.p1 = d_p1; g.p0r = d_p0r;
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
+    const size_t smw = (sm + 15) & ~(size_t)15, sm_all = smw * LK_WPB;
+    const int nblk = (n_max + LK_WPB - 1) / LK_WPB;
     const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;   // runs per lane (win <= 40: <= 5)
     switch (nr) {
-    case 1: lk_kernel<1><<<n_max, 64, sm, c->stream>>>(g); break;
-    case 2: lk_kernel<2><<<n_max, 64, sm, c->stream>>>(g); break;
-    case 3: lk_kernel<3><<<n_max, 64, sm, c->stream>>>(g); break;
-    case 4: lk_kernel<4><<<n_max, 64, sm, c->stream>>>(g); break;
-    default: lk_kernel<5><<<n_max, 64, sm, c->stream>>>(g); break;
+    case 1: lk_kernel<1><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
+    case 2: lk_kernel<2><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
+    case 3: lk_kernel<3><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
+    case 4: lk_kernel<4><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
+    default: lk_kernel<5><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
     }
     KM_LAUNCH_CHECK(c);
     return KM_OK;
