@@ -244,20 +244,37 @@ __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long lo
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> TK_SHIFT;
     const unsigned D = cut[0];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // pass 1: the workgroup's total over all its trips -> ONE reservation in the output (an atomic with return on the
+    // shared cursor costs microseconds at device scope; one per trip made this kernel latency-bound)
+    unsigned mine = 0;
+    for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
+        const unsigned i = b + threadIdx.x;
+        if (i < n) { const unsigned long long k = keys[i]; mine += (tk_above(k, thr) && tk_bin(k, top) <= D) ? 1u : 0u; }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += (unsigned)__shfl_xor((int)mine, o);
+    if (lane == 0) s_wave[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < 16; w++) tot += s_wave[w];
+        s_base = tot ? atomicAdd(&cut[2], tot) : 0u;
+    }
+    __syncthreads();
+    unsigned base = s_base;
+    // pass 2: write (the keys come from L2 this time)
     for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
         const unsigned i = b + threadIdx.x;
         unsigned long long k = 0;
         bool keep = false;
         if (i < n) { k = keys[i]; keep = tk_above(k, thr) && tk_bin(k, top) <= D; }
         const unsigned long long bal = __ballot(keep);
+        __syncthreads();                                  // s_wave of the previous trip fully consumed
         if (lane == 0) s_wave[wv] = (unsigned)__popcll(bal);
         __syncthreads();
         unsigned off = 0, tot = 0;
         for (int w = 0; w < 16; w++) { const unsigned cn = s_wave[w]; if (w < wv) off += cn; tot += cn; }
-        if (threadIdx.x == 0 && tot) s_base = atomicAdd(&cut[2], tot);
-        __syncthreads();
-        if (keep) out[s_base + off + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = k;
-        __syncthreads();
+        if (keep) out[base + off + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = k;
+        base += tot;
     }
 }
 
