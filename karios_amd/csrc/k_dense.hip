@@ -710,11 +710,16 @@ __device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
 }
 
 #define LAPM_VALID 248
+#ifndef LAPM_SPLIT
+#define LAPM_SPLIT 0   // 1: one image per wavefront (88 VGPRs, 5 waves/SIMD) - measured SLOWER (0.30 vs 0.264 ms: loop, address and mask work duplicated); 0: both images in one wave
+#endif
 #ifndef LAPM_PF
 #define LAPM_PF 3      // source rows in flight per wave
 #endif
 
-template <int R, typename T, bool MASK>
+// SPLIT: the two images of a work item go to two different wavefronts (wave parity) - half the register ring per wave
+// (76 instead of 123 VGPRs: 6 instead of 4 waves per SIMD); the image-0 wave also loads image 1's raw row for the mask.
+template <int R, typename T, bool MASK, bool SPLIT>
 __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
                                                         ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
                                                         lap_coef cf, int invert1, nodata_t nd,
@@ -727,9 +732,11 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     const int tid = threadIdx.x, lane = tid & 63;
     // work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
     unsigned tile;
-    if (!km_xcd_tile((unsigned)(nitems + 3) / 4u, tile)) return;
-    const int wave_id = (int)tile * 4 + (tid >> 6);
-    if (wave_id >= nitems) { if (MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
+    if (!km_xcd_tile((unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u, tile)) return;
+    const int wave_lin = (int)tile * 4 + (tid >> 6);
+    const int wave_id = SPLIT ? wave_lin >> 1 : wave_lin;           // work item
+    const int img_sel = SPLIT ? __builtin_amdgcn_readfirstlane(wave_lin & 1) : -1;
+    if (wave_id >= nitems) { if (!SPLIT && MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
     const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
     stretcher<T> st[2];
     st[0].init(mm, 0, nullptr); st[1].init(mm, 1, nullptr);
@@ -790,13 +797,17 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     unsigned cnt = 0;
     uint8_t *outs[2] = {out0, out1};
     // FAST: every lane of the strip is an interior, aligned lane (wave-uniform) -> no per-lane fallbacks in the loop
-    auto march = [&](auto fast_tag) {
+    auto march = [&](auto fast_tag, auto img_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr int IMG = decltype(img_tag)::value;                   // -1: both images in this wave, 0 / 1: only that one
+    constexpr int I0 = IMG < 0 ? 0 : IMG, I1 = IMG < 0 ? 2 : IMG + 1;
+    constexpr bool LOAD0 = IMG != 1, LOAD1 = IMG != 0 || MASK;      // the mask needs both raw rows (image-0 wave)
     auto load_raw = [&](int m, T (&v)[2][4]) {
         const int r = km_reflect101(m, H);
         const T *r0 = img0 + (size_t)r * stride0, *r1 = img1 + (size_t)r * stride1;
         const unsigned lx = opaque_lane_offset(ugx_load * (unsigned)sizeof(T));   // byte offset of the lane's first column
-        if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic
+        if (!LOAD0) {
+        } else if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 8); }
             else { uint4 q = *(const uint4 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 16); }
@@ -808,7 +819,8 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
 #pragma unroll
             for (int k = 0; k < 4; k++) v[0][k] = r0[rc[k]];
         }
-        if (FAST) {
+        if (!LOAD1) {
+        } else if (FAST) {
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 8); }
             else { uint4 q = *(const uint4 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 16); }
@@ -824,7 +836,7 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
 
     int ring[2][NR][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = I0; i < I1; i++)
 #pragma unroll
         for (int k = 0; k < NR; k++)
 #pragma unroll
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
                 }
             if (m + LAPM_PF < y1 + R) load_raw(m + LAPM_PF, nxt[LAPM_PF - 1]);
             // ---- auto mask of source row m (it is an output row when y0 <= m < y1)
-            if constexpr (MASK && FAST && sizeof(T) == 2) {
+            if constexpr (MASK && IMG != 1 && FAST && sizeof(T) == 2) {
                 // packed form: a pixel pair is valid iff min(mon, ref, mon ^ nodata_mon, ref ^ nodata_ref) != 0 (unsigned)
                 if (m >= y0 && m < y1 && out_lane) {
                     uint2 qm, qr;
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
                     cnt += (unsigned)__popc(mp);
                     *(uint32_t *)((mask_out + (size_t)m * W) + opaque_lane_offset(ugx)) = mp;
                 }
-            } else if constexpr (MASK) {
+            } else if constexpr (MASK && IMG != 1) {
                 if (m >= y0 && m < y1 && out_lane) {
                     uint32_t mp = 0;
 #pragma unroll
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = I0; i < I1; i++) {
                 // ---- stretch to uint8 (biased by -128 for the signed dot products)
                 uint32_t cw = 0;
 #pragma unroll
@@ -915,7 +927,7 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
             const int y = m - R;
             if (y >= y0 && out_lane) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = I0; i < I1; i++) {
                     uint32_t packed = 0;
 #pragma unroll
                     for (int o = 0; o < 4; o++) {
@@ -940,11 +952,18 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     const bool fast = (W % 4 == 0) && (stride0 % 4 == 0) && (stride1 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0) &&
                       ((uintptr_t)img1 % (4 * sizeof(T)) == 0) && ((uintptr_t)out0 % 4 == 0) && ((uintptr_t)out1 % 4 == 0) &&
                       (!MASK || (uintptr_t)mask_out % 4 == 0);   // wave-uniform
-    if (fast) march(std::true_type{});
-    else march(std::false_type{});
+    if constexpr (SPLIT) {
+        if (img_sel == 0) { if (fast) march(std::true_type{}, std::integral_constant<int, 0>{}); else march(std::false_type{}, std::integral_constant<int, 0>{}); }
+        else { if (fast) march(std::true_type{}, std::integral_constant<int, 1>{}); else march(std::false_type{}, std::integral_constant<int, 1>{}); }
+    } else {
+        if (fast) march(std::true_type{}, std::integral_constant<int, -1>{});
+        else march(std::false_type{}, std::integral_constant<int, -1>{});
+    }
     if constexpr (MASK) {
-        const unsigned c64 = (unsigned)wave_sum_u64((unsigned long long)cnt);
-        if (lane == 0) valid_partial[wave_id] = c64;
+        if (!SPLIT || img_sel == 0) {
+            const unsigned c64 = (unsigned)wave_sum_u64((unsigned long long)cnt);
+            if (lane == 0) valid_partial[wave_id] = c64;
+        }
     }
 }
 
@@ -960,23 +979,24 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, fn, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 4;
         return (long)c->n_cu * 4 * wg_per_cu;
     };
-    const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK>
-                                                                                  : (const void *)lap_march_kernel<3, T, MASK>;
-    int rows = km_pick_rows(H, nstrips, 2 * R, slots_of(fn), 32, 160);
+    constexpr bool SPLIT = LAPM_SPLIT != 0;
+    const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK, SPLIT> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK, SPLIT>
+                                                                                         : (const void *)lap_march_kernel<3, T, MASK, SPLIT>;
+    int rows = km_pick_rows(H, (SPLIT ? 2 : 1) * nstrips, 2 * R, slots_of(fn), 32, 160);
     if (const char *e = getenv("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
-    const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
+    const unsigned ntiles = (unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u;
     dim3 grid(km_xcd_grid(ntiles));
-    const size_t nwaves = (size_t)ntiles * 4;
+    const size_t nwaves = SPLIT ? (size_t)nitems : (size_t)ntiles * 4;     // entries of the per-item valid counts
     unsigned *valid = nullptr;
     if (MASK) {
-        valid = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
+        valid = (unsigned *)km_ws(c, WS_PARTIAL, ((size_t)ntiles * 4 + 4) * sizeof(unsigned));
         if (!valid) return KM_E_NOMEM;
     }
     switch (R) {
-    case 1: lap_march_kernel<1, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
-    case 2: lap_march_kernel<2, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
-    case 3: lap_march_kernel<3, T, MASK><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 1: lap_march_kernel<1, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 2: lap_march_kernel<2, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 3: lap_march_kernel<3, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
