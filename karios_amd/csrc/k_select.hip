@@ -89,22 +89,23 @@ __global__ __launch_bounds__(256) void sel_sweep_kernel(const unsigned long long
         undecided = true;
         for (int sweep = 0; sweep < SEL_SWEEPS && undecided; sweep++) {
             bool blocked = false, rejected = false;
-            for (int yy = y1; yy <= y2 && !rejected; yy++)
-                for (int xx = x1; xx <= x2 && !rejected; xx++) {
-                    const int g = yy * gw + xx;
-                    const unsigned o = cell_off[g], cnt = cell_cnt[g];
-                    for (unsigned k = 0; k < cnt; k++) {
-                        const unsigned j = items[o + k];
-                        if (j >= i) continue;  // only higher-ranked candidates matter
-                        int xj, yj;
-                        key_xy(keys[j], W, xj, yj);
-                        const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
-                        if (!((double)(dx * dx + dy * dy) < md2)) continue;
-                        const unsigned sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (sj == ST_ACCEPT) { rejected = true; break; }
-                        if (sj == ST_UNDECIDED) blocked = true;
-                    }
+            for (int yy = y1; yy <= y2 && !rejected; yy++) {
+                // the (up to) three cells of a grid row are neighbours in the cell order, so their candidates form ONE
+                // contiguous range of `items`: two offset loads per row instead of two per cell
+                const int g0 = yy * gw + x1;
+                const unsigned o = cell_off[g0], e = cell_off[g0 + (x2 - x1 + 1)];
+                for (unsigned k = o; k < e; k++) {
+                    const unsigned j = items[k];
+                    if (j >= i) continue;  // only higher-ranked candidates matter
+                    int xj, yj;
+                    key_xy(keys[j], W, xj, yj);
+                    const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
+                    if (!((double)(dx * dx + dy * dy) < md2)) continue;
+                    const unsigned sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sj == ST_ACCEPT) { rejected = true; break; }
+                    if (sj == ST_UNDECIDED) blocked = true;
                 }
+            }
             if (rejected) { __hip_atomic_store(&state[i], (unsigned)ST_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
             else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)ST_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
         }
