@@ -160,12 +160,13 @@ __device__ __forceinline__ uint32_t lk_pack16(int lo, int hi) { return __builtin
 // run_desc[t] = y | x0 << 8 | n << 16 (n = 0: the lane has no t-th run).
 template <int NR>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
-                               const int (&run_desc)[NR], uint8_t *raw, int *der, uint8_t *jp, float &outx, float &outy)
+                               const int (&run_desc)[NR], uint8_t *raw, short *derx, uint8_t *jp, float &outx, float &outy)
 {
     const int lane = threadIdx.x & 63;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int RW = win + 3, DW = win + 1;
+    short *dery = derx + DW * DW + 8;                 // second derivative plane (8 shorts of slack behind each plane)
     const int RP = (RW + 3 + 3) & ~3;                 // raw patch pitch
     const int JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     float resx = px, resy = py;
@@ -225,13 +226,13 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 for (int k = 0; k < 4; k++) {
                     const int cx = cx0 + k;
                     if (cx < DW) {
-                        int v = 0;
+                        int ix = 0, iy = 0;
                         if (row_in && (unsigned)(ipx + cx) < (unsigned)IW) {
-                            const int ix = sv[k + 2] - sv[k];
-                            const int iy = (dv[k] + dv[k + 2]) * 3 + dv[k + 1] * 10;
-                            v = (ix & 0xffff) | (iy << 16);
+                            ix = sv[k + 2] - sv[k];
+                            iy = (dv[k] + dv[k + 2]) * 3 + dv[k + 1] * 10;
                         }
-                        der[r * DW + cx] = v;
+                        derx[r * DW + cx] = (short)ix;      // two 16-bit planes: a run reads its 6 consecutive values per
+                        dery[r * DW + cx] = (short)iy;      // row with one (unaligned) 16-byte LDS read
                     }
                 }
             }
@@ -240,30 +241,51 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         // per-lane window pixels -> registers (16-bit pairs along the run: Q5 intensity, Ix, Iy); exact integer normal matrix
         uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
         int sA11 = 0, sA12 = 0, sA22 = 0;  // per-lane partial sums stay below 2^31 (<= 25 pixels per lane: 25 * 4080^2 = 4.2e8)
+        {
+            const lk_s2 wt0 = lk_as_s2(lk_pack16(w00, w01)), wt1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
 #pragma unroll
-        for (int t = 0; t < NR; t++) {
-            const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff, n = run_desc[t] >> 16;
-            int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
+            for (int t = 0; t < NR; t++) {
+                int rd = run_desc[t];
+                asm volatile("" : "+v"(rd));   // opaque: the LDS addresses of the run are recomputed here instead of living in registers across the kernel
+                const int y = rd & 0xff, x0 = (rd >> 8) & 0xff, n = rd >> 16;
+                // template intensity (Q5): bytes x0+1 .. x0+6 of raw rows y+1, y+2
+                const uint8_t *pr = raw + (y + 1) * RP + (x0 + 1);
+                uint2 r0, r1;
+                __builtin_memcpy(&r0, pr, 8);
+                __builtin_memcpy(&r1, pr + RP, 8);
+                // derivatives: values x0 .. x0+5 of rows y, y+1 of both planes
+                uint4 gx0, gx1, gy0, gy1;
+                __builtin_memcpy(&gx0, derx + y * DW + x0, 16);
+                __builtin_memcpy(&gx1, derx + (y + 1) * DW + x0, 16);
+                __builtin_memcpy(&gy0, dery + y * DW + x0, 16);
+                __builtin_memcpy(&gy1, dery + (y + 1) * DW + x0, 16);
+                const uint32_t ax0[4] = {gx0.x, gx0.y, gx0.z, gx0.w}, ax1[4] = {gx1.x, gx1.y, gx1.z, gx1.w};
+                const uint32_t ay0[4] = {gy0.x, gy0.y, gy0.z, gy0.w}, ay1[4] = {gy1.x, gy1.y, gy1.z, gy1.w};
+                int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
+                iv[LK_RUN] = 0; ixv[LK_RUN] = 0; iyv[LK_RUN] = 0;
 #pragma unroll
-            for (int j = 0; j <= LK_RUN; j++) { iv[j] = 0; ixv[j] = 0; iyv[j] = 0; }
-#pragma unroll
-            for (int j = 0; j < LK_RUN; j++) {
-                if (j < n) {
-                    const uint8_t *p = raw + (y + 1) * RP + (x0 + j + 1);
-                    iv[j] = descale(__mul24(p[0], w00) + __mul24(p[1], w01) + __mul24(p[RP], w10) + __mul24(p[RP + 1], w11), 14 - 5);
-                    const int *dp = der + y * DW + (x0 + j);
-                    const int d00 = dp[0], d01 = dp[1], d10 = dp[DW], d11 = dp[DW + 1];
-                    ixv[j] = descale(__mul24((int)(short)(d00 & 0xffff), w00) + __mul24((int)(short)(d01 & 0xffff), w01) +
-                                         __mul24((int)(short)(d10 & 0xffff), w10) + __mul24((int)(short)(d11 & 0xffff), w11), 14);
-                    iyv[j] = descale(__mul24(d00 >> 16, w00) + __mul24(d01 >> 16, w01) + __mul24(d10 >> 16, w10) + __mul24(d11 >> 16, w11), 14);
-                    sA11 += __mul24(ixv[j], ixv[j]); sA12 += __mul24(ixv[j], iyv[j]); sA22 += __mul24(iyv[j], iyv[j]);
+                for (int k = 0; k < LK_RUN; k++) {
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);
+                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
+                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, __builtin_amdgcn_sdot2(c1, wt1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                    // 16-bit pair (value k, value k+1) of a row held as 4 dwords
+                    auto pair = [&](const uint32_t (&a)[4]) -> lk_s2 {
+                        return lk_as_s2((k & 1) ? __builtin_amdgcn_alignbyte(a[(k + 1) / 2], a[k / 2], 2) : a[k / 2]);
+                    };
+                    ixv[k] = __builtin_amdgcn_sdot2(pair(ax0), wt0, __builtin_amdgcn_sdot2(pair(ax1), wt1, 1 << 13, false), false) >> 14;
+                    iyv[k] = __builtin_amdgcn_sdot2(pair(ay0), wt0, __builtin_amdgcn_sdot2(pair(ay1), wt1, 1 << 13, false), false) >> 14;
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                IvP[t][q] = lk_pack16(iv[2 * q], iv[2 * q + 1]);
-                IxP[t][q] = lk_pack16(ixv[2 * q], ixv[2 * q + 1]);
-                IyP[t][q] = lk_pack16(iyv[2 * q], iyv[2 * q + 1]);
+                for (int q = 0; q < 3; q++) {
+                    // pixels beyond the run's length (window edge, surplus lanes) contribute nothing
+                    const uint32_t pm = n >= 2 * q + 2 ? 0xffffffffu : (n == 2 * q + 1 ? 0x0000ffffu : 0u);
+                    IvP[t][q] = lk_pack16(iv[2 * q], iv[2 * q + 1]) & pm;
+                    IxP[t][q] = lk_pack16(ixv[2 * q], ixv[2 * q + 1]) & pm;
+                    IyP[t][q] = lk_pack16(iyv[2 * q], iyv[2 * q + 1]) & pm;
+                    sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
+                    sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
+                    sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
+                }
             }
         }
         const long long iA11 = wave_sum_split(sA11), iA12 = wave_sum_split(sA12), iA22 = wave_sum_split(sA22);
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(64 * LK_WPB) KM_LK_OCC void lk_kernel(lk_args g, in
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     uint8_t *raw = smem;
     uint8_t *jp = smem + (((win + 3) * RP + 15) & ~15);
-    int *der = (int *)(jp + ((JS * JP + 15) & ~15));
+    short *derx = (short *)(jp + ((JS * JP + 15) & ~15));   // two int16 planes of (win+1)^2 values, 8 shorts of slack each
     const int rpr = (win + LK_RUN - 1) / LK_RUN, total = win * rpr;
     int run_desc[NR];
 #pragma unroll
@@ -354,11 +376,11 @@ __global__ __launch_bounds__(64 * LK_WPB) KM_LK_OCC void lk_kernel(lk_args g, in
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
-    lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, der, jp, fx, fy);
+    lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, fx, fy);
     if ((threadIdx.x & 63) == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, der, jp, rx, ry);
+        lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, rx, ry);
         if ((threadIdx.x & 63) == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }
@@ -377,7 +399,7 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     g.epsilon = e * e;
     g.p1 = d_p1; g.p0r = d_p0r;
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
-    const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + (size_t)(win + 1) * (win + 1) * 4;
+    const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + ((size_t)(win + 1) * (win + 1) + 8) * 2 * sizeof(short) + 16;
     const size_t smw = (sm + 15) & ~(size_t)15, sm_all = smw * LK_WPB;
     const int nblk = (n_max + LK_WPB - 1) / LK_WPB;
     const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;   // runs per lane (win <= 40: <= 5)
