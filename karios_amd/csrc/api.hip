@@ -45,6 +45,32 @@ void *km_ws(km_ctx *c, int slot, size_t bytes)
     return p;
 }
 
+int km_wait_readback(km_ctx *c)
+{
+    if (!c->ev_readback) KM_HIP(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
+    static const bool no_defer = getenv("KARIOS_HIP_NO_DEFER") != nullptr;   // A/B switch: wait first, run the jobs afterwards
+    KM_HIP(c, hipEventRecord(c->ev_readback, c->stream));
+    if (!c->deferred.empty() && !no_defer) {
+        std::function<int()> job = std::move(c->deferred.front());
+        c->deferred.erase(c->deferred.begin());
+        const int rc = job();
+        if (rc) return rc;
+    }
+    KM_HIP(c, hipEventSynchronize(c->ev_readback));
+    return KM_OK;
+}
+
+int km_run_deferred(km_ctx *c)
+{
+    while (!c->deferred.empty()) {
+        std::function<int()> job = std::move(c->deferred.front());
+        c->deferred.erase(c->deferred.begin());
+        const int rc = job();
+        if (rc) return rc;
+    }
+    return KM_OK;
+}
+
 extern "C" {
 
 int km_version(void) { return 100; }
@@ -84,6 +110,7 @@ int km_ctx_destroy(km_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     kp_destroy(c);
+    if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     for (int i = 0; i < WS_COUNT; i++)
         if (c->ws[i].p) (void)hipFree(c->ws[i].p);
     if (c->ev_ready)
@@ -211,6 +238,29 @@ static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride,
 }
 
 static km_scalars *scalars(km_ctx *c) { return (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars)); }
+
+// pyramid of one image into caller-provided storage (levels >= 1 packed from `store`); returns the bytes used
+static int build_pyramid_single(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, uint8_t *store, km_pyr *P, size_t *used)
+{
+    P->img[0] = d_img; P->H[0] = H; P->W[0] = W; P->levels = 0;
+    if (max_level > 4) max_level = 4;
+    size_t off = 0;
+    int w = W, h = H;
+    for (int l = 1; l <= max_level; l++) {
+        const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+        if (nw <= win || nh <= win) break;
+        if (store) {
+            int rc = kd_pyrdown_u8(c, P->img[l - 1], h, w, store + off);
+            if (rc) return rc;
+            P->img[l] = store + off;
+        }
+        P->H[l] = nh; P->W[l] = nw; P->levels = l;
+        off += ((size_t)nw * nh + 255) & ~(size_t)255;
+        w = nw; h = nh;
+    }
+    if (used) *used = off;
+    return KM_OK;
+}
 
 // both pyramids of a pair, one launch per level
 static int build_pyramid_pair(km_ctx *c, const uint8_t *d_a, const uint8_t *d_b, int H, int W, int win, int max_level, km_pyr *A, km_pyr *B)
@@ -347,15 +397,30 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             KM_HIP(c, hipMemcpyAsync(d_p0, d_p0_in, (size_t)n_p0 * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         KM_HIP(c, hipMemcpyAsync(&sc->n_corners, &n_p0, sizeof(int), hipMemcpyHostToDevice, c->stream));
         KM_HIP(c, hipStreamSynchronize(c->stream));  // n_p0 is a stack variable
-    } else {
-        if ((rc = gftt_dev(c, d_ref_lap, d_mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, d_p0,
-                           cap, sc)))
-            return rc;
     }
     km_pyr A, B;
-    {
+    if (d_p0_in) {
         km_stage_timer t(c, ST_PYRAMID);
         if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
+    } else {
+        // the pyramids do not depend on the corners: they are queued as deferred jobs and fill the GPU during the two
+        // host read-backs of the corner selection (km_wait_readback); whatever is left runs right after it
+        c->deferred.clear();
+        size_t pyr_bytes = 0;
+        build_pyramid_single(c, d_ref_lap, H, W, prm->win_size, prm->max_level, nullptr, &A, &pyr_bytes);   // sizes only
+        uint8_t *store_a = pyr_bytes ? (uint8_t *)km_ws(c, WS_PYR_A, pyr_bytes) : nullptr, *store_b = pyr_bytes ? (uint8_t *)km_ws(c, WS_PYR_B, pyr_bytes) : nullptr;
+        if (pyr_bytes && (!store_a || !store_b)) return KM_E_NOMEM;
+        B = A; B.img[0] = d_mon_lap;
+        if (pyr_bytes) {                       // one job per image: one for each of the two read-backs
+            c->deferred.push_back([=, &A]() -> int {
+                km_stage_timer t(c, ST_PYRAMID);
+                return build_pyramid_single(c, d_ref_lap, H, W, prm->win_size, prm->max_level, store_a, &A, nullptr);
+            });
+            c->deferred.push_back([=, &B]() -> int { return build_pyramid_single(c, d_mon_lap, H, W, prm->win_size, prm->max_level, store_b, &B, nullptr); });
+        }
+        rc = gftt_dev(c, d_ref_lap, d_mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, d_p0, cap, sc);
+        const int rc2 = rc ? (c->deferred.clear(), rc) : km_run_deferred(c);
+        if (rc2) return rc2;
     }
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
@@ -744,29 +809,6 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.n_init = ((const int *)host_out)[1];
-    return KM_OK;
-}
-
-// pyramid of one image into caller-provided storage (levels >= 1 packed from `store`); returns the bytes used
-static int build_pyramid_single(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, uint8_t *store, km_pyr *P, size_t *used)
-{
-    P->img[0] = d_img; P->H[0] = H; P->W[0] = W; P->levels = 0;
-    if (max_level > 4) max_level = 4;
-    size_t off = 0;
-    int w = W, h = H;
-    for (int l = 1; l <= max_level; l++) {
-        const int nw = (w + 1) / 2, nh = (h + 1) / 2;
-        if (nw <= win || nh <= win) break;
-        if (store) {
-            int rc = kd_pyrdown_u8(c, P->img[l - 1], h, w, store + off);
-            if (rc) return rc;
-            P->img[l] = store + off;
-        }
-        P->H[l] = nh; P->W[l] = nw; P->levels = l;
-        off += ((size_t)nw * nh + 255) & ~(size_t)255;
-        w = nw; h = nh;
-    }
-    if (used) *used = off;
     return KM_OK;
 }
 

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/karios_hip.h"
 
@@ -103,6 +105,10 @@ struct km_ctx {
     hipStream_t stream = nullptr;
     km_buf ws[WS_COUNT];
     std::string err;
+    // Independent device work queued by the caller to fill the GPU while the host waits for a small read-back (the two
+    // synchronisations of the corner selection): km_wait_readback runs ONE deferred job between the copy and the wait.
+    std::vector<std::function<int()>> deferred;
+    hipEvent_t ev_readback = nullptr;
     bool profiling = false;
     int fused_eig = 3;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip), 3 fused 2-px/lane kernel (k_eig2.hip)
     hipEvent_t ev[ST_COUNT][2];
@@ -149,6 +155,10 @@ static inline int km_pick_rows(int H, int nstrips, int halo, long wave_slots, in
     return best;
 }
 void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+// Call right after queuing device-to-host copies the host needs NOW: records an event, queues one deferred job (if any)
+// behind it, then waits for the event only - the GPU keeps working on the job while the host continues.
+int km_wait_readback(km_ctx *ctx);
+int km_run_deferred(km_ctx *ctx);   // runs every job still pending (call before results that depend on them are used)
 
 #define KM_HIP(ctx, call)                                                                   \
     do {                                                                                    \

@@ -296,7 +296,7 @@ int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_ke
     tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, k_target ? (unsigned)k_target : 0xffffffffu, cut, d_sc, quality);
     KM_LAUNCH_CHECK(c);
     KM_HIP(c, hipMemcpyAsync(hs, d_sc, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rcw = km_wait_readback(c); if (rcw) return rcw; }
     const size_t kept = hs->cut[1];
     *n_total = hs->cut[3];
     *n_kept = kept;
@@ -393,7 +393,7 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
             KM_LAUNCH_CHECK(c);
             unsigned back[8];
             KM_HIP(c, hipMemcpyAsync(back, d_sc->und, sizeof back, hipMemcpyDeviceToHost, c->stream));
-            KM_HIP(c, hipStreamSynchronize(c->stream));
+            { const int rcw = km_wait_readback(c); if (rcw) return rcw; }
             got = (int)back[7];
             if (back[3] == 0) break;   // every prefix member decided: the emitted list is final for this prefix
             if (rounds > 100000) return km_fail(c, KM_E_INTERNAL, "corner selection did not converge");
