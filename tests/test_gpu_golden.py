@@ -182,3 +182,17 @@ def test_results_step_matches_reference_golden(tmp_path):
     pair.no_data_ref = 0.0
     with pytest.raises(IndexError):
         filter_by_dn_values(bad, pair, [1])
+
+
+def test_dn_filter_reference_known_answers():
+    """The six cases of the reference's tests/test_dn_value_filtering.py on the device."""
+    from test_oracle_golden import DN_KATS, _dn_kat_case
+    from karios_amd.resident import ResidentPair
+    from karios_amd.results import filter_by_dn_values
+    for cfg, ro, mo, nv, want in DN_KATS:
+        ref, mon, xy = _dn_kat_case(cfg, ro, mo)
+        pts = pd.DataFrame({"x0": xy, "y0": xy, "dx": xy * 0.1, "dy": xy * 0.1, "score": 1 - xy * 0.1})
+        got = filter_by_dn_values(pts, ResidentPair.upload(mon, ref), nv)
+        assert list(got["x0"].astype(int)) == want and list(got["y0"].astype(int)) == want
+        if not nv:
+            assert got is pts                      # nothing requested: the frame comes back untouched (core.py:673-675)

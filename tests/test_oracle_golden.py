@@ -268,3 +268,33 @@ def test_results_step_oracle_matches_reference_golden():
                                      None if np.isnan(nd[1]) else nd[1])
         assert np.array_equal(idx[keep], g[f"dn_case{k}_kept_index"]), k
         assert np.array_equal(x0[keep], g[f"dn_case{k}_kept_x0"]), k
+
+# Known-answer cases of the reference's tests/test_dn_value_filtering.py (:33-396): 10x10 uint8 images, key points on the
+# diagonal, (ref overrides, mon overrides, no_values, expected x0 of the kept key points)
+DN_KATS = [
+    (dict(fill_ref=1, fill_mon=1, n=5), {}, {}, None, [1, 2, 3, 4, 5]),
+    (dict(fill_ref=1, fill_mon=1, n=5), {}, {}, [], [1, 2, 3, 4, 5]),
+    (dict(fill_ref=0, fill_mon=50, n=4), {1: 100, 2: 0, 3: 150, 4: 0}, {}, [0], [1, 3]),
+    (dict(fill_ref=50, fill_mon=50, n=5), {1: 0, 2: 100, 3: 150, 4: 255, 5: 75}, {}, [0, 100, 255], [3, 5]),
+    (dict(fill_ref=100, fill_mon=50, n=4), {}, {1: 0, 2: 50, 3: 0, 4: 50}, [0], [2, 4]),
+    (dict(fill_ref=100, fill_mon=50, n=4), {1: 0, 2: 100, 3: 100, 4: 100}, {1: 50, 2: 0, 3: 50, 4: 0}, [0], [3]),
+]
+
+
+def _dn_kat_case(cfg, ref_over, mon_over):
+    ref = np.full((10, 10), cfg["fill_ref"], np.uint8)
+    mon = np.full((10, 10), cfg["fill_mon"], np.uint8)
+    for k, v in ref_over.items():
+        ref[k, k] = v
+    for k, v in mon_over.items():
+        mon[k, k] = v
+    xy = np.arange(1, cfg["n"] + 1).astype(np.float32)
+    return ref, mon, xy
+
+
+def test_dn_filter_reference_known_answers():
+    from oracle import oracle as O
+    for cfg, ro, mo, nv, want in DN_KATS:
+        ref, mon, xy = _dn_kat_case(cfg, ro, mo)
+        keep = O.filter_by_dn_values(xy, xy, ref, mon, nv)
+        assert list(xy[keep].astype(int)) == want
