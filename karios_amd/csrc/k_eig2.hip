@@ -59,11 +59,15 @@ __device__ __forceinline__ float e2_sqrt(float x)
     return res;
 }
 
+#ifndef EIG2_PF
 #define EIG2_PF 3   // rows in flight per stream
+#endif
 
 #define EIG2_STAGE 512     // EMIT: candidate keys per wave in LDS (+ one dummy slot per lane behind them)
 #define EIG2_FLUSH_AT 128  // EMIT: flush between row segments once this many keys are staged
+#ifndef EIG2_SEG
 #define EIG2_SEG 3         // EMIT: row groups (of EIG2_PF rows) between two looks at the stage / the running threshold
+#endif
 
 // EMIT = false: writes the eig map.  EMIT = true: K3 + K4 fused - the map is never written; three lambda rows stay in
 // registers and every pixel that is a 3x3 local maximum, lies off the image border, passes the mask and exceeds a RUNNING
