@@ -125,7 +125,7 @@ def main():
     from karios_amd import synth
     from karios_amd._lib import Context
     from karios_amd.core import KLTConfiguration
-    from karios_amd.parallel import gather_blocks
+    from karios_amd.parallel import gather_rank_blocks
     from karios_amd.resident import ResidentPair
 
     S = a.size
@@ -154,8 +154,7 @@ def main():
         n_rows = raw.n_rows
         if world > 1:
             # the path's only exchange step: all-gather of the per-band key-point blocks (device pipeline layout) over RCCL
-            blocks = gather_blocks({rank: raw.block}, world, conf.maxCorners, True, device=dev)
-            n_rows = int(blocks[:, :1].view(np.int32).sum())
+            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=dev)   # gathered blocks stay in HBM
         nxt = pool.submit(host_half, raw)
         frame = pending.result() if pending is not None else None
         return nxt, frame, n_rows

@@ -137,6 +137,29 @@ def gather_blocks(local: dict[int, np.ndarray | None], n_units: int, cap: int, w
     return out
 
 
+def gather_rank_blocks(block: np.ndarray | None, cap: int, with_zncc: bool = False, device=None):
+    """The per-step exchange of a band-parallel run with ONE unit per rank: all-gather of every rank's frame block, left on
+    `device` (RCCL: the GPU; gloo: the CPU).  Returns (tensor (world, block_len) float32 in rank order, total key points).
+    No host staging of the gathered data - a consumer that needs another rank's rows reads them where they are
+    (`blocks_to_frames(t.cpu().numpy(), ...)` builds the DataFrames on demand)."""
+    import torch
+    import torch.distributed as dist
+
+    L = block_len(cap, with_zncc)
+    ws = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if ws > 1 and dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.zeros(L, dtype=torch.float32) if block is None else torch.from_numpy(np.ascontiguousarray(block[:L]))
+    t_send = mine.to(device, non_blocking=False)
+    if ws == 1:
+        t_recv = t_send.reshape(1, L)
+    else:
+        t_recv = torch.empty((ws, L), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(t_recv.reshape(-1), t_send)
+    total = int(t_recv[:, 0].contiguous().view(torch.int32).sum().item())      # header word 0 = n_rows (int32 bit pattern)
+    return t_recv, total
+
+
 def blocks_to_frames(blocks: np.ndarray, cap: int, with_zncc: bool = False):
     from .resident import ResidentPair
     return [ResidentPair._frame_from_block(b, cap, with_zncc) for b in blocks]

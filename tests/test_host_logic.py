@@ -192,6 +192,36 @@ print("rank", rank, "ok")
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_gather_rank_blocks_world_size_2_gloo(tmp_path):
+    """The lean per-step exchange of `bench.py --gpus N` (one frame block per rank, gathered tensor left on the device)."""
+    script = tmp_path / "worker3.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from karios_amd.parallel import gather_rank_blocks, blocks_to_frames, block_len
+rank = int(os.environ["RANK"]); cap = 6
+dist.init_process_group("gloo", rank=rank, world_size=2)
+b = np.zeros(block_len(cap, True) + 7, np.float32)          # longer than needed, like the host ring buffer
+n = 3 + rank
+b[:4].view(np.int32)[:2] = (n, n + 2)
+b[4:4 + n] = 100 * rank + np.arange(n)
+t, total = gather_rank_blocks(b, cap, True)
+assert tuple(t.shape) == (2, block_len(cap, True)) and total == 7, (t.shape, total)
+frames = blocks_to_frames(t.cpu().numpy(), cap, True)
+assert [len(f) for f in frames] == [3, 4] and float(frames[1]["x0"].iloc[2]) == 102.0
+t2, total2 = gather_rank_blocks(None if rank == 0 else b, cap, True)
+assert total2 == 4 and blocks_to_frames(t2.cpu().numpy(), cap, True)[0] is None
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_stretch_exact_multiples():
     """The integer formulation of `_to_uint8` the HIP kernels use (k_dense.hip, "uint8 stretch of 16-bit integer images"):
     numpy's trunc(fl(fl(d / r) * 255)) equals floor(255 * d / r) for every integer d in [0, r], r <= 65535 - in
