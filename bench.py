@@ -118,9 +118,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: karios_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if os.environ.get("KARIOS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL ("nccl" on ROCm) in production; KARIOS_BENCH_BACKEND=gloo lets the multi-rank logic be exercised with several
+        # ranks sharing one GPU (development box) - the collectives then run on CPU tensors
+        backend = os.environ.get("KARIOS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from karios_amd import synth
     from karios_amd._lib import Context
@@ -154,7 +161,7 @@ def main():
         n_rows = raw.n_rows
         if world > 1:
             # the path's only exchange step: all-gather of the per-band key-point blocks (device pipeline layout) over RCCL
-            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=dev)   # gathered blocks stay in HBM
+            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=coll_dev)   # gathered blocks stay in HBM
         nxt = pool.submit(host_half, raw)
         frame = pending.result() if pending is not None else None
         return nxt, frame, n_rows
@@ -188,7 +195,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
