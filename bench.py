@@ -247,7 +247,7 @@ def main():
                                         "frac": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "synth_seconds": round(t_gen, 2),
         }
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
         cb, _ = cpu_baseline(mon_t, ref_t, S, dict(maxCorners=conf.maxCorners), a.cpu_sample_rows)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]
