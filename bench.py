@@ -58,7 +58,7 @@ def cpu_baseline(mon_t, ref_t, size, conf_kw, sample_rows):
     ref = ref_t[:rows].cpu().numpy().view(np.uint16)
     frac = rows / size
     conf = O.default_conf(**dict(conf_kw, maxCorners=max(1, int(round(conf_kw["maxCorners"] * frac)))))
-    cores = O.max_threads()
+    cores = O.max_threads()      # OpenMP team = min(logical CPUs, affinity, cgroup CPU quota), see oracle.usable_cpus()
     O.klt_tile(mon[:256, :256], ref[:256, :256], conf)  # load / warm the library
     t0 = time.perf_counter()
     res = O.klt_tile(mon, ref, conf)
@@ -70,7 +70,8 @@ def cpu_baseline(mon_t, ref_t, size, conf_kw, sample_rows):
     dt = time.perf_counter() - t0
     out = {"value": rows * size / 1e6 / dt, "unit": "Mpx/s", "cores": cores, "kind": "port",
            "sample": f"top {rows} rows x {size} cols of the same pair, maxCorners {conf.maxCorners} "
-                     f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points",
+                     f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points; {cores} OpenMP threads = the CPUs this "
+                     f"process may use ({os.cpu_count()} logical CPUs visible)",
            "keypoints_per_s": n / dt}
     live = cv2_live(mon, ref, dict(maxCorners=conf.maxCorners), res)
     if live is not None:

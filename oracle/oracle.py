@@ -37,12 +37,30 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: min(logical CPUs, affinity mask, cgroup-v2 quota).  A container that shows
+    256 logical CPUs under a 16-CPU quota runs an all-cores OpenMP team slower than a 16-thread one (throttled spinning)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         L = C.CDLL(_SO)
         L.ko_auto_mask.restype = C.c_long
+        L.ko_set_threads(min(int(L.ko_max_threads()), usable_cpus()))
         _lib = L
     return _lib
 

@@ -1,0 +1,29 @@
+"""A fixed slice of the randomised parity sweep (`tools/fuzz_parity.py`) inside the GPU suite: random sizes, pixel types,
+no-data patterns, user masks, kernel sizes, polarity and tracker parameters; corners, tracks and frame columns
+bit-identical with the oracle, ZNCC within 1e-9."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+fuzz = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fuzz)
+
+
+def test_case_generator_is_deterministic():
+    a, b = fuzz.draw_case(5), fuzz.draw_case(5)
+    assert a == b and fuzz.draw_case(6) != a
+    m1, r1, k1 = fuzz.make_inputs(a)
+    m2, r2, k2 = fuzz.make_inputs(b)
+    assert m1.tobytes() == m2.tobytes() and r1.tobytes() == r2.tobytes() and (k1 is None) == (k2 is None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 121))
+def test_random_tile_case_matches_oracle(ops, O, seed):
+    from karios_amd.resident import ResidentPair
+    case = fuzz.draw_case(seed, max_size=420)
+    fails = fuzz.run_case(case, ops, O, ResidentPair)
+    assert not fails, f"{fails} for {case}"

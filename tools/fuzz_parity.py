@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep of the tile pipeline (run on the GPU box).
+
+Every case draws an image size, pixel type, shift, no-data pattern, user mask, Laplacian kernel sizes, polarity and
+tracker parameters from a seeded generator, runs the oracle (`oracle.klt_tile` + `zncc_batch`) and the library
+(`ops.klt_tile` through the C ABI from host buffers and `ResidentPair.match_tile` on resident data) and compares:
+
+  corners p0            bit-identical (same points, same strength order)
+  p1, p0r               bit-identical (the parity gate of SURVEY 8d is 1e-3 px; we report the stricter result)
+  frame x0,y0,dx,dy,score   bit-identical, same (x0, y0) order
+  zncc_score            <= 1e-9 (fp64), same NaN pattern
+
+    python tools/fuzz_parity.py --cases 200 --seed 1 [--max-size 700]
+
+Prints one line per failing case and a summary; exit code 1 when anything differed.  `tests/test_gpu_fuzz.py` runs a
+short fixed slice of the same generator inside the GPU suite.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DTYPES = (np.uint16, np.uint16, np.uint8, np.int16, np.float32)
+KSIZES = (1, 3, 5, 7, 7, 9, 11)
+BLOCKS = (3, 5, 7, 9, 15, 15, 4, 8, 21)
+WINS = (9, 15, 21, 25, 25, 31)
+MAXC = (0, 40, 500, 5000, 20000)
+QUAL = (0.001, 0.01, 0.1, 0.1, 0.3)
+
+
+def draw_case(seed: int, max_size: int = 700):
+    """-> dict describing one case (all randomness from `seed`)."""
+    rng = np.random.default_rng(1000003 * seed + 17)
+    H = int(rng.integers(40, max_size + 1))
+    W = int(rng.integers(40, max_size + 1))
+    if rng.random() < 0.15:                      # narrow / flat tiles: fewer strips than one wave covers, odd tails
+        if rng.random() < 0.5:
+            W = int(rng.integers(33, 130))
+        else:
+            H = int(rng.integers(33, 90))
+    case = dict(
+        seed=seed, H=H, W=W, dtype=DTYPES[rng.integers(len(DTYPES))],
+        sx=float(rng.uniform(-1.5, 1.5)), sy=float(rng.uniform(-1.5, 1.5)),
+        wedge=bool(rng.random() < 0.3), user_mask=bool(rng.random() < 0.3),
+        nodata_mon=(1.0 if rng.random() < 0.2 else None), nodata_ref=(None if rng.random() < 0.8 else 0.0),
+        mon_k=int(KSIZES[rng.integers(len(KSIZES))]), ref_k=int(KSIZES[rng.integers(len(KSIZES))]),
+        invert=bool(rng.random() < 0.25),
+        blocksize=int(BLOCKS[rng.integers(len(BLOCKS))]), winsize=int(WINS[rng.integers(len(WINS))]),
+        maxCorners=int(MAXC[rng.integers(len(MAXC))]), qualityLevel=float(QUAL[rng.integers(len(QUAL))]),
+        minDistance=float(rng.choice([0.0, 1.0, 2.5, 5.0, 10.0, 10.0, 14.3])),
+        noise=float(rng.choice([0.0, 15.0, 60.0])),
+    )
+    if rng.random() < 0.5:
+        case["ref_k"] = case["mon_k"]
+    return case
+
+
+def make_inputs(case):
+    from karios_amd import synth
+    rng = np.random.default_rng(case["seed"] * 7919 + 3)
+    mon, ref = synth.make_pair(case["H"], case["W"], case["sx"], case["sy"], seed=20260101 + case["seed"],
+                               noise_sigma=case["noise"], nodata_wedge=case["wedge"])
+    dt = case["dtype"]
+    if dt is np.uint8:
+        mon, ref = (mon >> 5).clip(0, 255).astype(np.uint8), (ref >> 5).clip(0, 255).astype(np.uint8)
+    elif dt is np.int16:
+        mon, ref = (mon.astype(np.int32) - 4000).astype(np.int16), (ref.astype(np.int32) - 4000).astype(np.int16)
+        if case["wedge"]:                         # keep the no-data value 0 where the wedge was
+            yy, xx = np.ogrid[:case["H"], :case["W"]]
+            wedge = (xx + yy) < 0.45 * case["W"]
+            mon[wedge] = 0
+            ref[wedge] = 0
+    elif dt is np.float32:
+        mon, ref = mon.astype(np.float32) * np.float32(0.37), ref.astype(np.float32) * np.float32(0.37)
+        if rng.random() < 0.5:                    # NaNs count as invalid pixels and are ignored by the stretch
+            for a in (mon, ref):
+                yy = rng.integers(0, case["H"], 20)
+                xx = rng.integers(0, case["W"], 20)
+                a[yy, xx] = np.nan
+    mask = None
+    if case["user_mask"]:
+        mask = np.full((case["H"], case["W"]), 255, np.uint8)
+        for _ in range(int(rng.integers(1, 6))):
+            y0, x0 = int(rng.integers(0, case["H"])), int(rng.integers(0, case["W"]))
+            mask[y0:y0 + int(rng.integers(5, 120)), x0:x0 + int(rng.integers(5, 120))] = 0
+    return mon, ref, mask
+
+
+def run_case(case, ops, O, ResidentPair):
+    """-> list of failure strings (empty = parity)."""
+    mon, ref, mask = make_inputs(case)
+    conf = O.default_conf(maxCorners=case["maxCorners"], blocksize=case["blocksize"], matching_winsize=case["winsize"],
+                          qualityLevel=case["qualityLevel"], minDistance=case["minDistance"],
+                          laplacian_kernel_size={"mon": case["mon_k"], "ref": case["ref_k"]},
+                          laplacian_invert_polarity=case["invert"])
+    fails = []
+    exp = O.klt_tile(mon, ref, conf, mask_box=mask, nodata_mon=case["nodata_mon"], nodata_ref=case["nodata_ref"],
+                     invert_mon=case["invert"])
+    status, tracks = ops.klt_tile(ref, mon, conf, mask_box=mask, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
+                                  mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
+    pair = ResidentPair.upload(mon, ref, mask=mask)
+    pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
+    frame = pair.match_tile(conf, zncc_threshold=0.4)
+    if exp is None:
+        if status == "ok":
+            fails.append(f"oracle None, library returned {len(tracks[0])} points")
+        if frame is not None:
+            fails.append("oracle None, resident frame not None")
+        return fails
+    if status != "ok":
+        return [f"oracle has {exp['Ninit']} corners, library status {status}"]
+    p0e = O.good_features(exp["lap_ref"], exp["mask"], conf.maxCorners, conf.qualityLevel, conf.minDistance, conf.blocksize)
+    p1e = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0e, case["winsize"])
+    p0re = O.pyr_lk(exp["lap_mon"], exp["lap_ref"], p1e, case["winsize"])
+    if tracks[0].shape != p0e.shape or not np.array_equal(tracks[0], p0e):
+        fails.append(f"p0 differs ({len(tracks[0])} vs {len(p0e)} corners)")
+        return fails
+    for name, got, want in (("p1", tracks[1], p1e), ("p0r", tracks[2], p0re)):
+        if not np.array_equal(got, want):
+            fails.append(f"{name} not bit-identical: max |diff| {np.abs(got - want).max():.3g} at {int(np.abs(got - want).argmax()) // 2}")
+    n_exp = len(exp["x0"])
+    if frame is None:
+        if n_exp:
+            fails.append(f"resident frame None, oracle has {n_exp} rows")
+        return fails
+    if len(frame) != n_exp:
+        fails.append(f"frame rows {len(frame)} vs {n_exp}")
+        return fails
+    for col in ("x0", "y0", "dx", "dy", "score"):
+        if not np.array_equal(frame[col].to_numpy(), exp[col]):
+            fails.append(f"frame column {col} differs: max |diff| {np.abs(frame[col].to_numpy() - exp[col]).max():.3g}")
+    keep = exp["score"] >= np.float32(0.4)
+    z = np.full(n_exp, np.nan)
+    if keep.any():
+        z[keep] = O.zncc_batch(ref, mon, exp["x0"][keep], exp["y0"][keep], exp["dx"][keep], exp["dy"][keep])
+    got = frame["zncc_score"].to_numpy()
+    if not np.array_equal(np.isnan(got), np.isnan(z)):
+        fails.append("zncc NaN pattern differs")
+    elif np.nanmax(np.abs(got - z), initial=0.0) > 1e-9:
+        fails.append(f"zncc max |diff| {np.nanmax(np.abs(got - z)):.3g}")
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1, help="first case seed")
+    ap.add_argument("--max-size", type=int, default=700)
+    ap.add_argument("--budget-s", type=float, default=1e9, help="stop starting new cases after this many seconds")
+    a = ap.parse_args()
+    from oracle import oracle as O
+    O.build()
+    from karios_amd import ops
+    from karios_amd.resident import ResidentPair
+    t0 = time.time()
+    bad = done = 0
+    for s in range(a.seed, a.seed + a.cases):
+        if time.time() - t0 > a.budget_s:
+            break
+        case = draw_case(s, a.max_size)
+        try:
+            fails = run_case(case, ops, O, ResidentPair)
+        except Exception as e:   # noqa: BLE001 - a crash in one case must not hide the others
+            fails = [f"exception {type(e).__name__}: {e}"]
+        done += 1
+        if fails:
+            bad += 1
+            print(f"FAIL seed {s}: {'; '.join(fails)}\n     {case}", flush=True)
+    print(f"fuzz_parity: {done} cases (seeds {a.seed}..{a.seed + done - 1}), {bad} failing, {time.time() - t0:.1f} s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
