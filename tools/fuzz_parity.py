@@ -57,6 +57,10 @@ def draw_case(seed: int, max_size: int = 700):
     )
     if rng.random() < 0.5:
         case["ref_k"] = case["mon_k"]
+    case["box"] = None
+    if rng.random() < 0.35 and H >= 80 and W >= 80:   # an inner tile of the resident pair (row-strided views on the host path)
+        bx, by = int(rng.integers(40, W + 1)), int(rng.integers(40, H + 1))
+        case["box"] = (int(rng.integers(0, W - bx + 1)), int(rng.integers(0, H - by + 1)), bx, by)
     return case
 
 
@@ -99,13 +103,18 @@ def run_case(case, ops, O, ResidentPair):
                           laplacian_kernel_size={"mon": case["mon_k"], "ref": case["ref_k"]},
                           laplacian_invert_polarity=case["invert"])
     fails = []
-    exp = O.klt_tile(mon, ref, conf, mask_box=mask, nodata_mon=case["nodata_mon"], nodata_ref=case["nodata_ref"],
-                     invert_mon=case["invert"])
-    status, tracks = ops.klt_tile(ref, mon, conf, mask_box=mask, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
+    box = case.get("box")
+    x_off, y_off, bx, by = box if box is not None else (0, 0, case["W"], case["H"])
+    sl = (slice(y_off, y_off + by), slice(x_off, x_off + bx))
+    mon_b, ref_b, mask_b = mon[sl], ref[sl], (None if mask is None else mask[sl])      # views: rows keep the full stride
+    exp = O.klt_tile(np.ascontiguousarray(mon_b), np.ascontiguousarray(ref_b), conf,
+                     mask_box=None if mask_b is None else np.ascontiguousarray(mask_b), nodata_mon=case["nodata_mon"],
+                     nodata_ref=case["nodata_ref"], x_off=x_off, y_off=y_off, invert_mon=case["invert"])
+    status, tracks = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
                                   mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
     pair = ResidentPair.upload(mon, ref, mask=mask)
     pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
-    frame = pair.match_tile(conf, zncc_threshold=0.4)
+    frame = pair.match_tile(conf, box=box, zncc_threshold=0.4)
     if exp is None:
         if status == "ok":
             fails.append(f"oracle None, library returned {len(tracks[0])} points")
