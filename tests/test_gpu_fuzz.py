@@ -27,3 +27,12 @@ def test_random_tile_case_matches_oracle(ops, O, seed):
     case = fuzz.draw_case(seed, max_size=420)
     fails = fuzz.run_case(case, ops, O, ResidentPair)
     assert not fails, f"{fails} for {case}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 25))
+def test_random_aux_case_matches_oracle(ops, O, seed):
+    """Phase correlation, shift_image, ZNCC / MI on random (also out-of-range) key points, outlier-filter tile."""
+    from karios_amd.resident import ResidentPair
+    fails = fuzz.run_aux_case(seed, ops, O, ResidentPair)
+    assert not fails, fails

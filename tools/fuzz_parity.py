@@ -155,8 +155,69 @@ def run_case(case, ops, O, ResidentPair):
     return fails
 
 
+def run_aux_case(seed, ops, O, ResidentPair):
+    """Entry points around the tile pipeline: phase correlation, shift_image, MI / NMI, DN filter, the outlier-filter
+    branch of `match_tile`.  -> list of failure strings."""
+    from karios_amd import synth
+    rng = np.random.default_rng(424243 * seed + 5)
+    fails = []
+    H, W = int(rng.integers(64, 420)), int(rng.integers(64, 420))
+    dt = (np.uint16, np.uint8, np.int16, np.float32)[rng.integers(4)]
+    # --- phase correlation of an integer-shifted copy (random shape: odd sizes, large prime factors) ---------------
+    base, _ = synth.make_pair(H + 120, W + 120, 0.0, 0.0, seed=777 + seed, noise_sigma=0.0)
+    sy, sx = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+    a = base[60:60 + H, 60:60 + W]
+    b = base[60 - sy:60 - sy + H, 60 - sx:60 - sx + W]
+    if dt is np.uint8:
+        a, b = (a >> 5).astype(np.uint8), (b >> 5).astype(np.uint8)
+    else:
+        a, b = a.astype(dt), b.astype(dt)
+    got, want = ops.phase_cross_correlation(b, a), O.phase_cross_correlation(b, a)
+    if not np.array_equal(got, want):
+        fails.append(f"phase correlation {got} vs oracle {want} (true shift {sy},{sx}; {H}x{W} {np.dtype(dt).name})")
+    # --- shift_image, also beyond the image ------------------------------------------------------------------------
+    yo, xo = int(rng.integers(-H - 3, H + 4)), int(rng.integers(-W - 3, W + 4))
+    if rng.random() < 0.7:
+        yo, xo = int(rng.integers(-50, 51)), int(rng.integers(-50, 51))
+    img = a if rng.random() < 0.5 else a.astype(np.float64)
+    if not np.array_equal(ops.shift_image(img, yo, xo), O.shift_image(img, yo, xo)):
+        fails.append(f"shift_image({yo},{xo}) differs ({H}x{W} {img.dtype})")
+    # --- scores and filters on random key points, including out-of-range ones ---------------------------------------
+    mon, ref = synth.make_pair(H, W, float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), seed=99 + seed,
+                               nodata_wedge=bool(rng.random() < 0.4))
+    n = int(rng.integers(1, 300))
+    x0 = rng.integers(-5, W + 5, n).astype(np.float32)
+    y0 = rng.integers(-5, H + 5, n).astype(np.float32)
+    dx = rng.uniform(-3, 3, n).astype(np.float32)
+    dy = rng.uniform(-3, 3, n).astype(np.float32)
+    if rng.random() < 0.3:                        # x.5 sums: Python's banker's rounding of the float32 sum
+        dx[: n // 2] = np.float32(0.5)
+        dy[: n // 2] = np.float32(-1.5)
+    gz, wz = ops.zncc_batch(ref, mon, x0, y0, dx, dy), O.zncc_batch(ref, mon, x0, y0, dx, dy)
+    if not np.array_equal(np.isnan(gz), np.isnan(wz)) or np.nanmax(np.abs(gz - wz), initial=0.0) > 1e-9:
+        fails.append("zncc_batch differs on random key points")
+    (gs, gn), (ws, wn) = ops.mi_batch(ref, mon, x0, y0, dx, dy), O.mi_batch(ref, mon, x0, y0, dx, dy)
+    for nm, g, w in (("studholme", gs, ws), ("nmi", gn, wn)):
+        if not np.array_equal(np.isnan(g), np.isnan(w)) or np.nanmax(np.abs(g - w), initial=0.0) > 1e-9:
+            fails.append(f"mi_batch {nm} differs: {np.nanmax(np.abs(g - w), initial=0.0):.3g}")
+    # --- tile with the iterative outlier filter (klt.py:52-71) ------------------------------------------------------
+    conf = O.default_conf(maxCorners=int(rng.choice([200, 2000])), outliers_filtering=True,
+                          laplacian_kernel_size=int(rng.choice([3, 5, 7])))
+    exp = O.klt_tile(mon, ref, conf)
+    frame = ResidentPair.upload(mon, ref).match_tile(conf)
+    if (exp is None) != (frame is None):
+        fails.append("outlier-filter tile: None mismatch")
+    elif exp is not None:
+        for col in ("x0", "y0", "dx", "dy", "score"):
+            if len(frame) != len(exp[col]) or not np.array_equal(frame[col].to_numpy(), exp[col]):
+                fails.append(f"outlier-filter tile: column {col} differs")
+                break
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--what", choices=("tile", "aux"), default="tile")
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1, help="first case seed")
     ap.add_argument("--max-size", type=int, default=700)
@@ -171,9 +232,9 @@ def main():
     for s in range(a.seed, a.seed + a.cases):
         if time.time() - t0 > a.budget_s:
             break
-        case = draw_case(s, a.max_size)
+        case = draw_case(s, a.max_size) if a.what == "tile" else {"aux_seed": s}
         try:
-            fails = run_case(case, ops, O, ResidentPair)
+            fails = run_case(case, ops, O, ResidentPair) if a.what == "tile" else run_aux_case(s, ops, O, ResidentPair)
         except Exception as e:   # noqa: BLE001 - a crash in one case must not hide the others
             fails = [f"exception {type(e).__name__}: {e}"]
         done += 1
