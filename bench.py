@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured str
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (0 = half the image)")
@@ -145,27 +145,41 @@ def main():
     ctx = Context(local_rank)
     pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
 
-    # One step = one band pair through the whole hot path.  The device half (KLT tile + FB score + ZNCC, ONE library call
-    # ending with the D2H copy of the finished frame block) runs on this thread; the host half (frame block -> pandas
-    # DataFrame + radial error / angle columns, numpy as in the reference) runs on a worker thread and overlaps the
-    # device half of the NEXT step (ctypes releases the GIL inside the library).  Every frame is complete before the
-    # closing fence, so K timed steps are K finished pairs.
+    # One step = one band pair through the whole hot path.  The main thread SUBMITS the pair (km_klt_tile_frame_submit: the
+    # call returns when the pair's last kernel and the copy of its frame block are enqueued, so the next pair's dense
+    # stages queue right behind them); a worker thread waits for the block and runs the host half (frame block -> pandas
+    # DataFrame + radial error / angle columns, numpy as in the reference) while the device already works on the next
+    # pair (ctypes releases the GIL inside the library).  Every frame is complete before the closing fence, so K timed
+    # steps are K finished pairs.
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=1)
+    stage_sum = {}
+    totals = {"rows": 0, "frames": 0, "n_init": 0}
 
-    def host_half(raw):
+    def host_half(pend):
+        raw = pend.wait()
+        spans = pend.stage_ms()
         frame = raw.to_frame()
-        return None if frame is None else pair.score_frame(frame, 0.4)
+        return raw, spans, (None if frame is None else pair.score_frame(frame, 0.4))
 
-    def step(pending):
-        raw = pair.match_tile_raw(conf, zncc_threshold=0.4)
+    def collect(pending):
+        """Result of an earlier step: its frame, and - the path's only exchange step - the all-gather of every rank's
+        key-point block (device pipeline layout) over RCCL; the gathered blocks stay in HBM."""
+        raw, spans, frame = pending.result()
         n_rows = raw.n_rows
         if world > 1:
-            # the path's only exchange step: all-gather of the per-band key-point blocks (device pipeline layout) over RCCL
-            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=coll_dev)   # gathered blocks stay in HBM
-        nxt = pool.submit(host_half, raw)
-        frame = pending.result() if pending is not None else None
-        return nxt, frame, n_rows
+            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=coll_dev)
+        totals["rows"] += n_rows
+        totals["frames"] += 1
+        totals["n_init"] = int(raw.block[:4].view(np.int32)[1])
+        for k, v in spans.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        return frame
+
+    def step(pending):
+        nxt = pool.submit(host_half, pair.submit_tile(conf, zncc_threshold=0.4))
+        frame = collect(pending) if pending is not None else None
+        return nxt, frame
 
     def fence():
         ctx.sync()
@@ -176,25 +190,24 @@ def main():
 
     pending = None
     for _ in range(a.warmup):
-        pending, _, _ = step(pending)
+        pending, _ = step(pending)
     if pending is not None:
-        pending.result()
+        collect(pending)
         pending = None
     ctx.set_profiling(True)
-    stage_sum = {}
+    stage_sum.clear()
+    totals.update(rows=0, frames=0)
     fence()
     t0 = time.perf_counter()
-    n_kp_total = 0
     frame = None
     for _ in range(a.steps):
-        pending, prev_frame, n_all = step(pending)
-        n_kp_total += n_all
-        for k, v in ctx.stage_ms().items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-    frame = pending.result()          # the last pair's frame: part of the timed region
+        pending, _ = step(pending)
+    frame = collect(pending)          # the last pair's frame: part of the timed region
     fence()
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
+    assert totals["frames"] == a.steps
+    n_kp_total = totals["rows"]
     if world > 1:
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,6 +215,7 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     mpx_per_s = world * S * S / 1e6 / (dt / a.steps)
     stats = ctx.stats()
+    stats.n_init = totals["n_init"]       # asynchronous submissions: the count travels in the frame block's header
 
     out = None
     if rank == 0:

@@ -197,6 +197,21 @@ int km_klt_tile_frame_zncc_dev(km_ctx *ctx, const void *d_ref, const void *d_mon
                                const km_klt_params *prm, float x_off, float y_off, const void *d_ref_full, const void *d_mon_full,
                                int H_full, int W_full, ptrdiff_t stride_ref_full, ptrdiff_t stride_mon_full,
                                double zncc_threshold, void *host_out, int cap);
+/* Stream-of-tiles form of the two calls above (a KLT.match loop over tiles, klt.py:220-234, or the per-band loop of
+ * KariosAPI, core.py:845-871): km_klt_tile_frame_submit returns once the last kernel and the copy of the frame block
+ * are ENQUEUED; the next submission then queues its dense stages right behind this frame's tail.  d_ref_full == NULL:
+ * no ZNCC column.  km_frame_wait blocks until frame `ticket` is complete and returns its block (layout above) in pinned
+ * host memory owned by the context, valid until KM_FRAME_SLOTS (3) further submissions; it touches nothing but that
+ * frame's slot, so another thread may call it while this context is already submitting the next frame.
+ * km_frame_stage_ms: the frame's stage spans (km_set_profiling), order of km_stage_name. */
+int km_klt_tile_frame_submit(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W,
+                             ptrdiff_t stride_ref, ptrdiff_t stride_mon, const uint8_t *d_mask,
+                             ptrdiff_t stride_mask, const double *nodata_ref, const double *nodata_mon,
+                             const km_klt_params *prm, float x_off, float y_off, const void *d_ref_full,
+                             const void *d_mon_full, int H_full, int W_full, ptrdiff_t stride_ref_full,
+                             ptrdiff_t stride_mon_full, double zncc_threshold, int cap, int *ticket);
+int km_frame_wait(km_ctx *ctx, int ticket, const void **block, size_t *bytes);
+int km_frame_stage_ms(km_ctx *ctx, int ticket, float *out, int cap, int *n);
 int km_zncc_batch_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype,
                       int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
                       ptrdiff_t stride_mon, const float *d_x0, const float *d_y0,

@@ -78,6 +78,10 @@ SIGNATURES = {
                                    C.c_float, _vp, _i]),
     "km_klt_tile_frame_zncc_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), C.c_float,
                                         C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _vp, _i]),
+    "km_klt_tile_frame_submit": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), C.c_float,
+                                      C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _i, C.POINTER(C.c_int)]),
+    "km_frame_wait": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "km_frame_stage_ms": (_i, [_vp, _i, _vp, _i, C.POINTER(C.c_int)]),
     "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_mi_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "km_klt_auto_ksize_frame_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp, _i, C.c_float,

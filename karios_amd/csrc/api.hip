@@ -91,7 +91,7 @@ int km_ctx_create(int device, km_ctx **out)
     if (!c) return km_fail(nullptr, KM_E_NOMEM, "out of host memory");
     c->device = device;
     memset(&c->stats, 0, sizeof c->stats);
-    memset(c->ev_used, 0, sizeof c->ev_used);
+    memset(c->evs_used, 0, sizeof c->evs_used);
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         int rc = km_fail(nullptr, KM_E_HIP, "stream creation on device %d: %s", device, hipGetErrorString(e));
         delete c;
@@ -111,10 +111,15 @@ int km_ctx_destroy(km_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     kp_destroy(c);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+    for (km_frame_slot &f : c->fslot) {
+        if (f.host) (void)hipHostFree(f.host);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
     for (int i = 0; i < WS_COUNT; i++)
         if (c->ws[i].p) (void)hipFree(c->ws[i].p);
     if (c->ev_ready)
-        for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->ev[i][0]); (void)hipEventDestroy(c->ev[i][1]); }
+        for (int k = 0; k <= KM_FRAME_SLOTS; k++)
+            for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->evs[k][i][0]); (void)hipEventDestroy(c->evs[k][i][1]); }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return KM_OK;
@@ -138,7 +143,8 @@ int km_set_profiling(km_ctx *c, int enable)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     if (enable && !c->ev_ready) {
-        for (int i = 0; i < ST_COUNT; i++) { KM_HIP(c, hipEventCreate(&c->ev[i][0])); KM_HIP(c, hipEventCreate(&c->ev[i][1])); }
+        for (int k = 0; k <= KM_FRAME_SLOTS; k++)
+            for (int i = 0; i < ST_COUNT; i++) { KM_HIP(c, hipEventCreate(&c->evs[k][i][0])); KM_HIP(c, hipEventCreate(&c->evs[k][i][1])); }
         c->ev_ready = true;
     }
     c->profiling = enable != 0;
@@ -157,9 +163,9 @@ int km_get_stage_ms(km_ctx *c, float *out, int cap, int *n)
     int m = cap < ST_COUNT ? cap : ST_COUNT;
     for (int i = 0; i < m; i++) {
         out[i] = 0.f;
-        if (c->ev_ready && c->ev_used[i]) {
+        if (c->ev_ready && c->evs_used[0][i]) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) out[i] = ms;
+            if (hipEventElapsedTime(&ms, c->evs[0][i][0], c->evs[0][i][1]) == hipSuccess) out[i] = ms;
         }
     }
     if (n) *n = m;
@@ -212,9 +218,9 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
     if (reset == RESET_KLT)
-        { for (int i = ST_MINMAX; i <= ST_LK; i++) c->ev_used[i] = false; c->ev_used[ST_FRAME] = false; }
+        { for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false; c->evs_used[c->ev_cur][ST_FRAME] = false; }
     else if (reset == RESET_ZNCC)
-        c->ev_used[ST_ZNCC] = false;
+        c->evs_used[c->ev_cur][ST_ZNCC] = false;
     return KM_OK;
 }
 
@@ -768,8 +774,10 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
 static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
                            const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon, const km_klt_params *prm, float x_off,
                            float y_off, const void *d_ref_full, const void *d_mon_full, int Hf, int Wf, ptrdiff_t sref_f, ptrdiff_t smon_f,
-                           bool with_zncc, double zncc_threshold, void *host_out, int cap)
+                           bool with_zncc, double zncc_threshold, void *host_out, int cap, km_frame_slot *slot = nullptr)
 {
+    // slot != nullptr: km_klt_tile_frame_submit - the block goes to the slot's pinned buffer and the call returns without
+    // waiting for the tail of the pipeline (LK, FB test, ZNCC, copy), which then overlaps the caller's next submission
     int rc;
     if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
         (rc = check_image(c, d_mon, H, W, smon, "klt_tile_frame_dev")))
@@ -778,10 +786,10 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                       (rc = check_image(c, d_mon_full, Hf, Wf, smon_f, "klt_tile_frame_zncc_dev"))))
         return rc;
     if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: bad dtype %d", dtype);
-    if (!host_out || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: null output");
+    if ((!host_out && !slot) || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: null output");
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
-    c->ev_used[ST_ZNCC] = false;
+    c->evs_used[c->ev_cur][ST_ZNCC] = false;
     km_scalars *sc = scalars(c);
     const size_t pb = (size_t)cap * 2 * sizeof(float);
     const size_t fb = 16 + (size_t)cap * 6 * sizeof(float), ob = fb + (with_zncc ? (size_t)cap * sizeof(double) : 0);
@@ -805,6 +813,19 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                                    f + 3 * (size_t)cap, n_max, (const int *)d_out, f + 4 * (size_t)cap, (float)zncc_threshold,
                                    (double *)(d_out + fb))))
             return rc;
+    }
+    if (slot) {
+        if (slot->cap < ob) {
+            if (slot->host) KM_HIP(c, hipHostFree(slot->host));
+            slot->host = nullptr; slot->cap = 0;
+            KM_HIP(c, hipHostMalloc(&slot->host, ob + ob / 8, hipHostMallocDefault));
+            slot->cap = ob + ob / 8;
+        }
+        if (!slot->done) KM_HIP(c, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+        KM_HIP(c, hipMemcpyAsync(slot->host, d_out, ob, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipEventRecord(slot->done, c->stream));
+        slot->bytes = ob;
+        return KM_OK;
     }
     KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
@@ -963,6 +984,64 @@ int km_klt_tile_frame_zncc_dev(km_ctx *c, const void *d_ref, const void *d_mon, 
                            Hf, Wf, sref_f, smon_f, true, zncc_threshold, host_out, cap);
 }
 
+// Asynchronous form of km_klt_tile_frame[_zncc]_dev for a stream of tiles / band pairs: returns as soon as the last
+// kernel and the copy of the frame block are ENQUEUED (the corner selection still synchronises inside), so the caller's
+// next submission queues its dense stages right behind this frame's tail and the GPU never idles between frames.
+// km_frame_wait (any thread) blocks until frame `ticket` is complete and hands out its block in pinned host memory, valid
+// until KM_FRAME_SLOTS further submissions.  d_ref_full == NULL: no ZNCC column.
+int km_klt_tile_frame_submit(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t sref, ptrdiff_t smon,
+                             const uint8_t *d_mask, ptrdiff_t smask, const double *nodata_ref, const double *nodata_mon,
+                             const km_klt_params *prm, float x_off, float y_off, const void *d_ref_full, const void *d_mon_full, int Hf,
+                             int Wf, ptrdiff_t sref_f, ptrdiff_t smon_f, double zncc_threshold, int cap, int *ticket)
+{
+    if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    if (!ticket) return km_fail(c, KM_E_ARG, "klt_tile_frame_submit: null ticket");
+    const int k = c->fslot_next;
+    km_frame_slot *slot = &c->fslot[k];
+    if (slot->pending.load(std::memory_order_acquire)) {   // never waited for: its block is about to be overwritten
+        KM_HIP(c, hipEventSynchronize(slot->done));
+        slot->pending.store(0, std::memory_order_release);
+    }
+    c->ev_cur = 1 + k;
+    const int rc = tile_frame_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, x_off, y_off, d_ref_full,
+                                   d_mon_full, Hf, Wf, sref_f, smon_f, d_ref_full != nullptr, zncc_threshold, nullptr, cap, slot);
+    c->ev_cur = 0;
+    if (rc) return rc;
+    slot->pending.store(1, std::memory_order_release);
+    c->fslot_next = (k + 1) % KM_FRAME_SLOTS;
+    *ticket = k;
+    return KM_OK;
+}
+
+// Touches only the slot (no context state, no error string): safe from another thread while the context is submitting.
+int km_frame_wait(km_ctx *c, int ticket, const void **block, size_t *bytes)
+{
+    if (!c || ticket < 0 || ticket >= KM_FRAME_SLOTS || !block) return KM_E_ARG;
+    km_frame_slot *slot = &c->fslot[ticket];
+    if (!slot->done || !slot->pending.load(std::memory_order_acquire)) return KM_E_ARG;
+    if (hipEventSynchronize(slot->done) != hipSuccess) return KM_E_HIP;
+    slot->pending.store(0, std::memory_order_release);
+    *block = slot->host;
+    if (bytes) *bytes = slot->bytes;
+    return KM_OK;
+}
+
+// Stage spans of frame `ticket` (after km_frame_wait; profiling enabled), same order as km_get_stage_ms.
+int km_frame_stage_ms(km_ctx *c, int ticket, float *out, int cap, int *n)
+{
+    if (!c || ticket < 0 || ticket >= KM_FRAME_SLOTS || !out) return KM_E_ARG;
+    const int m = cap < ST_COUNT ? cap : ST_COUNT;
+    for (int i = 0; i < m; i++) {
+        out[i] = 0.f;
+        float ms = 0.f;
+        if (c->ev_ready && c->evs_used[1 + ticket][i] &&
+            hipEventElapsedTime(&ms, c->evs[1 + ticket][i][0], c->evs[1 + ticket][i][1]) == hipSuccess)
+            out[i] = ms;
+    }
+    if (n) *n = m;
+    return KM_OK;
+}
+
 int km_zncc_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
                       ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out)
 {
@@ -1010,7 +1089,7 @@ int km_mi_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
     if ((rc = begin_call(c)) || (rc = check_image(c, d_ref, Href, Wref, sref, "mi")) || (rc = check_image(c, d_mon, Hmon, Wmon, smon, "mi")))
         return rc;
     if (n < 0 || (n > 0 && (!d_x0 || !d_y0 || !d_dx || !d_dy || (!d_st && !d_nmi)))) return km_fail(c, KM_E_ARG, "mi: bad keypoint arrays");
-    c->ev_used[ST_MI] = false;
+    c->evs_used[c->ev_cur][ST_MI] = false;
     km_stage_timer t(c, ST_MI);
     return kmi_batch(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, nullptr, nullptr, 0.f, d_st, d_nmi);
 }

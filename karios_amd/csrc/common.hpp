@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <functional>
 #include <string>
 #include <vector>
@@ -99,6 +100,15 @@ struct km_scalars {
     unsigned int run_max_shard[64]; // sharded running max-eig keys of the 2-px fused kernel (same-address device-scope traffic serialises)
 };
 
+// One frame in flight of km_klt_tile_frame_submit: pinned host block, completion event.
+#define KM_FRAME_SLOTS 3
+struct km_frame_slot {
+    void *host = nullptr;
+    size_t cap = 0, bytes = 0;
+    hipEvent_t done = nullptr;
+    std::atomic<int> pending{0};
+};
+
 struct km_ctx {
     int device = 0;
     int n_cu = 256;            // compute units of the device (wave slots = n_cu * 4 SIMDs * waves per SIMD)
@@ -111,9 +121,14 @@ struct km_ctx {
     hipEvent_t ev_readback = nullptr;
     bool profiling = false;
     int fused_eig = 3;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip), 3 fused 2-px/lane kernel (k_eig2.hip)
-    hipEvent_t ev[ST_COUNT][2];
-    bool ev_used[ST_COUNT];
+    // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
+    // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)
+    hipEvent_t evs[KM_FRAME_SLOTS + 1][ST_COUNT][2];
+    bool evs_used[KM_FRAME_SLOTS + 1][ST_COUNT];
+    int ev_cur = 0;
     bool ev_ready = false;
+    km_frame_slot fslot[KM_FRAME_SLOTS];
+    int fslot_next = 0;
     km_klt_stats stats;
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
@@ -175,8 +190,8 @@ struct km_stage_timer {
     int s;
     km_stage_timer(km_ctx *ctx, int stage) : c(ctx), s(stage)
     {
-        if (c->profiling && c->ev_ready && !c->ev_used[s]) {
-            (void)hipEventRecord(c->ev[s][0], c->stream);
+        if (c->profiling && c->ev_ready && !c->evs_used[c->ev_cur][s]) {
+            (void)hipEventRecord(c->evs[c->ev_cur][s][0], c->stream);
         } else if (c->profiling && c->ev_ready) {
             s = -1;  // stage already timed in this call (only the first span is kept)
         }
@@ -184,8 +199,8 @@ struct km_stage_timer {
     ~km_stage_timer()
     {
         if (s >= 0 && c->profiling && c->ev_ready) {
-            (void)hipEventRecord(c->ev[s][1], c->stream);
-            c->ev_used[s] = true;
+            (void)hipEventRecord(c->evs[c->ev_cur][s][1], c->stream);
+            c->evs_used[c->ev_cur][s] = true;
         }
     }
 };

@@ -67,6 +67,36 @@ class RawFrame:
         return ResidentPair._frame_from_block(self.block, self.cap, self.with_zncc)
 
 
+class PendingFrame:
+    """A tile submitted with `ResidentPair.submit_tile`: the device is still working on its tail (LK, FB test, ZNCC, copy)
+    while the caller already submits the next tile.  `wait()` (any thread) -> `RawFrame`."""
+
+    def __init__(self, ctx: Context, ticket: int, cap: int, with_zncc: bool):
+        self.ctx, self.ticket, self.cap, self.with_zncc = ctx, ticket, cap, with_zncc
+        self._raw = None
+
+    def wait(self) -> "RawFrame":
+        if self._raw is None:
+            c = self.ctx
+            blk, nbytes = C.c_void_p(), C.c_size_t()
+            rc = c.lib.km_frame_wait(c.handle, self.ticket, C.byref(blk), C.byref(nbytes))
+            if rc != 0:
+                raise KariosHipError(f"km_frame_wait(ticket {self.ticket}) failed with status {rc}")
+            n32 = 4 + (8 if self.with_zncc else 6) * self.cap
+            pinned = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_float)), shape=(n32,))
+            self._raw = RawFrame(pinned.copy(), self.cap, self.with_zncc)   # the pinned slot is reused 3 submissions later
+        return self._raw
+
+    def stage_ms(self) -> dict:
+        """Stage spans of this frame (after `wait`, with `Context.set_profiling(True)`)."""
+        c = self.ctx
+        buf, n = (C.c_float * 16)(), C.c_int()
+        rc = c.lib.km_frame_stage_ms(c.handle, self.ticket, buf, 16, C.byref(n))
+        if rc != 0:
+            raise KariosHipError(f"km_frame_stage_ms failed with status {rc}")
+        return {c.lib.km_stage_name(i).decode(): float(buf[i]) for i in range(n.value)}
+
+
 class ResidentPair:
     """A monitored / reference image pair (plus optional user mask) resident in HBM."""
 
@@ -267,15 +297,43 @@ class ResidentPair:
         block, ring[slot], self._host_frame = self._host_frame, self._host_frame, None
         return RawFrame(block[:4 + (8 if with_zncc else 6) * cap], cap, with_zncc)
 
+    def submit_tile(self, conf, box=None, zncc_threshold=None) -> PendingFrame:
+        """Asynchronous `match_tile_raw` (km_klt_tile_frame_submit): returns when the tile's last kernel and the copy of
+        its frame block are enqueued, so the next `submit_tile` queues its dense stages right behind them - no GPU idle
+        time between tiles.  Up to three tiles may be pending; `PendingFrame.wait()` may run in another thread."""
+        if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
+            raise KariosHipError("ResidentPair.submit_tile: 'auto' modes and outlier filtering need ResidentPair.match_tile / matcher.KLT")
+        c = self.ctx
+        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
+        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
+            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        mon_k, ref_k = KLT._resolve_ksize(conf.laplacian_kernel_size)
+        prm = make_params(conf, mon_k, ref_k, bool(conf.laplacian_invert_polarity))
+        cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
+        es = self.dtype.itemsize
+        off = by_off * self.x_size + bx_off
+        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
+        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
+        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        with_zncc = zncc_threshold is not None
+        ticket = C.c_int(-1)
+        c.check(c.lib.km_klt_tile_frame_submit(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
+                                               by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(bx_off), float(by_off),
+                                               C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
+                                               self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
+                                               C.byref(ticket)), "km_klt_tile_frame_submit")
+        return PendingFrame(c, ticket.value, cap, with_zncc)
+
     def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
-        """`match` with the host half of tile i (DataFrame construction, optional `host_stage(frame)` such as
-        `score_frame`) overlapped with the device half of tile i+1.  Yields the frames in tile order, like `KLT.match`."""
+        """`match` as a pipeline: tile i+1 is submitted to the device (`submit_tile`) while a worker thread waits for tile i
+        and runs its host half (DataFrame construction, optional `host_stage(frame)` such as `score_frame`).  Yields the
+        frames in tile order, like `KLT.match`."""
         from concurrent.futures import ThreadPoolExecutor
         if boxes is None:
             boxes = KLT(conf).tile_boxes(self.x_size, self.y_size)
 
-        def host_half(raw):
-            frame = raw.to_frame()
+        def host_half(pend):
+            frame = pend.wait().to_frame()
             if frame is not None and host_stage is not None:
                 frame = host_stage(frame)
             return frame
@@ -283,7 +341,7 @@ class ResidentPair:
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
             for box in boxes:
-                raw = self.match_tile_raw(conf, box, zncc_threshold)
+                raw = self.submit_tile(conf, box, zncc_threshold)
                 nxt = pool.submit(host_half, raw)
                 if pending is not None:
                     frame = pending.result()

@@ -388,6 +388,47 @@ def test_resident_pair_pipelined_match_equals_tile_by_tile(ops, O):
         pd.testing.assert_frame_equal(ref_frame[sorted(ref_frame.columns)], b[sorted(b.columns)])
 
 
+def test_submit_wait_frames_in_flight(ops, O):
+    """km_klt_tile_frame_submit / km_frame_wait: three tiles in flight, waited for out of order and from another thread,
+    give the blocks of the synchronous call; an unwaited slot is recycled; a stale ticket is refused."""
+    import threading
+    import pandas as pd
+    from karios_amd._lib import KariosHipError
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(420, 610, -0.3, 0.45, seed=11, nodata_wedge=True)
+    conf = KLTConfiguration(maxCorners=700)
+    pair = ResidentPair.upload(mon, ref)
+    boxes = [(0, 0, 300, 200), (300, 0, 310, 420), (5, 200, 280, 220), None]
+    want = [pair.match_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
+    pair.ctx.set_profiling(True)
+    try:
+        pend = [pair.submit_tile(conf, box=b, zncc_threshold=0.4) for b in boxes[:3]]
+        got = [None] * 3
+        th = threading.Thread(target=lambda: got.__setitem__(2, pend[2].wait().to_frame()))
+        th.start()
+        got[1] = pend[1].wait().to_frame()
+        got[0] = pend[0].wait().to_frame()
+        th.join()
+        spans = pend[1].stage_ms()
+        assert spans["lk_fwd_bwd"] > 0 and spans["stretch_laplacian_mask"] > 0 and spans["zncc"] > 0
+    finally:
+        pair.ctx.set_profiling(False)
+    for a, b in zip(want[:3], got):
+        pd.testing.assert_frame_equal(a, b)
+    # four submissions without a wait: the first slot is recycled (its frame is lost), the last three are intact
+    pend = [pair.submit_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
+    for a, p in zip(want[1:], pend[1:]):
+        pd.testing.assert_frame_equal(a, p.wait().to_frame())
+    with pytest.raises(KariosHipError):
+        pend[1].__class__(pair.ctx, pend[1].ticket, pend[1].cap, True).wait()   # that slot has been consumed
+    # no ZNCC column, no-features tile
+    p = pair.submit_tile(conf, box=boxes[0])
+    pd.testing.assert_frame_equal(pair.match_tile(conf, box=boxes[0]), p.wait().to_frame())
+    flat = ResidentPair.upload(np.full((64, 64), 7, np.uint16), np.full((64, 64), 7, np.uint16))
+    assert flat.submit_tile(conf).wait().to_frame() is None
+
+
 def test_auto_ksize_batched_search_matches_oracle_loop(ops, O):
     """km_klt_auto_ksize_frame_dev == the reference's 5x5 loop (klt.py:465-545) done with the oracle:
     every inlier ratio, the winning pair (first maximum in itertools.product order) and the winner's frame."""
