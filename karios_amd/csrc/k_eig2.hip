@@ -36,6 +36,18 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ int e2_dpp(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
+__device__ __forceinline__ unsigned e2_opaque(unsigned x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// lo16(a) * lo16(b) + c  (v_mad_i32_i16: the halves are selected by the instruction, no extraction)
+__device__ __forceinline__ int e2_mad_lo(uint32_t a, uint32_t b, int c)
+{
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ int e2_lane_m1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane-1, 0 at lane 0
 __device__ __forceinline__ int e2_lane_p1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }   // lane+1, 0 at lane 63
 __device__ __forceinline__ int e2_scan(int v)
@@ -126,9 +138,9 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     auto run = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;   // interior strip: no column border handling at all
     auto load_raw = [&](const uint8_t *base, int r) -> uint32_t {   // two bytes of row r (inside the image)
-        const uint8_t *rowp = base + (size_t)r * W;
+        const uint8_t *rowp = base + (size_t)r * W;   // wave-uniform row base + opaque 32-bit lane offset: no per-lane 64-bit arithmetic
         unsigned short v;
-        __builtin_memcpy(&v, rowp + (unsigned)(FAST ? c0 : c_load), 2);
+        __builtin_memcpy(&v, rowp + e2_opaque((unsigned)(FAST ? c0 : c_load)), 2);
         return (uint32_t)v;
     };
     auto unpack_src = [&](uint32_t w) -> uint32_t {      // bytes (b0, b1) -> 16-bit pair
@@ -168,16 +180,18 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
         dy = e2u(e2s(t1_m) + t1 + t1 + e2s(t1_p));
         if (!FAST) { dx &= inimg_pair; dy &= inimg_pair; }   // products of outside columns are 0
     };
-    int V[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    // vertical box sums of the three products: VP = pixel 0 + pixel 1 of the lane's pair (one v_dot2_i32_i16 per product and
+    // row), V0 = pixel 0 alone (one v_mad_i32_i16 on the low halves); the windows need exactly these two
+    int VP[3] = {0, 0, 0}, V0[3] = {0, 0, 0};
     auto accumulate = [&](uint32_t dx, uint32_t dy, bool subtract) {
         const e2_s2 x = e2s(dx), y = e2s(dy);
         const e2_s2 sx = subtract ? -x : x, sy = subtract ? -y : y;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            V[0][k] += (int)x[k] * (int)sx[k];
-            V[1][k] += (int)x[k] * (int)sy[k];
-            V[2][k] += (int)y[k] * (int)sy[k];
-        }
+        VP[0] = __builtin_amdgcn_sdot2(x, sx, VP[0], false);
+        VP[1] = __builtin_amdgcn_sdot2(x, sy, VP[1], false);
+        VP[2] = __builtin_amdgcn_sdot2(y, sy, VP[2], false);
+        V0[0] = e2_mad_lo(dx, e2u(sx), V0[0]);
+        V0[1] = e2_mad_lo(dx, e2u(sy), V0[1]);
+        V0[2] = e2_mad_lo(dy, e2u(sy), V0[2]);
     };
     // horizontal window W(i) = S(i + Rr) - S(i - L - 1), S = inclusive pixel prefix over the strip (i = 2*lane + p)
     constexpr int UO[2] = {(0 + Rr) / 2, (1 + Rr) / 2}, UJ[2] = {(0 + Rr) % 2, (1 + Rr) % 2};
@@ -188,8 +202,8 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     auto windows = [&](int (&Wd)[3][2]) {
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            const int A = e2_scan(V[q][0] + V[q][1]), Ap = e2_lane_m1(A);
-            const int X[2] = {Ap + V[q][0], A};
+            const int A = e2_scan(VP[q]), Ap = e2_lane_m1(A);
+            const int X[2] = {Ap + V0[q], A};
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int up = UO[p] == 0 ? X[UJ[p]] : bperm_from(UO[p], X[UJ[p]]);
