@@ -241,7 +241,6 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     float best = -INFINITY;
     // ---- EMIT: candidate staging and the running threshold (see k_eigc.hip for the derivation)
     unsigned long long *st = stage[EMIT ? wv : 0];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned cnt = 0;
     const unsigned shard = (unsigned)wave_id % KM_NSHARD;
     const size_t cap_s = cap / KM_NSHARD;
@@ -329,9 +328,10 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
                     const float nb = fmaxf(fmaxf(left, right), fmaxf(e2r[p], e[p]));
                     const bool is = cand_px[p] && e1r[p] > thr_run && e1r[p] != 0.f && e1r[p] >= nb && ((mk1 >> (8 * p)) & 0xffu) != 0u;
                     const unsigned long long bal = __ballot(is);
-                    const unsigned slot = cnt + (unsigned)__popcll(bal & lt_mask);
-                    // unconditional store (no branch in the row body): non-candidates and overflow go to the lane's dummy slot
-                    st[(is && slot < EIG2_STAGE) ? slot : EIG2_STAGE + (unsigned)lane] =
+                    const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    // unconditional store (no branch in the row body): non-candidates go to the lane's dummy slot, an overflowing
+                    // candidate to some dummy slot (min: never beyond the array; the overflow flag is raised by flush_if)
+                    st[min(is ? slot : ~0u, EIG2_STAGE + (unsigned)lane)] =
                         ((unsigned long long)__float_as_uint(e1r[p]) << 32) | (unsigned long long)((unsigned)(y - 1) * (unsigned)W + (unsigned)(c0 + p));
                     cnt += (unsigned)__popcll(bal);
                 }
