@@ -733,8 +733,8 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     // work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
     unsigned tile;
     if (!km_xcd_tile((unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u, tile)) return;
-    const int wave_lin = (int)tile * 4 + (tid >> 6);
-    const int wave_id = SPLIT ? wave_lin >> 1 : wave_lin;           // work item
+    const int wave_lin = (int)tile * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);   // readfirstlane: the compiler must know it is wave-uniform
+    const int wave_id = SPLIT ? wave_lin >> 1 : wave_lin;           // work item (row arithmetic, loop control and row bases stay scalar)
     const int img_sel = SPLIT ? __builtin_amdgcn_readfirstlane(wave_lin & 1) : -1;
     if (wave_id >= nitems) { if (!SPLIT && MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
     const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
     unsigned tile;
     if (!km_xcd_tile((unsigned)(gxw * gyw), tile)) return;
     const int bx = (int)tile % gxw, by = (int)tile / gxw;
-    const int strip = bx * 4 + (threadIdx.x >> 6);
+    const int strip = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, known to the compiler
     const int wave_id = by * (gxw * 4) + strip;
     if (strip >= nstrips) { if (lane == 0) max_partial[wave_id] = 0u; return; }
     const int xs = strip * STRIDE;
@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(256) void cand_kernel(const float *__restrict__ eig
     unsigned tile;
     if (!km_xcd_tile((unsigned)(gxw * gyw), tile)) return;
     const int bx = (int)tile % gxw, by = (int)tile / gxw;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strip = bx * 4 + wv;
     if (strip >= nstrips) return;
     unsigned long long *st = stage[wv];

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
 {
     __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
     __shared__ double s_edges[4][2][MI_BINS + 1];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
     if (k >= (d_n ? min(*d_n, n) : n)) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);

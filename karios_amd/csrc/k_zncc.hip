@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
                                                    const float *__restrict__ dy, int n, const int *__restrict__ d_n,
                                                    const float *__restrict__ score, float score_thr, double *__restrict__ out)
 {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // key point of this wave: uniform, scalar addressing
     const int lane = threadIdx.x & 63;
     if (k >= (d_n ? min(*d_n, n) : n)) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
