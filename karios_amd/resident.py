@@ -333,15 +333,17 @@ class ResidentPair:
             boxes = KLT(conf).tile_boxes(self.x_size, self.y_size)
 
         def host_half(pend):
-            frame = pend.wait().to_frame()
+            frame = (pend.wait() if isinstance(pend, PendingFrame) else pend).to_frame()
             if frame is not None and host_stage is not None:
                 frame = host_stage(frame)
             return frame
 
+        # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
+        submit = self.submit_tile if conf.maxCorners > 0 else self.match_tile_raw
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
             for box in boxes:
-                raw = self.submit_tile(conf, box, zncc_threshold)
+                raw = submit(conf, box, zncc_threshold)
                 nxt = pool.submit(host_half, raw)
                 if pending is not None:
                     frame = pending.result()
