@@ -45,6 +45,17 @@ void *km_ws(km_ctx *c, int slot, size_t bytes)
     return p;
 }
 
+void *km_pinned_rb(km_ctx *c, size_t bytes)
+{
+    if (c->pinned_rb_cap >= bytes) return c->pinned_rb;
+    if (c->pinned_rb) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pinned_rb); c->pinned_rb = nullptr; c->pinned_rb_cap = 0; }
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes + 256, hipHostMallocDefault);
+    if (e != hipSuccess) { km_fail(c, KM_E_NOMEM, "hipHostMalloc(%zu): %s", bytes + 256, hipGetErrorString(e)); return nullptr; }
+    c->pinned_rb = p; c->pinned_rb_cap = bytes + 256;
+    return p;
+}
+
 int km_wait_readback(km_ctx *c)
 {
     if (!c->ev_readback) KM_HIP(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
@@ -111,6 +122,7 @@ int km_ctx_destroy(km_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     kp_destroy(c);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
+    if (c->pinned_rb) (void)hipHostFree(c->pinned_rb);
     for (km_frame_slot &f : c->fslot) {
         if (f.host) (void)hipHostFree(f.host);
         if (f.done) (void)hipEventDestroy(f.done);

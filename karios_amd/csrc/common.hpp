@@ -129,6 +129,10 @@ struct km_ctx {
     bool ev_ready = false;
     km_frame_slot fslot[KM_FRAME_SLOTS];
     int fslot_next = 0;
+    // pinned landing zone of the small mid-pipeline read-backs: a copy into pageable memory blocks the host until the
+    // stream has drained, so nothing could be queued behind it (the deferred jobs of km_wait_readback arrived too late)
+    void *pinned_rb = nullptr;
+    size_t pinned_rb_cap = 0;
     km_klt_stats stats;
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
@@ -136,6 +140,7 @@ struct km_ctx {
 };
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
+void *km_pinned_rb(km_ctx *c, size_t bytes);   // >= bytes of pinned host memory owned by the context (nullptr on failure)
 
 // MI355X dispatches workgroup w of a grid to XCD w % 8, and every XCD has its own L2.  The marching kernels therefore
 // launch km_xcd_grid(ntiles) workgroups and let workgroup w process tile (w % 8) * ceil(ntiles / 8) + w / 8: each XCD

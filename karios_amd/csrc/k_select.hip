@@ -295,8 +295,11 @@ int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_ke
     KM_LAUNCH_CHECK(c);
     tk_cut_kernel<<<1, 1024, 0, c->stream>>>(hist, k_target ? (unsigned)k_target : 0xffffffffu, cut, d_sc, quality);
     KM_LAUNCH_CHECK(c);
-    KM_HIP(c, hipMemcpyAsync(hs, d_sc, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
+    km_scalars *land = (km_scalars *)km_pinned_rb(c, sizeof *hs);   // pinned: the copy is asynchronous, the deferred job queues right behind it
+    if (!land) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(land, d_sc, sizeof *hs, hipMemcpyDeviceToHost, c->stream));
     { const int rcw = km_wait_readback(c); if (rcw) return rcw; }
+    *hs = *land;
     const size_t kept = hs->cut[1];
     *n_total = hs->cut[3];
     *n_kept = kept;
@@ -391,8 +394,9 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
             KM_HIP(c, rocprim::exclusive_scan(tmp, sk, accept_flags, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
             sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
             KM_LAUNCH_CHECK(c);
-            unsigned back[8];
-            KM_HIP(c, hipMemcpyAsync(back, d_sc->und, sizeof back, hipMemcpyDeviceToHost, c->stream));
+            unsigned *back = (unsigned *)km_pinned_rb(c, sizeof(km_scalars));   // pinned landing zone (see km_pinned_rb)
+            if (!back) return KM_E_NOMEM;
+            KM_HIP(c, hipMemcpyAsync(back, d_sc->und, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             { const int rcw = km_wait_readback(c); if (rcw) return rcw; }
             got = (int)back[7];
             if (back[3] == 0) break;   // every prefix member decided: the emitted list is final for this prefix
