@@ -95,8 +95,12 @@ def make_inputs(case):
     return mon, ref, mask
 
 
+LAST = {}   # arrays of the case that ran last (dumped by main() when it failed: post-mortem of rare mismatches)
+
+
 def run_case(case, ops, O, ResidentPair):
     """-> list of failure strings (empty = parity)."""
+    LAST.clear()
     mon, ref, mask = make_inputs(case)
     conf = O.default_conf(maxCorners=case["maxCorners"], blocksize=case["blocksize"], matching_winsize=case["winsize"],
                           qualityLevel=case["qualityLevel"], minDistance=case["minDistance"],
@@ -115,6 +119,12 @@ def run_case(case, ops, O, ResidentPair):
     pair = ResidentPair.upload(mon, ref, mask=mask)
     pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
     frame = pair.match_tile(conf, box=box, zncc_threshold=0.4)
+    if status == "ok":
+        LAST.update(gpu_p0=tracks[0].copy(), gpu_p1=tracks[1].copy(), gpu_p0r=tracks[2].copy())
+    if frame is not None:
+        LAST.update({f"gpu_frame_{c}": frame[c].to_numpy() for c in frame.columns})
+    if exp is not None:
+        LAST.update({f"exp_{k}": np.asarray(v) for k, v in exp.items() if k in ("x0", "y0", "dx", "dy", "score", "Ninit")})
     if exp is None:
         if status == "ok":
             fails.append(f"oracle None, library returned {len(tracks[0])} points")
@@ -126,6 +136,7 @@ def run_case(case, ops, O, ResidentPair):
     p0e = O.good_features(exp["lap_ref"], exp["mask"], conf.maxCorners, conf.qualityLevel, conf.minDistance, conf.blocksize)
     p1e = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0e, case["winsize"])
     p0re = O.pyr_lk(exp["lap_mon"], exp["lap_ref"], p1e, case["winsize"])
+    LAST.update(exp_p0=p0e, exp_p1=p1e, exp_p0r=p0re)
     if tracks[0].shape != p0e.shape or not np.array_equal(tracks[0], p0e):
         fails.append(f"p0 differs ({len(tracks[0])} vs {len(p0e)} corners)")
         return fails
@@ -240,6 +251,9 @@ def main():
         done += 1
         if fails:
             bad += 1
+            if LAST:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{a.what}_{s}.npz"), **LAST)
             print(f"FAIL seed {s}: {'; '.join(fails)}\n     {case}", flush=True)
     print(f"fuzz_parity: {done} cases (seeds {a.seed}..{a.seed + done - 1}), {bad} failing, {time.time() - t0:.1f} s", flush=True)
     sys.exit(1 if bad else 0)
