@@ -229,6 +229,12 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
+    // debugging aid: KARIOS_HIP_POISON_WS=<byte> fills every workspace buffer at the start of a tile call, so a kernel that reads
+    // workspace it (or its predecessors in the call) never wrote shows up as a parity failure instead of a once-in-a-while one
+    static const char *const poison = getenv("KARIOS_HIP_POISON_WS");
+    if (poison && reset == RESET_KLT)
+        for (int i = 0; i < WS_COUNT; i++)
+            if (c->ws[i].p && i != WS_AUTO) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
     if (reset == RESET_KLT)
         { for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false; c->evs_used[c->ev_cur][ST_FRAME] = false; }
     else if (reset == RESET_ZNCC)
