@@ -235,3 +235,16 @@ def test_stretch_exact_multiples():
         assert np.array_equal(want, got.astype(np.uint8)), r
         fma_form = np.floor(d.astype(np.float64) * (255.0 / r) + 0.5 / r)          # what the kernel evaluates (one fma)
         assert np.array_equal(fma_form.astype(np.int64), got), r
+
+
+def test_oracle_thread_team_respects_the_cpu_quota(O):
+    """The oracle's OpenMP team is sized from the CPUs the process may use (affinity, cgroup quota), not from the logical
+    CPU count: on the GPU box 256 logical CPUs hide a 16-CPU quota and an all-cores team ran ~50x slower on small tiles."""
+    import os
+    n = O.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        assert n <= len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    assert 1 <= O.max_threads() <= max(n, 1) or O.max_threads() == 1
