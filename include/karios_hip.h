@@ -72,7 +72,13 @@ typedef struct km_klt_stats {
     double min_ref, max_ref, min_mon, max_mon; /* _to_uint8 stretch bounds */
     float max_eig;            /* maxVal of minMaxLoc */
     float emitted_ratio;      /* candidate keys emitted by the fused eig kernel / exact candidate count */
+    int32_t path_flags;       /* KM_PATH_* bits: which retry paths of the corner detector the call went through */
+    int32_t reserved;
 } km_klt_stats;
+#define KM_PATH_KEY_REGROW 1      /* a key-buffer shard overflowed: buffer regrown, detection repeated */
+#define KM_PATH_STAGE_FALLBACK 2  /* the fused kernel's key stage overflowed: eig map + candidate kernel instead */
+#define KM_PATH_SECOND_PASS 4     /* the top-K slice held too few mutually distant corners: selection on all candidates */
+#define KM_PATH_PREFIX_GROWN 8    /* the selection's first ranked prefix was enlarged */
 
 /* ---- context ------------------------------------------------------------ */
 int km_version(void);
@@ -82,10 +88,16 @@ const char *km_last_error(km_ctx *ctx);   /* ctx may be NULL: last global error 
 int km_ctx_sync(km_ctx *ctx);
 /* enable (1) / disable (0) hipEvent stage timing; read back after a call */
 int km_set_profiling(km_ctx *ctx, int enable);
-/* Tuning knobs (no counterpart in the reference; results never depend on them):
- *   "fused_eig" 0..3  GFTT: 3 (default) = minimum-eigenvalue + candidate detection fused in one pass, 2 pixels per lane
- *                     (no eig map); 0 = eig map + candidate scan; 1, 2 = earlier fused kernels kept for comparison.
- *                     Initial value from the environment variable KARIOS_HIP_FUSED_EIG.
+/* Knobs (no counterpart in the reference; results NEVER depend on them - tests/test_gpu_forced_paths.py):
+ *   "fused_eig"    1 (default) = GFTT's minimum-eigenvalue + candidate detection fused in one pass (no eig map);
+ *                  0 = eig map + candidate scan.  Initial value from the environment variable KARIOS_HIP_FUSED_EIG.
+ *   Test knobs that shrink internal capacities so that the corner detector's retry paths run on every call
+ *   (0 restores the default):
+ *   "key_cap"      candidate keys per shard of the first attempt          -> key-buffer overflow + regrow
+ *   "stage_cap"    usable slots of the fused kernel's per-wave key stage  -> stage overflow + two-kernel repeat
+ *   "topk_factor"  top-K pre-filter keeps factor * maxCorners keys (8)    -> second selection pass on all candidates
+ *   "select_first" first ranked prefix of the selection sweeps (3 * maxCorners) -> prefix growth
+ *   "defer"        0: pyramid jobs run after the selection's read-back waits instead of under them
  * Returns KM_E_ARG for an unknown name. */
 int km_set_option(km_ctx *ctx, const char *name, int value);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */

@@ -35,7 +35,10 @@ class KltStats(C.Structure):
     _fields_ = [("valid_pixels", C.c_int64), ("n_candidates", C.c_int64), ("n_init", C.c_int32),
                 ("n_select_batches", C.c_int32), ("min_ref", C.c_double), ("max_ref", C.c_double),
                 ("min_mon", C.c_double), ("max_mon", C.c_double), ("max_eig", C.c_float),
-                ("emitted_ratio", C.c_float)]
+                ("emitted_ratio", C.c_float), ("path_flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+PATH_KEY_REGROW, PATH_STAGE_FALLBACK, PATH_SECOND_PASS, PATH_PREFIX_GROWN = 1, 2, 4, 8
 
 
 _vp, _i, _d, _sz, _pd = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.POINTER(C.c_double)
@@ -204,7 +207,8 @@ class Context:
         self.check(self.lib.km_set_profiling(self.handle, int(bool(on))), "km_set_profiling")
 
     def set_option(self, name: str, value: int):
-        """Tuning knob (include/karios_hip.h km_set_option), e.g. set_option("fused_eig", 1)."""
+        """Knob of include/karios_hip.h km_set_option, e.g. set_option("fused_eig", 0) or the test knobs "key_cap",
+        "stage_cap", "topk_factor", "select_first", "defer" (0 restores a default)."""
         self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
 
     def stage_ms(self) -> dict:

@@ -61,7 +61,7 @@ int km_wait_readback(km_ctx *c)
     if (!c->ev_readback) KM_HIP(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
     static const bool no_defer = getenv("KARIOS_HIP_NO_DEFER") != nullptr;   // A/B switch: wait first, run the jobs afterwards
     KM_HIP(c, hipEventRecord(c->ev_readback, c->stream));
-    if (!c->deferred.empty() && !no_defer) {
+    if (!c->deferred.empty() && !no_defer && !c->opt_no_defer) {
         std::function<int()> job = std::move(c->deferred.front());
         c->deferred.erase(c->deferred.begin());
         const int rc = job();
@@ -108,7 +108,7 @@ int km_ctx_create(int device, km_ctx **out)
         delete c;
         return rc;
     }
-    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) < 0 ? 0 : atoi(e) > 3 ? 3 : atoi(e);
+    if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -147,7 +147,14 @@ int km_ctx_sync(km_ctx *c)
 int km_set_option(km_ctx *c, const char *name, int value)
 {
     if (!c || !name) return km_fail(c, KM_E_ARG, "km_set_option: null argument");
-    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value < 0 ? 0 : value > 3 ? 3 : value; return KM_OK; }
+    if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value != 0; return KM_OK; }
+    // the remaining knobs shrink internal capacities so that the retry paths of the corner detector, which otherwise fire
+    // only on unusual images or by timing, run on every call (tests / tools/fuzz_parity.py --force-paths); 0 = default
+    if (strcmp(name, "key_cap") == 0) { c->opt_key_cap = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "stage_cap") == 0) { c->opt_stage_cap = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "topk_factor") == 0) { c->opt_topk_factor = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
@@ -325,8 +332,9 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
     int rc;
     // Strongest-first shortcut: rank and select on the top slice only (a rank prefix, so a sufficient slice gives the
     // exact result); fall back to the complete list when that slice cannot supply maxCorners corners.
-    size_t k_target = (max_corners > 0 && min_distance >= 1) ? (size_t)max_corners * 8 : 0;
+    size_t k_target = (max_corners > 0 && min_distance >= 1) ? (size_t)max_corners * (c->opt_topk_factor > 0 ? c->opt_topk_factor : 8) : 0;
     size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
+    if (c->opt_key_cap > 0) capk = (size_t)c->opt_key_cap * KM_NSHARD;   // test knob: tiny shards, so that the regrow path runs
     unsigned long long *kept = nullptr;
     size_t nkept = 0, ntotal = 0;
     km_scalars hs;
@@ -335,13 +343,11 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
         if (!keys) return KM_E_NOMEM;
         // K3 + K4 fused (2 pixels per lane, no eig map: k_eig2.hip) when it covers the case, else eig map + candidate kernel.
-        // km_set_option("fused_eig") selects 0 = two kernels, 1 / 2 = the earlier fused experiments, 3 = default.
+        // km_set_option("fused_eig", 0) selects the two-kernel path.
         bool fused = false;
         if (c->fused_eig && !fused_overflow) {
             km_stage_timer t(c, ST_EIGEN);
-            rc = c->fused_eig == 3   ? k2_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
-                 : c->fused_eig == 2 ? ke_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0)
-                                     : kd_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk);
+            rc = k2_eig_candidates(c, d_img, d_mask, H, W, block, quality, sc, keys, capk, attempt > 0);
             if (rc == KM_OK) fused = true;
             else if (rc != KM_E_UNSUPPORTED) return rc;
         }
@@ -366,11 +372,13 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         c->stats.min_ref = hs.mm[0]; c->stats.max_ref = hs.mm[1]; c->stats.min_mon = hs.mm[2]; c->stats.max_mon = hs.mm[3];
         if (fused && hs.pad0 != 0u) {   // candidates were dropped: repeat with the eig-map + candidate kernels
             fused_overflow = true;
+            c->stats.path_flags |= KM_PATH_STAGE_FALLBACK;
             KM_HIP(c, hipMemsetAsync(&sc->run_max_key, 0, (2 + KM_NSHARD) * sizeof(unsigned), c->stream));
             continue;
         }
         if ((size_t)hs.n_cand <= capk) break;
         capk = (size_t)hs.n_cand + hs.n_cand / 4 + 4096 * KM_NSHARD;   // a shard overflowed: grow the key buffer and redo
+        c->stats.path_flags |= KM_PATH_KEY_REGROW;
         if (attempt == 3) return km_fail(c, KM_E_INTERNAL, "candidate buffer kept overflowing");
     }
     c->stats.n_candidates = (int64_t)ntotal;
@@ -390,6 +398,7 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
         if (nkept >= ntotal || found >= max_corners) break;
         // the top slice did not contain maxCorners mutually distant corners: repeat on every candidate
         k_target = 0;
+        c->stats.path_flags |= KM_PATH_SECOND_PASS;
         km_scalars hs2;
         if ((rc = ks_topk_prefilter(c, keys, capk, 0, sc, quality, &kept, &nkept, &ntotal, &hs2, true))) return rc;
     }
@@ -499,12 +508,9 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
     // "No valid pixels" (klt.py:276-279) needs no early exit: an all-zero mask gives max-eig 0, no candidate, no corner.
     // The count itself reaches the host with the candidate count (gftt_dev), i.e. without an extra synchronisation.
     *no_valid = false;
-    {
-        int rc2 = klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
-        *no_valid = c->stats.valid_pixels == 0;
-        return rc2;
-    }
-    return klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
+    const int rc2 = klt_track_dev(c, lap_ref, lap_mon, d_mask ? d_mask : mask_auto, H, W, prm, nullptr, 0, d_p0, d_p1, d_p0r, cap, sc);
+    *no_valid = c->stats.valid_pixels == 0;
+    return rc2;
 }
 
 extern "C" {
@@ -594,6 +600,7 @@ int km_good_features(km_ctx *c, const uint8_t *img, const uint8_t *mask, int H, 
     if (!(quality > 0)) return km_fail(c, KM_E_ARG, "qualityLevel must be > 0");
     if (min_distance < 0) return km_fail(c, KM_E_ARG, "minDistance must be >= 0");
     if (max_corners > 0 && cap < max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, max_corners);
+    memset(&c->stats, 0, sizeof c->stats);
     void *d_img, *d_mask = nullptr;
     if ((rc = upload_image(c, WS_RAW_A, img, 1, H, W, W, &d_img))) return rc;
     if (mask && (rc = upload_image(c, WS_MASK_IN, mask, 1, H, W, W, &d_mask))) return rc;

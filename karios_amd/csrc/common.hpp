@@ -120,7 +120,13 @@ struct km_ctx {
     std::vector<std::function<int()>> deferred;
     hipEvent_t ev_readback = nullptr;
     bool profiling = false;
-    int fused_eig = 3;         // km_set_option("fused_eig"): 0 eig map + candidate scan, 1 fused 1-px/lane kernel (eig_march EMIT), 2 fused 4-px/lane kernel (k_eigc.hip), 3 fused 2-px/lane kernel (k_eig2.hip)
+    int fused_eig = 1;         // km_set_option("fused_eig"): 1 = K3+K4 fused (k_eig2.hip, no eig map), 0 = eig map + candidate scan
+    // test knobs (km_set_option, 0 = default): shrunken capacities that force the corner detector's retry paths
+    int opt_key_cap = 0;       // "key_cap": candidate keys per shard of the first attempt (forces the regrow path)
+    int opt_stage_cap = 0;     // "stage_cap": usable slots of the fused kernel's per-wave LDS stage (forces the two-kernel fallback)
+    int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
+    int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
+    bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
     // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)
     hipEvent_t evs[KM_FRAME_SLOTS + 1][ST_COUNT][2];
@@ -241,8 +247,6 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
                               unsigned long long *d_valid);
 int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block,
                  float *d_eig, unsigned int *d_max_key);
-int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality,
-                      km_scalars *sc, unsigned long long *d_keys, size_t cap);
 // k_frame.hip: DN-value filter of the key points (core.py:650-737)
 // count of tracks passing the forward-backward test (max |p0 - p0r| < thr) among the first min(*d_n, n_max) points
 int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d_n, int n_max, float back_thr, int *d_count);
@@ -251,9 +255,6 @@ int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H
 // k_eig2.hip: minimum-eigenvalue map + masked maximum, 2 pixels per lane (KM_E_UNSUPPORTED when the case is not covered)
 int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig, unsigned *d_max_key);
 int k2_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
-                      unsigned long long *d_keys, size_t cap, bool rezero);
-// k_eigc.hip: fused minimum-eigenvalue + candidate pass, 4 pixels per lane (no eig map)
-int ke_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
                       unsigned long long *d_keys, size_t cap, bool rezero);
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
                   double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap, bool rezero);

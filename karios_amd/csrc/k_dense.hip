@@ -1242,21 +1242,14 @@ __device__ __forceinline__ float dpp_shl1(float v)  // value of lane+1 (0 for la
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-// EMIT = false: writes the eig map (km_min_eigen, generic GFTT path).
-// EMIT = true : K3+K4 fused -- the map is never written; three eig rows stay in registers and every pixel that is a
-//   3x3 local maximum (thr-independent: a pixel above thr only loses to neighbours that are above thr too), passes the
-//   mask / border rules and exceeds a RUNNING lower bound of the final threshold (quality * max seen so far) is emitted
-//   as a candidate key.  The exact threshold is applied afterwards, when the global maximum is known (tk_* kernels).
-template <int BLOCK, bool EMIT>
+// Writes the eig map + per-wave masked maxima (fallback of k_eig2.hip for images too small for its 128-column strips).
+template <int BLOCK>
 __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W,
                                                         double scale2, float *__restrict__ eig, unsigned int *__restrict__ max_partial,
-                                                        int nstrips, double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
-                                                        size_t cap, int gyw)
+                                                        int nstrips, int gyw)
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L, VALID = 64 - BLOCK - 1;
-    constexpr int STRIDE = EMIT ? VALID - 2 : VALID;     // EMIT: the outer two computed columns only serve as neighbours
-    constexpr int STAGE = 1024;                          // >= (keys already staged at a group start) + BLOCK rows * 48 lanes
-    __shared__ unsigned long long stage[EMIT ? 4 : 1][EMIT ? STAGE : 1];
+    constexpr int STRIDE = VALID;
     const int lane = threadIdx.x & 63;
     const int gxw = (nstrips + 3) / 4;                  // workgroups per row block (logical grid gxw x gyw, XCD-swizzled)
     unsigned tile;
@@ -1274,29 +1267,8 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
     const bool out_lane = lane >= L + 1 && lane < L + 1 + VALID && gx < W;
     const int hi_addr = min(lane + Rr, 63) * 4, lo_addr = max(lane - L - 1, 0) * 4;
     const bool lo_zero = lane - L - 1 < 0;
-    // EMIT: candidate rows [ya, yb) need the eig rows ya-1 .. yb
-    const int ya = 1 + by * EIG_RS, yb = min(H - 1, ya + EIG_RS);
-    const int y0 = EMIT ? ya - 1 : by * EIG_RS, y1 = EMIT ? yb + 1 : min(H, y0 + EIG_RS);
+    const int y0 = by * EIG_RS, y1 = min(H, y0 + EIG_RS);
     const uint8_t *col = src + cx;
-    const bool cand_lane = lane >= L + 2 && lane <= L + VALID - 1 && gx >= 1 && gx <= W - 2;
-    unsigned long long *st = stage[EMIT ? (threadIdx.x >> 6) : 0];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned cnt = 0;                 // keys in this wave's stage (wave-uniform)
-    float e_m2 = 0.f, e_m1 = 0.f;     // eig rows y-2, y-1 of this lane's column
-    int pm_m1 = 0;                    // mask byte of row y-1
-    float thr_run = 0.f;
-    unsigned published = 0u;
-    const unsigned shard = (unsigned)wave_id % KM_NSHARD;
-    const size_t cap_s = cap / KM_NSHARD;
-    auto flush = [&]() {
-        if (cnt == 0) return;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&sc->shard_cnt[shard], cnt);
-        base = __shfl(base, 0);
-        for (unsigned i = lane; i < cnt; i += 64)
-            if ((size_t)base + i < cap_s) keys[shard * cap_s + base + i] = st[i];
-        cnt = 0;
-    };
 
     int ring[BLOCK][3];
 #pragma unroll
@@ -1315,19 +1287,6 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
         // registers, i.e. resident waves, and the resident waves are what hides the latency of this kernel
         constexpr int CH = BLOCK < EIGM_CH ? BLOCK : EIGM_CH;
         int pre[CH], pmask[CH];
-        if constexpr (EMIT) {
-            // the stage is only flushed here, between row groups: the row loop itself never touches global memory for
-            // the keys (a group adds at most BLOCK * 48 of them)
-            if (cnt + BLOCK * 48 > STAGE) flush();
-            // refresh the running lower bound of the threshold: quality * max(own wave so far, published by others)
-            unsigned wk = have ? eig_key(best) : 0u;
-            for (int o = 32; o > 0; o >>= 1) wk = max(wk, (unsigned)__shfl_xor((int)wk, o));
-            const unsigned gk = __hip_atomic_load(&sc->run_max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wk > gk && published == 0u && lane == 0) atomicMax(&sc->run_max_key, wk);   // one early publication per wave
-            if (wk > gk) published = 1u;
-            const unsigned mk = max(wk, gk);
-            thr_run = mk ? (float)__dmul_rn((double)eig_unkey(mk), quality) : 0.f;
-        }
         if (steady) {
             if (!(c1 == mbase - 1 && c2 == mbase)) {
                 a1 = col[(size_t)(mbase - 1) * W]; a2 = col[(size_t)mbase * W];
@@ -1384,7 +1343,6 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
             V0 += h0 - ring[k][0]; V1 += h1 - ring[k][1]; V2 += h2 - ring[k][2];
             ring[k][0] = h0; ring[k][1] = h1; ring[k][2] = h2;
             const int y = m - Rr;                         // output row completed by this step
-            float e_cur = 0.f;
             if (y >= y0 && out_lane) {
                 const float cxx = (float)__dmul_rn((double)V0, scale2);
                 const float cxy = (float)__dmul_rn((double)V1, scale2);
@@ -1393,34 +1351,15 @@ __global__ __launch_bounds__(256) KM_EIGM_OCC void eig_march_kernel(const uint8_
                 const float t = __fsub_rn(a, cc);
                 const float sq = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
                 const float e = __fsub_rn(__fadd_rn(a, cc), sqrt_rn_normal(sq));
-                if constexpr (!EMIT) eig[(size_t)y * W + gx] = e;
-                e_cur = e;
+                eig[(size_t)y * W + gx] = e;
                 if (pmask[k % CH]) { best = have ? fmaxf(best, e) : e; have = true; }
             }
-            if constexpr (EMIT) {
-                if (y >= y0 + 2) {
-                    // candidate test of row y-1 with eig rows y-2, y-1, y (all lanes take part in the DPP shifts)
-                    const float m3 = fmaxf(fmaxf(e_m2, e_m1), e_cur);
-                    const float nb = fmaxf(fmaxf(dpp_shr1(m3), dpp_shl1(m3)), fmaxf(e_m2, e_cur));
-                    const bool is = cand_lane && e_m1 > thr_run && e_m1 != 0.f && e_m1 >= nb && pm_m1 != 0;
-                    const unsigned long long bal = __ballot(is);
-                    // straight-line (predicated) append: no branch inside the unrolled row loop
-                    if (is) st[cnt + __popcll(bal & lt_mask)] = ((unsigned long long)__float_as_uint(e_m1) << 32) |
-                                                               (unsigned long long)((unsigned)(y - 1) * (unsigned)W + (unsigned)gx);
-                    cnt += (unsigned)__popcll(bal);
-                }
-                if (y >= y0) { e_m2 = e_m1; e_m1 = e_cur; pm_m1 = pmask[k % CH]; }
-            }
         }
-    }
-    if constexpr (EMIT) {
-        flush();
     }
     unsigned key = have ? eig_key(best) : 0u;
     for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
     if (lane == 0) {
         max_partial[wave_id] = key;
-        if constexpr (EMIT) { if (key > __hip_atomic_load(&sc->run_max_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&sc->run_max_key, key); }
     }
 }
 
@@ -1434,49 +1373,11 @@ static int launch_eig_march(km_ctx *c, const uint8_t *d_src, const uint8_t *d_ma
     const size_t nwaves = (size_t)grid.x * 4 * grid.y;
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
-    eig_march_kernel<BLOCK, false><<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, 0.0, nullptr,
-                                                                                          nullptr, 0, (int)grid.y);
+    eig_march_kernel<BLOCK><<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, (int)grid.y);
     KM_LAUNCH_CHECK(c);
     max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, (unsigned)nwaves, d_max_key);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
-}
-
-// K3+K4 fused: candidate keys (a superset, bounded below by the running threshold) + the exact masked maximum
-template <int BLOCK>
-static int launch_eig_emit(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, double scale2, double quality,
-                           km_scalars *sc, unsigned long long *d_keys, size_t cap)
-{
-    constexpr int STRIDE = 64 - BLOCK - 1 - 2;
-    const int nstrips = (W - 2 + STRIDE - 1) / STRIDE;
-    dim3 grid((nstrips + 3) / 4, (H - 2 + EIG_RS - 1) / EIG_RS);
-    const size_t nwaves = (size_t)grid.x * 4 * grid.y;
-    unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, nwaves * sizeof(unsigned));
-    if (!partial) return KM_E_NOMEM;
-    KM_HIP(c, hipMemsetAsync(&sc->run_max_key, 0, (2 + KM_NSHARD) * sizeof(unsigned), c->stream));   // run_max_key, pad, shard counters
-    eig_march_kernel<BLOCK, true><<<km_xcd_grid(grid.x * grid.y), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, nullptr, partial, nstrips, quality, sc,
-                                                                                         d_keys, cap, (int)grid.y);
-    KM_LAUNCH_CHECK(c);
-    max_u32_kernel<<<1, 1024, 0, c->stream>>>(partial, (unsigned)nwaves, &sc->max_eig_key);
-    KM_LAUNCH_CHECK(c);
-    return KM_OK;
-}
-
-// returns KM_E_UNSUPPORTED (without an error message) when the fused kernel does not cover this case
-int kd_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
-                      unsigned long long *d_keys, size_t cap)
-{
-    if (!(W >= 2 * block + 4 && H >= 2 * block + 4)) return KM_E_UNSUPPORTED;
-    const double scale = 1.0 / (4.0 * (double)block * 255.0), s2 = scale * scale;
-    switch (block) {
-    case 3: return launch_eig_emit<3>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    case 5: return launch_eig_emit<5>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    case 7: return launch_eig_emit<7>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    case 9: return launch_eig_emit<9>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    case 11: return launch_eig_emit<11>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    case 15: return launch_eig_emit<15>(c, d_src, d_mask, H, W, s2, quality, sc, d_keys, cap);
-    default: return KM_E_UNSUPPORTED;
-    }
 }
 
 int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig,

@@ -89,7 +89,7 @@ __device__ __forceinline__ float e2_sqrt(float x)
 template <int BLOCK, bool EMIT>
 __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, double scale2,
                                                    float *__restrict__ eig, unsigned *__restrict__ max_partial, int nstrips, int rows_per_item,
-                                                   int nitems, double quality, km_scalars *sc, unsigned long long *__restrict__ keys, size_t cap)
+                                                   int nitems, double quality, km_scalars *sc, unsigned long long *__restrict__ keys, size_t cap, unsigned stage_cap)
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L;
     constexpr int XM = EMIT ? 1 : 0;                 // EMIT: one more margin pixel per side (the candidates' neighbours)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void eig2_kernel(const uint8_t *__restrict__ s
     const size_t cap_s = cap / KM_NSHARD;
     auto flush_if = [&](unsigned threshold) {
         if (cnt <= threshold) return;
-        if (cnt > EIG2_STAGE) { if (lane == 0) atomicOr(&sc->pad0, 1u); cnt = EIG2_STAGE; }
+        if (cnt > stage_cap) { if (lane == 0) atomicOr(&sc->pad0, 1u); cnt = min(cnt, (unsigned)EIG2_STAGE); }   // stage_cap = EIG2_STAGE unless a test shrank it
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(&sc->shard_cnt[shard], cnt);
         base = __shfl(base, 0);
@@ -421,8 +421,9 @@ int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
     const unsigned ntiles = (unsigned)(nitems + 3) / 4u;
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)ntiles * 4 * sizeof(unsigned));
     if (!partial) return KM_E_NOMEM;
+    const unsigned stage_cap = c->opt_stage_cap > 0 && c->opt_stage_cap < EIG2_STAGE ? (unsigned)c->opt_stage_cap : (unsigned)EIG2_STAGE;
     eig2_kernel<BLOCK, EMIT><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, d_eig, partial, nstrips, rows, nitems, quality, sc,
-                                                                         d_keys, cap);
+                                                                         d_keys, cap, stage_cap);
     KM_LAUNCH_CHECK(c);
     eig2_max_kernel<<<1, 1024, 0, c->stream>>>(partial, ntiles * 4, d_max_key);
     KM_LAUNCH_CHECK(c);

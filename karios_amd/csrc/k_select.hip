@@ -367,7 +367,8 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
     if (!tmp) return KM_E_NOMEM;
 
     KM_HIP(c, hipMemsetAsync(cell_cnt, 0, (2 * cells + 1) * sizeof(unsigned), c->stream));   // counts + fill cursors
-    unsigned k0 = 0, k1 = (max_corners > 0) ? (unsigned)((size_t)max_corners * 3 < n ? (size_t)max_corners * 3 : n) : N;
+    const size_t first = c->opt_select_first > 0 ? (size_t)c->opt_select_first : (size_t)max_corners * 3;
+    unsigned k0 = 0, k1 = (max_corners > 0 || c->opt_select_first > 0) ? (unsigned)(first < n ? first : n) : N;
     int rounds = 0;
     bool und_fresh = fresh_scalars;   // d_sc->und[] was zeroed with the scalar block at the start of the call
     for (;;) {
@@ -407,6 +408,7 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
         if (max_corners > 0 && got >= max_corners) break;
         k0 = k1;
         k1 = (unsigned)((size_t)k1 * 4 < n ? (size_t)k1 * 4 : n);
+        c->stats.path_flags |= KM_PATH_PREFIX_GROWN;
     }
     return KM_OK;
 }

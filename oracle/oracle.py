@@ -37,32 +37,100 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _cgroup_cpu_limit() -> float | None:
+    """CPU quota of this process's cgroup (and its ancestors), in CPUs: cgroup v2 `cpu.max`, cgroup v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`.  None when no quota is visible."""
+    best = None
+
+    def note(quota, period):
+        nonlocal best
+        if quota > 0 and period > 0:
+            v = quota / period
+            best = v if best is None else min(best, v)
+
+    rel_v2, rel_v1 = "", ""
+    try:
+        for line in open("/proc/self/cgroup"):
+            _, ctrl, path = line.rstrip("\n").split(":", 2)
+            if ctrl == "":
+                rel_v2 = path
+            elif "cpu" in ctrl.split(","):
+                rel_v1 = path
+    except (OSError, ValueError):
+        pass
+    # v2: the process's own directory and every ancestor up to the mount point (inside a cgroup namespace the own
+    # directory IS the mount point)
+    parts = [p for p in rel_v2.split("/") if p]
+    for k in range(len(parts), -1, -1):
+        try:
+            quota, period = open(os.path.join("/sys/fs/cgroup", *parts[:k], "cpu.max")).read().split()[:2]
+            if quota != "max":
+                note(int(quota), int(period))
+        except (OSError, ValueError):
+            pass
+    parts = [p for p in rel_v1.split("/") if p]
+    for root in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+        for k in range(len(parts), -1, -1):
+            try:
+                d = os.path.join(root, *parts[:k])
+                note(int(open(os.path.join(d, "cpu.cfs_quota_us")).read()), int(open(os.path.join(d, "cpu.cfs_period_us")).read()))
+            except (OSError, ValueError):
+                pass
+    return best
+
+
 def usable_cpus() -> int:
-    """CPUs this process may actually use: min(logical CPUs, affinity mask, cgroup-v2 quota).  A container that shows
+    """CPUs this process may actually use: min(logical CPUs, affinity mask, cgroup quota).  A container that shows
     256 logical CPUs under a 16-CPU quota runs an all-cores OpenMP team slower than a 16-thread one (throttled spinning)."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        pass
+    q = _cgroup_cpu_limit()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.999)))
     return max(1, n)
+
+
+# The parity tests call the oracle thousands of times on small images: the team is capped (a quota this module cannot see -
+# a parent cgroup outside the namespace, a hypervisor - would otherwise make every call spin against the throttle; the
+# round-1 GPU suite took 855 s on the driver's box and 38 s on the builder's for that reason) and the OpenMP runtime is
+# told to block instead of spinning.  bench.py's cpu_baseline sets its team explicitly.
+DEFAULT_TEAM_CAP = 16
+
+
+def team_size() -> int:
+    env = os.environ.get("KARIOS_ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(usable_cpus(), DEFAULT_TEAM_CAP))
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
+        # read by libgomp when it is first loaded (a libgomp bundled with torch is a different library instance)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("GOMP_SPINCOUNT", "0")
         L = C.CDLL(_SO)
         L.ko_auto_mask.restype = C.c_long
-        L.ko_set_threads(min(int(L.ko_max_threads()), usable_cpus()))
+        L.ko_set_threads(min(int(L.ko_max_threads()), team_size()))
         _lib = L
     return _lib
+
+
+def describe_cpu() -> str:
+    """One line for test / bench headers: what the oracle sees of the host."""
+    q = _cgroup_cpu_limit()
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = -1
+    return (f"oracle: logical CPUs {os.cpu_count()}, affinity {aff}, cgroup quota {q if q is not None else 'none'}, usable {usable_cpus()}, "
+            f"team {min(max_threads(), team_size())} (libgomp max {max_threads()}), OMP_WAIT_POLICY={os.environ.get('OMP_WAIT_POLICY')}, "
+            f"GOMP_SPINCOUNT={os.environ.get('GOMP_SPINCOUNT')}")
 
 
 def max_threads() -> int:

@@ -1,12 +1,29 @@
 import os
 import sys
 
+# before anything loads an OpenMP runtime: the oracle's team must block, not spin, when the box throttles it (oracle.py)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def pytest_report_header(config):
+    try:
+        from oracle import oracle
+        return [oracle.describe_cpu()]
+    except Exception as e:  # noqa: BLE001 - a header line must never break the run
+        return [f"oracle: not available ({e})"]
+
+
+def pytest_terminal_summary(terminalreporter):
+    # shown with -q too (the report header is not): the driver's log then tells how the oracle's team was sized
+    terminalreporter.write_line(pytest_report_header(None)[0])
 
 
 def pytest_configure(config):

@@ -1,0 +1,68 @@
+"""The corner detector's retry paths - key-buffer regrow, stage-overflow fallback to the two-kernel path, second selection
+pass on all candidates, growth of the ranked prefix - and the wrap of the 3-slot frame ring fire only on unusual images or
+by timing in normal operation.  The `km_set_option` test knobs shrink the capacities behind them so that each path runs
+here on ordinary images; the result must not change (oracle parity, reference selection semantics klt.py:120)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from karios_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+fuzz = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fuzz)
+
+
+def _lap(O, H, W, seed=0):
+    mon, ref = synth.make_pair(H, W, 0.4, -0.3, seed=seed)
+    return O.laplacian_u8(O.to_uint8(ref), 7)
+
+
+@pytest.mark.parametrize("knobs,flag", [
+    (dict(key_cap=48), 1), (dict(stage_cap=3), 2), (dict(topk_factor=1), 4), (dict(select_first=8), 8),
+    (dict(key_cap=48, stage_cap=3, topk_factor=1, select_first=8, defer=0), 1 | 2 | 4 | 8),
+    (dict(key_cap=48, topk_factor=1, select_first=8, fused_eig=0), 1 | 4 | 8),
+])
+def test_each_retry_path_runs_and_keeps_the_corners(ops, O, knobs, flag):
+    img = _lap(O, 420, 610, seed=5)
+    exp = O.good_features(img, None, 600, 0.01, 6.0, 15)
+    with fuzz.forced_paths(knobs) as fp:
+        got = ops.good_features_to_track(img, 600, 0.01, 6.0, blockSize=15)
+        flags = int(fp.ctx.stats().path_flags)
+    np.testing.assert_array_equal(got, exp)
+    assert flags & flag == flag, f"path flags {flags:#x}: knobs {knobs} did not reach path(s) {flag:#x}"
+    # and the knobs are gone again
+    ops.good_features_to_track(img, 600, 0.01, 6.0, blockSize=15)
+    assert int(fp.ctx.stats().path_flags) == 0
+
+
+@pytest.mark.parametrize("seed", range(2000, 2060))
+def test_forced_path_tile_case_matches_oracle(ops, O, seed):
+    from karios_amd.resident import ResidentPair
+    case = fuzz.draw_case(seed, max_size=380)
+    case["knobs"] = fuzz.draw_knobs(seed)
+    case["async_ring"] = (seed % 4) + 3 if seed % 2 else 0
+    fails = fuzz.run_case(case, ops, O, ResidentPair)
+    assert not fails, f"{fails} for {case}"
+
+
+def test_frame_ring_wrap_keeps_every_waited_frame(ops, O):
+    """Five submissions without a wait (3 slots): the library must finish an overwritten slot's frame before reusing it,
+    and the three newest frames must be the synchronous ones."""
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(300, 340, 0.3, 0.2, seed=11)
+    conf = O.default_conf(maxCorners=300)
+    pair = ResidentPair.upload(mon, ref)
+    boxes = [(0, 0, 340, 300), (10, 20, 300, 250), (40, 0, 280, 300), (0, 30, 340, 260), (5, 5, 330, 290)]
+    want = [pair.match_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
+    pend = [pair.submit_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
+    for p, w in list(zip(pend, want))[-3:]:
+        f = p.wait().to_frame()
+        assert list(f.columns) == list(w.columns) and len(f) == len(w)
+        for col in f.columns:
+            np.testing.assert_array_equal(f[col].to_numpy(), w[col].to_numpy())

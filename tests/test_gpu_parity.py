@@ -186,14 +186,16 @@ def test_good_features_plateau_falls_back_from_fused_kernel(ops, O, block):
     img = (g[np.arange(700) % len(g)][None, :] + h[np.arange(330) % 3][:, None]).astype(np.uint8)
     exp = O.good_features(img, None, 2000, 0.01, 4, block)
     ctx = default_context()
-    for fused in (3, 2, 1, 0):
+    from karios_amd._lib import PATH_STAGE_FALLBACK
+    for fused in (1, 0):
         ctx.set_option("fused_eig", fused)
         try:
             got = ops.good_features_to_track(img, 2000, 0.01, 4, blockSize=block)
         finally:
-            ctx.set_option("fused_eig", 0)
+            ctx.set_option("fused_eig", 1)
         np.testing.assert_array_equal(got, exp)
         assert ctx.stats().n_candidates > img.size // 2
+        assert bool(ctx.stats().path_flags & PATH_STAGE_FALLBACK) == bool(fused)
 
 
 @pytest.mark.parametrize("params", [dict(maxCorners=1500, q=0.05, md=7, bs=15), dict(maxCorners=0, q=0.2, md=3, bs=3),
@@ -207,7 +209,7 @@ def test_good_features_fused_kernel_bit_exact(ops, O, params, shape):
     mask, _ = O.auto_mask(mon, ref)
     ctx = default_context()
     try:
-        for fused in (1, 2, 3):
+        for fused in (1, 0):
             ctx.set_option("fused_eig", fused)
             for mk in (None, mask):
                 got = ops.good_features_to_track(lap_ref, params["maxCorners"], params["q"], params["md"], mask=mk, blockSize=params["bs"])
@@ -217,7 +219,7 @@ def test_good_features_fused_kernel_bit_exact(ops, O, params, shape):
                 else:
                     np.testing.assert_array_equal(got, exp)
     finally:
-        ctx.set_option("fused_eig", 0)
+        ctx.set_option("fused_eig", 1)
 
 
 def test_good_features_flat_image_is_none(ops):

@@ -30,7 +30,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from karios_amd._lib import KltParams, KltStats
     assert ctypes.sizeof(KltParams) == 8 * 4 + 3 * 8
-    assert ctypes.sizeof(KltStats) == 2 * 8 + 2 * 4 + 4 * 8 + 2 * 4
+    assert ctypes.sizeof(KltStats) == 2 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 2 * 4 and KltStats.path_flags.offset == 64
     assert KltParams.quality_level.offset == 32 and KltStats.min_ref.offset == 24
 
 

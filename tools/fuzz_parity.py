@@ -95,6 +95,44 @@ def make_inputs(case):
     return mon, ref, mask
 
 
+KNOB_DEFAULTS = dict(key_cap=0, stage_cap=0, topk_factor=0, select_first=0, defer=1, fused_eig=1)
+PATHS_HIT = {}   # KM_PATH_* bit -> number of library calls that went through it (coverage report of --force-paths)
+
+
+def draw_knobs(seed: int) -> dict:
+    """Test knobs of km_set_option for one case: shrunken capacities that make the corner detector's retry paths (key-buffer
+    regrow, stage-overflow fallback, second selection pass, prefix growth) run in EVERY case instead of by timing luck."""
+    rng = np.random.default_rng(31 * seed + 7)
+    return dict(key_cap=int(rng.choice([0, 48, 256, 2048])), stage_cap=int(rng.choice([0, 0, 3, 40, 200])),
+                topk_factor=int(rng.choice([0, 1, 1, 2])), select_first=int(rng.choice([0, 8, 100, 1000])),
+                defer=int(rng.choice([1, 1, 0])), fused_eig=int(rng.choice([1, 1, 1, 0])))
+
+
+class forced_paths:
+    """Context manager: apply / restore the knobs on the thread's default context and tally the paths taken."""
+
+    def __init__(self, knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        from karios_amd._lib import default_context
+        self.ctx = default_context()
+        for k, v in (self.knobs or {}).items():
+            self.ctx.set_option(k, v)
+        return self
+
+    def tally(self):
+        f = int(self.ctx.stats().path_flags)
+        for bit in (1, 2, 4, 8):
+            if f & bit:
+                PATHS_HIT[bit] = PATHS_HIT.get(bit, 0) + 1
+
+    def __exit__(self, *exc):
+        for k, v in KNOB_DEFAULTS.items():
+            self.ctx.set_option(k, v)
+        return False
+
+
 LAST = {}   # arrays of the case that ran last (dumped by main() when it failed: post-mortem of rare mismatches)
 
 
@@ -114,11 +152,20 @@ def run_case(case, ops, O, ResidentPair):
     exp = O.klt_tile(np.ascontiguousarray(mon_b), np.ascontiguousarray(ref_b), conf,
                      mask_box=None if mask_b is None else np.ascontiguousarray(mask_b), nodata_mon=case["nodata_mon"],
                      nodata_ref=case["nodata_ref"], x_off=x_off, y_off=y_off, invert_mon=case["invert"])
-    status, tracks = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
-                                  mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
-    pair = ResidentPair.upload(mon, ref, mask=mask)
-    pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
-    frame = pair.match_tile(conf, box=box, zncc_threshold=0.4)
+    with forced_paths(case.get("knobs")) as fp:
+        status, tracks = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
+                                      mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
+        fp.tally()
+        pair = ResidentPair.upload(mon, ref, mask=mask)
+        pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
+        if case.get("async_ring"):
+            # ring stress: 4..6 submissions without a wait in between (3 slots: the oldest blocks are overwritten), the last
+            # one is the frame under test
+            pend = [pair.submit_tile(conf, box=box, zncc_threshold=0.4) for _ in range(case["async_ring"])] if conf.maxCorners > 0 else []
+            frame = pend[-1].wait().to_frame() if pend else pair.match_tile(conf, box=box, zncc_threshold=0.4)
+        else:
+            frame = pair.match_tile(conf, box=box, zncc_threshold=0.4)
+        fp.tally()
     if status == "ok":
         LAST.update(gpu_p0=tracks[0].copy(), gpu_p1=tracks[1].copy(), gpu_p0r=tracks[2].copy())
     if frame is not None:
@@ -233,6 +280,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1, help="first case seed")
     ap.add_argument("--max-size", type=int, default=700)
     ap.add_argument("--budget-s", type=float, default=1e9, help="stop starting new cases after this many seconds")
+    ap.add_argument("--force-paths", action="store_true", help="draw km_set_option test knobs per case so that the retry paths of the corner "
+                    "detector (regrow, stage fallback, second pass, prefix growth) and the frame-ring wrap run in every case")
     a = ap.parse_args()
     from oracle import oracle as O
     O.build()
@@ -244,6 +293,9 @@ def main():
         if time.time() - t0 > a.budget_s:
             break
         case = draw_case(s, a.max_size) if a.what == "tile" else {"aux_seed": s}
+        if a.force_paths and a.what == "tile":
+            case["knobs"] = draw_knobs(s)
+            case["async_ring"] = int(np.random.default_rng(s).integers(0, 7)) if s % 3 == 0 else 0
         try:
             fails = run_case(case, ops, O, ResidentPair) if a.what == "tile" else run_aux_case(s, ops, O, ResidentPair)
         except Exception as e:   # noqa: BLE001 - a crash in one case must not hide the others
@@ -255,6 +307,9 @@ def main():
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{a.what}_{s}.npz"), **LAST)
             print(f"FAIL seed {s}: {'; '.join(fails)}\n     {case}", flush=True)
+    if a.force_paths:
+        names = {1: "key regrow", 2: "stage fallback", 4: "second selection pass", 8: "prefix growth"}
+        print("paths taken (library calls): " + ", ".join(f"{names[b]} {PATHS_HIT.get(b, 0)}" for b in (1, 2, 4, 8)), flush=True)
     print(f"fuzz_parity: {done} cases (seeds {a.seed}..{a.seed + done - 1}), {bad} failing, {time.time() - t0:.1f} s", flush=True)
     sys.exit(1 if bad else 0)
 
