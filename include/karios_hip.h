@@ -33,8 +33,8 @@ extern "C" {
 
 typedef struct km_ctx km_ctx;
 
-/* pixel types accepted for raw images */
-enum { KM_U8 = 0, KM_U16 = 1, KM_I16 = 2, KM_F32 = 3 };
+/* pixel types accepted for raw images (KM_F64 / KM_I32 / KM_U32: km_zncc_windows only) */
+enum { KM_U8 = 0, KM_U16 = 1, KM_I16 = 2, KM_F32 = 3, KM_F64 = 4, KM_I32 = 5, KM_U32 = 6 };
 
 /* status codes */
 enum {
@@ -164,6 +164,13 @@ int km_zncc_batch(km_ctx *ctx, const void *ref, const void *mon, int dtype, int 
                   int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon,
                   const float *x0, const float *y0, const float *dx, const float *dy, int n,
                   double *out);
+/* _zncc2(img1, img2, u1, v1, u2, v2, n) for `count` window pairs of any half-size n >= 0 (matcher/zncc_service.py:45-126;
+ * the reference's known-answer tests use 3x3 and 5x5 windows, tests/test_zncc_service.py:107-125) and any two pixel types:
+ * uv = u1[count] | v1[count] | u2[count] | v2[count] (rows, columns of the window centres).  out[k] = NaN for a window
+ * without variance; out_outside[k] = 1 (and NaN) where a window leaves its image - the reference raises IndexError there. */
+int km_zncc_windows(km_ctx *ctx, const void *img1, const void *img2, int dtype1, int dtype2, int H1, int W1, int H2,
+                    int W2, ptrdiff_t stride1, ptrdiff_t stride2, const int32_t *uv, int half_size, int count,
+                    double *out, uint8_t *out_outside);
 /* Mutual-information scores per keypoint on the 57x57 chips (next to ZNCC in _handle_klt_results, api/core.py:894-907):
  * out_studholme[k] = MutualInfoService._mutual_info  (matcher/mutual_info_service.py:32-63, column mutual_info_score)
  * out_nmi[k]       = ZNCCService._mutual_information (matcher/zncc_service.py:129-151,      column mi_score)

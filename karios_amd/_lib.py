@@ -73,6 +73,7 @@ SIGNATURES = {
     "km_tile_prefilter": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "km_zncc_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_mi_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "km_zncc_windows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _sz, _sz, _vp, _i, _i, _vp, _vp]),
     "km_phase_shift": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd]),
     "km_shift_image": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _i, _vp]),
     "km_klt_tile_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp,
@@ -137,6 +138,17 @@ def load():
                 fn.restype, fn.argtypes = res, args
             _lib = lib
     return _lib
+
+
+_ANY_DTYPES = {np.dtype("float64"): 4, np.dtype("int32"): 5, np.dtype("uint32"): 6}
+
+
+def any_dtype_code(arr: np.ndarray) -> int:
+    """Pixel-type code for the entry points that read every numeric type (km_zncc_windows)."""
+    code = _DTYPES.get(arr.dtype, _ANY_DTYPES.get(arr.dtype))
+    if code is None:
+        raise KariosHipError(f"unsupported pixel type {arr.dtype}")
+    return code
 
 
 def dtype_code(arr: np.ndarray) -> int:

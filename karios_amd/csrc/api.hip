@@ -1106,6 +1106,31 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
     return KM_OK;
 }
 
+int km_zncc_windows(km_ctx *c, const void *img1, const void *img2, int dtype1, int dtype2, int H1, int W1, int H2, int W2, ptrdiff_t stride1,
+                    ptrdiff_t stride2, const int32_t *uv, int half_size, int count, double *out, uint8_t *out_outside)
+{
+    int rc;
+    if ((rc = begin_call(c)) || (rc = check_image(c, img1, H1, W1, stride1, "zncc_windows")) || (rc = check_image(c, img2, H2, W2, stride2, "zncc_windows")))
+        return rc;
+    const size_t e1 = km_any_dtype_size(dtype1), e2 = km_any_dtype_size(dtype2);
+    if (!e1 || !e2) return km_fail(c, KM_E_ARG, "zncc_windows: bad dtypes %d / %d", dtype1, dtype2);
+    if (half_size < 0) return km_fail(c, KM_E_ARG, "zncc_windows: window half-size must be non-negative");
+    if (count < 0 || (count > 0 && (!uv || !out))) return km_fail(c, KM_E_ARG, "zncc_windows: bad window arrays");
+    if (count == 0) return KM_OK;
+    void *d1, *d2;
+    if ((rc = upload_image(c, WS_RAW_A, img1, e1, H1, W1, stride1, &d1)) || (rc = upload_image(c, WS_RAW_B, img2, e2, H2, W2, stride2, &d2))) return rc;
+    int *d_uv = (int *)km_ws(c, WS_MISC0, (size_t)count * 4 * sizeof(int));
+    double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)count * sizeof(double));
+    uint8_t *d_fl = (uint8_t *)km_ws(c, WS_MISC2, (size_t)count);
+    if (!d_uv || !d_out || !d_fl) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(d_uv, uv, (size_t)count * 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if ((rc = kz_zncc_windows(c, d1, d2, dtype1, dtype2, H1, W1, H2, W2, W1, W2, d_uv, half_size, count, d_out, d_fl))) return rc;
+    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (out_outside) KM_HIP(c, hipMemcpyAsync(out_outside, d_fl, (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
 int km_mi_batch_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
                     ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_st,
                     double *d_nmi)

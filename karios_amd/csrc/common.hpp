@@ -223,8 +223,13 @@ static inline size_t km_dtype_size(int dtype)
     case KM_U16: return 2;
     case KM_I16: return 2;
     case KM_F32: return 4;
-    default: return 0;
+    default: return 0;   // KM_F64 / KM_I32 / KM_U32 are read by km_zncc_windows only (km_any_dtype_size)
     }
+}
+
+static inline size_t km_any_dtype_size(int dtype)
+{
+    return dtype == KM_F64 ? 8 : (dtype == KM_I32 || dtype == KM_U32) ? 4 : km_dtype_size(dtype);
 }
 
 // ---- launchers implemented in the kernel translation units (all asynchronous) ----
@@ -287,6 +292,8 @@ int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href
 int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon,
                      ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx,
                      const float *d_dy, int n, const int *d_n, const float *d_score, float score_thr, double *d_out);
+int kz_zncc_windows(km_ctx *c, const void *d_img1, const void *d_img2, int dt1, int dt2, int H1, int W1, int H2, int W2, ptrdiff_t s1, ptrdiff_t s2,
+                    const int *d_uv, int half, int count, double *d_out, uint8_t *d_flags);
 // k_mi.hip
 int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t stride_ref,
               ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, const int *d_n,

@@ -93,3 +93,61 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
+
+// ---- _zncc2 for ANY window half-size and any pair of pixel types (reference zncc_service.py:45-126): out[k] = ZNCC of the
+// (2n+1)^2 windows centred at row u1[k], column v1[k] of image 1 and (u2[k], v2[k]) of image 2; NaN when a window has no
+// variance; windows leaving their image are the CALLER's IndexError (flagged here as NaN with out_flags[k] = 1).
+// One wavefront per window pair, two passes over the pixels (mean, then centred sums), fp64 like numpy on integer / float64 data.
+__device__ __forceinline__ double zn_load(const void *img, int dtype, size_t idx)
+{
+    switch (dtype) {   // wave-uniform
+    case KM_U8: return (double)((const uint8_t *)img)[idx];
+    case KM_U16: return (double)((const uint16_t *)img)[idx];
+    case KM_I16: return (double)((const int16_t *)img)[idx];
+    case KM_F32: return (double)((const float *)img)[idx];
+    case KM_F64: return ((const double *)img)[idx];
+    case KM_I32: return (double)((const int32_t *)img)[idx];
+    default: return (double)((const uint32_t *)img)[idx];
+    }
+}
+
+__global__ __launch_bounds__(256) void zncc_win_kernel(const void *__restrict__ img1, const void *__restrict__ img2, int dt1, int dt2, int H1, int W1,
+                                                       int H2, int W2, ptrdiff_t s1, ptrdiff_t s2, const int *__restrict__ uv /* 4 x count */,
+                                                       int half, int count, double *__restrict__ out, uint8_t *__restrict__ flags)
+{
+    const int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= count) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const int u1 = uv[k], v1 = uv[count + k], u2 = uv[2 * count + k], v2 = uv[3 * count + k];
+    const bool outside = u1 - half < 0 || u1 + half >= H1 || v1 - half < 0 || v1 + half >= W1 || u2 - half < 0 || u2 + half >= H2 ||
+                         v2 - half < 0 || v2 + half >= W2;
+    if (outside) { if (lane == 0) { out[k] = nan; if (flags) flags[k] = 1; } return; }
+    const int side = 2 * half + 1, npx = side * side;
+    double a_sum = 0, b_sum = 0;
+    for (int i = lane; i < npx; i += 64) {
+        const int r = i / side, cx = i - r * side;
+        a_sum += zn_load(img1, dt1, (size_t)(u1 - half + r) * s1 + (v1 - half + cx));
+        b_sum += zn_load(img2, dt2, (size_t)(u2 - half + r) * s2 + (v2 - half + cx));
+    }
+    const double m1 = wave_sum_f64(a_sum) / (double)npx, m2 = wave_sum_f64(b_sum) / (double)npx;
+    double q1 = 0, q2 = 0, cc = 0;
+    for (int i = lane; i < npx; i += 64) {
+        const int r = i / side, cx = i - r * side;
+        const double a = zn_load(img1, dt1, (size_t)(u1 - half + r) * s1 + (v1 - half + cx)) - m1;
+        const double b = zn_load(img2, dt2, (size_t)(u2 - half + r) * s2 + (v2 - half + cx)) - m2;
+        q1 += a * a; q2 += b * b; cc += a * b;
+    }
+    q1 = wave_sum_f64(q1); q2 = wave_sum_f64(q2); cc = wave_sum_f64(cc);
+    const double sd1 = sqrt(q1 / (double)npx), sd2 = sqrt(q2 / (double)npx);
+    if (lane == 0) { out[k] = (sd1 == 0.0 || sd2 == 0.0) ? nan : cc / (sd1 * sd2) / (double)npx; if (flags) flags[k] = 0; }
+}
+
+int kz_zncc_windows(km_ctx *c, const void *d_img1, const void *d_img2, int dt1, int dt2, int H1, int W1, int H2, int W2, ptrdiff_t s1, ptrdiff_t s2,
+                    const int *d_uv, int half, int count, double *d_out, uint8_t *d_flags)
+{
+    if (count <= 0) return KM_OK;
+    zncc_win_kernel<<<(count + 3) / 4, 256, 0, c->stream>>>(d_img1, d_img2, dt1, dt2, H1, W1, H2, W2, s1, s2, d_uv, half, count, d_out, d_flags);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

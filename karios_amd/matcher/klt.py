@@ -1,348 +1,256 @@
-"""KLT matcher -- drop-in for `karios.matcher.klt` with the numeric work on MI355X.
+"""KLT matcher on MI355X behind the `karios.matcher.klt` surface.
 
-Same public surface as the reference module (`karios/matcher/klt.py`):
-`KLT(conf, gen_laplacian=False, out_dir=None).match(mon, ref, mask)`, the properties
-`auto_selected_ksize` / `auto_selected_polarity`, and the module function
-`klt_tracker(ref_data, image_data, mask, conf, p0=None)`.  Where the reference calls
-cv2 / numpy on whole tiles, this module calls `karios_amd.ops` (HIP kernels through the
-C ABI).  Tile ordering, None conventions, DataFrame columns/dtypes and the float32
-forward-backward arithmetic follow the reference line by line (cited inline).
+Public names and contracts are the reference's (`karios/matcher/klt.py:83-234, 351-405`): `KLT(conf, gen_laplacian, out_dir)`,
+`KLT.match(mon_img, ref_img, mask)` yielding one float32 `x0, y0, dx, dy, score` frame per productive tile in x-outer / y-inner
+order, the `auto_selected_ksize` / `auto_selected_polarity` properties and `klt_tracker(ref, img, mask, conf, p0)`.
+
+Everything behind them is organised around the device instead of around cv2 calls: a tile's two boxes are uploaded ONCE
+(`ResidentPair`), every trial the configuration asks for - fixed parameters, the 5x5 Laplacian kernel-size search, both
+polarities - runs on that resident copy (stretch, Laplacians, mask, corners, LK forward / backward, forward-backward test and
+the (x0, y0) ordering in libkarios_hip), and only finished frames and inlier counts come back; the host compares trials and
+keeps tallies.
 """
 from __future__ import annotations
 
-import itertools
 import logging
 import os
 from collections import Counter
 from collections.abc import Iterator
+from dataclasses import dataclass
 
 import numpy as np
 from pandas import DataFrame
 
-from .. import ops
+from .. import frames, ops, tiling
+from ..resident import ResidentPair
 
 logger = logging.getLogger(__name__)
 
-LAPLACIAN_AUTO_CANDIDATES = [3, 5, 7, 9, 11]  # reference klt.py:39
-
-
-def _to_uint8(arr: np.ndarray) -> np.ndarray:
-    """Normalize an array to uint8, no-op if already uint8 (reference klt.py:42-49)."""
-    if arr.dtype == np.uint8:
-        return arr
-    return ops.to_uint8(arr)
-
-
-def _filter_outliers(x0, y0, x1, y1, score):
-    """Iterative 3-sigma / 20 px clip (reference klt.py:52-71, `__filter_outliers`)."""
-    dx = x1 - x0
-    dy = y1 - y0
-    while True:
-        ind = (
-            (np.abs(dx - dx.mean()) < 3 * dx.std())
-            & (np.abs(dy - dy.mean()) < 3 * dy.std())
-            & (np.abs(dx - dx.mean()) < 20)
-            & (np.abs(dy - dy.mean()) < 20)
-        )
-        if int(np.count_nonzero(ind)) == len(dx):
-            break
-        dx, dy = dx[ind], dy[ind]
-        x0, x1, y0, y1, score = x0[ind], x1[ind], y0[ind], y1[ind], score[ind]
-    return x0, y0, x1, y1, score
-
-
-def _frame_from_tracks(p0, p1, p0r, conf) -> tuple[DataFrame, int]:
-    """Forward-backward test, score and DataFrame assembly (reference klt.py:142-170).
-    LK status is deliberately ignored, as in the reference (klt.py:142-144)."""
-    d = abs(p0 - p0r).reshape(-1, 2).max(-1)
-    back_threshold = 0.1
-    st = d < back_threshold
-    ninit = len(p0)
-    p0, p1, d = p0[st], p1[st], d[st]
-    score = 1 - d / back_threshold
-    x0 = p0[:, 0, 0].reshape(len(p0))
-    y0 = p0[:, 0, 1].reshape(len(p0))
-    x1 = p1[:, 0, 0].reshape(len(p1))
-    y1 = p1[:, 0, 1].reshape(len(p1))
-    if conf.outliers_filtering:
-        logger.info("Filter outliers")
-        x0, y0, x1, y1, score = _filter_outliers(x0, y0, x1, y1, score)
-    frame = DataFrame.from_dict({"x0": x0, "y0": y0, "dx": x1 - x0, "dy": y1 - y0, "score": score})
-    return frame, ninit
-
-
-def _sorted_tile_frame(p0, p1, p0r, conf, x_off=0, y_off=0) -> tuple[DataFrame, int]:
-    """`_frame_from_tracks` + tile offsets + `sort_values(by=["x0", "y0"])` (reference klt.py:341-348) built in
-    one go: same rows, same values, same (permuted) index labels as the reference's in-place sort, without
-    the pandas sort machinery (key pairs are unique, so the order is fully determined)."""
-    frame, ninit = _frame_from_tracks(p0, p1, p0r, conf)
-    x0 = frame["x0"].to_numpy() + x_off
-    y0 = frame["y0"].to_numpy() + y_off
-    order = np.lexsort((y0, x0))
-    cols = {"x0": x0[order], "y0": y0[order]}
-    for c in ("dx", "dy", "score"):
-        cols[c] = frame[c].to_numpy()[order]
-    return DataFrame(cols, index=order, copy=False), ninit
+LAPLACIAN_AUTO_CANDIDATES = list(tiling.AUTO_KSIZE_CANDIDATES)
+_DEVICE_DTYPES = (np.uint8, np.uint16, np.int16, np.float32)
 
 
 def klt_tracker(ref_data, image_data, mask, conf, p0=None, ctx=None) -> tuple[DataFrame, int] | None:
-    """Run KLT (reference klt.py:83-172): Shi-Tomasi corners on `ref_data` (unless `p0` is
-    given), pyramidal LK ref->image and image->ref, forward-backward filtering.
+    """Corners of `ref_data` (or the given `p0`), tracked into `image_data` and back; the tracks whose return trip ends
+    within 0.1 px of their start are scored (reference klt.py:83-172; the LK status flags are ignored there too).
 
-    Returns:
-        (DataFrame[x0, y0, dx, dy, score] float32, Ninit) or None when no feature is extracted.
-    """
-    logger.info("Start tracking")
+    Returns (frame[x0, y0, dx, dy, score] float32 in corner order, number of corners), or None without corners."""
     tracks = ops.klt_track(ref_data, image_data, mask, conf, p0=p0, ctx=ctx)
     if tracks is None:
-        logger.info("No features extracted")
+        logger.info("klt_tracker: no corner found")
         return None
-    result = _frame_from_tracks(*tracks, conf)
-    logger.info("Tracking finished")
-    return result
+    cols, n_init = frames.track_columns(*tracks)
+    frame = frames.assemble(cols, clip_outliers=bool(getattr(conf, "outliers_filtering", False)), ordered=False)
+    logger.info("klt_tracker: %d of %d corners survive the forward-backward test", len(frame), n_init)
+    return frame, n_init
+
+
+@dataclass
+class _Trial:
+    """Outcome of one (polarity, kernel sizes) attempt on a tile."""
+    frame: DataFrame          # ordered tile frame, offsets applied
+    n_init: int               # corners the tracker started from
+    ksizes: tuple[int, int]   # (mon, ref) Laplacian kernel sizes used
+    inverted: bool
+
+    @property
+    def inlier_ratio(self) -> float:
+        return len(self.frame) / self.n_init if self.n_init > 0 else 0.0
+
+    @property
+    def polarity(self) -> str:
+        return "inverted" if self.inverted else "normal"
+
+
+class _TileSession:
+    """A tile resident on the device for the duration of its trials."""
+
+    def __init__(self, conf, tile: tiling.Tile, mon_box, ref_box, mask_box, nodata_mon, nodata_ref, ctx):
+        self.conf, self.tile = conf, tile
+        mon_box, ref_box = np.asarray(mon_box), np.asarray(ref_box)
+        if mask_box is not None:
+            mask_box = np.ascontiguousarray(mask_box, np.uint8)
+        if mon_box.dtype != ref_box.dtype or mon_box.dtype.type not in _DEVICE_DTYPES:
+            # Cross-sensor pairs (a uint8 chip against uint16 data) and pixel types the kernels do not read (int32, float64 ...):
+            # the reference stretches each image on its own and derives the mask from the raw values, so do exactly that
+            # up front and hand the device a uint8 pair with an explicit mask.
+            if mask_box is None:
+                mask_box = _validity_mask(mon_box, ref_box, nodata_mon, nodata_ref)
+            mon_box, ref_box = _stretch_any(mon_box, ctx), _stretch_any(ref_box, ctx)
+            nodata_mon = nodata_ref = None
+        self.pair = ResidentPair.upload(mon_box, ref_box, mask_box, ctx=ctx, no_data_mon=nodata_mon, no_data_ref=nodata_ref)
+        self._host = (mon_box, ref_box)
+        self.valid_pixels = -1                     # unknown until a fixed-parameter trial has run
+
+    def fixed(self, ksizes: tuple[int, int], inverted: bool) -> _Trial | None:
+        frame = self.pair.match_tile(self.conf, ksizes=ksizes, invert_mon=inverted, origin=self.tile[:2])
+        self.valid_pixels = int(self.pair.ctx.stats().valid_pixels)
+        if frame is None:
+            return None
+        return _Trial(frame, int(frame.attrs.get("Ninit", len(frame))), ksizes, inverted)
+
+    def kernel_search(self, inverted: bool) -> _Trial | None:
+        """Best of the 25 (mon, ref) kernel-size pairs by inlier ratio; the first pair in (mon outer, ref inner) order keeps a
+        tie (klt.py:534-539)."""
+        if not getattr(self.conf, "outliers_filtering", False):
+            frame, ratios, best, n_init = self.pair.match_tile_auto_ksize(self.conf, invert_mon=inverted, candidates=LAPLACIAN_AUTO_CANDIDATES,
+                                                                          origin=self.tile[:2])
+            _log_search(ratios, best, inverted)
+            return None if frame is None else _Trial(frame, n_init, best, inverted)
+        # with the sigma clip the inlier count of a pair is only known after numpy's float32 statistics: one device run per pair
+        winner, ratios = None, {}
+        for mon_k in LAPLACIAN_AUTO_CANDIDATES:
+            for ref_k in LAPLACIAN_AUTO_CANDIDATES:
+                trial = self.fixed((mon_k, ref_k), inverted)
+                ratios[(mon_k, ref_k)] = trial.inlier_ratio if trial else 0.0
+                if trial and (winner is None or trial.inlier_ratio > winner.inlier_ratio):
+                    winner = trial
+        _log_search(ratios, winner.ksizes if winner else None, inverted)
+        return winner
+
+    def laplacians(self, trial: _Trial) -> tuple[np.ndarray, np.ndarray]:
+        """(monitored, reference) Laplacian images of a trial, for the optional debug dump."""
+        mon_box, ref_box = self._host
+        lap_ref, lap_mon, _, _ = ops.tile_prefilter(ref_box, mon_box, ref_ksize=trial.ksizes[1], mon_ksize=trial.ksizes[0],
+                                                    invert_mon=trial.inverted, with_mask=False, ctx=self.pair.ctx)
+        return lap_mon, lap_ref
+
+
+def _validity_mask(mon_box, ref_box, nodata_mon, nodata_ref) -> np.ndarray:
+    """The automatic mask (klt.py:268-273) for pixel types the device does not read: 1 where both images hold a non-zero,
+    finite value different from their no-data value."""
+    valid = np.ones(mon_box.shape, bool)
+    for box, nodata in ((mon_box, nodata_mon), (ref_box, nodata_ref)):
+        valid &= box != 0
+        if box.dtype.kind in "fc":
+            valid &= np.isfinite(box)
+        if nodata is not None:
+            valid &= box != nodata
+    return valid.view(np.uint8)
+
+
+def _stretch_any(box: np.ndarray, ctx) -> np.ndarray:
+    """Min-max stretch to uint8 with the reference's arithmetic (klt.py:42-49) for any numeric dtype: on the device for the
+    types it reads, else numpy's own promotion rules."""
+    if box.dtype == np.uint8:
+        return box
+    if box.dtype.type in _DEVICE_DTYPES:
+        return ops.to_uint8(box, ctx=ctx)
+    lo, hi = float(np.nanmin(box)), float(np.nanmax(box))
+    if not hi > lo:
+        return np.zeros(box.shape, np.uint8)
+    return ((box - lo) / (hi - lo) * 255).astype(np.uint8)
+
+
+def _log_search(ratios, best, inverted):
+    if logger.isEnabledFor(logging.DEBUG):
+        for pair, ratio in ratios.items():
+            logger.debug("kernel-size search (%s polarity): mon %d / ref %d -> inlier ratio %.3f", "inverted" if inverted else "normal",
+                         pair[0], pair[1], ratio)
+    if best is None:
+        logger.info("kernel-size search: no pair produced corners")
+    else:
+        logger.info("kernel-size search: mon %d / ref %d wins with inlier ratio %.3f", best[0], best[1], ratios[best])
 
 
 class KLT:
-    # pylint: disable=too-few-public-methods
-    """Class to execute KLT matcher (reference klt.py:175-545)."""
+    """Tile-wise KLT matching of a monitored image against a reference image."""
 
     def __init__(self, conf, gen_laplacian: bool = False, out_dir: str | None = None, ctx=None):
         self._conf = conf
         self._gen_laplacian = gen_laplacian
         self._out_dir = out_dir
         self._ctx = ctx
-        self._auto_selected_ksizes: list[tuple[int, int]] = []
-        self._selected_polarities: list[str] = []
+        self._ksize_votes: Counter = Counter()      # (mon, ref) chosen per tile by the kernel-size search
+        self._polarity_votes: Counter = Counter()   # "normal" / "inverted" chosen per tile by the polarity search
 
-    # ------------------------------------------------------------------ tiling
-    def tile_boxes(self, x_size: int, y_size: int) -> list[tuple[int, int, int, int]]:
-        """(x_off, y_off, x_size, y_size) of every tile in the reference's order: x outer
-        (skipping x_off < xStart), y inner, edge tiles clipped (klt.py:220-249)."""
-        boxes = []
-        ts = self._conf.tile_size
-        for x_off in range(0, x_size, ts):
-            if x_off < self._conf.xStart:
-                continue
-            for y_off in range(0, y_size, ts):
-                bx = ts if x_off + ts < x_size else x_size - x_off
-                by = ts if y_off + ts < y_size else y_size - y_off
-                boxes.append((x_off, y_off, bx, by))
-        return boxes
-
+    # ------------------------------------------------------------------ public surface
     def match(self, mon_img, ref_img, mask) -> Iterator[DataFrame]:
-        """Run KLT on the image to monitor against a reference image (klt.py:198-234).
-
-        Yields one DataFrame per tile that produced points."""
-        logger.info("KLT...")
-        logger.info("%s %s", mon_img.x_size, mon_img.y_size)
-        self._log_polarity_setting()
-        for x_off, y_off, _, _ in self.tile_boxes(mon_img.x_size, mon_img.y_size):
-            points = self._match_tile(x_off, y_off, mon_img, ref_img, mask)
-            if points is None:
-                continue
-            yield points
-        self._log_polarity_summary()
-
-    def _match_tile(self, x_off, y_off, mon_img, ref_img, mask) -> DataFrame | None:
-        logger.info("Tile: %s %s (%s %s)", x_off, y_off, mon_img.x_size, mon_img.y_size)
-        ts = self._conf.tile_size
-        x_size = ts if x_off + ts < mon_img.x_size else mon_img.x_size - x_off
-        y_size = ts if y_off + ts < mon_img.y_size else mon_img.y_size - y_off
-
-        ref_box = ref_img.read(1, x_off, y_off, x_size, y_size)
-        img_box = mon_img.read(1, x_off, y_off, x_size, y_size)
-        mask_box = mask.read(1, x_off, y_off, x_size, y_size) if mask else None
-        nodata = (getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None))
-
-        polarity_mode = self._conf.laplacian_invert_polarity
-        ksize = self._conf.laplacian_kernel_size
-        fused = polarity_mode != "auto" and ksize != "auto" and not self._gen_laplacian
-        if fused:
-            # whole tile in one device pipeline (stretch, Laplacians, mask, GFTT, LK)
-            mon_k, ref_k = self._resolve_ksize(ksize)
-            status, tracks = ops.klt_tile(ref_box, img_box, self._conf, mask_box=mask_box, nodata_ref=nodata[1],
-                                          nodata_mon=nodata[0], mon_ksize=mon_k, ref_ksize=ref_k,
-                                          invert_mon=bool(polarity_mode), ctx=self._ctx)
-            if status == "no_valid_pixels":
-                logger.info("-- No valid pixels, skipping this tile")
-                return None
-            results = None if tracks is None else _frame_from_tracks(*tracks, self._conf)
-            dump = None
-        else:
-            if mask_box is None:
-                mask_box, valid_pixels = ops.auto_mask(img_box, ref_box, nodata[0], nodata[1], ctx=self._ctx)
+        """Match every tile of the pair; yields the frames of the tiles that produced key points (klt.py:198-234)."""
+        grid = self.tile_boxes(mon_img.x_size, mon_img.y_size)
+        logger.info("KLT: %dx%d px in %d tile(s) of %d px, polarity %s, Laplacian kernel %s", mon_img.x_size, mon_img.y_size, len(grid),
+                    self._conf.tile_size, self._describe_polarity(), self._conf.laplacian_kernel_size)
+        for tile in grid:
+            frame = self._match_tile(tile.x_off, tile.y_off, mon_img, ref_img, mask)
+            if frame is not None:
+                yield frame
+        if self._conf.laplacian_invert_polarity == "auto":
+            total = sum(self._polarity_votes.values())
+            if total:
+                logger.info("polarity search: %s", ", ".join(f"{name} kept on {n}/{total} tiles" for name, n in self._polarity_votes.most_common()))
             else:
-                valid_pixels = int(np.count_nonzero(np.asarray(mask_box) > 0))
-            if valid_pixels == 0:
-                logger.info("-- No valid pixels, skipping this tile")
-                return None
-            logger.info("Nb valid pixels: %s/%s", valid_pixels, x_size * y_size)
-            if polarity_mode == "auto":
-                normal_res, normal_dump = self._laplacian_track_once(img_box, ref_box, mask_box, invert_mon=False)
-                inverted_res, inverted_dump = self._laplacian_track_once(img_box, ref_box, mask_box, invert_mon=True)
-                results, dump = self._select_best_polarity(normal_res, normal_dump, inverted_res, inverted_dump)
-            else:
-                results, dump = self._laplacian_track_once(img_box, ref_box, mask_box, invert_mon=bool(polarity_mode))
+                logger.info("polarity search: no tile produced key points")
 
-        if dump is not None:
-            img_lap, ref_lap, mon_ksize, ref_ksize, invert_mon = dump
-            if self._conf.laplacian_kernel_size == "auto":
-                self._auto_selected_ksizes.append((mon_ksize, ref_ksize))
-            if self._gen_laplacian:
-                suffix = "_inv" if invert_mon else ""
-                self._write_laplacian(f"mon_laplacian{suffix}_k{mon_ksize}_{x_off}_{y_off}_{x_size}_{y_size}", img_lap)
-                self._write_laplacian(f"ref_laplacian_k{ref_ksize}_{x_off}_{y_off}_{x_size}_{y_size}", ref_lap)
-
-        if not results:
-            logger.warning("No result for tile %s %s (%s %s)", x_off, y_off, mon_img.x_size, mon_img.y_size)
-            return None
-
-        points, initial_nb_points = results
-        points["x0"] = points["x0"] + x_off
-        points["y0"] = points["y0"] + y_off
-        logger.info("NbPoints(init/final): %s / %s", initial_nb_points, len(points.dx))
-        logger.info("DX/DY(KLT) MEAN: %s / %s", points.dx.mean(), points.dy.mean())
-        logger.info("DX/DY(KLT) STD: %s / %s", points.dx.std(), points.dy.std())
-        points.sort_values(by=["x0", "y0"], inplace=True)
-        return points
-
-    def _write_laplacian(self, stem: str, lap: np.ndarray) -> None:
-        """Debug dump of a Laplacian (reference uses skimage.io.imsave, klt.py:307-322)."""
-        path = os.path.join(self._out_dir or ".", stem)
-        try:
-            from skimage import io  # type: ignore
-            io.imsave(path + ".tif", lap)
-        except ImportError:
-            np.save(path + ".npy", lap)
-
-    # ------------------------------------------------------------------ properties
     @property
     def auto_selected_ksize(self) -> tuple[int, int] | None:
-        """Most common (mon_ksize, ref_ksize) pair across auto-mode tiles (klt.py:351-356)."""
-        if not self._auto_selected_ksizes:
-            return None
-        return Counter(self._auto_selected_ksizes).most_common(1)[0][0]
+        """The (mon, ref) kernel-size pair the search chose most often (None outside 'auto' mode / before `match`)."""
+        return self._ksize_votes.most_common(1)[0][0] if self._ksize_votes else None
 
     @property
     def auto_selected_polarity(self) -> str | None:
-        """Most common polarity ('normal' / 'inverted') across tiles in 'auto' mode (klt.py:399-405)."""
-        if not self._selected_polarities:
+        """'normal' or 'inverted', whichever the polarity search chose most often (None outside 'auto' mode)."""
+        return self._polarity_votes.most_common(1)[0][0] if self._polarity_votes else None
+
+    # ------------------------------------------------------------------ helpers other modules and tests rely on
+    def tile_boxes(self, x_size: int, y_size: int) -> list[tiling.Tile]:
+        return tiling.tile_grid(x_size, y_size, self._conf.tile_size, self._conf.xStart)
+
+    _resolve_ksize = staticmethod(tiling.kernel_sizes)
+
+    # ------------------------------------------------------------------ one tile
+    def _match_tile(self, x_off, y_off, mon_img, ref_img, mask) -> DataFrame | None:
+        """Frame of the tile whose origin is (x_off, y_off), or None (no valid pixel, no corner)."""
+        size = self._conf.tile_size
+        tile = tiling.Tile(x_off, y_off, min(size, mon_img.x_size - x_off), min(size, mon_img.y_size - y_off))
+        window = (1, *tile)
+        session = _TileSession(self._conf, tile, mon_img.read(*window), ref_img.read(*window), mask.read(*window) if mask else None,
+                               getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None), self._ctx)
+        trial = self._best_trial(session)
+        if trial is None:
+            logger.info("tile (%d, %d): no valid pixels or no corners - skipped", x_off, y_off)
+            fixed_run = self._conf.laplacian_kernel_size != "auto" and self._conf.laplacian_invert_polarity != "auto"
+            if self._gen_laplacian and fixed_run and session.valid_pixels > 0:   # the reference still writes its Laplacians then
+                self._dump(session, _Trial(DataFrame(), 0, tiling.kernel_sizes(self._conf.laplacian_kernel_size),
+                                           bool(self._conf.laplacian_invert_polarity)))
             return None
-        return Counter(self._selected_polarities).most_common(1)[0][0]
+        if self._conf.laplacian_kernel_size == "auto":
+            self._ksize_votes[trial.ksizes] += 1
+        if self._gen_laplacian:
+            self._dump(session, trial)
+        pts = trial.frame
+        pts.attrs.clear()
+        logger.info("tile (%d, %d): %d of %d corners kept, mean shift (%.4f, %.4f), std (%.4f, %.4f)", x_off, y_off, len(pts), trial.n_init,
+                    *(float(v) if len(pts) else float("nan") for v in (pts.dx.mean(), pts.dy.mean(), pts.dx.std(), pts.dy.std())))
+        return pts
 
-    # ------------------------------------------------------------------ unfused path
-    @staticmethod
-    def _resolve_ksize(ksize):
-        """int | {"mon","ref"} -> (mon_ksize, ref_ksize) (klt.py:431-432)."""
-        if isinstance(ksize, dict):
-            return ksize.get("mon", ksize.get("ref", 1)), ksize.get("ref", ksize.get("mon", 1))
-        return ksize, ksize
-
-    def _apply_laplacian_and_track(self, img_box, ref_box, mask_box, mon_ksize, ref_ksize):
-        lap_img = ops.laplacian_u8(_to_uint8(img_box), mon_ksize, ctx=self._ctx)
-        lap_ref = ops.laplacian_u8(_to_uint8(ref_box), ref_ksize, ctx=self._ctx)
-        return klt_tracker(lap_ref, lap_img, mask_box, self._conf, ctx=self._ctx)
-
-    def _laplacian_track_once(self, img_box, ref_box, mask_box, invert_mon: bool):
-        """Laplacian + KLT once (klt.py:407-436) -> (result, (img_lap, ref_lap, mon_k, ref_k, invert) | None)."""
-        img_for_lap = ops.to_uint8(img_box, invert=True, ctx=self._ctx) if invert_mon else img_box
-        ksize = self._conf.laplacian_kernel_size
-        if ksize == "auto":
-            result, _, best_ksize = self._match_tile_auto_ksize(img_for_lap, ref_box, mask_box)
-            if best_ksize is None:
-                return result, None
-            mon_ksize, ref_ksize = best_ksize
-            img_lap = ops.laplacian_u8(_to_uint8(img_for_lap), mon_ksize, ctx=self._ctx)
-            ref_lap = ops.laplacian_u8(_to_uint8(ref_box), ref_ksize, ctx=self._ctx)
-            return result, (img_lap, ref_lap, mon_ksize, ref_ksize, invert_mon)
-        mon_ksize, ref_ksize = self._resolve_ksize(ksize)
-        img_lap = ops.laplacian_u8(_to_uint8(img_for_lap), mon_ksize, ctx=self._ctx)
-        ref_lap = ops.laplacian_u8(_to_uint8(ref_box), ref_ksize, ctx=self._ctx)
-        result = klt_tracker(ref_lap, img_lap, mask_box, self._conf, ctx=self._ctx)
-        return result, (img_lap, ref_lap, mon_ksize, ref_ksize, invert_mon)
-
-    def _select_best_polarity(self, normal_res, normal_dump, inverted_res, inverted_dump):
-        """Keep the polarity with the higher inlier ratio, 'normal' first on ties (klt.py:438-463)."""
-        candidates = []
-        for label, res, dump in (("normal", normal_res, normal_dump), ("inverted", inverted_res, inverted_dump)):
-            if res is None:
-                continue
-            points, ninit = res
-            ratio = len(points) / ninit if ninit > 0 else 0.0
-            candidates.append((label, ratio, res, dump))
-        if not candidates:
-            logger.info("Auto polarity: no candidate produced a result")
-            return None, None
-        candidates.sort(key=lambda c: c[1], reverse=True)
-        label, ratio, result, dump = candidates[0]
-        self._selected_polarities.append(label)
-        logger.info("Auto polarity selected: %s (inlier ratio=%.3f)", label, ratio)
-        return result, dump
-
-    def _match_tile_auto_ksize(self, img_box, ref_box, mask_box):
-        """Try the 25 (mon_ksize, ref_ksize) pairs, keep the highest inlier ratio, first wins
-        ties (klt.py:465-545).  Returns (best result | None, {pair: ratio}, best pair | None)."""
-        combinations = list(itertools.product(LAPLACIAN_AUTO_CANDIDATES, repeat=2))
-        if not getattr(self._conf, "outliers_filtering", False):
-            # batched search on the device (km_klt_auto_ksize_frame_dev): the tile is uploaded once, the 10 Laplacians,
-            # their pyramids and the 5 corner lists are shared by the 25 tracker runs
-            from ..resident import ResidentPair
-            pair = ResidentPair.upload(np.ascontiguousarray(img_box), np.ascontiguousarray(ref_box), mask_box, ctx=self._ctx)
-            frame, scores, best_ksize, ninit = pair.match_tile_auto_ksize(self._conf, candidates=LAPLACIAN_AUTO_CANDIDATES)
-            for (mk, rk) in combinations:
-                logger.info("Auto laplacian: mon_ksize=%s ref_ksize=%s inlier ratio=%.3f", mk, rk, scores[(mk, rk)])
-            logger.info("Auto laplacian selected: mon_ksize=%s ref_ksize=%s", *(best_ksize if best_ksize else (None, None)))
-            return (None if frame is None else (frame, ninit)), scores, best_ksize
-        img_uint8 = _to_uint8(img_box)
-        ref_uint8 = _to_uint8(ref_box)
-        mon_laplacians = {k: ops.laplacian_u8(img_uint8, k, ctx=self._ctx) for k in LAPLACIAN_AUTO_CANDIDATES}
-        ref_laplacians = {k: ops.laplacian_u8(ref_uint8, k, ctx=self._ctx) for k in LAPLACIAN_AUTO_CANDIDATES}
-        ref_p0s = {
-            k: ops.good_features_to_track(lap, self._conf.maxCorners, self._conf.qualityLevel, self._conf.minDistance,
-                                          mask=mask_box, blockSize=self._conf.blocksize, ctx=self._ctx)
-            for k, lap in ref_laplacians.items()
-        }
-        scores: dict[tuple[int, int], float] = {}
-        best_result, best_ratio, best_ksize = None, -1.0, None
-        # The reference maps these runs over a ThreadPoolExecutor and consumes them in submission
-        # order; one GPU stream runs them back to back in the same order, same tie rule.
-        for mon_ksize, ref_ksize in combinations:
-            logger.info("Auto laplacian: trying mon_ksize=%s ref_ksize=%s", mon_ksize, ref_ksize)
-            p0 = ref_p0s[ref_ksize]
-            result = None
-            if p0 is not None:
-                result = klt_tracker(ref_laplacians[ref_ksize], mon_laplacians[mon_ksize], mask_box, self._conf, p0=p0,
-                                     ctx=self._ctx)
-            if result is None:
-                scores[(mon_ksize, ref_ksize)] = 0.0
-                continue
-            points, ninit = result
-            ratio = len(points) / ninit if ninit > 0 else 0.0
-            scores[(mon_ksize, ref_ksize)] = ratio
-            if ratio > best_ratio:
-                best_ratio, best_result, best_ksize = ratio, result, (mon_ksize, ref_ksize)
-        logger.info("Auto laplacian selected: mon_ksize=%s ref_ksize=%s (inlier ratio=%.3f)",
-                    best_ksize[0] if best_ksize else None, best_ksize[1] if best_ksize else None, best_ratio)
-        return best_result, scores, best_ksize
-
-    # ------------------------------------------------------------------ logging
-    def _log_polarity_setting(self) -> None:
+    def _best_trial(self, session: _TileSession) -> _Trial | None:
+        search_kernels = self._conf.laplacian_kernel_size == "auto"
+        run = session.kernel_search if search_kernels else (lambda inv: session.fixed(tiling.kernel_sizes(self._conf.laplacian_kernel_size), inv))
         mode = self._conf.laplacian_invert_polarity
-        if mode == "auto":
-            logger.info("Laplacian polarity: 'auto' - each tile runs twice, the higher inlier ratio is kept")
-        elif mode:
-            logger.info("Laplacian polarity: 'inverted' - monitored pixels are inverted (255 - pixel) before Laplacian")
-        else:
-            logger.info("Laplacian polarity: 'normal' - no inversion before Laplacian")
+        if mode != "auto":
+            return run(bool(mode))
+        # both polarities; the higher inlier ratio wins and 'normal' keeps a tie (klt.py:438-463)
+        trials = [t for t in (run(False), run(True)) if t is not None]
+        if not trials:
+            return None
+        best = max(trials, key=lambda t: t.inlier_ratio)   # max() returns the first of equal maxima: 'normal'
+        self._polarity_votes[best.polarity] += 1
+        logger.info("polarity search: %s kept (inlier ratio %.3f)", best.polarity, best.inlier_ratio)
+        return best
 
-    def _log_polarity_summary(self) -> None:
-        if self._conf.laplacian_invert_polarity != "auto":
-            return
-        if not self._selected_polarities:
-            logger.info("Auto polarity: no tile produced a result")
-            return
-        counts = Counter(self._selected_polarities)
-        total = sum(counts.values())
-        dominant, dominant_count = counts.most_common(1)[0]
-        details = ", ".join(f"{name}={n}/{total}" for name, n in counts.most_common())
-        logger.info("Auto polarity dominant choice: '%s' (%d/%d tiles, %s)", dominant, dominant_count, total, details)
+    def _describe_polarity(self) -> str:
+        mode = self._conf.laplacian_invert_polarity
+        return "searched per tile" if mode == "auto" else ("inverted (255 - pixel of the monitored image)" if mode else "normal")
+
+    def _dump(self, session: _TileSession, trial: _Trial) -> None:
+        """Debug output of the two Laplacians of a tile, named like the reference's (klt.py:307-322)."""
+        lap_mon, lap_ref = session.laplacians(trial)
+        box = "_".join(str(v) for v in session.tile)
+        stems = (f"mon_laplacian{'_inv' if trial.inverted else ''}_k{trial.ksizes[0]}_{box}", f"ref_laplacian_k{trial.ksizes[1]}_{box}")
+        for stem, lap in zip(stems, (lap_mon, lap_ref)):
+            path = os.path.join(self._out_dir or ".", stem)
+            try:
+                from skimage import io  # type: ignore
+                io.imsave(path + ".tif", lap)
+            except ImportError:
+                np.save(path + ".npy", lap)

@@ -1,7 +1,9 @@
-"""Mutual-information scoring -- drop-in for `karios.matcher.mutual_info_service.MutualInfoService`
-(`compute_mutual_info`, Studholme NMI in [1, 2]).  The reference scores each key point with a pandas `apply`
-(~0.7 ms per key point); here one HIP kernel builds the 32x32 joint histogram of every key point's 57x57
-chips in LDS.  `ZNCCService.compute_mi` (the [0, 1] variant) shares the kernel.
+"""Studholme normalised mutual information of the matched key points on MI355X, behind
+`karios.matcher.mutual_info_service.MutualInfoService` (reference `mutual_info_service.py:32-130`): per key point the 57x57
+chips around `(int(x0), int(y0))` / `(round(x0 + dx), round(y0 + dy))`, a 32x32 joint histogram, (H(X) + H(Y)) / H(X, Y) in
+[1, 2]; NaN where a chip leaves its image or the joint entropy vanishes.  The reference spends ~0.7 ms per key point in a
+pandas `apply`; here one kernel launch builds every key point's histogram in LDS (k_mi.hip), shared with
+`ZNCCService.compute_mi`.
 """
 from __future__ import annotations
 
@@ -11,31 +13,31 @@ import numpy as np
 from pandas import DataFrame, Series
 
 from .. import ops
+from .zncc_service import CHIP_SIZE, _common_pixel_type, _kernel_ready
 
 logger = logging.getLogger(__name__)
 
 
 class MutualInfoService:
-    """Service class to compute normalized mutual information between two image patches."""
+    """Scores the key points of a frame against the raw (full-resolution) images."""
 
     def __init__(self, ctx=None):
-        self._chip_size = 57
-        self._chip_margin = int((self._chip_size - 1) / 2)
+        self._chip_size = CHIP_SIZE
+        self._chip_margin = (CHIP_SIZE - 1) // 2
         self._ctx = ctx
 
     def compute_mutual_info(self, df: DataFrame, monitored, reference) -> Series:
-        """Normalized mutual information for each KP of the dataframe (reference mutual_info_service.py:73-97).
-
-        Returns:
-            Series with the index of `df`; NaN where the reference skips the point."""
-        logger.info("Compute mutual information for %s points", len(df))
-        if len(df) == 0:
-            score = Series([], index=df.index, dtype=np.float64)
-        else:
-            cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
-            st, _ = ops.mi_batch(reference.array, monitored.array, *cols, ctx=self._ctx)
-            score = Series(st, index=df.index, dtype=np.float64)
-        monitored.clear_cache()
-        reference.clear_cache()
-        logger.info("Mutual information computation finish")
-        return score
+        """Score per row of `df` (columns x0, y0, dx, dy) on the frame's index; NaN where the reference skips the row."""
+        try:
+            values = np.empty(0, np.float64)
+            if len(df):
+                ref, mon = np.asarray(reference.array), np.asarray(monitored.array)
+                if not _kernel_ready(df, ref, mon):
+                    ref, mon = _common_pixel_type(ref, mon)
+                cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
+                values = ops.mi_batch(ref, mon, *cols, ctx=self._ctx)[0]
+        finally:
+            monitored.clear_cache()
+            reference.clear_cache()
+        logger.info("mutual information: %d key points scored", len(df))
+        return Series(values, index=df.index, dtype=np.float64)

@@ -229,6 +229,27 @@ def zncc_batch(ref, mon, x0, y0, dx, dy, ctx: Context | None = None):
     return out
 
 
+def zncc_windows(img1, img2, u1, v1, u2, v2, half_size: int, ctx: Context | None = None):
+    """`_zncc2(img1, img2, u1, v1, u2, v2, n)` (zncc_service.py:45-126) for arrays of window centres (rows u, columns v),
+    any half-size n >= 0 and any two numeric pixel types (other types are read as float64).
+    -> (float64 values, bool mask of the windows that leave their image: the reference raises IndexError for those)."""
+    c = _ctx(ctx)
+    a, b = np.asarray(img1), np.asarray(img2)
+    if a.dtype not in _lib._DTYPES and a.dtype not in _lib._ANY_DTYPES:
+        a = a.astype(np.float64)
+    if b.dtype not in _lib._DTYPES and b.dtype not in _lib._ANY_DTYPES:
+        b = b.astype(np.float64)
+    a, b = as_image(a), as_image(b)
+    uv = np.ascontiguousarray(np.stack([np.asarray(v).ravel() for v in (u1, v1, u2, v2)]), np.int32)
+    count = uv.shape[1]
+    out, outside = np.empty(count, np.float64), np.zeros(count, np.uint8)
+    if count:
+        c.check(c.lib.km_zncc_windows(c.handle, ptr(a), ptr(b), _lib.any_dtype_code(a), _lib.any_dtype_code(b), a.shape[0], a.shape[1],
+                                      b.shape[0], b.shape[1], row_stride(a), row_stride(b), ptr(uv), int(half_size), count, ptr(out),
+                                      ptr(outside)), "km_zncc_windows")
+    return out, outside.astype(bool)
+
+
 def mi_batch(ref, mon, x0, y0, dx, dy, ctx: Context | None = None):
     """Per-keypoint mutual-information scores on the 57x57 chips -> (studholme, nmi) float64 arrays:
     `MutualInfoService._compute_mutual_info` (mutual_info_service.py:99-130, (H(X)+H(Y))/H(X,Y) in [1,2]) and
@@ -275,5 +296,5 @@ def shift_image(img, y_off=0, x_off=0, ctx: Context | None = None):
 
 
 __all__ = ["Context", "KariosHipError", "to_uint8", "auto_mask", "laplacian_u8", "min_eigen", "good_features_to_track",
-           "pyr_down", "calc_optical_flow_pyr_lk", "klt_track", "klt_tile", "zncc_batch", "mi_batch", "phase_cross_correlation",
+           "pyr_down", "calc_optical_flow_pyr_lk", "klt_track", "klt_tile", "zncc_batch", "zncc_windows", "mi_batch", "phase_cross_correlation",
            "shift_image", "make_params", "_lib"]

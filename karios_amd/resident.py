@@ -15,7 +15,7 @@ from pandas import DataFrame
 
 from . import _lib
 from ._lib import Context, KariosHipError, default_context, dtype_code
-from .matcher.klt import KLT, _sorted_tile_frame
+from . import frames, tiling
 from .ops import make_params
 
 
@@ -148,17 +148,34 @@ class ResidentPair:
         base = self._out.ptr
         return base, base + cap * 8, base + 2 * cap * 8, base + 3 * cap * 8
 
+    def _box(self, box):
+        """-> (x_off, y_off, x_size, y_size, element offset of the box origin) of a validated box (None = whole pair)."""
+        x_off, y_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
+        if x_off < 0 or y_off < 0 or x_off + bx > self.x_size or y_off + by > self.y_size or bx <= 0 or by <= 0:
+            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        return x_off, y_off, bx, by, y_off * self.x_size + x_off
+
+    def _image_args(self, off):
+        """ctypes arguments shared by the tile entry points: ref, mon pointers of the box, the mask / no-data pointers."""
+        es = self.dtype.itemsize
+        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
+        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
+        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        return C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), mask, nr, nm
+
+    @staticmethod
+    def _params(conf, ksizes=None, invert_mon=None):
+        mon_k, ref_k = ksizes if ksizes is not None else tiling.kernel_sizes(conf.laplacian_kernel_size)
+        invert = bool(conf.laplacian_invert_polarity) if invert_mon is None else bool(invert_mon)
+        return make_params(conf, mon_k, ref_k, invert)
+
     def track_tile(self, conf, box=None, mon_ksize=None, ref_ksize=None, invert_mon=False, out_ptrs=None):
         """km_klt_tile_dev on one box (x_off, y_off, x_size, y_size) of the resident pair.
         -> (status, (p0, p1, p0r) | None) like `ops.klt_tile`; with `out_ptrs` (p0, p1, p0r, n device
         pointers, capacity) the results stay on the device and only (status, n) is returned."""
         c = self.ctx
-        x_off, y_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
-        if x_off < 0 or y_off < 0 or x_off + bx > self.x_size or y_off + by > self.y_size or bx <= 0 or by <= 0:
-            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
-        if mon_ksize is None or ref_ksize is None:
-            mon_ksize, ref_ksize = KLT._resolve_ksize(conf.laplacian_kernel_size)
-        prm = make_params(conf, mon_ksize, ref_ksize, invert_mon)
+        _, _, bx, by, off = self._box(box)
+        prm = self._params(conf, None if mon_ksize is None or ref_ksize is None else (mon_ksize, ref_ksize), invert_mon)
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
         if out_ptrs is not None:
             d0, d1, d2, dn, ocap = out_ptrs
@@ -166,14 +183,9 @@ class ResidentPair:
                 raise KariosHipError("track_tile: output capacity below maxCorners")
         else:
             d0, d1, d2, dn = self._outputs(cap)
-        es = self.dtype.itemsize
-        off = (y_off * self.x_size + x_off)
-        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
-        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
-        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
-        c.check(c.lib.km_klt_tile_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                      by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), C.c_void_p(d0), C.c_void_p(d1),
-                                      C.c_void_p(d2), cap, C.c_void_p(dn)), "km_klt_tile_dev")
+        ref, mon, mask, nr, nm = self._image_args(off)
+        c.check(c.lib.km_klt_tile_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                      C.byref(prm), C.c_void_p(d0), C.c_void_p(d1), C.c_void_p(d2), cap, C.c_void_p(dn)), "km_klt_tile_dev")
         st = c.stats()  # valid_pixels is known on the host as soon as the call returns
         if st.valid_pixels == 0:
             return "no_valid_pixels", None
@@ -189,19 +201,25 @@ class ResidentPair:
             c.check(c.lib.km_d2h(c.handle, pts[i].ctypes.data_as(C.c_void_p), C.c_void_p(d), n * 8), "km_d2h")
         return "ok", tuple(p.reshape(-1, 1, 2) for p in pts)
 
-    def match_tile(self, conf, box=None, zncc_threshold=None) -> DataFrame | None:
-        """One tile of `KLT.match` (reference klt.py:236-349) on resident data; fixed kernel size and
-        polarity (the 'auto' modes go through `karios_amd.matcher.KLT`).  With `zncc_threshold` the frame also
-        carries the `zncc_score` column of `_handle_klt_results` (core.py:876-893) computed in the same device call."""
-        if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto":
-            raise KariosHipError("ResidentPair.match_tile: 'auto' modes are handled by karios_amd.matcher.KLT")
-        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
+    def match_tile(self, conf, box=None, zncc_threshold=None, ksizes=None, invert_mon=None, origin=None) -> DataFrame | None:
+        """One tile of `KLT.match` (reference klt.py:236-349) on resident data with fixed Laplacian kernel sizes and
+        polarity: `ksizes` (mon, ref) / `invert_mon` default to the configuration's (its 'auto' values are the caller's
+        business: `karios_amd.matcher.KLT`).  `origin` (x, y) is added to the key points (default: the box offset).
+        With `zncc_threshold` the frame also carries the `zncc_score` column of `_handle_klt_results` (core.py:876-893)
+        computed in the same device call."""
+        if ksizes is None and conf.laplacian_kernel_size == "auto" or invert_mon is None and conf.laplacian_invert_polarity == "auto":
+            raise KariosHipError("ResidentPair.match_tile: 'auto' modes are resolved by karios_amd.matcher.KLT")
+        x_off, y_off = origin if origin is not None else ((box[0], box[1]) if box is not None else (0, 0))
         if getattr(conf, "outliers_filtering", False):
-            # the iterative 3-sigma filter (klt.py:52-71) runs on the host between the FB test and the sort
-            status, tracks = self.track_tile(conf, box, invert_mon=bool(conf.laplacian_invert_polarity))
+            # the iterative sigma clip (klt.py:52-71) needs numpy's float32 statistics: FB test and ordering on the host
+            mon_k, ref_k = ksizes if ksizes is not None else tiling.kernel_sizes(conf.laplacian_kernel_size)
+            invert = bool(conf.laplacian_invert_polarity) if invert_mon is None else bool(invert_mon)
+            status, tracks = self.track_tile(conf, box, mon_k, ref_k, invert)
             if status != "ok":
                 return None
-            points, _ = _sorted_tile_frame(*tracks, conf, x_off=x_off, y_off=y_off)
+            cols, n_init = frames.track_columns(*tracks)
+            points = frames.assemble(cols, x_off, y_off, clip_outliers=True)
+            points.attrs["Ninit"] = n_init
             if zncc_threshold is not None:
                 keep = points["score"].to_numpy() >= zncc_threshold
                 z = np.full(len(points), np.nan)
@@ -209,47 +227,45 @@ class ResidentPair:
                     z[keep] = self.zncc(*(points[c].to_numpy()[keep] for c in ("x0", "y0", "dx", "dy")))
                 points["zncc_score"] = z
             return points
-        return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold)
+        return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, ksizes=ksizes, invert_mon=invert_mon)
 
-    def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None, build_frame=True) -> DataFrame | None:
+    def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None, build_frame=True, ksizes=None,
+                                 invert_mon=None) -> DataFrame | None:
         """Tile pipeline + FB test + score + (x0, y0) ordering on the device, one D2H copy of the finished frame."""
         c = self.ctx
-        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
-        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
-            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
-        mon_k, ref_k = KLT._resolve_ksize(conf.laplacian_kernel_size)
-        prm = make_params(conf, mon_k, ref_k, bool(conf.laplacian_invert_polarity))
+        _, _, bx, by, off = self._box(box)
+        prm = self._params(conf, ksizes, invert_mon)
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
         if self._host_frame is None or self._host_frame.size < 4 + 8 * cap:
             self._host_frame = np.empty(4 + 8 * cap, np.float32)
         buf = self._host_frame
-        es = self.dtype.itemsize
-        off = by_off * self.x_size + bx_off
-        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
-        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
-        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        ref, mon, mask, nr, nm = self._image_args(off)
         if zncc_threshold is None:
-            c.check(c.lib.km_klt_tile_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                                by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(x_off), float(y_off),
-                                                buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_dev")
+            c.check(c.lib.km_klt_tile_frame_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                                C.byref(prm), float(x_off), float(y_off), buf.ctypes.data_as(C.c_void_p), cap),
+                    "km_klt_tile_frame_dev")
         else:
-            c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es),
-                                                     self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(x_off),
-                                                     float(y_off), C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.y_size,
-                                                     self.x_size, self.x_size, self.x_size, float(zncc_threshold),
-                                                     buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
-        return self._frame_from_block(buf, cap, zncc_threshold is not None) if build_frame else None
+            c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                                     C.byref(prm), float(x_off), float(y_off), C.c_void_p(self.ref_ptr),
+                                                     C.c_void_p(self.mon_ptr), self.y_size, self.x_size, self.x_size, self.x_size,
+                                                     float(zncc_threshold), buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
+        if not build_frame:
+            return None
+        frame = frames.block_to_frame(buf, cap, zncc_threshold is not None)
+        if frame is not None:
+            frame.attrs["Ninit"] = int(buf[:2].view(np.int32)[1])
+        return frame
 
-    def match_tile_auto_ksize(self, conf, box=None, invert_mon: bool = False, candidates=(3, 5, 7, 9, 11)):
-        """`KLT._match_tile_auto_ksize` (klt.py:465-545) for one tile of the resident pair in ONE device call: all
-        Laplacians, pyramids and corner lists are built once on the device and shared by the 25 tracker runs.
+    def match_tile_auto_ksize(self, conf, box=None, invert_mon: bool = False, candidates=tiling.AUTO_KSIZE_CANDIDATES, origin=None):
+        """The Laplacian kernel-size search of the reference (klt.py:465-545) for one tile of the resident pair in ONE
+        device call: every Laplacian, pyramid and corner list is built once on the device and shared by the
+        len(candidates)^2 tracker runs; the winner is the (mon, ref) pair with the highest inlier ratio, first in
+        (mon outer, ref inner) order on ties.
         -> (frame | None, {(mon_k, ref_k): inlier ratio}, (mon_k, ref_k) | None, Ninit).  No outlier filtering."""
         if getattr(conf, "outliers_filtering", False):
-            raise KariosHipError("match_tile_auto_ksize: outlier filtering runs through karios_amd.matcher.KLT")
+            raise KariosHipError("match_tile_auto_ksize: the sigma clip changes the inlier counts - use karios_amd.matcher.KLT")
         c = self.ctx
-        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
-        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
-            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
+        bx_off, by_off, bx, by, off = self._box(box)
         prm = make_params(conf, 1, 1, bool(invert_mon))
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
         buf = np.empty(4 + 6 * cap, np.float32)
@@ -257,26 +273,17 @@ class ResidentPair:
         nk = len(ks)
         ratios = np.zeros(nk * nk, np.float64)
         best = np.zeros(2, np.int32)
-        es = self.dtype.itemsize
-        off = by_off * self.x_size + bx_off
-        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
-        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
-        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
-        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
-        c.check(c.lib.km_klt_auto_ksize_frame_dev(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                                  by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm),
-                                                  ks.ctypes.data_as(C.c_void_p), nk, float(x_off), float(y_off),
+        ref, mon, mask, nr, nm = self._image_args(off)
+        x_off, y_off = origin if origin is not None else (bx_off, by_off)
+        c.check(c.lib.km_klt_auto_ksize_frame_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                                  C.byref(prm), ks.ctypes.data_as(C.c_void_p), nk, float(x_off), float(y_off),
                                                   buf.ctypes.data_as(C.c_void_p), cap, ratios.ctypes.data_as(C.c_void_p),
                                                   best.ctypes.data_as(C.c_void_p)), "km_klt_auto_ksize_frame_dev")
         scores = {(int(ks[i]), int(ks[j])): float(ratios[i * nk + j]) for i in range(nk) for j in range(nk)}
         if best[0] < 0:
             return None, scores, None, 0
-        hdr = buf[:4].view(np.int32)
-        n, n_init = int(hdr[0]), int(hdr[1])
-        body = buf[4:]
-        cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
-        index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
-        return DataFrame(cols, index=index, copy=False), scores, (int(best[0]), int(best[1])), n_init
+        n_init = int(buf[:2].view(np.int32)[1])
+        return frames.block_to_frame(buf, cap), scores, (int(best[0]), int(best[1])), n_init
 
     def match_tile_raw(self, conf, box=None, zncc_threshold=None) -> "RawFrame":
         """GPU half of `match_tile`: runs the device pipeline and returns the raw frame block (a private copy), leaving
@@ -304,21 +311,14 @@ class ResidentPair:
         if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
             raise KariosHipError("ResidentPair.submit_tile: 'auto' modes and outlier filtering need ResidentPair.match_tile / matcher.KLT")
         c = self.ctx
-        bx_off, by_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
-        if bx_off < 0 or by_off < 0 or bx_off + bx > self.x_size or by_off + by > self.y_size or bx <= 0 or by <= 0:
-            raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
-        mon_k, ref_k = KLT._resolve_ksize(conf.laplacian_kernel_size)
-        prm = make_params(conf, mon_k, ref_k, bool(conf.laplacian_invert_polarity))
+        bx_off, by_off, bx, by, off = self._box(box)
+        prm = self._params(conf)
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
-        es = self.dtype.itemsize
-        off = by_off * self.x_size + bx_off
-        mask = C.c_void_p(self.mask_ptr + off) if self.mask_ptr else None
-        nr = C.byref(C.c_double(float(self.no_data_ref))) if self.no_data_ref is not None else None
-        nm = C.byref(C.c_double(float(self.no_data_mon))) if self.no_data_mon is not None else None
+        ref, mon, mask, nr, nm = self._image_args(off)
         with_zncc = zncc_threshold is not None
         ticket = C.c_int(-1)
-        c.check(c.lib.km_klt_tile_frame_submit(c.handle, C.c_void_p(self.ref_ptr + off * es), C.c_void_p(self.mon_ptr + off * es), self.code,
-                                               by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm, C.byref(prm), float(bx_off), float(by_off),
+        c.check(c.lib.km_klt_tile_frame_submit(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                               C.byref(prm), float(bx_off), float(by_off),
                                                C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
                                                self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
                                                C.byref(ticket)), "km_klt_tile_frame_submit")
@@ -330,7 +330,7 @@ class ResidentPair:
         frames in tile order, like `KLT.match`."""
         from concurrent.futures import ThreadPoolExecutor
         if boxes is None:
-            boxes = KLT(conf).tile_boxes(self.x_size, self.y_size)
+            boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
 
         def host_half(pend):
             frame = (pend.wait() if isinstance(pend, PendingFrame) else pend).to_frame()
@@ -355,19 +355,7 @@ class ResidentPair:
                 if frame is not None:
                     yield frame
 
-    @staticmethod
-    def _frame_from_block(buf: np.ndarray, cap: int, with_zncc: bool) -> DataFrame | None:
-        """Host view of one tile's frame block (layout of km_klt_tile_frame[_zncc]_dev) -> DataFrame."""
-        hdr = buf[:4].view(np.int32)
-        n, n_init = int(hdr[0]), int(hdr[1])
-        if n_init == 0:
-            return None           # no valid pixels / no features (klt.py:122-124, 276-279, 329-337)
-        body = buf[4:]
-        cols = {name: body[i * cap:i * cap + n].copy() for i, name in enumerate(("x0", "y0", "dx", "dy", "score"))}
-        index = body[5 * cap:5 * cap + n].view(np.int32).astype(np.int64)
-        if with_zncc:
-            cols["zncc_score"] = body[6 * cap:8 * cap].view(np.float64)[:n].copy()
-        return DataFrame(cols, index=index, copy=False)
+    _frame_from_block = staticmethod(frames.block_to_frame)
 
     def last_block(self, cap: int, with_zncc: bool) -> np.ndarray:
         """The raw frame block of the last `match_tile` call: 4 int32 header + 6*cap float32 (+ cap float64), the unit of
@@ -376,7 +364,7 @@ class ResidentPair:
 
     def match(self, conf):
         """All tiles in the reference order (x outer, y inner; klt.py:220-232)."""
-        for box in KLT(conf).tile_boxes(self.x_size, self.y_size):
+        for box in tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart):
             frame = self.match_tile(conf, box)
             if frame is not None:
                 yield frame

@@ -338,7 +338,8 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
     assembly of the same tracks, row for row including the permuted index labels; tiles of a resident image."""
     import pandas as pd
     from karios_amd.core import KLTConfiguration
-    from karios_amd.matcher.klt import KLT, _sorted_tile_frame
+    from karios_amd import frames as F
+    from karios_amd.matcher.klt import KLT
     from karios_amd.resident import ResidentPair
     mon, ref = synth.make_pair(420, 500, 0.5, 0.25)
     conf = KLTConfiguration(tile_size=260, maxCorners=700)
@@ -348,7 +349,7 @@ def test_resident_pair_device_frame_equals_host_frame(ops, O):
     assert len(frames) == len(boxes) == 4
     for f, (xo, yo, bx, by) in zip(frames, boxes):
         status, tracks = pair.track_tile(conf, (xo, yo, bx, by))
-        exp, _ = _sorted_tile_frame(*tracks, conf, x_off=xo, y_off=yo)
+        exp = F.assemble(F.track_columns(*tracks)[0], x_off=xo, y_off=yo)
         pd.testing.assert_frame_equal(f, exp, check_exact=True)
         o = O.klt_tile(mon[yo:yo + by, xo:xo + bx], ref[yo:yo + by, xo:xo + bx], conf, x_off=xo, y_off=yo)
         np.testing.assert_array_equal(f["x0"].to_numpy(), o["x0"])

@@ -64,10 +64,10 @@ def test_tile_boxes_reference_order():
 
 
 def test_frame_from_tracks_matches_reference_fb_arithmetic():
-    from karios_amd.core import KLTConfiguration
-    from karios_amd.matcher.klt import _frame_from_tracks
+    from karios_amd import frames
     g = np.load(os.path.join(G, "fb_score.npz"))
-    frame, ninit = _frame_from_tracks(g["p0"], g["p1"], g["p0r"], KLTConfiguration())
+    cols, ninit = frames.track_columns(g["p0"], g["p1"], g["p0r"])
+    frame = frames.assemble(cols, ordered=False)
     assert ninit == int(g["ninit"])
     assert list(frame.columns) == ["x0", "y0", "dx", "dy", "score"]
     for c in frame.columns:
@@ -77,10 +77,26 @@ def test_frame_from_tracks_matches_reference_fb_arithmetic():
 
 
 def test_filter_outliers_matches_reference():
-    from karios_amd.matcher.klt import _filter_outliers
+    from karios_amd import frames
     g = np.load(os.path.join(G, "outliers.npz"))
-    for i, v in enumerate(_filter_outliers(g["x0"], g["y0"], g["x1"], g["y1"], g["score"])):
-        np.testing.assert_array_equal(v, g[f"out_{i}"])
+    keep = frames.sigma_clip(g["x1"] - g["x0"], g["y1"] - g["y0"])
+    assert 0 < len(keep) < len(g["x0"])
+    for i, name in enumerate(("x0", "y0", "x1", "y1", "score")):
+        np.testing.assert_array_equal(g[name][keep], g[f"out_{i}"])
+    assert len(frames.sigma_clip(np.zeros(0, np.float32), np.zeros(0, np.float32))) == 0
+
+
+def test_ordered_frame_keeps_the_labels_of_an_inplace_sort():
+    """`assemble(ordered=True)` == DataFrame + offsets + sort_values(["x0", "y0"], inplace=True) (klt.py:341-348)."""
+    from karios_amd import frames
+    g = np.load(os.path.join(G, "fb_score.npz"))
+    cols, _ = frames.track_columns(g["p0"], g["p1"], g["p0r"])
+    got = frames.assemble(cols, x_off=130, y_off=260)
+    want = pd.DataFrame({k: v.copy() for k, v in cols.items()})
+    want["x0"] = want["x0"] + 130
+    want["y0"] = want["y0"] + 260
+    want.sort_values(by=["x0", "y0"], inplace=True)
+    pd.testing.assert_frame_equal(got, want)
 
 
 def test_resolve_ksize():

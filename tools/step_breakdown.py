@@ -7,7 +7,6 @@ import torch
 from karios_amd import synth
 from karios_amd._lib import Context
 from karios_amd.core import KLTConfiguration
-from karios_amd.matcher.klt import _frame_from_tracks
 from karios_amd.resident import ResidentPair
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 10980
