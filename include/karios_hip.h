@@ -110,6 +110,28 @@ int km_dev_alloc(km_ctx *ctx, size_t bytes, void **dptr);
 int km_dev_free(km_ctx *ctx, void *dptr);
 int km_h2d(km_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int km_d2h(km_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Page-locked host memory for image buffers that GDAL (or numpy) fills and the GPU fetches: an upload from such a buffer
+ * runs at full PCIe rate and asynchronously (a pageable source is staged chunk by chunk and blocks the caller). */
+int km_host_alloc(km_ctx *ctx, size_t bytes, void **hptr);
+int km_host_free(km_ctx *ctx, void *hptr);
+/* Asynchronous strided upload on the context's COPY stream: `rows` rows of `width_bytes` bytes, pitches in bytes.  Returns
+ * at once when `src_host` is page-locked; every later call on the context that launches kernels waits (on the device, not
+ * on the host) for the uploads queued so far, so pair / tile i+1 can travel while pair / tile i computes.  The caller keeps
+ * `src_host` alive and unmodified, and `dst_dev` unused by earlier work, until km_upload_wait or that later call returns. */
+int km_upload_async(km_ctx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch,
+                    size_t width_bytes, size_t rows);
+int km_upload_wait(km_ctx *ctx);   /* host-side wait for the uploads queued so far */
+/* The buffers passed as full images to the ZNCC / MI entry points (km_klt_tile_frame_zncc_dev, km_klt_tile_frame_submit,
+ * km_zncc_batch[_dev], km_mi_batch[_dev]) hold only a WINDOW of the H_image x W_image image, starting at image pixel (ox, oy) -
+ * a multi-GPU rank keeps just its tile plus a margin resident.  Key-point coordinates stay image coordinates (the float32
+ * sum x0 + dx that the reference rounds, zncc_service.py:195-196, depends on their magnitude), the reference's bounds rule
+ * is applied with the image size, pixels are fetched relative to (ox, oy).  A chip inside the image but outside the window
+ * scores the NaN with bit pattern KM_NAN_OUTSIDE_WINDOW (the caller's margin was too small).  H_image = W_image = 0: off. */
+#define KM_NAN_OUTSIDE_WINDOW 0x7ff80000dead0000ull
+int km_set_image_window(km_ctx *ctx, int ox, int oy, int H_image, int W_image);
+/* Optional device-side copy of every frame block the km_klt_tile_frame_* entry points produce (same layout), e.g. a slice of
+ * the send buffer of an RCCL all-gather: the block then never bounces through host memory.  NULL switches it off. */
+int km_set_frame_sink(km_ctx *ctx, void *d_dst, size_t capacity_bytes);
 
 /* ---- fine-grained mirrors (host buffers) -------------------------------- */
 /* _to_uint8 (matcher/klt.py:42-49) [+ 255-x, klt.py:419]; out_minmax[2] nullable */

@@ -38,6 +38,7 @@ class KltStats(C.Structure):
                 ("emitted_ratio", C.c_float), ("path_flags", C.c_int32), ("reserved", C.c_int32)]
 
 
+NAN_OUTSIDE_WINDOW = 0x7FF80000DEAD0000   # km_set_image_window: score of a chip outside the resident window
 PATH_KEY_REGROW, PATH_STAGE_FALLBACK, PATH_SECOND_PASS, PATH_PREFIX_GROWN = 1, 2, 4, 8
 
 
@@ -60,6 +61,12 @@ SIGNATURES = {
     "km_dev_free": (_i, [_vp, _vp]),
     "km_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "km_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "km_host_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "km_host_free": (_i, [_vp, _vp]),
+    "km_upload_async": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "km_upload_wait": (_i, [_vp]),
+    "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
+    "km_set_image_window": (_i, [_vp, _i, _i, _i, _i]),
     "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
     "km_auto_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _vp, C.POINTER(C.c_int64)]),
     "km_laplacian_u8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -191,6 +198,42 @@ class Context:
         self.handle = h
         self.device = device
 
+    # ---- device buffers are recycled: a tile loop would otherwise pay a hipMalloc / hipFree pair (and their implicit device
+    # synchronisations) per image and tile
+    POOL_LIMIT_BYTES = 16 << 30
+
+    def dev_alloc(self, nbytes: int) -> tuple[int, int]:
+        """-> (device pointer, capacity).  Capacities are multiples of 2 MiB so that boxes of similar size share buffers."""
+        cap = max(1, (int(nbytes) + (2 << 20) - 1) >> 21) << 21
+        pool = self.__dict__.setdefault("_pool", {})
+        free = pool.get(cap)
+        if free:
+            self._pool_bytes -= cap
+            return free.pop(), cap
+        p = C.c_void_p()
+        self.check(self.lib.km_dev_alloc(self.handle, cap, C.byref(p)), "km_dev_alloc")
+        return p.value, cap
+
+    def dev_release(self, ptr_: int, cap: int):
+        """Give a buffer back.  Work queued on the context that still uses it is waited for first."""
+        if not getattr(self, "handle", None):
+            return
+        pool = self.__dict__.setdefault("_pool", {})
+        held = self.__dict__.setdefault("_pool_bytes", 0)
+        self.lib.km_ctx_sync(self.handle)
+        self.lib.km_upload_wait(self.handle)
+        if held + cap <= self.POOL_LIMIT_BYTES:
+            pool.setdefault(cap, []).append(ptr_)
+            self._pool_bytes = held + cap
+        else:
+            self.lib.km_dev_free(self.handle, C.c_void_p(ptr_))
+
+    def trim_pool(self):
+        for cap, ptrs in self.__dict__.get("_pool", {}).items():
+            for p in ptrs:
+                self.lib.km_dev_free(self.handle, C.c_void_p(p))
+        self._pool, self._pool_bytes = {}, 0
+
     def check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.km_last_error(self.handle)
@@ -198,6 +241,7 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            self.trim_pool()
             self.lib.km_ctx_destroy(self.handle)
             self.handle = None
 
@@ -228,6 +272,21 @@ class Context:
         n = C.c_int()
         self.check(self.lib.km_get_stage_ms(self.handle, buf, 16, C.byref(n)), "km_get_stage_ms")
         return {self.lib.km_stage_name(i).decode(): float(buf[i]) for i in range(n.value)}
+
+
+def pinned_empty(shape, dtype, ctx: "Context | None" = None) -> np.ndarray:
+    """numpy array over page-locked host memory (km_host_alloc): let GDAL / numpy write the image into it
+    (`band.ReadAsArray(buf_obj=arr)`, `np.copyto(arr, img)`) and uploads from it run asynchronously at full PCIe rate.
+    The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    ctx = ctx if ctx is not None else default_context()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    ctx.check(ctx.lib.km_host_alloc(ctx.handle, max(n, 1), C.byref(p)), "km_host_alloc")
+    raw = (C.c_char * max(n, 1)).from_address(p.value)
+    weakref.finalize(raw, lambda lib=ctx.lib, h=ctx.handle, q=p.value: lib.km_host_free(h, C.c_void_p(q)))
+    return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 _tls = threading.local()

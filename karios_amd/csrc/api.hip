@@ -82,9 +82,20 @@ int km_run_deferred(km_ctx *c)
     return KM_OK;
 }
 
+// uploads queued on the copy stream (km_upload_async): whatever the compute stream does next starts behind them
+static int join_uploads(km_ctx *c)
+{
+    if (c->copy_pending) {
+        KM_HIP(c, hipEventRecord(c->ev_copy, c->copy_stream));
+        KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        c->copy_pending = false;
+    }
+    return KM_OK;
+}
+
 extern "C" {
 
-int km_version(void) { return 100; }
+int km_version(void) { return 101; }
 
 const char *km_last_error(km_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
@@ -132,6 +143,8 @@ int km_ctx_destroy(km_ctx *c)
     if (c->ev_ready)
         for (int k = 0; k <= KM_FRAME_SLOTS; k++)
             for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->evs[k][i][0]); (void)hipEventDestroy(c->evs[k][i][1]); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return KM_OK;
@@ -140,6 +153,7 @@ int km_ctx_destroy(km_ctx *c)
 int km_ctx_sync(km_ctx *c)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipStreamSynchronize(c->stream));
     return KM_OK;
 }
@@ -209,12 +223,14 @@ int km_dev_free(km_ctx *c, void *dptr)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
     KM_HIP(c, hipFree(dptr));
     return KM_OK;
 }
 int km_h2d(km_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
+    { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     return KM_OK;
@@ -222,8 +238,61 @@ int km_h2d(km_ctx *c, void *dst, const void *src, size_t bytes)
 int km_d2h(km_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
+    { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_host_alloc(km_ctx *c, size_t bytes, void **hptr)
+{
+    if (!c || !hptr) return km_fail(c, KM_E_ARG, "km_host_alloc: null argument");
+    KM_HIP(c, hipSetDevice(c->device));
+    KM_HIP(c, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return KM_OK;
+}
+int km_host_free(km_ctx *c, void *hptr)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
+    KM_HIP(c, hipHostFree(hptr));
+    return KM_OK;
+}
+int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows)
+{
+    if (!c || !dst || !src) return km_fail(c, KM_E_ARG, "km_upload_async: null argument");
+    if (dst_pitch < width_bytes || src_pitch < width_bytes) return km_fail(c, KM_E_ARG, "km_upload_async: pitch below the row width");
+    KM_HIP(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {
+        KM_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        KM_HIP(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    }
+    if (rows == 0 || width_bytes == 0) return KM_OK;
+    if (dst_pitch == width_bytes && src_pitch == width_bytes)
+        KM_HIP(c, hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyHostToDevice, c->copy_stream));
+    else
+        KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
+    c->copy_pending = true;
+    return KM_OK;
+}
+int km_upload_wait(km_ctx *c)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
+    return KM_OK;
+}
+int km_set_image_window(km_ctx *c, int ox, int oy, int H_image, int W_image)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (H_image < 0 || W_image < 0 || ox < 0 || oy < 0 || (H_image > 0) != (W_image > 0)) return km_fail(c, KM_E_ARG, "km_set_image_window: bad window");
+    c->window.ox = ox; c->window.oy = oy; c->window.H = H_image; c->window.W = W_image;
+    return KM_OK;
+}
+int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    c->frame_sink = d_dst;
+    c->frame_sink_cap = d_dst ? capacity_bytes : 0;
     return KM_OK;
 }
 
@@ -236,6 +305,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
+    { const int rcj = join_uploads(c); if (rcj) return rcj; }
     // debugging aid: KARIOS_HIP_POISON_WS=<byte> fills every workspace buffer at the start of a tile call, so a kernel that reads
     // workspace it (or its predecessors in the call) never wrote shows up as a parity failure instead of a once-in-a-while one
     static const char *const poison = getenv("KARIOS_HIP_POISON_WS");
@@ -838,6 +908,10 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                                    f + 3 * (size_t)cap, n_max, (const int *)d_out, f + 4 * (size_t)cap, (float)zncc_threshold,
                                    (double *)(d_out + fb))))
             return rc;
+    }
+    if (c->frame_sink) {
+        if (c->frame_sink_cap < ob) return km_fail(c, KM_E_ARG, "frame sink of %zu bytes is smaller than the %zu-byte frame block", c->frame_sink_cap, ob);
+        KM_HIP(c, hipMemcpyAsync(c->frame_sink, d_out, ob, hipMemcpyDeviceToDevice, c->stream));
     }
     if (slot) {
         if (slot->cap < ob) {

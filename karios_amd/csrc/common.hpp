@@ -100,6 +100,13 @@ struct km_scalars {
     unsigned int run_max_shard[64]; // sharded running max-eig keys of the 2-px fused kernel (same-address device-scope traffic serialises)
 };
 
+// km_set_image_window: the buffers handed to the ZNCC / MI kernels as "full images" hold only a window of the real image.
+// Key-point coordinates stay IMAGE coordinates (the float32 sum x0 + dx the reference rounds depends on their magnitude), the
+// bounds rule is the image's, the pixels are fetched relative to (ox, oy).  H == 0: no window.
+struct km_window {
+    int ox = 0, oy = 0, H = 0, W = 0;
+};
+
 // One frame in flight of km_klt_tile_frame_submit: pinned host block, completion event.
 #define KM_FRAME_SLOTS 3
 struct km_frame_slot {
@@ -113,6 +120,12 @@ struct km_ctx {
     int device = 0;
     int n_cu = 256;            // compute units of the device (wave slots = n_cu * 4 SIMDs * waves per SIMD)
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // km_upload_async: uploads of the next pair / tile under the compute of the current one
+    hipEvent_t ev_copy = nullptr;
+    bool copy_pending = false;           // uploads queued since the compute stream last waited for the copy stream
+    km_window window;                    // km_set_image_window
+    void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
+    size_t frame_sink_cap = 0;
     km_buf ws[WS_COUNT];
     std::string err;
     // Independent device work queued by the caller to fill the GPU while the host waits for a small read-back (the two
@@ -291,7 +304,7 @@ int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href
             const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out);
 int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon,
                      ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0, const float *d_y0, const float *d_dx,
-                     const float *d_dy, int n, const int *d_n, const float *d_score, float score_thr, double *d_out);
+                     const float *d_dy, int n, const int *d_n, const float *d_score, float score_thr, double *d_out);   // honours c->window
 int kz_zncc_windows(km_ctx *c, const void *d_img1, const void *d_img2, int dt1, int dt2, int H1, int W1, int H2, int W2, ptrdiff_t s1, ptrdiff_t s2,
                     const int *d_uv, int half, int count, double *d_out, uint8_t *d_flags);
 // k_mi.hip

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
                                                  const float *__restrict__ y0, const float *__restrict__ dx,
                                                  const float *__restrict__ dy, int n, const int *__restrict__ d_n,
                                                  const float *__restrict__ score, float score_thr, double *__restrict__ out_studholme,
-                                                 double *__restrict__ out_nmi)
+                                                 double *__restrict__ out_nmi, km_window win)
 {
     __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
     __shared__ double s_edges[4][2][MI_BINS + 1];
@@ -66,16 +66,26 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
     auto give_up = [&]() { if (lane == 0) { if (out_studholme) out_studholme[k] = nan; if (out_nmi) out_nmi[k] = nan; } };
     if (score && !(score[k] >= score_thr)) { give_up(); return; }
     const float fx0 = x0[k], fy0 = y0[k];
-    const int X0 = (int)fx0, Y0 = (int)fy0;
+    int X0 = (int)fx0, Y0 = (int)fy0;
     const float sx = __fadd_rn(fx0, dx[k]), sy = __fadd_rn(fy0, dy[k]);
     bool ok = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
     int X1 = 0, Y1 = 0;
     if (ok) {
         X1 = __float2int_rn(sx); Y1 = __float2int_rn(sy);
+        const int Wr = win.H ? win.W : Wref, Hr = win.H ? win.H : Href, Wm = win.H ? win.W : Wmon, Hm = win.H ? win.H : Hmon;   // see k_zncc.hip
         ok = !(X0 - MI_MARGIN < 0 || Y0 - MI_MARGIN < 0 || X1 - MI_MARGIN < 0 || Y1 - MI_MARGIN < 0) &&
-             !(X0 >= Wref - MI_MARGIN || Y0 >= Href - MI_MARGIN || X1 >= Wmon - MI_MARGIN || Y1 >= Hmon - MI_MARGIN);
+             !(X0 >= Wr - MI_MARGIN || Y0 >= Hr - MI_MARGIN || X1 >= Wm - MI_MARGIN || Y1 >= Hm - MI_MARGIN);
     }
     if (!ok) { give_up(); return; }
+    if (win.H) {
+        X0 -= win.ox; X1 -= win.ox; Y0 -= win.oy; Y1 -= win.oy;
+        if (X0 - MI_MARGIN < 0 || Y0 - MI_MARGIN < 0 || X1 - MI_MARGIN < 0 || Y1 - MI_MARGIN < 0 || X0 + MI_MARGIN >= Wref || Y0 + MI_MARGIN >= Href ||
+            X1 + MI_MARGIN >= Wmon || Y1 + MI_MARGIN >= Hmon) {
+            const double miss = __longlong_as_double((long long)KM_NAN_OUTSIDE_WINDOW);
+            if (lane == 0) { if (out_studholme) out_studholme[k] = miss; if (out_nmi) out_nmi[k] = miss; }
+            return;
+        }
+    }
     unsigned *hist = s_hist[wv];
     double *e1 = s_edges[wv][0], *e2 = s_edges[wv][1];
     for (int i = lane; i < MI_BINS * MI_BINS; i += 64) hist[i] = 0;
@@ -141,7 +151,7 @@ int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Hr
 {
     if (n <= 0) return KM_OK;
     const int nb = (n + 3) / 4;
-#define KM_MI(T) mi_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_studholme, d_nmi)
+#define KM_MI(T) mi_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_studholme, d_nmi, c->window)
     switch (dtype) {
     case KM_U8: KM_MI(uint8_t); break;
     case KM_U16: KM_MI(uint16_t); break;

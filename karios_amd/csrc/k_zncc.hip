@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
                                                    int Wmon, ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0,
                                                    const float *__restrict__ y0, const float *__restrict__ dx,
                                                    const float *__restrict__ dy, int n, const int *__restrict__ d_n,
-                                                   const float *__restrict__ score, float score_thr, double *__restrict__ out)
+                                                   const float *__restrict__ score, float score_thr, double *__restrict__ out, km_window win)
 {
     const int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // key point of this wave: uniform, scalar addressing
     const int lane = threadIdx.x & 63;
@@ -31,17 +31,27 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
     // rows below the confidence threshold are not scored (core.py:878-893): NaN, like the reference's column
     if (score && !(score[k] >= score_thr)) { if (lane == 0) out[k] = nan; return; }
     const float fx0 = x0[k], fy0 = y0[k];
-    const int X0 = (int)fx0, Y0 = (int)fy0;  // int(series["x0"])
+    int X0 = (int)fx0, Y0 = (int)fy0;  // int(series["x0"])
     // round(np.float32 + np.float32): half-to-even on the f32 sum
     const float sx = __fadd_rn(fx0, dx[k]), sy = __fadd_rn(fy0, dy[k]);
     bool ok = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
     int X1 = 0, Y1 = 0;
     if (ok) {
         X1 = __float2int_rn(sx); Y1 = __float2int_rn(sy);
+        // the bounds rule is stated on the IMAGE (the window's extent only decides whether the pixels are resident)
+        const int Wr = win.H ? win.W : Wref, Hr = win.H ? win.H : Href, Wm = win.H ? win.W : Wmon, Hm = win.H ? win.H : Hmon;
         ok = !(X0 - ZN_MARGIN < 0 || Y0 - ZN_MARGIN < 0 || X1 - ZN_MARGIN < 0 || Y1 - ZN_MARGIN < 0) &&
-             !(X0 >= Wref - ZN_MARGIN || Y0 >= Href - ZN_MARGIN || X1 >= Wmon - ZN_MARGIN || Y1 >= Hmon - ZN_MARGIN);
+             !(X0 >= Wr - ZN_MARGIN || Y0 >= Hr - ZN_MARGIN || X1 >= Wm - ZN_MARGIN || Y1 >= Hm - ZN_MARGIN);
     }
     if (!ok) { if (lane == 0) out[k] = nan; return; }
+    if (win.H) {
+        X0 -= win.ox; X1 -= win.ox; Y0 -= win.oy; Y1 -= win.oy;
+        if (X0 - ZN_HW < 0 || Y0 - ZN_HW < 0 || X1 - ZN_HW < 0 || Y1 - ZN_HW < 0 || X0 + ZN_HW >= Wref || Y0 + ZN_HW >= Href || X1 + ZN_HW >= Wmon ||
+            Y1 + ZN_HW >= Hmon) {
+            if (lane == 0) out[k] = __longlong_as_double((long long)KM_NAN_OUTSIDE_WINDOW);
+            return;
+        }
+    }
     double va[ZN_PER_LANE], vb[ZN_PER_LANE];
     double s1 = 0, s2 = 0;
 #pragma unroll
@@ -81,7 +91,7 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
 {
     if (n <= 0) return KM_OK;
     const int nb = (n + 3) / 4;
-#define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out)
+#define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
     switch (dtype) {
     case KM_U8: KM_Z(uint8_t); break;
     case KM_U16: KM_Z(uint16_t); break;

@@ -77,3 +77,12 @@ def block_to_frame(block: np.ndarray, cap: int, with_zncc: bool = False) -> Data
         data["zncc_score"] = body[6 * cap:8 * cap].view(np.float64)[:rows].copy()
     labels = body[5 * cap:5 * cap + rows].view(np.int32).astype(np.int64)
     return DataFrame(data, index=labels, copy=False)
+
+
+def radial_angle_columns(frame: DataFrame) -> DataFrame:
+    """Adds `radial error` = |(dx, dy)| and `angle` = atan2(dy, dx) in degrees, float32 like the displacement columns they are
+    computed from (core.py:872-873).  numpy on the host: a device atan2 would not reproduce numpy's last bit."""
+    dx, dy = frame["dx"].to_numpy(), frame["dy"].to_numpy()
+    frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
+    frame["angle"] = np.degrees(np.arctan2(dy, dx))
+    return frame

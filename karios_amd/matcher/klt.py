@@ -22,7 +22,7 @@ import numpy as np
 from pandas import DataFrame
 
 from .. import frames, ops, tiling
-from ..resident import ResidentPair
+from ..resident import ResidentPair, shared_pair
 
 logger = logging.getLogger(__name__)
 
@@ -79,6 +79,7 @@ class _TileSession:
             mon_box, ref_box = _stretch_any(mon_box, ctx), _stretch_any(ref_box, ctx)
             nodata_mon = nodata_ref = None
         self.pair = ResidentPair.upload(mon_box, ref_box, mask_box, ctx=ctx, no_data_mon=nodata_mon, no_data_ref=nodata_ref)
+        shared_pair(mon_box, ref_box, ctx, publish=self.pair)      # the scoring services find a whole-image tile resident
         self._host = (mon_box, ref_box)
         self.valid_pixels = -1                     # unknown until a fixed-parameter trial has run
 
@@ -170,8 +171,13 @@ class KLT:
         grid = self.tile_boxes(mon_img.x_size, mon_img.y_size)
         logger.info("KLT: %dx%d px in %d tile(s) of %d px, polarity %s, Laplacian kernel %s", mon_img.x_size, mon_img.y_size, len(grid),
                     self._conf.tile_size, self._describe_polarity(), self._conf.laplacian_kernel_size)
-        for tile in grid:
-            frame = self._match_tile(tile.x_off, tile.y_off, mon_img, ref_img, mask)
+        upcoming = None
+        for k, tile in enumerate(grid):
+            session = upcoming or self._open(tile, mon_img, ref_img, mask)
+            # the next tile is read and its upload queued BEFORE this one is matched: from page-locked buffers the copy
+            # travels while the device works on the current tile
+            upcoming = self._open(grid[k + 1], mon_img, ref_img, mask) if k + 1 < len(grid) else None
+            frame = self._finish(session)
             if frame is not None:
                 yield frame
         if self._conf.laplacian_invert_polarity == "auto":
@@ -202,9 +208,15 @@ class KLT:
         """Frame of the tile whose origin is (x_off, y_off), or None (no valid pixel, no corner)."""
         size = self._conf.tile_size
         tile = tiling.Tile(x_off, y_off, min(size, mon_img.x_size - x_off), min(size, mon_img.y_size - y_off))
+        return self._finish(self._open(tile, mon_img, ref_img, mask))
+
+    def _open(self, tile: tiling.Tile, mon_img, ref_img, mask) -> _TileSession:
         window = (1, *tile)
-        session = _TileSession(self._conf, tile, mon_img.read(*window), ref_img.read(*window), mask.read(*window) if mask else None,
-                               getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None), self._ctx)
+        return _TileSession(self._conf, tile, mon_img.read(*window), ref_img.read(*window), mask.read(*window) if mask else None,
+                            getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None), self._ctx)
+
+    def _finish(self, session: _TileSession) -> DataFrame | None:
+        x_off, y_off = session.tile[:2]
         trial = self._best_trial(session)
         if trial is None:
             logger.info("tile (%d, %d): no valid pixels or no corners - skipped", x_off, y_off)

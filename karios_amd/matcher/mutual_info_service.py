@@ -12,8 +12,7 @@ import logging
 import numpy as np
 from pandas import DataFrame, Series
 
-from .. import ops
-from .zncc_service import CHIP_SIZE, _common_pixel_type, _kernel_ready
+from .zncc_service import CHIP_SIZE, _common_pixel_type, _kernel_ready, _mi_scores
 
 logger = logging.getLogger(__name__)
 
@@ -34,8 +33,7 @@ class MutualInfoService:
                 ref, mon = np.asarray(reference.array), np.asarray(monitored.array)
                 if not _kernel_ready(df, ref, mon):
                     ref, mon = _common_pixel_type(ref, mon)
-                cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
-                values = ops.mi_batch(ref, mon, *cols, ctx=self._ctx)[0]
+                values = _mi_scores(df, ref, mon, self._ctx)[0]
         finally:
             monitored.clear_cache()
             reference.clear_cache()

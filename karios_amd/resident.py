@@ -14,23 +14,21 @@ import numpy as np
 from pandas import DataFrame
 
 from . import _lib
-from ._lib import Context, KariosHipError, default_context, dtype_code
+from ._lib import Context, KariosHipError, as_image, default_context, dtype_code
 from . import frames, tiling
 from .ops import make_params
 
 
 class DeviceBuffer:
-    """hipMalloc'ed buffer owned by a context."""
+    """Device buffer drawn from the context's pool (`Context.dev_alloc`)."""
 
     def __init__(self, ctx: Context, nbytes: int):
         self.ctx, self.nbytes = ctx, int(nbytes)
-        p = C.c_void_p()
-        ctx.check(ctx.lib.km_dev_alloc(ctx.handle, self.nbytes, C.byref(p)), "km_dev_alloc")
-        self.ptr = p.value
+        self.ptr, self._cap = ctx.dev_alloc(self.nbytes)
 
     def free(self):
         if self.ptr:
-            self.ctx.lib.km_dev_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ctx.dev_release(self.ptr, self._cap)
             self.ptr = None
 
     def __del__(self):
@@ -40,9 +38,21 @@ class DeviceBuffer:
             pass
 
     def upload(self, arr: np.ndarray):
+        """Blocking upload of a whole array."""
         a = np.ascontiguousarray(arr)
         assert a.nbytes <= self.nbytes
         self.ctx.check(self.ctx.lib.km_h2d(self.ctx.handle, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes), "km_h2d")
+
+    def upload_image_async(self, img: np.ndarray) -> np.ndarray:
+        """Queue the upload of a 2-D image (rows may be strided views of a larger array) on the context's copy stream and
+        return the array that must stay alive until the context's next call: from page-locked memory (`pinned_empty`) this
+        returns at once and the copy overlaps whatever the device is computing; pageable memory is staged by the runtime."""
+        a = as_image(img)
+        assert a.shape[0] * a.shape[1] * a.itemsize <= self.nbytes
+        w = a.shape[1] * a.itemsize
+        self.ctx.check(self.ctx.lib.km_upload_async(self.ctx.handle, C.c_void_p(self.ptr), w, a.ctypes.data_as(C.c_void_p),
+                                                    a.strides[0] if a.shape[0] > 1 else w, w, a.shape[0]), "km_upload_async")
+        return a
 
     def download(self, shape, dtype) -> np.ndarray:
         out = np.empty(shape, dtype)
@@ -109,6 +119,9 @@ class ResidentPair:
         self.y_size, self.x_size = int(y_size), int(x_size)
         self.no_data_mon, self.no_data_ref = no_data_mon, no_data_ref
         self._owned = list(owned)
+        # (ox, oy, image y_size, image x_size) when the buffers are only a window of a larger image (km_set_image_window):
+        # key points are then image coordinates everywhere (tile `origin`s, zncc / mutual_info arguments)
+        self.window = None
         self._out = None
         self._zbuf = None
         self._host_frame = None
@@ -117,20 +130,28 @@ class ResidentPair:
     def upload(cls, mon: np.ndarray, ref: np.ndarray, mask: np.ndarray | None = None, ctx: Context | None = None,
                no_data_mon=None, no_data_ref=None) -> "ResidentPair":
         ctx = ctx if ctx is not None else default_context()
-        mon, ref = np.ascontiguousarray(mon), np.ascontiguousarray(ref)
+        mon, ref = np.asarray(mon), np.asarray(ref)
         if mon.shape != ref.shape or mon.dtype != ref.dtype or mon.ndim != 2:
             raise KariosHipError("ResidentPair: mon/ref must be 2-D arrays of equal shape and dtype")
+        dtype_code(mon)                                   # unsupported pixel types fail before anything is allocated
         bm, br = DeviceBuffer(ctx, mon.nbytes), DeviceBuffer(ctx, ref.nbytes)
-        bm.upload(mon)
-        br.upload(ref)
+        # the copies travel on the context's copy stream; the pair's first device call waits for them ON THE DEVICE, so a
+        # pair uploaded from page-locked memory while the previous one is being matched costs no time
+        keep = [br.upload_image_async(ref), bm.upload_image_async(mon)]
         owned, mptr = [bm, br], None
         if mask is not None:
-            mk = np.ascontiguousarray(mask, np.uint8)
+            mk = np.asarray(mask)
+            if mk.dtype != np.uint8:
+                mk = mk.astype(np.uint8)
+            if mk.shape != mon.shape:
+                raise KariosHipError("ResidentPair: mask shape differs from the images'")
             bk = DeviceBuffer(ctx, mk.nbytes)
-            bk.upload(mk)
+            keep.append(bk.upload_image_async(mk))
             owned.append(bk)
             mptr = bk.ptr
-        return cls(ctx, bm.ptr, br.ptr, mon.dtype, mon.shape[0], mon.shape[1], mptr, no_data_mon, no_data_ref, owned)
+        pair = cls(ctx, bm.ptr, br.ptr, mon.dtype, mon.shape[0], mon.shape[1], mptr, no_data_mon, no_data_ref, owned)
+        pair._upload_sources = keep
+        return pair
 
     @classmethod
     def from_device_pointers(cls, mon_ptr: int, ref_ptr: int, dtype, y_size: int, x_size: int, ctx: Context | None = None,
@@ -147,6 +168,23 @@ class ResidentPair:
             self._out = DeviceBuffer(self.ctx, need)
         base = self._out.ptr
         return base, base + cap * 8, base + 2 * cap * 8, base + 3 * cap * 8
+
+    def _windowed(self):
+        """Context manager: the ZNCC / MI kernels of the calls inside see this pair's image window."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def scope():
+            if self.window is None:
+                yield
+                return
+            c = self.ctx
+            c.check(c.lib.km_set_image_window(c.handle, *(int(v) for v in self.window)), "km_set_image_window")
+            try:
+                yield
+            finally:
+                c.lib.km_set_image_window(c.handle, 0, 0, 0, 0)
+        return scope()
 
     def _box(self, box):
         """-> (x_off, y_off, x_size, y_size, element offset of the box origin) of a validated box (None = whole pair)."""
@@ -245,10 +283,11 @@ class ResidentPair:
                                                 C.byref(prm), float(x_off), float(y_off), buf.ctypes.data_as(C.c_void_p), cap),
                     "km_klt_tile_frame_dev")
         else:
-            c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
-                                                     C.byref(prm), float(x_off), float(y_off), C.c_void_p(self.ref_ptr),
-                                                     C.c_void_p(self.mon_ptr), self.y_size, self.x_size, self.x_size, self.x_size,
-                                                     float(zncc_threshold), buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
+            with self._windowed():
+                c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                                         C.byref(prm), float(x_off), float(y_off), C.c_void_p(self.ref_ptr),
+                                                         C.c_void_p(self.mon_ptr), self.y_size, self.x_size, self.x_size, self.x_size,
+                                                         float(zncc_threshold), buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
         if not build_frame:
             return None
         frame = frames.block_to_frame(buf, cap, zncc_threshold is not None)
@@ -304,7 +343,7 @@ class ResidentPair:
         block, ring[slot], self._host_frame = self._host_frame, self._host_frame, None
         return RawFrame(block[:4 + (8 if with_zncc else 6) * cap], cap, with_zncc)
 
-    def submit_tile(self, conf, box=None, zncc_threshold=None) -> PendingFrame:
+    def submit_tile(self, conf, box=None, zncc_threshold=None, origin=None) -> PendingFrame:
         """Asynchronous `match_tile_raw` (km_klt_tile_frame_submit): returns when the tile's last kernel and the copy of
         its frame block are enqueued, so the next `submit_tile` queues its dense stages right behind them - no GPU idle
         time between tiles.  Up to three tiles may be pending; `PendingFrame.wait()` may run in another thread."""
@@ -317,41 +356,44 @@ class ResidentPair:
         ref, mon, mask, nr, nm = self._image_args(off)
         with_zncc = zncc_threshold is not None
         ticket = C.c_int(-1)
-        c.check(c.lib.km_klt_tile_frame_submit(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
-                                               C.byref(prm), float(bx_off), float(by_off),
-                                               C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
-                                               self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
-                                               C.byref(ticket)), "km_klt_tile_frame_submit")
+        x_off, y_off = origin if origin is not None else (bx_off, by_off)
+        with self._windowed():
+            c.check(c.lib.km_klt_tile_frame_submit(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
+                                                   C.byref(prm), float(x_off), float(y_off),
+                                                   C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
+                                                   self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
+                                                   C.byref(ticket)), "km_klt_tile_frame_submit")
         return PendingFrame(c, ticket.value, cap, with_zncc)
 
     def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
         """`match` as a pipeline: tile i+1 is submitted to the device (`submit_tile`) while a worker thread waits for tile i
-        and runs its host half (DataFrame construction, optional `host_stage(frame)` such as `score_frame`).  Yields the
-        frames in tile order, like `KLT.match`."""
+        and builds its DataFrame.  `host_stage(frame)` (e.g. `score_frame`) runs on the CALLING thread when the frame is
+        collected: a context is not thread-safe, and a stage that calls back into the library (ZNCC / MI of rows the device
+        call did not score) must not run beside `submit_tile`.  Yields the frames in tile order, like `KLT.match`."""
         from concurrent.futures import ThreadPoolExecutor
         if boxes is None:
             boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
 
-        def host_half(pend):
-            frame = (pend.wait() if isinstance(pend, PendingFrame) else pend).to_frame()
-            if frame is not None and host_stage is not None:
-                frame = host_stage(frame)
-            return frame
+        def host_half(pend):     # touches the frame slot only (km_frame_wait) + numpy / pandas
+            return (pend.wait() if isinstance(pend, PendingFrame) else pend).to_frame()
+
+        def collect(future):
+            frame = future.result()
+            return host_stage(frame) if frame is not None and host_stage is not None else frame
 
         # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
         submit = self.submit_tile if conf.maxCorners > 0 else self.match_tile_raw
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
             for box in boxes:
-                raw = submit(conf, box, zncc_threshold)
-                nxt = pool.submit(host_half, raw)
+                nxt = pool.submit(host_half, submit(conf, box, zncc_threshold))
                 if pending is not None:
-                    frame = pending.result()
+                    frame = collect(pending)
                     if frame is not None:
                         yield frame
                 pending = nxt
             if pending is not None:
-                frame = pending.result()
+                frame = collect(pending)
                 if frame is not None:
                     yield frame
 
@@ -385,9 +427,10 @@ class ResidentPair:
         kp = np.concatenate(cols)
         c.check(c.lib.km_h2d(c.handle, C.c_void_p(base + n * 8), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
         f = base + n * 8
-        c.check(c.lib.km_zncc_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
-                                        self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
-                                        C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base)), "km_zncc_batch_dev")
+        with self._windowed():
+            c.check(c.lib.km_zncc_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
+                                            self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
+                                            C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base)), "km_zncc_batch_dev")
         c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), n * 8), "km_d2h")
         return out
 
@@ -400,6 +443,12 @@ class ResidentPair:
         out = np.empty((2, n), np.float64)
         if n == 0:
             return out[0], out[1]
+        # the two scores come out of ONE kernel run; the reference asks for them in two separate service calls on the same
+        # key points (core.py:894-907), so the last result is remembered
+        digest = hash(b"".join(v.tobytes() for v in cols))
+        memo = self.__dict__.get("_mi_memo")
+        if memo is not None and memo[0] == digest:
+            return memo[1].copy(), memo[2].copy()
         need = n * (4 * 4 + 2 * 8)
         if self._zbuf is None or self._zbuf.nbytes < need:
             self._zbuf = DeviceBuffer(c, need + need // 4)
@@ -407,20 +456,21 @@ class ResidentPair:
         kp = np.concatenate(cols)
         f = base + 2 * n * 8
         c.check(c.lib.km_h2d(c.handle, C.c_void_p(f), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
-        c.check(c.lib.km_mi_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
-                                      self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
-                                      C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base), C.c_void_p(base + 8 * n)),
-                "km_mi_batch_dev")
+        with self._windowed():
+            c.check(c.lib.km_mi_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
+                                          self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
+                                          C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base), C.c_void_p(base + 8 * n)),
+                    "km_mi_batch_dev")
         c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), 2 * n * 8), "km_d2h")
+        self._mi_memo = (digest, out[0].copy(), out[1].copy())
         return out[0], out[1]
 
     def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4, mutual_info: bool = False) -> DataFrame:
         """`_handle_klt_results` numeric columns (core.py:872-907): radial error, angle, the ZNCC of the rows with
         score >= confidence_threshold (NaN elsewhere) and, with `mutual_info`, the `mutual_info_score` / `mi_score`
         columns of the same rows."""
+        frame = frames.radial_angle_columns(frame)
         dx, dy, score = frame["dx"].to_numpy(), frame["dy"].to_numpy(), frame["score"].to_numpy()
-        frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
-        frame["angle"] = np.degrees(np.arctan2(dy, dx))
         keep = score >= confidence_threshold
         if "zncc_score" not in frame.columns:   # else: already scored on the device (match_tile(..., zncc_threshold=...))
             z = np.full(len(frame), np.nan, np.float64)
@@ -455,4 +505,43 @@ class ResidentPair:
                             self.no_data_ref, owned=[buf, self])
 
 
-__all__ = ["ResidentPair", "DeviceBuffer", "_lib"]
+# ---------------------------------------------------------------------------- pairs shared between the matcher services
+# `KariosAPI._handle_klt_results` (core.py:888-907) hands the SAME two rasters to KLT.match, ZNCCService.compute_zncc,
+# MutualInfoService.compute_mutual_info and ZNCCService.compute_mi, one after the other; each of them uploading both images
+# again would cost 3 x 482 MB over PCIe for a Sentinel-2 pair.  The services therefore look the images up here first.
+_SHARED: "dict[tuple, tuple]" = {}
+_SHARED_LIMIT = 2
+
+
+def _identity(arr: np.ndarray) -> tuple:
+    """Cheap fingerprint of a host image: where it lives, its layout and a sparse sample of its content (an array that is
+    overwritten in place between two calls must not be mistaken for its former self)."""
+    a = np.asarray(arr)
+    step = (max(1, a.shape[0] // 61), max(1, a.shape[1] // 67)) if a.ndim == 2 and a.size else (1, 1)
+    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, hash(a[::step[0], ::step[1]].tobytes()) if a.ndim == 2 else 0)
+
+
+def shared_pair(mon: np.ndarray, ref: np.ndarray, ctx: Context | None = None, publish: "ResidentPair | None" = None) -> "ResidentPair":
+    """The resident copy of (mon, ref) on `ctx`: a pair published earlier for the same two host arrays (e.g. by `KLT.match` for
+    a tile that covers the whole image), else a fresh upload that is remembered for the next service.  `publish` registers
+    an existing pair instead of looking one up."""
+    ctx = ctx if ctx is not None else default_context()
+    key = (id(ctx), _identity(mon), _identity(ref))
+    if publish is None:
+        hit = _SHARED.get(key)
+        if hit is not None:
+            return hit[0]
+        publish = ResidentPair.upload(mon, ref, ctx=ctx)
+    _SHARED.pop(key, None)
+    while len(_SHARED) >= _SHARED_LIMIT:
+        _SHARED.pop(next(iter(_SHARED)))
+    _SHARED[key] = (publish, mon, ref)       # the host arrays stay referenced: their addresses cannot be recycled meanwhile
+    return publish
+
+
+def forget_shared_pairs() -> None:
+    """Drop the shared resident pairs (their device buffers return to the context's pool)."""
+    _SHARED.clear()
+
+
+__all__ = ["ResidentPair", "DeviceBuffer", "shared_pair", "forget_shared_pairs", "_lib"]

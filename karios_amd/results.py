@@ -19,6 +19,7 @@ import numpy as np
 import pandas as pd
 
 from ._lib import KariosHipError
+from .frames import radial_angle_columns
 from .resident import ResidentPair
 
 CSV_COLUMNS = ["x0", "y0", "dx", "dy", "score", "radial error", "angle", "zncc_score", "mutual_info_score", "mi_score"]
@@ -32,9 +33,7 @@ def handle_klt_results(results: Iterable[pd.DataFrame], csv_file, pair: Resident
     all_frame = pd.DataFrame()
     for frame in results:
         if large_shift_applied:
-            dx, dy = frame["dx"].to_numpy(), frame["dy"].to_numpy()
-            frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
-            frame["angle"] = np.degrees(np.arctan2(dy, dx))
+            frame = radial_angle_columns(frame)
             if "zncc_score" in frame.columns:
                 frame = frame.drop(columns=["zncc_score"])
         else:

@@ -128,10 +128,15 @@ def test_zncc2_mirror_error_contract():
 def test_pack_unpack_and_unit_enumeration():
     from karios_amd.core import KLTConfiguration
     from karios_amd.parallel import enumerate_units, pack_frame, unpack_frame, units_of_rank
-    f = pd.DataFrame(np.random.default_rng(0).random((7, 5)).astype(np.float32), columns=["x0", "y0", "dx", "dy", "score"])
+    f = pd.DataFrame(np.random.default_rng(0).random((7, 5)).astype(np.float32), columns=["x0", "y0", "dx", "dy", "score"],
+                     index=[5, 0, 3, 6, 1, 2, 4])              # the permuted labels an in-place sort leaves
     back = unpack_frame(pack_frame(f, 10))
     pd.testing.assert_frame_equal(back, f)
+    scored = f.assign(zncc_score=np.linspace(0, 1, 7))
+    scored.loc[3, "zncc_score"] = np.nan
+    pd.testing.assert_frame_equal(unpack_frame(pack_frame(scored, 10, True), with_zncc=True), scored)
     assert unpack_frame(pack_frame(None, 4)) is None
+    assert len(unpack_frame(pack_frame(f.iloc[:0], 4))) == 0          # corners found, none survived: an empty frame, not None
     with pytest.raises(ValueError):
         pack_frame(f, 3)
     units = enumerate_units(4, 10980, 10980, KLTConfiguration(tile_size=5490))
