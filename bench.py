@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the KARIOS matching hot path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one synthetic Sentinel-2-sized pair that is already
-resident in HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK
-forward/backward -> forward-backward score -> per-key-point ZNCC of the rows with score >= 0.4
-(BASELINE config 2: "Sentinel-2 10 m band pair (10980x10980), KLT only, 1 MI355X"; default
-processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000).
-With N > 1 every rank matches its own band pair (weak scaling; the reference's tiles / bands are
-independent) and the per-band key-point frames are all-gathered over RCCL inside the timed region.
+Default (`--config 2`): one "step" = one pass of the hot path over one synthetic Sentinel-2-sized pair that is already
+resident in HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK forward/backward ->
+forward-backward score -> per-key-point ZNCC of the rows with score >= 0.4 (BASELINE config 2: "Sentinel-2 10 m band pair
+(10980x10980), KLT only, 1 MI355X"; default processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000).
+With N > 1 every rank matches its own band pair (weak scaling: the reference's tiles / bands are independent) and the
+per-band key-point blocks are all-gathered over RCCL inside the timed region.
 
-Prints ONE JSON line on rank 0.  `roofline` is computed from hipEvent stage times recorded on the
-library's stream during the timed steps; `cpu_baseline` times the CPU oracle (oracle/, a port of the
-reference path) on a bounded sample of the same workload.
+The same JSON line carries
+  roofline      dominant dense kernel: algorithmic bytes / hipEvent stage time on the library's stream;
+  cpu_baseline  the CPU oracle (a port of the reference path) on the same pair: median of 5 runs with all usable cores and a
+                1-thread figure on a bounded sample (rank 0, N = 1 only);
+  end_to_end    the drop-in path a KARIOS user gets: page-locked host rasters -> `karios_amd.matcher.KLT.match` ->
+                DataFrame + ZNCC column per pair, upload of pair i+1 under the compute of pair i (PCIe-inclusive; never `value`);
+  config4       BASELINE config 4 as a FIXED workload (4 bands x tile_size 5490 = 16 units) split over the N ranks -
+                strong scaling; at N = 1 one GPU runs all 16 units;
+  oracle_sensitivity  how far the two defensible roundings of the OpenCV-defined arithmetic can move the result
+                (profiles/r02_oracle_sensitivity.json, produced by tools/oracle_sensitivity.py).
+
+`--config 3` prints the line of BASELINE config 3 instead (large-shift pre-alignment: phase correlation + shift_image + KLT).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,7 +43,9 @@ STAGE_BYTES_PER_PX = {
     "candidates": 5.0,               # read eig 4 + mask 1
     "pyramid": 2.5,                  # read 1+1, write 1/4+1/4
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
+PHASE_BYTES_PER_PX_F64 = 116.0       # SURVEY 8(d) large-shift model executed in fp64 (reference precision)
+SHIFT_BYTES_PER_PX = 4.0
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
 
 
 def parse():
@@ -42,47 +53,62 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config of the headline line")
     ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU sample (0 = half the image)")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=5)
     return ap.parse_args()
 
 
-def cpu_baseline(mon_t, ref_t, size, conf_kw, sample_rows):
-    """Oracle (kind 'port') on the top `rows` rows of the same pair, maxCorners scaled to keep the
-    corner density of the full tile; all host cores via OpenMP."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(mon, ref, conf_kw, runs):
+    """Oracle (kind 'port') on the SAME full pair, all usable cores: median of `runs` timed passes after one warm-up;
+    plus a 1-thread figure on the top tenth of the image (maxCorners scaled to the same corner density)."""
     from oracle import oracle as O
-    rows = sample_rows if sample_rows > 0 else max(64, size // 2)
-    rows = min(rows, size)
-    mon = mon_t[:rows].cpu().numpy().view(np.uint16)
-    ref = ref_t[:rows].cpu().numpy().view(np.uint16)
-    frac = rows / size
-    conf = O.default_conf(**dict(conf_kw, maxCorners=max(1, int(round(conf_kw["maxCorners"] * frac)))))
-    cores = O.max_threads()      # OpenMP team = min(logical CPUs, affinity, cgroup CPU quota), see oracle.usable_cpus()
-    O.klt_tile(mon[:256, :256], ref[:256, :256], conf)  # load / warm the library
-    t0 = time.perf_counter()
-    res = O.klt_tile(mon, ref, conf)
-    n = 0
-    if res is not None:
-        keep = res["score"] >= 0.4
-        O.zncc_batch(ref, mon, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
-        n = len(res["x0"])
-    dt = time.perf_counter() - t0
-    out = {"value": rows * size / 1e6 / dt, "unit": "Mpx/s", "cores": cores, "kind": "port",
-           "sample": f"top {rows} rows x {size} cols of the same pair, maxCorners {conf.maxCorners} "
-                     f"(same corner density), KLT + ZNCC, {dt:.2f} s, {n} matched key points; {cores} OpenMP threads = the CPUs this "
-                     f"process may use ({os.cpu_count()} logical CPUs visible)",
-           "keypoints_per_s": n / dt}
+    S = mon.shape[0]
+    conf = O.default_conf(**conf_kw)
+    cores = min(O.usable_cpus(), int(os.environ.get("KARIOS_ORACLE_THREADS", "1024")))
+    O.set_threads(cores)
+
+    def one_pass(m, r, c):
+        t0 = time.perf_counter()
+        res = O.klt_tile(m, r, c)
+        n = 0
+        if res is not None:
+            keep = res["score"] >= 0.4
+            O.zncc_batch(r, m, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
+            n = len(res["x0"])
+        return time.perf_counter() - t0, n, res
+
+    one_pass(mon[:512], ref[:512], conf)                    # load / warm the library
+    times, n, res = [], 0, None
+    for _ in range(max(1, runs)):
+        dt, n, res = one_pass(mon, ref, conf)
+        times.append(dt)
+    med = statistics.median(times)
+    rows1 = max(256, S // 10)
+    conf1 = O.default_conf(**dict(conf_kw, maxCorners=max(1, conf_kw["maxCorners"] * rows1 // S)))
+    O.set_threads(1)
+    t1 = sorted(one_pass(mon[:rows1], ref[:rows1], conf1)[0] for _ in range(3))[1]
+    O.set_threads(min(O.max_threads(), O.team_size()))
+    out = {"value": S * S / 1e6 / med, "unit": "Mpx/s", "cores": cores, "kind": "port",
+           "sample": f"the full {S}x{S} pair of the GPU run, KLT + ZNCC, median of {len(times)} passes ({min(times):.2f} .. {max(times):.2f} s), "
+                     f"{n} matched key points; {cores} OpenMP threads = the CPUs this process may use ({os.cpu_count()} logical CPUs visible)",
+           "keypoints_per_s": n / med,
+           "single_thread": {"value": rows1 * S / 1e6 / t1, "unit": "Mpx/s", "cores": 1,
+                             "sample": f"top {rows1} rows, maxCorners {conf1.maxCorners}, median of 3 passes, {t1:.2f} s"}}
     live = cv2_live(mon, ref, dict(maxCorners=conf.maxCorners), res)
     if live is not None:
         out["opencv_live"] = live
-    return out, res
+    return out
 
 
 def cv2_live(mon, ref, conf_kw, oracle_res):
     """Only if OpenCV happens to be importable on the box (it is not part of the image): time the reference-equivalent
     sequence (`_to_uint8` -> cv2.Laplacian -> goodFeaturesToTrack -> 2x calcOpticalFlowPyrLK -> FB test, klt.py:83-172,
-    407-436) on the CPU sample and report how the oracle's key points compare - the true reference arithmetic."""
+    407-436) and report how the oracle's key points compare - the true reference arithmetic."""
     try:
         import cv2
     except Exception:
@@ -107,6 +133,195 @@ def cv2_live(mon, ref, conf_kw, oracle_res):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------- end to end
+def end_to_end(mon, ref, ctx, steps):
+    """What `KariosAPI._compute_matches` + `_handle_klt_results` would call (core.py:845-921): host rasters in, a scored
+    DataFrame out, through the drop-in classes.  Two page-locked raster pairs alternate (GDAL would read into them); the next
+    pair's upload is queued (`KLT.prefetch`) before the current pair is matched, so it travels under the compute."""
+    from karios_amd import pinned_empty
+    from karios_amd.core import KLTConfiguration, NumpyRasterImage
+    from karios_amd.matcher import KLT, ZNCCService
+    from karios_amd.resident import forget_shared_pairs
+    conf = KLTConfiguration()
+    pairs = []
+    for k in range(2):
+        pm, pr = pinned_empty(mon.shape, mon.dtype, ctx), pinned_empty(ref.shape, ref.dtype, ctx)
+        np.copyto(pm, mon)
+        np.copyto(pr, ref)
+        pairs.append((NumpyRasterImage(pm), NumpyRasterImage(pr)))
+    klt, zncc = KLT(conf, ctx=ctx), ZNCCService(ctx=ctx)
+
+    def one(i):
+        cur, nxt = pairs[i % 2], pairs[(i + 1) % 2]
+        frames = klt.match(cur[0], cur[1], None)
+        klt.prefetch(nxt[0], nxt[1], None)                  # queued BEFORE the generator runs: its copy overlaps this pair's kernels
+        out = []
+        for f in frames:
+            dx, dy = f["dx"].to_numpy(), f["dy"].to_numpy()
+            f["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
+            f["angle"] = np.degrees(np.arctan2(dy, dx))
+            cand = f[f["score"] >= 0.4]
+            f["zncc_score"] = zncc.compute_zncc(cand, cur[0], cur[1])
+            out.append(f)
+        return out
+
+    klt.prefetch(*pairs[0], None)
+    for i in range(2):
+        one(i)
+    t0 = time.perf_counter()
+    rows = 0
+    for i in range(steps):
+        rows += sum(len(f) for f in one(2 + i))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    # the same loop from ordinary (pageable) numpy arrays: what an unmodified caller gets
+    plain = (NumpyRasterImage(mon), NumpyRasterImage(ref))
+    klt2 = KLT(conf, ctx=ctx)
+    list(klt2.match(*plain, None))
+    t1 = time.perf_counter()
+    for _ in range(max(2, steps // 3)):
+        for f in klt2.match(*plain, None):
+            zncc.compute_zncc(f[f["score"] >= 0.4], *plain)
+    dt_plain = (time.perf_counter() - t1) / max(2, steps // 3)
+    klt._prefetched.clear()
+    forget_shared_pairs()
+    S = mon.shape[0]
+    return {"ms_per_pair": dt * 1e3, "Mpx_per_s": S * S / 1e6 / dt, "keypoints_per_pair": rows // steps, "pairs": steps,
+            "path": "page-locked host rasters (karios_amd.pinned_empty) -> KLT.match -> DataFrame + radial error / angle + ZNCCService.compute_zncc; "
+                    "upload of pair i+1 (482 MB) on the copy stream under the compute of pair i",
+            "upload_bytes_per_pair": int(mon.nbytes + ref.nbytes), "pcie_GBps": (mon.nbytes + ref.nbytes) / dt / 1e9,
+            "pageable_numpy_ms_per_pair": dt_plain * 1e3}
+
+
+# ---------------------------------------------------------------------------------------------------- config 4
+def config4(ctx, dev, rank, world, coll_dev, steps):
+    """4 bands x tile_size 5490 = 16 work units of 10980^2 pairs (seeds 20260101 + 10 b), split round-robin over the ranks;
+    every rank keeps only its units' regions (box + ZNCC halo) resident; a step = all 16 units + ONE all-gather of their blocks."""
+    import torch
+    import torch.distributed as dist
+    from karios_amd import synth
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.parallel import DEFAULT_HALO, block_len, enumerate_units, gather_block_tensor, units_of_rank
+    from karios_amd.resident import ResidentPair
+    S, conf = 10980, KLTConfiguration(tile_size=5490)
+    units = enumerate_units(4, S, S, conf)
+    mine = units_of_rank(units, rank, world)
+    cap, L = conf.maxCorners, block_len(conf.maxCorners, True)
+    per_rank = (len(units) + world - 1) // world
+    send = torch.zeros((per_rank, 1 + L), dtype=torch.float32, device=dev)
+    send[:, 0] = -1
+    resident = []
+    for b in sorted({u.band for u in mine}):
+        mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * b, device=dev)
+        for u in (u for u in mine if u.band == b):
+            rx, ry = max(0, u.x_off - DEFAULT_HALO), max(0, u.y_off - DEFAULT_HALO)
+            rw, rh = min(S, u.x_off + u.x_size + DEFAULT_HALO) - rx, min(S, u.y_off + u.y_size + DEFAULT_HALO) - ry
+            m, r = mon_t[ry:ry + rh, rx:rx + rw].contiguous(), ref_t[ry:ry + rh, rx:rx + rw].contiguous()
+            pair = ResidentPair.from_device_pointers(m.data_ptr(), r.data_ptr(), np.uint16, rh, rw, ctx=ctx, keepalive=(m, r))
+            pair.window = (rx, ry, S, S)
+            resident.append((u, pair, (u.x_off - rx, u.y_off - ry, u.x_size, u.y_size)))
+        del mon_t, ref_t
+    torch.cuda.synchronize()
+    for slot, (u, _, _) in enumerate(resident):
+        send[slot, 0] = u.index
+    torch.cuda.synchronize()
+
+    def step():
+        pend = []
+        for slot, (u, pair, box) in enumerate(resident):
+            ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, send[slot, 1:].data_ptr(), L * 4), "km_set_frame_sink")
+            pend.append(pair.submit_tile(conf, box=box, zncc_threshold=0.4, origin=(u.x_off, u.y_off)))
+        ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, None, 0), "km_set_frame_sink")
+        ctx.sync()
+        if coll_dev.type == "cuda":
+            blocks = gather_block_tensor(send, len(units))
+        else:                                  # development: several gloo ranks share one GPU
+            blocks = gather_block_tensor(send.cpu(), len(units))
+        return int(blocks[:, 0].contiguous().view(torch.int32).sum().item())
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(2):
+        rows = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    del resident
+    return {"workload": "BASELINE config 4: 4 synthetic band pairs 10980x10980 uint16 (seeds 20260101+10b), tile_size 5490 -> 16 units, KLT + ZNCC, "
+                        "each rank holds only its units' regions (box + 128 px halo); one all-gather of the 16 frame blocks per step",
+            "scaling": "strong", "units": len(units), "units_per_rank": [len(units_of_rank(units, r, world)) for r in range(world)],
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": 4 * S * S / 1e6 / (dt / steps), "unit": "Mpx/s",
+            "matched_keypoints_per_step": rows, "matched_keypoints_per_sec": rows / (dt / steps)}
+
+
+# ---------------------------------------------------------------------------------------------------- config 3
+def config3_line(a, ctx, dev):
+    """BASELINE config 3: the same pair shifted by (37.25, -20.75) px with --enable-large-shift-detection: phase correlation
+    (LargeOffsetMatcher.match) -> integer shift_image -> KLT on the shifted pair -> offsets added back (core.py:233-252)."""
+    import torch
+    from karios_amd import synth
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    S = a.size
+    conf = KLTConfiguration()
+    mon_t, ref_t = synth.make_pair_torch(S, S, 37.25, -20.75, device=dev)
+    torch.cuda.synchronize()
+    pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
+
+    def step():
+        off = pair.phase_offset()                                  # [row, col]
+        t_phase = ctx.stage_ms().get("phase_correlation", 0.0)
+        shifted = pair.shifted_monitored(int(off[0]), int(off[1]))
+        frame = shifted.match_tile(conf)
+        frame["dx"] = frame["dx"] + np.float32(off[1])
+        frame["dy"] = frame["dy"] + np.float32(off[0])
+        return off, frame, t_phase
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    ctx.set_profiling(True)
+    ctx.sync()
+    t0 = time.perf_counter()
+    phase_ms = 0.0
+    for _ in range(a.steps):
+        off, frame, tp = step()
+        phase_ms += tp
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    phase_ms /= a.steps
+    algo = PHASE_BYTES_PER_PX_F64 * S * S
+    achieved = algo / (phase_ms * 1e-3) / 1e9
+    return {
+        "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, large-shift pre-alignment + KLT",
+        "value": S * S / 1e6 / (dt / a.steps), "unit": "Mpx/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 FFT (reference precision), u8/int32 stencils, f32 LK solve", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: synthetic Sentinel-2 pair {S}x{S} uint16 shifted by (37.25, -20.75) px, phase correlation -> "
+                               "shift_image -> KLT (one tile, maxCorners 20000) -> offsets added back; inputs resident in HBM", "pairs_per_step": 1},
+        "detected_offset_row_col": [float(off[0]), float(off[1])],
+        "matched_keypoints_per_pair": len(frame), "median_dx_dy": [float(np.median(frame["dx"])), float(np.median(frame["dy"]))],
+        "stage_ms": {"phase_correlation": round(phase_ms, 3)},
+        "roofline": {"bound": "hbm", "kernel": "phase_correlation (2x D2Z FFT, cross-power, Z2D FFT, arg-max)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo, "kernel_ms": phase_ms},
+        "cpu_baseline": None,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -136,13 +351,19 @@ def main():
     from karios_amd.parallel import gather_rank_blocks
     from karios_amd.resident import ResidentPair
 
+    ctx = Context(local_rank)
+    if a.config == 3:
+        if world > 1:
+            raise SystemExit("config 3 (a global 2-D FFT) does not shard: replicas only, run it with --gpus 1")
+        print(json.dumps(config3_line(a, ctx, dev)))
+        return
+
     S = a.size
     conf = KLTConfiguration()  # processing_configuration.json defaults: one tile, k=7, maxCorners 20000
     t_gen = time.perf_counter()
     mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * rank, device=dev)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    ctx = Context(local_rank)
     pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
 
     # One step = one band pair through the whole hot path.  The main thread SUBMITS the pair (km_klt_tile_frame_submit: the
@@ -262,8 +483,28 @@ def main():
                                         "frac": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "synth_seconds": round(t_gen, 2),
         }
+        sens = os.path.join(ROOT, "profiles", "r02_oracle_sensitivity.json")
+        if os.path.exists(sens):
+            try:
+                out["oracle_sensitivity"] = json.load(open(sens))
+            except Exception:
+                pass
+    pool.shutdown()
+
+    host_pair = None
+    if rank == 0 and world == 1 and not (a.no_cpu_baseline and a.no_end_to_end):
+        host_pair = (mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16))
+    del pair
+    if rank == 0 and world == 1 and not a.no_end_to_end:
+        out["end_to_end"] = end_to_end(host_pair[0], host_pair[1], ctx, max(4, min(12, a.steps)))
+    del mon_t, ref_t
+    torch.cuda.empty_cache()
+    if not a.no_config4 and S == 10980:
+        c4 = config4(ctx, dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)))
+        if rank == 0:
+            out["config4"] = c4
     if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
-        cb, _ = cpu_baseline(mon_t, ref_t, S, dict(maxCorners=conf.maxCorners), a.cpu_sample_rows)
+        cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]
     elif rank == 0:

@@ -121,6 +121,11 @@ int km_host_free(km_ctx *ctx, void *hptr);
 int km_upload_async(km_ctx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch,
                     size_t width_bytes, size_t rows);
 int km_upload_wait(km_ctx *ctx);   /* host-side wait for the uploads queued so far */
+/* Finer ordering for pipelines: km_upload_mark returns a ticket for "the uploads queued so far" and takes them out of the
+ * automatic wait above; km_upload_join makes the compute stream wait (on the device) for that ticket only.  Upload pair i+1,
+ * mark, launch the kernels of pair i, join, launch the kernels of pair i+1: the copy hides under pair i's compute. */
+int km_upload_mark(km_ctx *ctx, int *ticket);
+int km_upload_join(km_ctx *ctx, int ticket);
 /* The buffers passed as full images to the ZNCC / MI entry points (km_klt_tile_frame_zncc_dev, km_klt_tile_frame_submit,
  * km_zncc_batch[_dev], km_mi_batch[_dev]) hold only a WINDOW of the H_image x W_image image, starting at image pixel (ox, oy) -
  * a multi-GPU rank keeps just its tile plus a margin resident.  Key-point coordinates stay image coordinates (the float32

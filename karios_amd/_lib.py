@@ -65,6 +65,8 @@ SIGNATURES = {
     "km_host_free": (_i, [_vp, _vp]),
     "km_upload_async": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t]),
     "km_upload_wait": (_i, [_vp]),
+    "km_upload_mark": (_i, [_vp, _pi]),
+    "km_upload_join": (_i, [_vp, _i]),
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
     "km_set_image_window": (_i, [_vp, _i, _i, _i, _i]),
     "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
@@ -214,14 +216,17 @@ class Context:
         self.check(self.lib.km_dev_alloc(self.handle, cap, C.byref(p)), "km_dev_alloc")
         return p.value, cap
 
-    def dev_release(self, ptr_: int, cap: int):
-        """Give a buffer back.  Work queued on the context that still uses it is waited for first."""
+    def dev_release(self, ptr_: int, cap: int, upload_in_flight: bool = False):
+        """Give a buffer back.  Kernels queued on the context that still use it are waited for first; the copy stream only
+        when an upload INTO this buffer was never joined (waiting for it unconditionally would serialise the release of pair
+        i-1 with the upload of pair i+1 that is travelling under pair i's compute)."""
         if not getattr(self, "handle", None):
             return
         pool = self.__dict__.setdefault("_pool", {})
         held = self.__dict__.setdefault("_pool_bytes", 0)
         self.lib.km_ctx_sync(self.handle)
-        self.lib.km_upload_wait(self.handle)
+        if upload_in_flight:
+            self.lib.km_upload_wait(self.handle)
         if held + cap <= self.POOL_LIMIT_BYTES:
             pool.setdefault(cap, []).append(ptr_)
             self._pool_bytes = held + cap

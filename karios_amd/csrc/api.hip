@@ -145,6 +145,8 @@ int km_ctx_destroy(km_ctx *c)
             for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->evs[k][i][0]); (void)hipEventDestroy(c->evs[k][i][1]); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    for (hipEvent_t e : c->upload_marks) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->free_marks) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return KM_OK;
@@ -185,7 +187,7 @@ int km_set_profiling(km_ctx *c, int enable)
 }
 
 static const char *const kStageNames[ST_COUNT] = {"minmax", "stretch_laplacian_mask", "min_eigen", "candidates", "sort",
-                                                  "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame", "mutual_info"};
+                                                  "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame", "mutual_info", "phase_correlation"};
 
 const char *km_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 
@@ -273,6 +275,36 @@ int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, siz
     else
         KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
     c->copy_pending = true;
+    return KM_OK;
+}
+// Tickets let a caller tie a LATER piece of compute to exactly the uploads it needs: mark after queuing the uploads of pair
+// i+1, join before the first kernel of pair i+1 - the kernels of pair i, launched in between, do not wait for them.
+int km_upload_mark(km_ctx *c, int *ticket)
+{
+    if (!c || !ticket) return km_fail(c, KM_E_ARG, "km_upload_mark: null argument");
+    *ticket = -1;
+    if (!c->copy_stream) return KM_OK;                      // nothing was ever uploaded asynchronously: ticket -1 = already complete
+    hipEvent_t ev = nullptr;
+    if (!c->free_marks.empty()) { ev = c->free_marks.back(); c->free_marks.pop_back(); }
+    else KM_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    KM_HIP(c, hipEventRecord(ev, c->copy_stream));
+    size_t slot = 0;
+    while (slot < c->upload_marks.size() && c->upload_marks[slot]) slot++;
+    if (slot == c->upload_marks.size()) c->upload_marks.push_back(nullptr);
+    c->upload_marks[slot] = ev;
+    c->copy_pending = false;                                // the caller took charge of the ordering
+    *ticket = (int)slot;
+    return KM_OK;
+}
+int km_upload_join(km_ctx *c, int ticket)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (ticket < 0) return KM_OK;
+    if ((size_t)ticket >= c->upload_marks.size() || !c->upload_marks[ticket]) return km_fail(c, KM_E_ARG, "km_upload_join: unknown ticket %d", ticket);
+    hipEvent_t ev = c->upload_marks[ticket];
+    KM_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));        // device-side wait: the host does not block
+    c->upload_marks[ticket] = nullptr;
+    c->free_marks.push_back(ev);
     return KM_OK;
 }
 int km_upload_wait(km_ctx *c)
@@ -1250,6 +1282,8 @@ int km_phase_shift_dev(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
     int rc;
     if ((rc = begin_call(c)) || (rc = check_image(c, d_a, H, W, sa, "phase_shift")) || (rc = check_image(c, d_b, H, W, sb, "phase_shift"))) return rc;
     if (!out_rc || !km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d or null output", dtype);
+    c->evs_used[c->ev_cur][ST_PHASE] = false;
+    km_stage_timer t(c, ST_PHASE);
     return kp_phase_shift(c, d_a, d_b, dtype, H, W, sa, sb, out_rc);
 }
 

@@ -40,6 +40,7 @@ enum km_stage {
     ST_ZNCC,
     ST_FRAME,
     ST_MI,
+    ST_PHASE,
     ST_COUNT
 };
 
@@ -122,7 +123,9 @@ struct km_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // km_upload_async: uploads of the next pair / tile under the compute of the current one
     hipEvent_t ev_copy = nullptr;
-    bool copy_pending = false;           // uploads queued since the compute stream last waited for the copy stream
+    bool copy_pending = false;           // uploads queued since the compute stream last waited for the whole copy stream
+    std::vector<hipEvent_t> upload_marks;   // km_upload_mark tickets: events on the copy stream, nullptr = ticket consumed
+    std::vector<hipEvent_t> free_marks;
     km_window window;                    // km_set_image_window
     void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
     size_t frame_sink_cap = 0;

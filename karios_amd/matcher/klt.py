@@ -164,6 +164,7 @@ class KLT:
         self._ctx = ctx
         self._ksize_votes: Counter = Counter()      # (mon, ref) chosen per tile by the kernel-size search
         self._polarity_votes: Counter = Counter()   # "normal" / "inverted" chosen per tile by the polarity search
+        self._prefetched: dict = {}                 # identity of the rasters -> first tile session queued by `prefetch`
 
     # ------------------------------------------------------------------ public surface
     def match(self, mon_img, ref_img, mask) -> Iterator[DataFrame]:
@@ -171,7 +172,7 @@ class KLT:
         grid = self.tile_boxes(mon_img.x_size, mon_img.y_size)
         logger.info("KLT: %dx%d px in %d tile(s) of %d px, polarity %s, Laplacian kernel %s", mon_img.x_size, mon_img.y_size, len(grid),
                     self._conf.tile_size, self._describe_polarity(), self._conf.laplacian_kernel_size)
-        upcoming = None
+        upcoming = self._prefetched.pop((id(mon_img), id(ref_img), id(mask)), None) if grid else None
         for k, tile in enumerate(grid):
             session = upcoming or self._open(tile, mon_img, ref_img, mask)
             # the next tile is read and its upload queued BEFORE this one is matched: from page-locked buffers the copy
@@ -186,6 +187,16 @@ class KLT:
                 logger.info("polarity search: %s", ", ".join(f"{name} kept on {n}/{total} tiles" for name, n in self._polarity_votes.most_common()))
             else:
                 logger.info("polarity search: no tile produced key points")
+
+    def prefetch(self, mon_img, ref_img, mask=None) -> None:
+        """Not in the reference: start reading and uploading the first tile of the NEXT pair now.  Called before the current
+        pair's `match` is consumed, the copy (asynchronous from page-locked rasters, `karios_amd.pinned_empty`) travels while
+        the device matches the current pair; the following `match(mon_img, ref_img, mask)` picks the tile up."""
+        grid = self.tile_boxes(mon_img.x_size, mon_img.y_size)
+        if grid:
+            while len(self._prefetched) >= 2:           # a caller that prefetches without matching must not pile up tiles in HBM
+                self._prefetched.pop(next(iter(self._prefetched)))
+            self._prefetched[(id(mon_img), id(ref_img), id(mask))] = self._open(grid[0], mon_img, ref_img, mask)
 
     @property
     def auto_selected_ksize(self) -> tuple[int, int] | None:

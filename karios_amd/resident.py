@@ -25,10 +25,11 @@ class DeviceBuffer:
     def __init__(self, ctx: Context, nbytes: int):
         self.ctx, self.nbytes = ctx, int(nbytes)
         self.ptr, self._cap = ctx.dev_alloc(self.nbytes)
+        self.upload_in_flight = False       # an asynchronous upload into this buffer has not been joined / waited for yet
 
     def free(self):
         if self.ptr:
-            self.ctx.dev_release(self.ptr, self._cap)
+            self.ctx.dev_release(self.ptr, self._cap, self.upload_in_flight)
             self.ptr = None
 
     def __del__(self):
@@ -52,6 +53,7 @@ class DeviceBuffer:
         w = a.shape[1] * a.itemsize
         self.ctx.check(self.ctx.lib.km_upload_async(self.ctx.handle, C.c_void_p(self.ptr), w, a.ctypes.data_as(C.c_void_p),
                                                     a.strides[0] if a.shape[0] > 1 else w, w, a.shape[0]), "km_upload_async")
+        self.upload_in_flight = True
         return a
 
     def download(self, shape, dtype) -> np.ndarray:
@@ -123,7 +125,6 @@ class ResidentPair:
         # key points are then image coordinates everywhere (tile `origin`s, zncc / mutual_info arguments)
         self.window = None
         self._out = None
-        self._zbuf = None
         self._host_frame = None
 
     @classmethod
@@ -151,6 +152,9 @@ class ResidentPair:
             mptr = bk.ptr
         pair = cls(ctx, bm.ptr, br.ptr, mon.dtype, mon.shape[0], mon.shape[1], mptr, no_data_mon, no_data_ref, owned)
         pair._upload_sources = keep
+        ticket = C.c_int(-1)
+        ctx.check(ctx.lib.km_upload_mark(ctx.handle, C.byref(ticket)), "km_upload_mark")
+        pair._upload_ticket = ticket.value      # joined by the pair's first device call: work queued for OTHER pairs meanwhile does not wait
         return pair
 
     @classmethod
@@ -186,8 +190,18 @@ class ResidentPair:
                 c.lib.km_set_image_window(c.handle, 0, 0, 0, 0)
         return scope()
 
+    def _ready(self):
+        """Before the first kernel on this pair: its uploads (and only its uploads) must have landed."""
+        t = self.__dict__.pop("_upload_ticket", -1)
+        if t >= 0:
+            self.ctx.check(self.ctx.lib.km_upload_join(self.ctx.handle, t), "km_upload_join")
+            for buf in self._owned:          # from here on the compute stream is ordered behind the copies: a context sync covers them
+                if isinstance(buf, DeviceBuffer):
+                    buf.upload_in_flight = False
+
     def _box(self, box):
         """-> (x_off, y_off, x_size, y_size, element offset of the box origin) of a validated box (None = whole pair)."""
+        self._ready()
         x_off, y_off, bx, by = box if box is not None else (0, 0, self.x_size, self.y_size)
         if x_off < 0 or y_off < 0 or x_off + bx > self.x_size or y_off + by > self.y_size or bx <= 0 or by <= 0:
             raise KariosHipError(f"box {box} outside the {self.x_size}x{self.y_size} image")
@@ -412,58 +426,64 @@ class ResidentPair:
                 yield frame
 
     # ------------------------------------------------------------------ ZNCC
+    def _scratch(self, n_keypoints: int, n_outputs: int):
+        """Page-locked staging for key-point columns in and scores out: the kernels read / write it DIRECTLY over PCIe (a few
+        hundred KB), so neither direction queues a copy behind an image upload that is in flight on the DMA engine.
+        -> (float32 view of 4 * n key-point values, float64 view of n_outputs * n scores, their addresses)."""
+        from ._lib import pinned_empty
+        need = n_keypoints * (4 * 4 + n_outputs * 8)
+        # one grow-only buffer per CONTEXT: releasing page-locked memory synchronises with every copy in flight, so a pair
+        # that owned its staging would stall the pipeline whenever it is dropped while the next pair's upload travels
+        raw = self.ctx.__dict__.get("_kp_staging")
+        if raw is None or raw.nbytes < need:
+            raw = self.ctx.__dict__["_kp_staging"] = pinned_empty(need + need // 2 + 64, np.uint8, self.ctx)
+        scores = raw[:n_outputs * n_keypoints * 8].view(np.float64)
+        kp = raw[n_outputs * n_keypoints * 8:n_outputs * n_keypoints * 8 + 16 * n_keypoints].view(np.float32)
+        return kp, scores, kp.ctypes.data, scores.ctypes.data
+
     def zncc(self, x0, y0, dx, dy) -> np.ndarray:
-        """ZNCCService.compute_zncc values (zncc_service.py:186-238) for key points of the full image."""
+        """ZNCCService.compute_zncc values (zncc_service.py:186-238) for key points given in image coordinates."""
+        self._ready()
         c = self.ctx
         cols = [np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy)]
         n = len(cols[0])
-        out = np.empty(n, np.float64)
         if n == 0:
-            return out
-        need = n * (4 * 4 + 8)
-        if self._zbuf is None or self._zbuf.nbytes < need:
-            self._zbuf = DeviceBuffer(c, need + need // 4)
-        base = self._zbuf.ptr
-        kp = np.concatenate(cols)
-        c.check(c.lib.km_h2d(c.handle, C.c_void_p(base + n * 8), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
-        f = base + n * 8
+            return np.empty(0, np.float64)
+        kp, scores, f, o = self._scratch(n, 1)
+        np.concatenate(cols, out=kp)
         with self._windowed():
             c.check(c.lib.km_zncc_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
                                             self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
-                                            C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base)), "km_zncc_batch_dev")
-        c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), n * 8), "km_d2h")
-        return out
+                                            C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(o)), "km_zncc_batch_dev")
+        c.sync()
+        return scores.copy()
 
     def mutual_info(self, x0, y0, dx, dy):
         """(mutual_info_score, mi_score) per key point on the resident images: `MutualInfoService.compute_mutual_info`
         (mutual_info_service.py:73-130) and `ZNCCService.compute_mi` (zncc_service.py:240-287)."""
+        self._ready()
         c = self.ctx
         cols = [np.ascontiguousarray(v, np.float32) for v in (x0, y0, dx, dy)]
         n = len(cols[0])
-        out = np.empty((2, n), np.float64)
         if n == 0:
-            return out[0], out[1]
+            return np.empty(0, np.float64), np.empty(0, np.float64)
         # the two scores come out of ONE kernel run; the reference asks for them in two separate service calls on the same
         # key points (core.py:894-907), so the last result is remembered
         digest = hash(b"".join(v.tobytes() for v in cols))
         memo = self.__dict__.get("_mi_memo")
         if memo is not None and memo[0] == digest:
             return memo[1].copy(), memo[2].copy()
-        need = n * (4 * 4 + 2 * 8)
-        if self._zbuf is None or self._zbuf.nbytes < need:
-            self._zbuf = DeviceBuffer(c, need + need // 4)
-        base = self._zbuf.ptr
-        kp = np.concatenate(cols)
-        f = base + 2 * n * 8
-        c.check(c.lib.km_h2d(c.handle, C.c_void_p(f), kp.ctypes.data_as(C.c_void_p), kp.nbytes), "km_h2d")
+        kp, scores, f, o = self._scratch(n, 2)
+        np.concatenate(cols, out=kp)
         with self._windowed():
             c.check(c.lib.km_mi_batch_dev(c.handle, C.c_void_p(self.ref_ptr), C.c_void_p(self.mon_ptr), self.code, self.y_size, self.x_size,
                                           self.y_size, self.x_size, self.x_size, self.x_size, C.c_void_p(f), C.c_void_p(f + 4 * n),
-                                          C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(base), C.c_void_p(base + 8 * n)),
+                                          C.c_void_p(f + 8 * n), C.c_void_p(f + 12 * n), n, C.c_void_p(o), C.c_void_p(o + 8 * n)),
                     "km_mi_batch_dev")
-        c.check(c.lib.km_d2h(c.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(base), 2 * n * 8), "km_d2h")
-        self._mi_memo = (digest, out[0].copy(), out[1].copy())
-        return out[0], out[1]
+        c.sync()
+        st, nmi = scores[:n].copy(), scores[n:].copy()
+        self._mi_memo = (digest, st, nmi)
+        return st.copy(), nmi.copy()
 
     def score_frame(self, frame: DataFrame, confidence_threshold: float = 0.4, mutual_info: bool = False) -> DataFrame:
         """`_handle_klt_results` numeric columns (core.py:872-907): radial error, angle, the ZNCC of the rows with
@@ -489,6 +509,7 @@ class ResidentPair:
     # ------------------------------------------------------------------ large offset
     def phase_offset(self) -> np.ndarray:
         """LargeOffsetMatcher.match() on resident data (large_offset.py:39): [row, col]."""
+        self._ready()
         c = self.ctx
         out = (C.c_double * 2)()
         c.check(c.lib.km_phase_shift_dev(c.handle, C.c_void_p(self.mon_ptr), C.c_void_p(self.ref_ptr), self.code, self.y_size, self.x_size,
@@ -497,6 +518,7 @@ class ResidentPair:
 
     def shifted_monitored(self, y_off: int, x_off: int) -> "ResidentPair":
         """shift_image(mon, y_off, x_off) on the device (image.py:70-101); returns a new pair sharing ref."""
+        self._ready()
         c = self.ctx
         buf = DeviceBuffer(c, self.y_size * self.x_size * self.dtype.itemsize)
         c.check(c.lib.km_shift_image_dev(c.handle, C.c_void_p(self.mon_ptr), self.dtype.itemsize, self.y_size, self.x_size, self.x_size,

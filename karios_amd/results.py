@@ -57,6 +57,7 @@ def filter_by_dn_values(points: pd.DataFrame, pair: ResidentPair, no_values=None
     if n == 0:
         return points[np.ones(0, bool)].copy()
     c = pair.ctx
+    pair._ready()
     x0 = np.ascontiguousarray(points["x0"].to_numpy(), np.float32)
     y0 = np.ascontiguousarray(points["y0"].to_numpy(), np.float32)
     nv = np.ascontiguousarray([float(v) for v in (no_values or [])], np.float64)
