@@ -28,8 +28,8 @@ _DT = {np.dtype("uint8"): 0, np.dtype("uint16"): 1, np.dtype("int16"): 2,
 
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc).  Building the checker is not using it."""
-    src = os.path.join(_HERE, "karios_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("karios_oracle.c", "karios_oracle_cvlit.c", "Makefile"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
     return _SO
 
@@ -210,6 +210,44 @@ def min_eigen(img, block: int):
     if lib().ko_min_eigen(_p(a), a.shape[0], a.shape[1], int(block), _p(out)) != 0:
         raise ValueError("min_eigen failed")
     return out
+
+
+def min_eigen_cv(img, block: int, fma: bool = False):
+    """cornerMinEigenVal the way OpenCV rounds it (float32 Sobel with the scale in the smoothing taps, float32 products,
+    double box sums cast to float32): karios_oracle_cvlit.c.  NOT the definition the kernels follow - the second opinion that
+    tools/oracle_sensitivity.py compares against."""
+    a = np.ascontiguousarray(img, np.uint8)
+    out = np.empty(a.shape, np.float32)
+    if lib().kl_min_eigen_cv(_p(a), a.shape[0], a.shape[1], int(block), _p(out), int(bool(fma))) != 0:
+        raise ValueError("min_eigen_cv failed")
+    return out
+
+
+def select_corners(eig, mask=None, maxCorners=0, qualityLevel=0.1, minDistance=10):
+    """Steps 4-8 of goodFeaturesToTrack on a given min-eigenvalue map -> (N,1,2) float32 | None."""
+    e = np.ascontiguousarray(eig, np.float32)
+    H, W = e.shape
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    cap = int(maxCorners) if maxCorners > 0 else H * W
+    out = np.empty((max(cap, 1), 2), np.float32)
+    n = lib().ko_select_corners(_p(e), None if m is None else _p(m), H, W, int(maxCorners), C.c_double(qualityLevel),
+                                C.c_double(minDistance), _p(out), cap, None)
+    if n < 0:
+        raise RuntimeError(f"ko_select_corners rc={n}")
+    return None if n == 0 else out[:n].reshape(n, 1, 2).copy()
+
+
+def pyr_lk_cv(prev, nxt, pts, win=25, max_level=1, max_count=30, eps=0.03):
+    """calcOpticalFlowPyrLK with OpenCV's four-lane float32 accumulation (karios_oracle_cvlit.c): second opinion only."""
+    a = np.ascontiguousarray(prev, np.uint8)
+    b = np.ascontiguousarray(nxt, np.uint8)
+    p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.empty_like(p)
+    rc = lib().kl_pyrlk_cv(_p(a), _p(b), a.shape[0], a.shape[1], _p(p), p.shape[0], int(win), int(max_level), int(max_count),
+                           C.c_double(eps), _p(out))
+    if rc != 0:
+        raise RuntimeError(f"kl_pyrlk_cv rc={rc}")
+    return out.reshape(-1, 1, 2)
 
 
 def good_features(img, mask=None, maxCorners=0, qualityLevel=0.1, minDistance=10, blockSize=3,

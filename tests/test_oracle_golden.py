@@ -298,3 +298,22 @@ def test_dn_filter_reference_known_answers():
         ref, mon, xy = _dn_kat_case(cfg, ro, mo)
         keep = O.filter_by_dn_values(xy, xy, ref, mon, nv)
         assert list(xy[keep].astype(int)) == want
+
+
+def test_opencv_literal_second_opinion_stays_close(O):
+    """oracle/karios_oracle_cvlit.c (OpenCV's float32 evaluation order) vs the exact-integer definition the kernels follow:
+    the two may differ by float32 rounding noise only (tools/oracle_sensitivity.py quantifies it at full size)."""
+    from karios_amd import synth
+    mon, ref = synth.make_pair(300, 340, 0.5, 0.25, seed=7)
+    lap_ref, lap_mon = O.laplacian_u8(O.to_uint8(ref), 7), O.laplacian_u8(O.to_uint8(mon), 7)
+    e0 = O.min_eigen(lap_ref, 15)
+    strong = e0 > e0.max() * 0.1
+    for fma in (False, True):
+        e1 = O.min_eigen_cv(lap_ref, 15, fma=fma)
+        assert (np.abs(e1 - e0)[strong] / e0[strong]).max() < 5e-6
+    p0 = O.select_corners(e0, None, 300, 0.1, 10)
+    np.testing.assert_array_equal(p0, O.good_features(lap_ref, None, 300, 0.1, 10, 15))       # select_corners == steps 4-8 of GFTT
+    p1 = O.select_corners(O.min_eigen_cv(lap_ref, 15), None, 300, 0.1, 10)
+    assert len(set(map(tuple, p0.reshape(-1, 2))) ^ set(map(tuple, p1.reshape(-1, 2)))) <= 4
+    a, b = O.pyr_lk(lap_ref, lap_mon, p0), O.pyr_lk_cv(lap_ref, lap_mon, p0)
+    assert np.abs(a - b).max() < 5e-3 and np.median(np.abs(a - b)) < 1e-5
