@@ -98,6 +98,9 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "topk_factor"  top-K pre-filter keeps factor * maxCorners keys (8)    -> second selection pass on all candidates
  *   "select_first" first ranked prefix of the selection sweeps (3 * maxCorners) -> prefix growth
  *   "defer"        0: pyramid jobs run after the selection's read-back waits instead of under them
+ *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
+ *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
+ *                  float32 correlation peak is not at least 1 % above every other sample
  * Returns KM_E_ARG for an unknown name. */
 int km_set_option(km_ctx *ctx, const char *name, int value);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */
@@ -134,6 +137,9 @@ int km_upload_join(km_ctx *ctx, int ticket);
  * scores the NaN with bit pattern KM_NAN_OUTSIDE_WINDOW (the caller's margin was too small).  H_image = W_image = 0: off. */
 #define KM_NAN_OUTSIDE_WINDOW 0x7ff80000dead0000ull
 int km_set_image_window(km_ctx *ctx, int ox, int oy, int H_image, int W_image);
+/* Which evaluation the last km_phase_shift* call used: *path = 1 float32 hand-written FFT (k_fft.hip), 2 double precision
+ * (rocFFT); *margin = (largest - second largest) / largest sample of |cross-correlation| seen by the float32 path. */
+int km_phase_info(km_ctx *ctx, int *path, double *margin);
 /* Optional device-side copy of every frame block the km_klt_tile_frame_* entry points produce (same layout), e.g. a slice of
  * the send buffer of an RCCL all-gather: the block then never bounces through host memory.  NULL switches it off. */
 int km_set_frame_sink(km_ctx *ctx, void *d_dst, size_t capacity_bytes);

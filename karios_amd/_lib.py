@@ -68,6 +68,7 @@ SIGNATURES = {
     "km_upload_mark": (_i, [_vp, _pi]),
     "km_upload_join": (_i, [_vp, _i]),
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
+    "km_phase_info": (_i, [_vp, _pi, _pd]),
     "km_set_image_window": (_i, [_vp, _i, _i, _i, _i]),
     "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
     "km_auto_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _vp, C.POINTER(C.c_int64)]),
@@ -271,6 +272,12 @@ class Context:
         """Knob of include/karios_hip.h km_set_option, e.g. set_option("fused_eig", 0) or the test knobs "key_cap",
         "stage_cap", "topk_factor", "select_first", "defer" (0 restores a default)."""
         self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
+
+    def phase_info(self) -> tuple[int, float]:
+        """(path, margin) of the last phase correlation: path 1 = float32 hand-written FFT, 2 = double precision (rocFFT)."""
+        path, margin = C.c_int(), C.c_double()
+        self.check(self.lib.km_phase_info(self.handle, C.byref(path), C.byref(margin)), "km_phase_info")
+        return path.value, margin.value
 
     def stage_ms(self) -> dict:
         buf = (C.c_float * 16)()

@@ -48,6 +48,47 @@ class NumpyRasterImage:
         """GdalRasterImage drops its cached array here; the in-memory image keeps its data."""
 
 
+class DeviceRasterImage:
+    """The same accessor surface over a raster that already lives in HBM (a 2-D torch tensor on the GPU): `.read()` hands out
+    device views, `ResidentPair.from_window` / `karios_amd.parallel.ResidentUnit.load` then copy device to device and nothing
+    crosses PCIe.  `dtype` names the pixel type when the tensor only stores its bit pattern (torch has no uint16: the
+    synthetic generator returns int16 storage)."""
+
+    def __init__(self, tensor, dtype=None, no_data_value=None, filepath: str = "device.tif"):
+        if tensor.dim() != 2 or not tensor.is_cuda:
+            raise ValueError("DeviceRasterImage expects a 2-D tensor on the GPU")
+        self.tensor = tensor
+        self.dtype = np.dtype(dtype) if dtype is not None else np.dtype(str(tensor.dtype).replace("torch.", ""))
+        self.no_data_value = no_data_value
+        self.filepath = filepath
+
+    file_name = NumpyRasterImage.file_name
+
+    @property
+    def x_size(self) -> int:
+        return int(self.tensor.shape[1])
+
+    @property
+    def y_size(self) -> int:
+        return int(self.tensor.shape[0])
+
+    def read(self, band: int, x_off: int, y_off: int, x_size: int, y_size: int):
+        if band != 1:
+            raise ValueError("single-band image")
+        return DeviceWindow(self.tensor[y_off:y_off + y_size, x_off:x_off + x_size], self.dtype)
+
+    def clear_cache(self) -> None:
+        pass
+
+
+class DeviceWindow:
+    """A box of a `DeviceRasterImage`: a (possibly strided) device tensor view + the pixel type it stands for."""
+
+    def __init__(self, view, dtype):
+        self.view, self.dtype = view, np.dtype(dtype)
+        self.shape = tuple(view.shape)
+
+
 def shift_image(img, y_off=0, x_off=0):
     """karios.core.image.shift_image (image.py:70-101), executed on the GPU."""
     return ops.shift_image(img, y_off=y_off, x_off=x_off)

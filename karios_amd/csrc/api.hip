@@ -171,6 +171,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "topk_factor") == 0) { c->opt_topk_factor = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
+    if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
@@ -318,6 +319,13 @@ int km_set_image_window(km_ctx *c, int ox, int oy, int H_image, int W_image)
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     if (H_image < 0 || W_image < 0 || ox < 0 || oy < 0 || (H_image > 0) != (W_image > 0)) return km_fail(c, KM_E_ARG, "km_set_image_window: bad window");
     c->window.ox = ox; c->window.oy = oy; c->window.H = H_image; c->window.W = W_image;
+    return KM_OK;
+}
+int km_phase_info(km_ctx *c, int *path, double *margin)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (path) *path = c->phase_path;
+    if (margin) *margin = c->phase_margin;
     return KM_OK;
 }
 int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)

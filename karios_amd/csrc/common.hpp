@@ -142,6 +142,7 @@ struct km_ctx {
     int opt_stage_cap = 0;     // "stage_cap": usable slots of the fused kernel's per-wave LDS stage (forces the two-kernel fallback)
     int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
     int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
+    bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
     // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)
@@ -156,6 +157,8 @@ struct km_ctx {
     void *pinned_rb = nullptr;
     size_t pinned_rb_cap = 0;
     km_klt_stats stats;
+    int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (rocFFT)
+    double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
     size_t fft_work_bytes = 0;
@@ -318,3 +321,7 @@ int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Hr
 int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W,
                    ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);
 void kp_destroy(km_ctx *c);
+// k_fft.hip: hand-written float32 phase correlation (sides with prime factors in {2,3,5,7,61}, <= 12288)
+bool kp_fast_supported(int H, int W);
+int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t stride_a, ptrdiff_t stride_b,
+                        double out_rc[2], double *margin);

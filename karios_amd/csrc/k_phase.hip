@@ -138,7 +138,19 @@ int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H
                    double out_rc[2])
 {
     if (H < 1 || W < 1) return km_fail(c, KM_E_ARG, "phase_shift: empty image");
-    int rc = ensure_plans(c, H, W);
+    int rc;
+    c->phase_path = 2; c->phase_margin = 0.0;
+    if (!c->opt_phase_fp64 && kp_fast_supported(H, W)) {
+        // float32, hand-written FFT (k_fft.hip).  An integer arg-max needs no more precision than that as long as the peak
+        // stands clear: when the two largest samples are within 1 % of each other (a shift of exactly x.5 pixels splits the
+        // peak evenly, a flat image has none) the double-precision evaluation below decides, as in the reference.
+        double margin = 0.0;
+        rc = kp_phase_shift_fast(c, d_a, d_b, dtype, H, W, stride_a, stride_b, out_rc, &margin);
+        c->phase_margin = margin;
+        if (rc == KM_OK && margin >= 0.01) { c->phase_path = 1; return KM_OK; }
+        if (rc != KM_OK && rc != KM_E_UNSUPPORTED) return rc;
+    }
+    rc = ensure_plans(c, H, W);
     if (rc) return rc;
     const size_t n = (size_t)H * W, nc = (size_t)H * (W / 2 + 1);
     // WS_FFT_A: real A, later the correlation surface; WS_FFT_B: real B

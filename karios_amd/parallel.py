@@ -76,8 +76,11 @@ class ResidentUnit:
         rw = min(mon_img.x_size, unit.x_off + unit.x_size + halo) - rx
         rh = min(mon_img.y_size, unit.y_off + unit.y_size + halo) - ry
         mask = None if mask_img is None else mask_img.read(1, rx, ry, rw, rh)
-        pair = ResidentPair.upload(mon_img.read(1, rx, ry, rw, rh), ref_img.read(1, rx, ry, rw, rh), mask, ctx=ctx,
-                                   no_data_mon=getattr(mon_img, "no_data_value", None), no_data_ref=getattr(ref_img, "no_data_value", None))
+        mon_box, ref_box = mon_img.read(1, rx, ry, rw, rh), ref_img.read(1, rx, ry, rw, rh)
+        from .core.image import DeviceWindow
+        make = ResidentPair.from_windows if isinstance(mon_box, DeviceWindow) else ResidentPair.upload   # rasters already in HBM: device copies
+        pair = make(mon_box, ref_box, mask, ctx=ctx, no_data_mon=getattr(mon_img, "no_data_value", None),
+                    no_data_ref=getattr(ref_img, "no_data_value", None))
         # key points are image coordinates from the first kernel on: the float32 sum x0 + dx that decides which pixel a ZNCC
         # chip is centred on depends on the magnitude of x0 (zncc_service.py:195-196)
         pair.window = (rx, ry, mon_img.y_size, mon_img.x_size)

@@ -158,6 +158,24 @@ class ResidentPair:
         return pair
 
     @classmethod
+    def from_windows(cls, mon, ref, mask=None, ctx: Context | None = None, no_data_mon=None, no_data_ref=None) -> "ResidentPair":
+        """Pair from boxes that already live in HBM (`karios_amd.core.DeviceWindow`, what `DeviceRasterImage.read` returns):
+        dense device copies (device-to-device, nothing crosses PCIe) owned by the pair."""
+        import torch
+        m, r = mon.view.contiguous(), ref.view.contiguous()
+        if m.data_ptr() == mon.view.data_ptr():
+            m = m.clone()                                   # the pair owns its pixels like an uploaded one
+        if r.data_ptr() == ref.view.data_ptr():
+            r = r.clone()
+        k = None
+        if mask is not None:
+            from .core.image import DeviceWindow
+            k = mask.view.contiguous() if isinstance(mask, DeviceWindow) else torch.as_tensor(np.ascontiguousarray(mask, np.uint8), device=m.device)
+        torch.cuda.synchronize(m.device)                    # the library runs on its own stream
+        return cls(ctx, m.data_ptr(), r.data_ptr(), mon.dtype, m.shape[0], m.shape[1], None if k is None else k.data_ptr(),
+                   no_data_mon, no_data_ref, owned=[m, r, k])
+
+    @classmethod
     def from_device_pointers(cls, mon_ptr: int, ref_ptr: int, dtype, y_size: int, x_size: int, ctx: Context | None = None,
                              mask_ptr: int | None = None, no_data_mon=None, no_data_ref=None, keepalive=()) -> "ResidentPair":
         """Wrap existing device memory (row-major, dense rows), e.g. torch tensors' data_ptr().

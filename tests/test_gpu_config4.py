@@ -19,20 +19,22 @@ def _band(dev, b):
     from karios_amd import synth
     mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * b, device=dev)   # seeds per SURVEY 8d
     torch.cuda.synchronize()
-    return mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16)
+    return mon_t, ref_t                                   # int16 storage of the uint16 bit patterns, resident in HBM
 
 
 def test_config4_sixteen_units_on_one_gpu(ops, O):
     import torch
-    from karios_amd.core import KLTConfiguration, NumpyRasterImage
+    from karios_amd.core import DeviceRasterImage, KLTConfiguration
     from karios_amd.parallel import enumerate_units, match_distributed
     from karios_amd.resident import ResidentPair
     dev = torch.device("cuda", 0)
     conf = KLTConfiguration(tile_size=TILE)
     units = enumerate_units(BANDS, S, S, conf)
     assert len(units) == 16 and [(u.band, u.x_off, u.y_off) for u in units[:5]] == [(0, 0, 0), (0, 0, TILE), (0, TILE, 0), (0, TILE, TILE), (1, 0, 0)]
-    host = {b: _band(dev, b) for b in range(BANDS)}
-    bands = {b: (NumpyRasterImage(m), NumpyRasterImage(r)) for b, (m, r) in host.items()}
+    # the bands stay in HBM (a unit's region is a device-to-device copy): the test moves no image over PCIe except the one
+    # 5490^2 unit the oracle needs
+    dev_bands = {b: _band(dev, b) for b in range(BANDS)}
+    bands = {b: (DeviceRasterImage(m, np.uint16), DeviceRasterImage(r, np.uint16)) for b, (m, r) in dev_bands.items()}
     got = match_distributed(bands, BANDS, S, S, conf, score=True)
     assert len(got) == 16 and all(f is not None and len(f) > 10000 for f in got)
     for u, f in zip(units, got):                                           # unit order = band major, x outer, y inner
@@ -42,21 +44,29 @@ def test_config4_sixteen_units_on_one_gpu(ops, O):
         assert abs(float(np.median(f["dx"])) - 0.5) < 0.03 and abs(float(np.median(f["dy"])) - 0.25) < 0.03
     # every unit == the same tile of the fully resident band (same kernels, ZNCC chips cut from the whole image)
     for b in (0, 3):
-        pair = ResidentPair.upload(host[b][0], host[b][1])
+        m_t, r_t = dev_bands[b]
+        pair = ResidentPair.from_device_pointers(m_t.data_ptr(), r_t.data_ptr(), np.uint16, S, S, keepalive=(m_t, r_t))
         for u in units[4 * b:4 * b + 4]:
             want = pair.score_frame(pair.match_tile(conf, u.box, zncc_threshold=0.4), 0.4)
             pd.testing.assert_frame_equal(got[u.index], want[list(got[u.index].columns)], check_exact=True)
     # one 5490^2 unit against the oracle
     u = units[6]                                                           # band 1, (5490, 0)
-    m, r = host[1]
-    sl = (slice(u.y_off, u.y_off + u.y_size), slice(u.x_off, u.x_off + u.x_size))
+    rx, ry = u.x_off - 128, 0                                               # the unit plus the margin its ZNCC chips may reach into
+    m, r = (t[ry:u.y_off + u.y_size + 128, rx:].contiguous().cpu().numpy().view(np.uint16) for t in dev_bands[1])
+    sl = (slice(u.y_off - ry, u.y_off - ry + u.y_size), slice(u.x_off - rx, u.x_off - rx + u.x_size))
     exp = O.klt_tile(np.ascontiguousarray(m[sl]), np.ascontiguousarray(r[sl]), conf, x_off=u.x_off, y_off=u.y_off)
     f = got[6]
     assert len(f) == len(exp["x0"])
     for col in ("x0", "y0", "dx", "dy", "score"):
         np.testing.assert_array_equal(f[col].to_numpy(), exp[col])
     keep = exp["score"] >= np.float32(0.4)
-    z = O.zncc_batch(r, m, exp["x0"][keep], exp["y0"][keep], exp["dx"][keep], exp["dy"][keep])
+    # ZNCC by the oracle on the cut-out (its right and top borders are the image's, the others lie >= 128 px outside the
+    # unit): the monitored centre round(x0 + dx) is taken in IMAGE coordinates - the float32 sum depends on the magnitude of
+    # x0 - and handed over as an integer displacement, which the cut-out's smaller coordinates cannot round differently
+    x0, y0 = exp["x0"][keep], exp["y0"][keep]
+    dxi = np.rint(x0 + exp["dx"][keep]) - x0
+    dyi = np.rint(y0 + exp["dy"][keep]) - y0
+    z = O.zncc_batch(r, m, x0 - np.float32(rx), y0 - np.float32(ry), dxi.astype(np.float32), dyi.astype(np.float32))
     gz = f["zncc_score"].to_numpy()
     assert np.all(np.isnan(gz[~keep])) and np.array_equal(np.isnan(gz[keep]), np.isnan(z)) and np.nanmax(np.abs(gz[keep] - z)) <= 1e-9
 

@@ -168,3 +168,34 @@ def test_kernel_search_with_inverted_and_searched_polarity_on_uint16(ops, O, pol
     assert len(frames) == 1 and len(frames[0]) == len(order)
     for col in ("x0", "y0", "dx", "dy", "score"):
         np.testing.assert_array_equal(frames[0][col].to_numpy(), np.asarray(pts[col], np.float32)[order])
+
+
+# ---------------------------------------------------------------------------- hand-written float32 phase correlation
+@pytest.mark.parametrize("shape", [(244, 183), (420, 360), (1098, 1220), (96, 250), (366, 366), (61, 122), (1830, 700)])
+def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape):
+    """k_fft.hip (float32, radices 2/3/4/5/7/61) against the double-precision rocFFT path and the oracle: same integer shifts
+    on shifted copies (clear peak -> fast path is trusted), and the double path takes over when the peak is split evenly."""
+    from karios_amd._lib import default_context
+    H, W = shape
+    ctx = default_context()
+    base, _ = synth.make_pair(H + 80, W + 80, 0.0, 0.0, seed=H + W, noise_sigma=0.0)
+    rng = np.random.default_rng(H * 7 + W)
+    for trial in range(4):
+        sy, sx = int(rng.integers(-min(30, H // 8), min(30, H // 8) + 1)), int(rng.integers(-min(30, W // 8), min(30, W // 8) + 1))
+        a = base[40:40 + H, 40:40 + W]
+        b = base[40 - sy:40 - sy + H, 40 - sx:40 - sx + W]
+        if trial == 3:
+            a, b = (a >> 6).astype(np.uint8), (b >> 6).astype(np.uint8)
+        got = ops.phase_cross_correlation(b, a)
+        path, margin = ctx.phase_info()
+        assert path == 1 and margin > 0.05, (path, margin)
+        ctx.set_option("phase_fp64", 1)
+        try:
+            ref64 = ops.phase_cross_correlation(b, a)
+            assert ctx.phase_info()[0] == 2
+        finally:
+            ctx.set_option("phase_fp64", 0)
+        np.testing.assert_array_equal(got, ref64)
+        np.testing.assert_array_equal(got, O.phase_cross_correlation(b, a))
+        if min(H, W) >= 200:                      # (a small image shifted by a good part of its size has no reliable peak)
+            np.testing.assert_array_equal(got, [sy, sx])
