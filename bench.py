@@ -237,6 +237,9 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
             blocks = gather_block_tensor(send, len(units))
         else:                                  # development: several gloo ranks share one GPU
             blocks = gather_block_tensor(send.cpu(), len(units))
+        flagged = int((blocks[:, 2].contiguous().view(torch.int32) != 0).sum().item())
+        if flagged:       # (a unit outside the fixed capacities of the sync-free corner path would have to be repeated exactly)
+            raise SystemExit(f"config 4: {flagged} unit(s) flagged by the speculative corner path")
         return int(blocks[:, 0].contiguous().view(torch.int32).sum().item())
 
     def fence():
@@ -373,6 +376,10 @@ def main():
     # pair (ctypes releases the GIL inside the library).  Every frame is complete before the closing fence, so K timed
     # steps are K finished pairs.
     from concurrent.futures import ThreadPoolExecutor
+    # the submitting thread now spends ~0.1 ms per pair inside the library (no host synchronisation in the corner path) and the
+    # rest in Python next to the worker: with CPython's default 5 ms switch interval a thread that needs the GIL can wait that
+    # long for the other to yield it
+    sys.setswitchinterval(1e-4)
     pool = ThreadPoolExecutor(max_workers=1)
     stage_sum = {}
     totals = {"rows": 0, "frames": 0, "n_init": 0}
@@ -380,19 +387,25 @@ def main():
     def host_half(pend):
         raw = pend.wait()
         spans = pend.stage_ms()
-        frame = raw.to_frame()
-        return raw, spans, (None if frame is None else pair.score_frame(frame, 0.4))
+        frame = None if raw.flags else raw.to_frame()
+        return pend, raw, spans, (None if frame is None else pair.score_frame(frame, 0.4))
 
     def collect(pending):
         """Result of an earlier step: its frame, and - the path's only exchange step - the all-gather of every rank's
         key-point block (device pipeline layout) over RCCL; the gathered blocks stay in HBM."""
-        raw, spans, frame = pending.result()
+        pend, raw, spans, frame = pending.result()
+        if raw.flags:                       # the tile did not fit the synchronisation-free corner path: exact repeat (counted in the step)
+            totals["redone"] = totals.get("redone", 0) + 1
+            raw = pend.redo()
+            frame = raw.to_frame()
+            frame = None if frame is None else pair.score_frame(frame, 0.4)
         n_rows = raw.n_rows
         if world > 1:
             _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=coll_dev)
         totals["rows"] += n_rows
         totals["frames"] += 1
         totals["n_init"] = int(raw.block[:4].view(np.int32)[1])
+        totals["n_candidates"] = raw.n_candidates
         for k, v in spans.items():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
         return frame
@@ -473,7 +486,8 @@ def main():
                        "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
             "matched_keypoints_per_sec": n_kp_total / dt,
             "matched_keypoints_per_pair": (0 if frame is None else len(frame)),
-            "n_init": int(stats.n_init), "n_candidates": int(stats.n_candidates), "select_batches": int(stats.n_select_batches),
+            "n_init": int(stats.n_init), "n_candidates": int(totals.get("n_candidates", 0) or stats.n_candidates),
+            "speculative_tiles_redone": int(totals.get("redone", 0)),
             "median_dx_dy": (None if frame is None else [float(np.median(frame["dx"])), float(np.median(frame["dy"]))]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -79,6 +79,7 @@ typedef struct km_klt_stats {
 #define KM_PATH_STAGE_FALLBACK 2  /* the fused kernel's key stage overflowed: eig map + candidate kernel instead */
 #define KM_PATH_SECOND_PASS 4     /* the top-K slice held too few mutually distant corners: selection on all candidates */
 #define KM_PATH_PREFIX_GROWN 8    /* the selection's first ranked prefix was enlarged */
+#define KM_PATH_SPEC_RETRY 16     /* the speculative (no host synchronisation) corner path flagged the tile: repeated exactly */
 
 /* ---- context ------------------------------------------------------------ */
 int km_version(void);
@@ -98,6 +99,12 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "topk_factor"  top-K pre-filter keeps factor * maxCorners keys (8)    -> second selection pass on all candidates
  *   "select_first" first ranked prefix of the selection sweeps (3 * maxCorners) -> prefix growth
  *   "defer"        0: pyramid jobs run after the selection's read-back waits instead of under them
+ *   "speculative"  1: the tile entry points detect corners without a host synchronisation and without library sorts (fixed
+ *                  capacities, k_select2.hip); a tile that does not fit is flagged (frame header word 2) and repeated through
+ *                  the exact path.  0 (default): always the exact path - on one GPU both take the same time per pair, the
+ *                  waits of the exact path being filled with independent work.  Initial value from
+ *                  the environment variable KARIOS_HIP_SPECULATIVE.
+ *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
  *                  float32 correlation peak is not at least 1 % above every other sample

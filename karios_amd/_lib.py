@@ -272,6 +272,11 @@ class Context:
         """Knob of include/karios_hip.h km_set_option, e.g. set_option("fused_eig", 0) or the test knobs "key_cap",
         "stage_cap", "topk_factor", "select_first", "defer" (0 restores a default)."""
         self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
+        self.__dict__.setdefault("_options", {})[name] = int(value)
+
+    def get_option(self, name: str, default: int = 0) -> int:
+        """Last value given to `set_option` (the library's own defaults are not queried)."""
+        return self.__dict__.get("_options", {}).get(name, default)
 
     def phase_info(self) -> tuple[int, float]:
         """(path, margin) of the last phase correlation: path 1 = float32 hand-written FFT, 2 = double precision (rocFFT)."""

@@ -120,6 +120,7 @@ int km_ctx_create(int device, km_ctx **out)
         return rc;
     }
     if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
+    if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -172,6 +173,8 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
+    if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
+    if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
 
@@ -346,6 +349,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
+    c->spec_used = false; c->spec_flags = 0;
     // debugging aid: KARIOS_HIP_POISON_WS=<byte> fills every workspace buffer at the start of a tile call, so a kernel that reads
     // workspace it (or its predecessors in the call) never wrote shows up as a parity failure instead of a once-in-a-while one
     static const char *const poison = getenv("KARIOS_HIP_POISON_WS");
@@ -524,6 +528,11 @@ static int read_stats(km_ctx *c, km_scalars *sc)
     c->stats.n_select_batches = h.n_batches;
     c->stats.max_eig = h.max_eig;
     c->stats.min_ref = h.mm[0]; c->stats.max_ref = h.mm[1]; c->stats.min_mon = h.mm[2]; c->stats.max_mon = h.mm[3];
+    if (c->spec_used) {   // the speculative corner path read nothing back on the way: its diagnostics arrive here
+        c->stats.valid_pixels = (int64_t)h.valid;
+        c->stats.n_candidates = (int64_t)h.cut[3];
+        c->spec_flags = h.flags;
+    }
     if (h.n_cand == 0xffffffffu) return km_fail(c, KM_E_INTERNAL, "corner grid cell overflow");
     return KM_OK;
 }
@@ -542,7 +551,43 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         KM_HIP(c, hipStreamSynchronize(c->stream));  // n_p0 is a stack variable
     }
     km_pyr A, B;
-    if (d_p0_in) {
+    // Speculative corner path (k_select2.hip): no host synchronisation, fixed capacities, flags instead of retries.  The
+    // caller reads sc->flags with the tile's result and repeats a flagged tile with c->spec_allowed = false.
+    bool spec = !d_p0_in && c->spec_allowed && c->opt_speculative && c->fused_eig && prm->max_corners > 0 && prm->min_distance >= 1 &&
+                !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor && !c->opt_select_first;
+    if (spec) {
+        const size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
+        unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
+        if (!keys) return KM_E_NOMEM;
+        {
+            km_stage_timer t(c, ST_EIGEN);
+            rc = k2_eig_candidates(c, d_ref_lap, d_mask, H, W, prm->block_size, prm->quality_level, sc, keys, capk, false);
+        }
+        if (rc == KM_E_UNSUPPORTED) spec = false;
+        else if (rc) return rc;
+        else {
+            {
+                km_stage_timer t(c, ST_SORT);
+                rc = kf_rank(c, keys, capk, H, W, prm->max_corners, prm->quality_level, prm->min_distance, sc);
+            }
+            if (rc == KM_OK) {
+                km_stage_timer t(c, ST_SELECT);
+                rc = kf_select(c, H, W, prm->max_corners, prm->min_distance, d_p0, cap, sc);
+            }
+            if (rc == KM_E_UNSUPPORTED) {   // (grid too large for the fixed-slot cells: nothing irreversible was enqueued)
+                spec = false;
+                KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
+            } else if (rc) return rc;
+        }
+        if (spec) {
+            c->spec_used = true;
+            km_stage_timer t(c, ST_PYRAMID);
+            if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
+        }
+    }
+    if (spec) {
+        // corners, their count and the pyramids are enqueued
+    } else if (d_p0_in) {
         km_stage_timer t(c, ST_PYRAMID);
         if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
     } else {
@@ -837,12 +882,20 @@ int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, i
     const size_t pb = (size_t)cap * 2 * sizeof(float);
     float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
     if (!sc || !d_p0 || !d_p1 || !d_p0r) return KM_E_NOMEM;
-    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
-    bool no_valid = false;
-    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, W, W, (const uint8_t *)d_mask, W, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r,
-                                cap, sc, &no_valid)))
-        return rc;
-    return fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
+        bool no_valid = false;
+        c->spec_allowed = attempt == 0; c->spec_used = false; c->spec_flags = 0;
+        rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, W, W, (const uint8_t *)d_mask, W, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
+                               &no_valid);
+        c->spec_allowed = false;
+        if (rc) return rc;
+        if ((rc = fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n))) return rc;
+        if (!(c->spec_used && c->spec_flags)) break;       // flagged speculative run: once more through the exact path
+        memset(&c->stats, 0, sizeof c->stats);
+        c->stats.path_flags |= KM_PATH_SPEC_RETRY;
+    }
+    return KM_OK;
 }
 
 // KLT._match_tile pre-filter on host buffers: uint8 stretch + Laplacian of both images and the automatic mask in the
@@ -931,15 +984,21 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
     char *d_out = (char *)km_ws(c, WS_FRAME, ob);
     if (!sc || !d_p0 || !d_p1 || !d_p0r || !d_out) return KM_E_NOMEM;
+    for (int attempt = 0;; attempt++) {
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     bool no_valid = false;
-    if ((rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc,
-                                &no_valid)))
-        return rc;
+    // corners without a host synchronisation where the case allows it; header word 2 of the frame block carries the flags of
+    // that speculative path: the synchronous variants repeat a flagged tile right here, a submitted one is repeated by the
+    // caller that waits for it (karios_amd.resident)
+    c->spec_allowed = attempt == 0; c->spec_used = false; c->spec_flags = 0;
+    rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc, &no_valid);
+    c->spec_allowed = false;
+    if (rc) return rc;
     const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
     {
         km_stage_timer t(c, ST_FRAME);
         if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out))) return rc;
+        if (c->spec_used && (rc = kf_stamp_header(c, d_out, sc))) return rc;
     }
     if (with_zncc) {
         km_stage_timer t(c, ST_ZNCC);
@@ -966,10 +1025,24 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
         slot->bytes = ob;
         return KM_OK;
     }
+    km_scalars *land = c->spec_used ? (km_scalars *)km_pinned_rb(c, sizeof(km_scalars)) : nullptr;
+    if (land) KM_HIP(c, hipMemcpyAsync(land, sc, sizeof *land, hipMemcpyDeviceToHost, c->stream));   // diagnostics of the sync-free corner path
     KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
     c->stats.n_init = ((const int *)host_out)[1];
+    if (land) {
+        c->stats.valid_pixels = (int64_t)land->valid;
+        c->stats.n_candidates = (int64_t)land->cut[3];
+        c->stats.max_eig = land->max_eig;
+        c->stats.min_ref = land->mm[0]; c->stats.max_ref = land->mm[1]; c->stats.min_mon = land->mm[2]; c->stats.max_mon = land->mm[3];
+        if (land->flags) {                                   // did not fit the fixed capacities: the exact path decides
+            memset(&c->stats, 0, sizeof c->stats);
+            c->stats.path_flags |= KM_PATH_SPEC_RETRY;
+            continue;
+        }
+    }
     return KM_OK;
+    }
 }
 
 // KLT._match_tile_auto_ksize (klt.py:465-545) on resident data: every Laplacian, pyramid and corner list is built ONCE

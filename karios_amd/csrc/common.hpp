@@ -99,7 +99,18 @@ struct km_scalars {
     unsigned int und[8];           // undecided counters of the selection sweeps (one per launch slot)
     unsigned int hist[KM_TK_NB];   // top-K pre-filter histogram (zeroed with the block at the start of a call)
     unsigned int run_max_shard[64]; // sharded running max-eig keys of the 2-px fused kernel (same-address device-scope traffic serialises)
+    unsigned int flags;            // KM_FLAG_*: the speculative (no host sync) corner path could not complete, repeat through the exact path
+    unsigned int pad1[3];
+    unsigned int bin_off[KM_TK_NB]; // k_select2.hip: first slot of every value bin in the kept list
+    unsigned int bin_cur[KM_TK_NB]; //                fill cursors of the bins
 };
+#define KM_FLAG_SHARD_OVERFLOW 1u   // a key-buffer shard overflowed
+#define KM_FLAG_STAGE_OVERFLOW 2u   // the fused kernel's per-wave key stage overflowed (plateau image)
+#define KM_FLAG_KEPT_OVERFLOW 4u    // more keys above the cut than the fixed-capacity kept list holds
+#define KM_FLAG_BIN_TOO_LARGE 8u    // a value bin does not fit one workgroup's LDS sort
+#define KM_FLAG_CELL_OVERFLOW 16u   // more candidates in one grid cell than its fixed slots
+#define KM_FLAG_NOT_CONVERGED 32u   // undecided candidates left after the fixed number of sweeps
+#define KM_FLAG_SLICE_SHORT 64u     // fewer than maxCorners corners in the top slice while weaker candidates exist
 
 // km_set_image_window: the buffers handed to the ZNCC / MI kernels as "full images" hold only a window of the real image.
 // Key-point coordinates stay IMAGE coordinates (the float32 sum x0 + dx the reference rounds depends on their magnitude), the
@@ -142,6 +153,11 @@ struct km_ctx {
     int opt_stage_cap = 0;     // "stage_cap": usable slots of the fused kernel's per-wave LDS stage (forces the two-kernel fallback)
     int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
     int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
+    bool opt_speculative = false;  // "speculative" 1: corners through the synchronisation-free, sort-free path (k_select2.hip); 0 (default): the exact path (k_select.hip)
+    int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)
+    bool spec_used = false;        // the running call went through the speculative corner path
+    unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
+    bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
@@ -292,6 +308,12 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
               int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found, bool fresh_scalars);
 int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,
                       unsigned long long **d_kept, size_t *n_kept, size_t *n_total, km_scalars *hs, bool rezero);
+// k_select2.hip: ranking + selection without host synchronisation or library sorts (flags instead of retries)
+size_t kf_kept_capacity(int max_corners);
+int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H, int W, int max_corners, double quality, double min_distance,
+            km_scalars *sc);
+int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc);
+int kf_stamp_header(km_ctx *c, void *d_block, const km_scalars *sc);
 // k_lk.hip
 struct km_pyr {
     const uint8_t *img[5];

@@ -279,6 +279,14 @@ __global__ __launch_bounds__(1024) void tk_compact_kernel(const unsigned long lo
     }
 }
 
+// the histogram pass alone (k_select2.hip continues on the device)
+int ks_topk_hist(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, km_scalars *d_sc, double quality)
+{
+    tk_hist_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, d_sc, quality, d_sc->hist);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
 // keeps (at least) the k_target strongest keys ABOVE the exact threshold (k_target = 0: all of them).  The number of keys
 // in d_keys is read on the device (sc->shard_cnt, clamped to the shard capacity).  The histogram and the cut live in the
 // scalar block, which the caller zeroed at the start of the call (`rezero` for a repeated pass).  One host

@@ -1,0 +1,390 @@
+// K5, speculative form: candidate ranking + greedy minimum-distance selection of cv2.goodFeaturesToTrack (reference call site
+// klt.py:120) WITHOUT a host synchronisation and without library sorts.
+//
+// k_select.hip sizes its launches and buffers from counts it reads back to the host (twice per tile) and ranks with rocPRIM.
+// Here every buffer has a fixed capacity, every kernel reads its element count from device memory, and anything that does not
+// fit - a key-buffer shard or the fused kernel's stage overflowed, more keys kept than KF_CAP, a value bin too large for one
+// workgroup, a grid cell with more than KF_CELL candidates, sweeps that did not converge, too few corners in the top slice -
+// only raises a bit in sc->flags.  The flags travel with the tile's result; a flagged tile is repeated through the exact
+// synchronising path.  An unflagged result IS the sequential algorithm's (same argument as k_select.hip: decisions on a
+// rank prefix are final and the sweeps' fixed point is unique).
+//
+// Ranking without a sort: OpenCV's order (value descending, address descending) is the order of the u64 keys
+// (value bits << 32 | raster index).  The selection only ever asks "does j outrank i?" - a key comparison - so the kept keys are
+// merely grouped by the 2048 value bins of the top-K pre-filter (scan of the bin populations in the cut kernel, scatter).  A
+// total order is needed for the ACCEPTED corners alone (OpenCV's output order and the cut at maxCorners): they are grouped by
+// bin again, and inside a bin every accepted corner counts the accepted ones with a larger key - a few thousand comparisons
+// per corner instead of sorting 160 000 candidates (a per-bin bitonic sort in LDS, the first version, took 0.2 ms: the
+// quantised eigenvalues of a Laplacian image put > 10 000 equal-valued keys into single bins).
+#include "common.hpp"
+
+#define KF_NB KM_TK_NB
+#define KF_SHIFT 14
+#define KF_CELL 64            // candidates a grid cell can hold (a 10 x 10 cell of a textured image holds up to ~25 local maxima)
+#define KF_SWEEPS 4
+#define KF_SLICE 4u           // the ranked top slice holds (at least) KF_SLICE * maxCorners keys (the exact path starts from 8x and can grow)
+
+namespace {
+
+enum { S_UNDECIDED = 0, S_ACCEPT = 1, S_REJECT = 2 };
+
+__device__ __forceinline__ unsigned kf_bin(unsigned long long key, unsigned top)
+{
+    const unsigned b = (unsigned)(key >> (32 + KF_SHIFT));
+    const unsigned d = top > b ? top - b : 0u;
+    return d < KF_NB - 1 ? d : KF_NB - 1;
+}
+__device__ __forceinline__ float kf_threshold(const km_scalars *sc, double quality)
+{
+    const unsigned mk = sc->max_eig_key;
+    const unsigned b = (mk & 0x80000000u) ? (mk & 0x7fffffffu) : ~mk;
+    const float maxv = mk ? __uint_as_float(b) : 0.f;
+    return (float)__dmul_rn((double)maxv, quality);
+}
+// candidates the selection works on: none when the kept list overflowed (its contents are then undefined)
+__device__ __forceinline__ unsigned kf_count(const km_scalars *sc, unsigned kept_cap) { return sc->cut[1] > kept_cap ? 0u : sc->cut[1]; }
+__device__ __forceinline__ bool kf_above(unsigned long long key, float thr) { return __uint_as_float((unsigned)(key >> 32)) > thr; }
+__device__ __forceinline__ void kf_xy(unsigned long long key, int W, int &x, int &y)
+{
+    const unsigned idx = (unsigned)(key & 0xffffffffull);
+    y = (int)(idx / (unsigned)W);
+    x = (int)(idx - (unsigned)y * (unsigned)W);
+}
+
+// hist[KF_NB] (filled by tk_hist_kernel) -> cut[0] = D (last kept bin), cut[1] = kept keys, cut[3] = exact candidate count,
+// bin_off[b] = first slot of bin b in the kept list; overflow flags of the emission stage
+__global__ __launch_bounds__(1024) void f_cut_kernel(km_scalars *sc, unsigned k_target, double quality, unsigned cap_keys, unsigned kept_cap, unsigned test_flags)
+{
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_first;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned a = sc->hist[2 * t], b = sc->hist[2 * t + 1];
+    unsigned v = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) s_wave[wv] = v;
+    if (t == 0) s_first = 0xffffffffu;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wv) base += s_wave[w]; total += s_wave[w]; }
+    const unsigned incl_b = base + v, incl_a = incl_b - b;
+    sc->bin_off[2 * t] = incl_a - a;
+    sc->bin_off[2 * t + 1] = incl_b - b;
+    unsigned mine = 0xffffffffu;
+    if (incl_a >= k_target) mine = 2 * t;
+    else if (incl_b >= k_target) mine = 2 * t + 1;
+    if (mine != 0xffffffffu) atomicMin(&s_first, mine);
+    __syncthreads();
+    const unsigned D = s_first == 0xffffffffu ? KF_NB - 1 : s_first;
+    unsigned kept = 0xffffffffu;
+    if (D == (unsigned)(2 * t)) kept = incl_a;
+    else if (D == (unsigned)(2 * t + 1)) kept = s_first == 0xffffffffu ? total : incl_b;
+    if (kept != 0xffffffffu) {
+        sc->cut[0] = D; sc->cut[1] = kept; sc->cut[2] = 0;
+        if (kept > kept_cap) atomicOr(&sc->flags, KM_FLAG_KEPT_OVERFLOW);
+    }
+    if (t == 0) {
+        sc->cut[3] = total;
+        sc->thr = kf_threshold(sc, quality);
+        const unsigned mk = sc->max_eig_key;
+        const unsigned bb = (mk & 0x80000000u) ? (mk & 0x7fffffffu) : ~mk;
+        sc->max_eig = mk ? __uint_as_float(bb) : 0.f;
+        unsigned fl = (sc->pad0 ? KM_FLAG_STAGE_OVERFLOW : 0u) | test_flags;
+        for (int s = 0; s < KM_NSHARD; s++) if (sc->shard_cnt[s] > cap_keys / KM_NSHARD) fl |= KM_FLAG_SHARD_OVERFLOW;
+        if (fl) atomicOr(&sc->flags, fl);
+    }
+}
+
+// kept keys -> their bin's range of `out` (order inside a bin is fixed by the sort that follows).  A workgroup first counts
+// its keys per bin in LDS, reserves one range per non-empty bin (a device-scope atomic with return costs microseconds and
+// same-address ones serialise: one per key made this the slowest kernel of the stage) and then places the keys.
+__global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
+                                                         unsigned long long *__restrict__ out, unsigned kept_cap)
+{
+    __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
+    const unsigned cap_s = cap / KM_NSHARD;
+    const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
+    keys += (size_t)blockIdx.y * cap_s;
+    const float thr = kf_threshold(sc, quality);
+    const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
+    const unsigned D = sc->cut[0];
+    if (sc->cut[1] > kept_cap) return;                   // flagged: the exact path takes over
+    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+        const unsigned long long k = keys[i];
+        if (!kf_above(k, thr)) continue;
+        const unsigned b = kf_bin(k, top);
+        if (b <= D) atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KF_NB; i += 1024) {
+        const unsigned cnt = s_cnt[i];
+        s_base[i] = cnt ? sc->bin_off[i] + atomicAdd(&sc->bin_cur[i], cnt) : 0u;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+        const unsigned long long k = keys[i];               // second read: from L2
+        if (!kf_above(k, thr)) continue;
+        const unsigned b = kf_bin(k, top);
+        if (b <= D) out[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = k;
+    }
+}
+
+// ranked candidates -> their grid cell (fixed capacity), state undecided
+__global__ __launch_bounds__(256) void f_cells_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw,
+                                                      unsigned *__restrict__ cell_cnt, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
+                                                      unsigned kept_cap)
+{
+    const unsigned n = kf_count(sc, kept_cap);
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    state[i] = S_UNDECIDED;
+    int x, y;
+    kf_xy(keys[i], W, x, y);
+    const unsigned g = (unsigned)(y / cell) * (unsigned)gw + (unsigned)(x / cell);
+    const unsigned slot = atomicAdd(&cell_cnt[g], 1u);
+    if (slot < KF_CELL) cell_items[(size_t)g * KF_CELL + slot] = i;
+    else atomicOr(&sc->flags, KM_FLAG_CELL_OVERFLOW);
+}
+
+__global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw, int gh,
+                                                      double md2, const unsigned *__restrict__ cell_cnt, const unsigned *__restrict__ cell_items,
+                                                      unsigned *state, unsigned *n_undecided, unsigned kept_cap)
+{
+    const unsigned n = kf_count(sc, kept_cap);
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    bool undecided = false;
+    if (i < n && __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S_UNDECIDED) {
+        int x, y;
+        const unsigned long long ki = keys[i];
+        kf_xy(ki, W, x, y);
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+        undecided = true;
+        for (int sweep = 0; sweep < KF_SWEEPS && undecided; sweep++) {
+            bool blocked = false, rejected = false;
+            for (int yy = y1; yy <= y2 && !rejected; yy++)
+                for (int xx = x1; xx <= x2 && !rejected; xx++) {
+                    const unsigned g = (unsigned)yy * (unsigned)gw + (unsigned)xx;
+                    const unsigned cnt = min(cell_cnt[g], (unsigned)KF_CELL);
+                    for (unsigned k = 0; k < cnt; k++) {
+                        const unsigned j = cell_items[(size_t)g * KF_CELL + k];
+                        const unsigned long long kj = keys[j];
+                        if (kj <= ki) continue;               // only higher-ranked candidates matter (rank = key order)
+                        int xj, yj;
+                        kf_xy(kj, W, xj, yj);
+                        const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
+                        if (!((double)(dx * dx + dy * dy) < md2)) continue;
+                        const unsigned sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sj == S_ACCEPT) { rejected = true; break; }
+                        if (sj == S_UNDECIDED) blocked = true;
+                    }
+                }
+            if (rejected) { __hip_atomic_store(&state[i], (unsigned)S_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+            else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)S_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+        }
+    }
+    const unsigned long long bal = __ballot(undecided);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_undecided, (unsigned)__popcll(bal));
+}
+
+// accepted corners per value bin.  Workgroup-aggregated like the scatter: thousands of accepted corners share a handful of bins
+// (equal eigenvalues), and one device-scope atomic per corner on the same address took 300 us.
+__global__ __launch_bounds__(1024) void f_acc_count_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
+                                                           const km_scalars *sc, unsigned *__restrict__ acc_cnt, unsigned kept_cap)
+{
+    __shared__ unsigned s_cnt[KF_NB];
+    const unsigned n = kf_count(sc, kept_cap);
+    const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
+    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+        if (state[i] == S_ACCEPT) atomicAdd(&s_cnt[kf_bin(keys[i], top)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < KF_NB; i += 1024)
+        if (s_cnt[i]) atomicAdd(&acc_cnt[i], s_cnt[i]);
+}
+
+// acc_off = exclusive scan of acc_cnt, chunk_off = exclusive scan of the bins' 64-corner chunks; corner count, flags
+__global__ __launch_bounds__(1024) void f_acc_scan_kernel(const unsigned *__restrict__ acc_cnt, unsigned *__restrict__ acc_off,
+                                                          unsigned *__restrict__ chunk_off, km_scalars *sc, int max_corners, unsigned und_slot)
+{
+    __shared__ unsigned s_wave[16], s_wave2[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned a = acc_cnt[2 * t], b = acc_cnt[2 * t + 1];
+    const unsigned ca = (a + 63) / 64, cb = (b + 63) / 64;
+    unsigned v = a + b, w = ca + cb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(v, o), u2 = __shfl_up(w, o);
+        if (lane >= o) { v += u; w += u2; }
+    }
+    if (lane == 63) { s_wave[wv] = v; s_wave2[wv] = w; }
+    __syncthreads();
+    unsigned base = 0, total = 0, base2 = 0, total2 = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) { base += s_wave[k]; base2 += s_wave2[k]; } total += s_wave[k]; total2 += s_wave2[k]; }
+    acc_off[2 * t] = base + v - a - b;
+    acc_off[2 * t + 1] = base + v - b;
+    chunk_off[2 * t] = base2 + w - ca - cb;
+    chunk_off[2 * t + 1] = base2 + w - cb;
+    if (t == 0) {
+        acc_off[KF_NB] = total;
+        chunk_off[KF_NB] = total2;
+        unsigned fl = 0;
+        if (sc->und[und_slot]) fl |= KM_FLAG_NOT_CONVERGED;
+        if (total < (unsigned)max_corners && sc->cut[1] < sc->cut[3]) fl |= KM_FLAG_SLICE_SHORT;   // the top slice ran dry: all candidates needed
+        if (fl) atomicOr(&sc->flags, fl);
+        sc->n_corners = (int)min(total, (unsigned)max_corners);
+        sc->n_batches = KF_SWEEPS * 4;
+    }
+}
+
+// accepted keys grouped by bin (any order inside a bin)
+__global__ __launch_bounds__(1024) void f_acc_fill_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
+                                                          const km_scalars *sc, const unsigned *__restrict__ acc_off, unsigned *__restrict__ acc_cur,
+                                                          unsigned long long *__restrict__ acc_keys, unsigned kept_cap)
+{
+    __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
+    const unsigned n = kf_count(sc, kept_cap);
+    const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
+    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+        if (state[i] == S_ACCEPT) atomicAdd(&s_cnt[kf_bin(keys[i], top)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < KF_NB; i += 1024) {
+        const unsigned cnt = s_cnt[i];
+        s_base[i] = cnt ? acc_off[i] + atomicAdd(&acc_cur[i], cnt) : 0u;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+        if (state[i] == S_ACCEPT) {
+            const unsigned long long k = keys[i];
+            const unsigned b = kf_bin(k, top);
+            acc_keys[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = k;
+        }
+}
+
+// Position of an accepted corner in OpenCV's output order = accepted corners in stronger bins + accepted corners of its own bin
+// with a larger key; the first maxCorners positions are the result.  One wavefront per chunk of 64 corners of ONE bin: the keys
+// it compares against then sit at wave-uniform addresses (scalar loads, eight keys per instruction).
+__global__ __launch_bounds__(256) void f_acc_emit_kernel(const unsigned long long *__restrict__ acc_keys, const unsigned *__restrict__ acc_off,
+                                                         const unsigned *__restrict__ chunk_off, int W, int max_corners, int cap,
+                                                         float *__restrict__ out_xy)
+{
+    const unsigned chunk = blockIdx.x * 4 + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (chunk >= chunk_off[KF_NB]) return;
+    unsigned lo_b = 0, hi_b = KF_NB;                           // bin of this chunk: last b with chunk_off[b] <= chunk
+    while (hi_b - lo_b > 1) {
+        const unsigned mid = (lo_b + hi_b) >> 1;
+        if (chunk_off[mid] <= chunk) lo_b = mid; else hi_b = mid;
+    }
+    const unsigned b = lo_b;
+    const unsigned lo = acc_off[b], hi = acc_off[b + 1];
+    if (lo >= (unsigned)max_corners) return;                 // the whole bin lies behind the cut
+    const unsigned s = lo + (chunk - chunk_off[b]) * 64 + (threadIdx.x & 63);
+    const bool live = s < hi;
+    const unsigned long long k = live ? acc_keys[s] : 0ull;
+    unsigned p = lo;
+    for (unsigned t = lo; t < hi; t++) p += acc_keys[t] > k ? 1u : 0u;      // uniform index: scalar loads
+    if (live && p < (unsigned)max_corners && p < (unsigned)cap) {
+        int x, y;
+        kf_xy(k, W, x, y);
+        out_xy[2 * p] = (float)x;
+        out_xy[2 * p + 1] = (float)y;
+    }
+}
+
+}  // namespace
+
+// Histogram kernel of the pre-filter lives in k_select.hip
+int ks_topk_hist(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, km_scalars *d_sc, double quality);
+
+size_t kf_kept_capacity(int max_corners) { return (size_t)max_corners * 2 * KF_SLICE; }
+
+struct kf_buffers {
+    unsigned long long *kept;
+    unsigned long long *acc_keys;
+    unsigned *cell_cnt, *cell_items, *state, *acc_cnt, *acc_cur, *acc_off, *chunk_off;
+    unsigned kept_cap;
+    int cell, gw, gh;
+    size_t cells;
+};
+
+static int kf_layout(km_ctx *c, int H, int W, int max_corners, double min_distance, kf_buffers *b)
+{
+    if (!(max_corners > 0) || !(min_distance >= 1)) return KM_E_UNSUPPORTED;
+    b->kept_cap = (unsigned)kf_kept_capacity(max_corners);
+    b->cell = (int)lrint(min_distance);
+    b->gw = (W + b->cell - 1) / b->cell; b->gh = (H + b->cell - 1) / b->cell;
+    b->cells = (size_t)b->gw * b->gh;
+    if (b->cells * KF_CELL > 0x7fffffffull) return KM_E_UNSUPPORTED;
+    b->kept = (unsigned long long *)km_ws(c, WS_MISC3, (2 * (size_t)b->kept_cap + 32) * sizeof(unsigned long long));
+    b->cell_cnt = (unsigned *)km_ws(c, WS_GRID, b->cells * (1 + KF_CELL) * sizeof(unsigned));
+    unsigned *per = (unsigned *)km_ws(c, WS_MISC2, ((size_t)b->kept_cap + 4 * KF_NB + 16) * sizeof(unsigned));
+    if (!b->kept || !b->cell_cnt || !per) return KM_E_NOMEM;
+    b->acc_keys = b->kept + b->kept_cap + 16;
+    b->cell_items = b->cell_cnt + b->cells; b->state = per;
+    b->acc_cnt = per + b->kept_cap; b->acc_cur = b->acc_cnt + KF_NB; b->acc_off = b->acc_cur + KF_NB;   // acc_off, chunk_off: KF_NB + 1 entries
+    b->chunk_off = b->acc_off + KF_NB + 4;
+    return KM_OK;
+}
+
+// Ranking of the keys the fused kernel emitted: histogram -> cut -> scatter by bin -> per-bin sort.  Everything is enqueued;
+// nothing is read back.  Requires max_corners > 0, min_distance >= 1 and a scalar block zeroed at the start of the call.
+int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H, int W, int max_corners, double quality, double min_distance, km_scalars *sc)
+{
+    kf_buffers b;
+    int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
+    if (rc) return rc;
+    if ((rc = ks_topk_hist(c, d_keys, cap_keys, sc, quality))) return rc;
+    f_cut_kernel<<<1, 1024, 0, c->stream>>>(sc, (unsigned)max_corners * KF_SLICE, quality, (unsigned)cap_keys, b.kept_cap, (unsigned)c->opt_spec_flag);
+    KM_LAUNCH_CHECK(c);
+    f_scatter_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// Greedy minimum-distance selection on the ranked keys of kf_rank: corners in d_xy, their count in sc->n_corners.
+int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc)
+{
+    kf_buffers b;
+    int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
+    if (rc) return rc;
+    const double md2 = min_distance * min_distance;
+    KM_HIP(c, hipMemsetAsync(b.cell_cnt, 0, b.cells * sizeof(unsigned), c->stream));
+    const unsigned g256 = (b.kept_cap + 255) / 256;
+    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_cnt, b.cell_items, b.state, b.kept_cap);
+    KM_LAUNCH_CHECK(c);
+    for (int g = 0; g < 4; g++) {
+        f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_cnt, b.cell_items, b.state, &sc->und[g], b.kept_cap);
+        KM_LAUNCH_CHECK(c);
+    }
+    KM_HIP(c, hipMemsetAsync(b.acc_cnt, 0, 2 * KF_NB * sizeof(unsigned), c->stream));      // acc_cnt + acc_cur
+    f_acc_count_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_cnt, b.kept_cap);
+    KM_LAUNCH_CHECK(c);
+    f_acc_scan_kernel<<<1, 1024, 0, c->stream>>>(b.acc_cnt, b.acc_off, b.chunk_off, sc, max_corners, 3u);
+    KM_LAUNCH_CHECK(c);
+    f_acc_fill_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_off, b.acc_cur, b.acc_keys, b.kept_cap);
+    KM_LAUNCH_CHECK(c);
+    // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
+    f_acc_emit_kernel<<<(b.kept_cap / 64 + KF_NB + 3) / 4, 256, 0, c->stream>>>(b.acc_keys, b.acc_off, b.chunk_off, W, max_corners, cap, d_xy);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// frame header words 2 / 3: speculation flags and the exact candidate count (the host sees them with the frame block)
+__global__ void kf_header_kernel(int *hdr, const km_scalars *sc) { hdr[2] = (int)sc->flags; hdr[3] = (int)sc->cut[3]; }
+
+int kf_stamp_header(km_ctx *c, void *d_block, const km_scalars *sc)
+{
+    kf_header_kernel<<<1, 1, 0, c->stream>>>((int *)d_block, sc);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}

@@ -9,6 +9,7 @@ device pointer, e.g. a torch CUDA tensor's `data_ptr()` (`from_device_pointers`)
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 from pandas import DataFrame
@@ -75,6 +76,16 @@ class RawFrame:
     def n_rows(self) -> int:
         return int(self.block[:1].view(np.int32)[0])
 
+    @property
+    def flags(self) -> int:
+        """Non-zero: the tile did not fit the fixed capacities of the synchronisation-free corner path (KM_FLAG_* of
+        csrc/common.hpp) and its rows are NOT the result - repeat it through the exact path (`PendingFrame.redo`)."""
+        return int(self.block[2:3].view(np.int32)[0])
+
+    @property
+    def n_candidates(self) -> int:
+        return int(self.block[3:4].view(np.int32)[0])
+
     def to_frame(self) -> DataFrame | None:
         return ResidentPair._frame_from_block(self.block, self.cap, self.with_zncc)
 
@@ -83,9 +94,23 @@ class PendingFrame:
     """A tile submitted with `ResidentPair.submit_tile`: the device is still working on its tail (LK, FB test, ZNCC, copy)
     while the caller already submits the next tile.  `wait()` (any thread) -> `RawFrame`."""
 
-    def __init__(self, ctx: Context, ticket: int, cap: int, with_zncc: bool):
+    def __init__(self, ctx: Context, ticket: int, cap: int, with_zncc: bool, redo=None):
         self.ctx, self.ticket, self.cap, self.with_zncc = ctx, ticket, cap, with_zncc
         self._raw = None
+        self._redo = redo
+
+    def redo(self) -> "RawFrame":
+        """The same tile through the exact (synchronising) corner path, for a frame whose `flags` are set.  Runs device work on
+        the context: call it on the thread that submits, not on a worker that only waits."""
+        if self._redo is None:
+            raise KariosHipError("this frame cannot be repeated")
+        self._raw = self._redo()
+        return self._raw
+
+    def result(self) -> "RawFrame":
+        """`wait()`, and `redo()` when the speculative path flagged the tile (submitting thread only)."""
+        raw = self.wait()
+        return self.redo() if raw.flags else raw
 
     def wait(self) -> "RawFrame":
         if self._raw is None:
@@ -356,13 +381,13 @@ class ResidentPair:
         n_init = int(buf[:2].view(np.int32)[1])
         return frames.block_to_frame(buf, cap), scores, (int(best[0]), int(best[1])), n_init
 
-    def match_tile_raw(self, conf, box=None, zncc_threshold=None) -> "RawFrame":
+    def match_tile_raw(self, conf, box=None, zncc_threshold=None, origin=None) -> "RawFrame":
         """GPU half of `match_tile`: runs the device pipeline and returns the raw frame block (a private copy), leaving
         the pandas half to `RawFrame.to_frame()` - which may run in another thread while this thread already drives the
         next tile (ctypes releases the GIL inside the library).  Fixed kernel size / polarity, no outlier filtering."""
         if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
             raise KariosHipError("ResidentPair.match_tile_raw: 'auto' modes and outlier filtering need ResidentPair.match_tile / matcher.KLT")
-        x_off, y_off = (box[0], box[1]) if box is not None else (0, 0)
+        x_off, y_off = origin if origin is not None else ((box[0], box[1]) if box is not None else (0, 0))
         with_zncc = zncc_threshold is not None
         # host blocks rotate through a ring of three: the previous block may still be read by the host half of the pipeline
         ring = self.__dict__.setdefault("_raw_ring", [None, None, None])
@@ -395,7 +420,14 @@ class ResidentPair:
                                                    C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
                                                    self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
                                                    C.byref(ticket)), "km_klt_tile_frame_submit")
-        return PendingFrame(c, ticket.value, cap, with_zncc)
+        def exact():
+            before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "0") or 0))
+            c.set_option("speculative", 0)
+            try:
+                return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off))
+            finally:
+                c.set_option("speculative", before)
+        return PendingFrame(c, ticket.value, cap, with_zncc, redo=exact)
 
     def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
         """`match` as a pipeline: tile i+1 is submitted to the device (`submit_tile`) while a worker thread waits for tile i
@@ -407,10 +439,13 @@ class ResidentPair:
             boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
 
         def host_half(pend):     # touches the frame slot only (km_frame_wait) + numpy / pandas
-            return (pend.wait() if isinstance(pend, PendingFrame) else pend).to_frame()
+            raw = pend.wait() if isinstance(pend, PendingFrame) else pend
+            return pend, (None if raw.flags else raw.to_frame())
 
         def collect(future):
-            frame = future.result()
+            pend, frame = future.result()
+            if isinstance(pend, PendingFrame) and pend.wait().flags:     # did not fit the synchronisation-free corner path: exact repeat, here
+                frame = pend.redo().to_frame()
             return host_stage(frame) if frame is not None and host_stage is not None else frame
 
         # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
@@ -418,7 +453,7 @@ class ResidentPair:
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
             for box in boxes:
-                nxt = pool.submit(host_half, submit(conf, box, zncc_threshold))
+                nxt = pool.submit(host_half, submit(conf, box, zncc_threshold))   # (match_tile_raw repeats a flagged tile itself)
                 if pending is not None:
                     frame = collect(pending)
                     if frame is not None:

@@ -41,6 +41,17 @@ def test_each_retry_path_runs_and_keeps_the_corners(ops, O, knobs, flag):
     assert int(fp.ctx.stats().path_flags) == 0
 
 
+@pytest.mark.parametrize("seed", range(3000, 3040))
+def test_speculative_path_tile_case_matches_oracle(ops, O, seed):
+    """Random tile cases with the synchronisation-free corner path switched on (flagged tiles are repeated exactly)."""
+    from karios_amd.resident import ResidentPair
+    case = fuzz.draw_case(seed, max_size=380)
+    case["knobs"] = dict(speculative=1)
+    case["async_ring"] = 3 if seed % 3 == 0 else 0
+    fails = fuzz.run_case(case, ops, O, ResidentPair)
+    assert not fails, f"{fails} for {case}"
+
+
 @pytest.mark.parametrize("seed", range(2000, 2060))
 def test_forced_path_tile_case_matches_oracle(ops, O, seed):
     from karios_amd.resident import ResidentPair
@@ -62,7 +73,42 @@ def test_frame_ring_wrap_keeps_every_waited_frame(ops, O):
     want = [pair.match_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
     pend = [pair.submit_tile(conf, box=b, zncc_threshold=0.4) for b in boxes]
     for p, w in list(zip(pend, want))[-3:]:
-        f = p.wait().to_frame()
+        f = p.result().to_frame()          # (a tile flagged by the synchronisation-free corner path is repeated exactly)
         assert list(f.columns) == list(w.columns) and len(f) == len(w)
         for col in f.columns:
             np.testing.assert_array_equal(f[col].to_numpy(), w[col].to_numpy())
+
+
+def test_speculative_corner_path_flags_and_repeats(ops, O):
+    """The synchronisation-free corner path (k_select2.hip) works with fixed capacities; a tile that does not fit raises a flag
+    and is repeated through the exact path.  The test knob "spec_flag" raises a flag artificially: the tile is repeated and
+    the result does not change; without it the same image is not flagged."""
+    from karios_amd._lib import default_context
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(420, 500, 0.4, 0.2, seed=3)
+    ctx = default_context()
+    for max_corners, expect_retry in ((700, True), (700, False), (3, False)):
+        ctx.set_option("speculative", 1)
+        ctx.set_option("spec_flag", 32 if expect_retry else 0)
+        conf = O.default_conf(maxCorners=max_corners, laplacian_kernel_size=5)
+        exp = O.klt_tile(mon, ref, conf)
+        status, tracks = ops.klt_tile(ref, mon, conf, mon_ksize=5, ref_ksize=5)
+        assert bool(ctx.stats().path_flags & 16) == expect_retry, ctx.stats().path_flags
+        assert status == "ok" and len(tracks[0]) == exp["Ninit"] == max_corners
+        pair = ResidentPair.upload(mon, ref)
+        frame = pair.match_tile(conf, zncc_threshold=0.4)
+        assert bool(ctx.stats().path_flags & 16) == expect_retry
+        for col in ("x0", "y0", "dx", "dy", "score"):
+            np.testing.assert_array_equal(frame[col].to_numpy(), exp[col])
+        pend = pair.submit_tile(conf, zncc_threshold=0.4)
+        raw = pend.wait()
+        assert bool(raw.flags) == expect_retry
+        f2 = pend.result().to_frame()
+        for col in ("x0", "y0", "dx", "dy", "score", "zncc_score"):
+            np.testing.assert_array_equal(f2[col].to_numpy(), frame[col].to_numpy())
+        ctx.set_option("speculative", 0)
+        f3 = pair.match_tile(conf, zncc_threshold=0.4)
+        assert ctx.stats().path_flags & 16 == 0
+        for col in ("x0", "y0", "dx", "dy", "score", "zncc_score"):
+            np.testing.assert_array_equal(f3[col].to_numpy(), frame[col].to_numpy())
+        ctx.set_option("spec_flag", 0)

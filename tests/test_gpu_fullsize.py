@@ -52,6 +52,12 @@ def test_config2_full_size_properties_and_band_parity(ops, O, torch_dev):
     f1 = pair.match_tile(conf, zncc_threshold=0.4)
     f2 = pair.match_tile(conf, zncc_threshold=0.4)
     assert f1.equals(f2)                                                                           # deterministic
+    pair.ctx.set_option("speculative", 1)            # the synchronisation-free, sort-free corner path: same frame, not flagged at S2 size
+    try:
+        raw = pair.submit_tile(conf, zncc_threshold=0.4).wait()
+        assert raw.flags == 0 and raw.to_frame().equals(f1)
+    finally:
+        pair.ctx.set_option("speculative", 0)
     assert len(f1) > 15000
     _check_frame(f1, conf)
     assert abs(np.median(f1["dx"]) - 0.5) < 0.02 and abs(np.median(f1["dy"]) - 0.25) < 0.02

@@ -95,7 +95,7 @@ def make_inputs(case):
     return mon, ref, mask
 
 
-KNOB_DEFAULTS = dict(key_cap=0, stage_cap=0, topk_factor=0, select_first=0, defer=1, fused_eig=1)
+KNOB_DEFAULTS = dict(key_cap=0, stage_cap=0, topk_factor=0, select_first=0, defer=1, fused_eig=1, speculative=0)
 PATHS_HIT = {}   # KM_PATH_* bit -> number of library calls that went through it (coverage report of --force-paths)
 
 
@@ -105,7 +105,7 @@ def draw_knobs(seed: int) -> dict:
     rng = np.random.default_rng(31 * seed + 7)
     return dict(key_cap=int(rng.choice([0, 48, 256, 2048])), stage_cap=int(rng.choice([0, 0, 3, 40, 200])),
                 topk_factor=int(rng.choice([0, 1, 1, 2])), select_first=int(rng.choice([0, 8, 100, 1000])),
-                defer=int(rng.choice([1, 1, 0])), fused_eig=int(rng.choice([1, 1, 1, 0])))
+                defer=int(rng.choice([1, 1, 0])), fused_eig=int(rng.choice([1, 1, 1, 0])), speculative=int(rng.choice([1, 1, 0])))
 
 
 class forced_paths:
@@ -123,7 +123,7 @@ class forced_paths:
 
     def tally(self):
         f = int(self.ctx.stats().path_flags)
-        for bit in (1, 2, 4, 8):
+        for bit in (1, 2, 4, 8, 16):
             if f & bit:
                 PATHS_HIT[bit] = PATHS_HIT.get(bit, 0) + 1
 
@@ -152,7 +152,7 @@ def run_case(case, ops, O, ResidentPair):
     exp = O.klt_tile(np.ascontiguousarray(mon_b), np.ascontiguousarray(ref_b), conf,
                      mask_box=None if mask_b is None else np.ascontiguousarray(mask_b), nodata_mon=case["nodata_mon"],
                      nodata_ref=case["nodata_ref"], x_off=x_off, y_off=y_off, invert_mon=case["invert"])
-    with forced_paths(case.get("knobs")) as fp:
+    with forced_paths(case.get("knobs") or {}) as fp:
         status, tracks = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
                                       mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
         fp.tally()
@@ -162,7 +162,7 @@ def run_case(case, ops, O, ResidentPair):
             # ring stress: 4..6 submissions without a wait in between (3 slots: the oldest blocks are overwritten), the last
             # one is the frame under test
             pend = [pair.submit_tile(conf, box=box, zncc_threshold=0.4) for _ in range(case["async_ring"])] if conf.maxCorners > 0 else []
-            frame = pend[-1].wait().to_frame() if pend else pair.match_tile(conf, box=box, zncc_threshold=0.4)
+            frame = pend[-1].result().to_frame() if pend else pair.match_tile(conf, box=box, zncc_threshold=0.4)
         else:
             frame = pair.match_tile(conf, box=box, zncc_threshold=0.4)
         fp.tally()
@@ -307,9 +307,9 @@ def main():
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{a.what}_{s}.npz"), **LAST)
             print(f"FAIL seed {s}: {'; '.join(fails)}\n     {case}", flush=True)
-    if a.force_paths:
-        names = {1: "key regrow", 2: "stage fallback", 4: "second selection pass", 8: "prefix growth"}
-        print("paths taken (library calls): " + ", ".join(f"{names[b]} {PATHS_HIT.get(b, 0)}" for b in (1, 2, 4, 8)), flush=True)
+    if True:
+        names = {1: "key regrow", 2: "stage fallback", 4: "second selection pass", 8: "prefix growth", 16: "speculative tile repeated"}
+        print("paths taken (library calls): " + ", ".join(f"{names[b]} {PATHS_HIT.get(b, 0)}" for b in (1, 2, 4, 8, 16)), flush=True)
     print(f"fuzz_parity: {done} cases (seeds {a.seed}..{a.seed + done - 1}), {bad} failing, {time.time() - t0:.1f} s", flush=True)
     sys.exit(1 if bad else 0)
 
