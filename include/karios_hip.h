@@ -307,6 +307,34 @@ int km_phase_shift_dev(km_ctx *ctx, const void *d_reference_image,
 int km_shift_image_dev(km_ctx *ctx, const void *d_img, int elem_size, int H, int W,
                        ptrdiff_t stride, int y_off, int x_off, void *d_out);
 
+/* ---- ONE tile matched exactly by several GPUs (row bands) ---------------------------------------------
+ * The reference's default is a single tile (tile_size 20000 > 10980): one global min / max for the uint8 stretch, one global
+ * maximum eigenvalue, ONE ranked greedy selection and one maxCorners cut (klt.py:42-49, 120).  A rank holds the rows of its band
+ * plus a halo; karios_amd.parallel.match_tile_banded runs these steps and exchanges, between them, min / max and the maximum
+ * eigenvalue key (all-reduce), the ranks' strongest candidate keys (all-gather) and finally the tracks.  Row origins must be
+ * even (pyramid alignment). */
+int km_minmax_dev(km_ctx *ctx, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, double out_minmax[2]);
+/* stretch with the GIVEN minmax = {min_ref, max_ref, min_mon, max_mon}, Laplacians, automatic (or user) mask cleared outside the
+ * band's own rows [own_y0, own_y1); *valid_owned = valid pixels in those rows */
+int km_band_prefilter_dev(km_ctx *ctx, const void *d_ref, const void *d_mon, int dtype, int H, int W, ptrdiff_t stride_ref,
+                          ptrdiff_t stride_mon, const double minmax[4], const double *nodata_ref, const double *nodata_mon,
+                          int ksize_ref, int ksize_mon, int invert_mon, int own_y0, int own_y1, const uint8_t *d_user_mask,
+                          uint8_t *d_lap_ref, uint8_t *d_lap_mon, uint8_t *d_mask, int64_t *valid_owned);
+/* cornerMinEigenVal + candidate detection of the band; *local_max_key = ordered key of its maximum over the mask (0: none) */
+int km_band_eigen_dev(km_ctx *ctx, const uint8_t *d_lap_ref, const uint8_t *d_mask, int H, int W, int block_size, double quality_level,
+                      unsigned *local_max_key);
+/* the band's candidate keys (value bits << 32 | raster index IN THE BAND IMAGE) above quality_level * global maximum: all of
+ * them (k_target = 0) or the strongest value bins holding at least k_target */
+int km_band_keys_dev(km_ctx *ctx, const uint8_t *d_mask, int H, int W, double quality_level, unsigned global_max_key, size_t k_target,
+                     unsigned long long *out_keys, size_t cap, size_t *n_out, size_t *n_total);
+/* goodFeaturesToTrack steps 6-8 (rank, greedy minDistance selection, maxCorners) on candidate keys of an H x W image, any order */
+int km_select_keys(km_ctx *ctx, const unsigned long long *keys, size_t n, int H, int W, int max_corners, double min_distance,
+                   float *out_xy, int cap, int *out_n);
+/* LK forward + backward of n points in IMAGE coordinates; rows [oy, oy + H) of the H_image-row Laplacian pair are resident.
+ * *left_band = 1: a window needed rows outside the band (halo too small for this displacement) */
+int km_band_track_dev(km_ctx *ctx, const uint8_t *d_lap_ref, const uint8_t *d_lap_mon, int H, int W, int oy, int H_image,
+                      const km_klt_params *prm, const float *p0, int n, float *p1, float *p0r, int *left_band);
+
 #ifdef __cplusplus
 }
 #endif

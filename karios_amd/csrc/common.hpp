@@ -138,6 +138,8 @@ struct km_ctx {
     std::vector<hipEvent_t> upload_marks;   // km_upload_mark tickets: events on the copy stream, nullptr = ticket consumed
     std::vector<hipEvent_t> free_marks;
     km_window window;                    // km_set_image_window
+    size_t band_capk = 0;                // km_band_eigen_dev -> km_band_keys_dev: capacity of the candidate keys left in WS_KEYS0
+    bool band_fused = false;             //   ... emitted by the fused kernel (else: eig map in WS_EIG, candidates still to be scanned)
     void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
     size_t frame_sink_cap = 0;
     km_buf ws[WS_COUNT];
@@ -319,10 +321,13 @@ struct km_pyr {
     const uint8_t *img[5];
     int H[5], W[5];
     int levels;  // highest level index actually built (<= max_level)
+    // Row band of a larger image (single-tile multi-GPU mode): only rows [oy, oy + Hres) of every level are resident, H stays
+    // the height of the WHOLE level and img points at the (virtual) row 0, i.e. resident pointer - oy * W.  Hres == 0: all rows.
+    int oy[5] = {0, 0, 0, 0, 0}, Hres[5] = {0, 0, 0, 0, 0};
 };
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n,
              int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
-             float *d_p0r);
+             float *d_p0r, int *d_left_band = nullptr);
 // k_frame.hip
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
              float x_off, float y_off, void *d_out);

@@ -31,7 +31,19 @@ struct lk_args {
     int n_max, win, max_count, backward;
     double epsilon;
     float *p1, *p0r;
+    int *left_band;   // row-band mode: raised when a point's window needs rows outside the resident band
 };
+
+// rows [gy0, gy0 + rows) of level `level`, clipped to the image (REFLECT_101 only folds rows back INTO that range), resident?
+__device__ __forceinline__ bool lk_rows_resident(const km_pyr &P, int level, int gy0, int rows)
+{
+    if (P.Hres[level] == 0) return true;
+    const int lo = max(gy0, 0), hi = min(gy0 + rows, P.H[level]);
+    // a window that overhangs the top / bottom of the image mirrors rows within `rows` of that border
+    const int need_lo = gy0 < 0 ? 0 : lo, need_hi = gy0 + rows > P.H[level] ? P.H[level] : hi;
+    return need_lo >= P.oy[level] && need_hi <= P.oy[level] + P.Hres[level] && (gy0 >= 0 || P.oy[level] == 0) &&
+           (gy0 + rows <= P.H[level] || P.oy[level] + P.Hres[level] == P.H[level]);
+}
 
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
@@ -160,7 +172,7 @@ __device__ __forceinline__ uint32_t lk_pack16(int lo, int hi) { return __builtin
 // run_desc[t] = y | x0 << 8 | n << 16 (n = 0: the lane has no t-th run).
 template <int NR>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
-                               const int (&run_desc)[NR], uint8_t *raw, short *derx, uint8_t *jp, float &outx, float &outy)
+                               const int (&run_desc)[NR], uint8_t *raw, short *derx, uint8_t *jp, float &outx, float &outy, bool &left_band)
 {
     const int lane = threadIdx.x & 63;
     const float half = (float)(win - 1) * 0.5f;
@@ -189,6 +201,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
         // stage the template neighbourhood and (speculatively) the search neighbourhood around the start position
         LK_WAVE_SYNC();
         int jx0 = (int)floorf(nx - half) - LK_M, jy0 = (int)floorf(ny - half) - LK_M;
+        if (!lk_rows_resident(I, level, ipy - 1, RW) || !lk_rows_resident(J, level, jy0, JS)) { left_band = true; break; }
         {
             constexpr int MAXIT = 2 * NR;                 // covers (win + 7)^2 / 4 words for every winSize served by NR runs per lane
             const bool in_i = lk_patch_inside(IW, IH, ipx - 1, ipy - 1, RW, RW, MAXIT), in_j = lk_patch_inside(JW, JH, jx0, jy0, JS, JS, MAXIT);
@@ -305,6 +318,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
                 // the window left the cached neighbourhood: re-centre it
                 LK_WAVE_SYNC();
                 jx0 = inx - LK_M; jy0 = iny - LK_M;
+                if (!lk_rows_resident(J, level, jy0, JS)) { left_band = true; break; }
                 stage_patch<2 * NR>(Jimg, JW, JH, jx0, jy0, JS, JS, jp, JP);
                 LK_WAVE_SYNC();
             }
@@ -348,6 +362,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             }
             pdx = ddx; pdy = ddy;
         }
+        if (left_band) break;
     }
     outx = resx; outy = resy;
 }
@@ -376,17 +391,19 @@ __global__ __launch_bounds__(64 * LK_WPB) KM_LK_OCC void lk_kernel(lk_args g, in
     }
     const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
     float fx, fy;
-    lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, fx, fy);
+    bool left_band = false;
+    lk_track_point<NR>(g.A, g.B, px, py, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, fx, fy, left_band);
     if ((threadIdx.x & 63) == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, rx, ry);
+        lk_track_point<NR>(g.B, g.A, fx, fy, win, g.max_count, g.epsilon, run_desc, raw, derx, jp, rx, ry, left_band);
         if ((threadIdx.x & 63) == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
+    if (left_band && g.left_band && (threadIdx.x & 63) == 0) atomicOr(g.left_band, 1);
 }
 
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
-             double epsilon, bool backward_too, float *d_p1, float *d_p0r)
+             double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {
     if (n_max <= 0) return KM_OK;
     if (win <= 2) return km_fail(c, KM_E_ARG, "winSize %d must be > 2", win);
@@ -397,7 +414,7 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     g.backward = backward_too ? 1 : 0;
     double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
     g.epsilon = e * e;
-    g.p1 = d_p1; g.p0r = d_p0r;
+    g.p1 = d_p1; g.p0r = d_p0r; g.left_band = d_left_band;
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + ((size_t)(win + 1) * (win + 1) + 8) * 2 * sizeof(short) + 16;
     const size_t smw = (sm + 15) & ~(size_t)15, sm_all = smw * LK_WPB;

@@ -260,3 +260,163 @@ def match_distributed(bands: dict, n_bands: int, x_size: int, y_size: int, conf,
     if score:
         out = [None if f is None else frames.radial_angle_columns(f) for f in out]
     return out
+
+
+# ---------------------------------------------------------------------------- one tile, several GPUs, exactly
+def band_rows(y_size: int, world_size: int) -> list[int]:
+    """Row boundaries of the bands: world_size + 1 even numbers (the pyramids of a band must align with the image's)."""
+    edges = [((y_size * r) // world_size) & ~1 for r in range(world_size)] + [y_size]
+    if any(b <= a for a, b in zip(edges, edges[1:])):
+        raise ValueError(f"{y_size} rows cannot be split into {world_size} bands")
+    return edges
+
+
+def match_tile_banded(mon_img, ref_img, mask_img, conf, zncc_threshold=None, halo: int = 96, ctx=None, device=None):
+    """The reference's DEFAULT configuration - one tile covering the whole image (tile_size 20000, klt.py:220-253) - matched by
+    all ranks of the process group together, with the single-GPU result: every rank reads and processes only the rows of its
+    band plus `halo` rows, and between the device stages the ranks exchange
+
+      * min / max of the two rasters (two all-reduces): the tile-wide uint8 stretch (klt.py:42-49);
+      * the maximum eigenvalue (one all-reduce): goodFeaturesToTrack's quality threshold;
+      * their strongest candidate keys (one all-gather, ~8 * maxCorners keys each): every rank then runs the SAME ranked
+        greedy selection with the one maxCorners cut (klt.py:120) on the merged list;
+      * the tracks of the corners they own (one all-reduce): the frame is assembled identically everywhere.
+
+    Returns the tile's frame (columns x0, y0, dx, dy, score [, zncc_score], rows by (x0, y0)) or None, on every rank."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import NAN_OUTSIDE_WINDOW, KariosHipError, as_image, default_context, dtype_code
+    from .ops import make_params
+    from .resident import DeviceBuffer, ResidentPair
+    ws, rank = _world()
+    ctx = ctx if ctx is not None else default_context()
+    H, W = mon_img.y_size, mon_img.x_size
+    if conf.tile_size < max(H, W) or conf.xStart > 0:
+        raise ValueError("match_tile_banded reproduces the single-tile configuration (tile_size >= image size, xStart 0)")
+    if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
+        raise ValueError("match_tile_banded: fixed kernel sizes / polarity, no outlier filtering")
+    if halo % 2 or halo < 32:
+        raise ValueError("halo must be an even number of rows >= 32")
+    coll = torch.device(device) if device is not None else (torch.device("cuda", ctx.device) if ws > 1 and dist.get_backend() == "nccl" else torch.device("cpu"))
+
+    def reduce_(values, op, dtype=torch.float64):
+        t = torch.as_tensor(np.asarray(values), dtype=dtype).to(coll)
+        if ws > 1:
+            dist.all_reduce(t, op=op)
+        return t.cpu().numpy()
+
+    edges = band_rows(H, ws)
+    y0, y1 = edges[rank], edges[rank + 1]
+    ys, ye = max(0, y0 - halo), min(H, y1 + halo)
+    hs = ye - ys
+    mon = as_image(mon_img.read(1, 0, ys, W, hs))
+    ref = as_image(ref_img.read(1, 0, ys, W, hs))
+    if mon.dtype != ref.dtype:
+        raise KariosHipError("match_tile_banded: both rasters must have the same pixel type")
+    code = dtype_code(mon)
+    pair = ResidentPair.upload(mon, ref, None if mask_img is None else mask_img.read(1, 0, ys, W, hs), ctx=ctx,
+                               no_data_mon=getattr(mon_img, "no_data_value", None), no_data_ref=getattr(ref_img, "no_data_value", None))
+    pair._ready()
+    pair.window = (0, ys, H, W)
+    lib, h = ctx.lib, ctx.handle
+    # ---- tile-wide min / max
+    mm = np.zeros(4)
+    for k, ptr in ((0, pair.ref_ptr), (2, pair.mon_ptr)):
+        out = (C.c_double * 2)()
+        ctx.check(lib.km_minmax_dev(h, C.c_void_p(ptr), code, hs, W, W, out), "km_minmax_dev")
+        mm[k], mm[k + 1] = out[0], out[1]
+    if code != 0:     # (uint8 rasters pass through the stretch unchanged)
+        lo = reduce_([mm[0], mm[2]], dist.ReduceOp.MIN)
+        hi = reduce_([mm[1], mm[3]], dist.ReduceOp.MAX)
+        mm = np.array([lo[0], hi[0], lo[1], hi[1]])
+    # ---- stretch, Laplacians, mask of the band's own rows
+    prm = make_params(conf, *tiling.kernel_sizes(conf.laplacian_kernel_size), bool(conf.laplacian_invert_polarity))
+    lap_ref, lap_mon, mask = (DeviceBuffer(ctx, hs * W) for _ in range(3))
+    valid = C.c_int64()
+    nr = C.byref(C.c_double(float(pair.no_data_ref))) if pair.no_data_ref is not None else None
+    nm = C.byref(C.c_double(float(pair.no_data_mon))) if pair.no_data_mon is not None else None
+    ctx.check(lib.km_band_prefilter_dev(h, C.c_void_p(pair.ref_ptr), C.c_void_p(pair.mon_ptr), code, hs, W, W, W, mm.ctypes.data_as(C.POINTER(C.c_double)),
+                                        nr, nm, prm.ksize_ref, prm.ksize_mon, prm.invert_mon, y0 - ys, y1 - ys,
+                                        C.c_void_p(pair.mask_ptr) if pair.mask_ptr else None, C.c_void_p(lap_ref.ptr), C.c_void_p(lap_mon.ptr),
+                                        C.c_void_p(mask.ptr), C.byref(valid)), "km_band_prefilter_dev")
+    if int(reduce_([valid.value], dist.ReduceOp.SUM)[0]) == 0:
+        return None                                                     # "No valid pixels" (klt.py:276-279)
+    # ---- maximum eigenvalue of the tile
+    key = C.c_uint()
+    ctx.check(lib.km_band_eigen_dev(h, C.c_void_p(lap_ref.ptr), C.c_void_p(mask.ptr), hs, W, prm.block_size, prm.quality_level, C.byref(key)),
+              "km_band_eigen_dev")
+    gkey = int(reduce_([key.value], dist.ReduceOp.MAX, torch.int64)[0])
+    if gkey == 0:
+        return None
+    # ---- candidates: every rank contributes its strongest value bins; the merged list is cut where the weakest contribution ends
+    max_corners = int(conf.maxCorners)
+    sliced = max_corners > 0 and conf.minDistance >= 1
+    cap = max_corners if max_corners > 0 else max(1, (H * W) // 4)
+    corners = None
+    for k_target in ((8 * max_corners, 0) if sliced else (0,)):
+        room = hs * W // 4 + 65536
+        buf = np.empty(room, np.uint64)
+        n_out, n_tot = C.c_size_t(), C.c_size_t()
+        ctx.check(lib.km_band_keys_dev(h, C.c_void_p(mask.ptr), hs, W, prm.quality_level, gkey, k_target, buf.ctypes.data_as(C.c_void_p), room,
+                                       C.byref(n_out), C.byref(n_tot)), "km_band_keys_dev")
+        mine = buf[:n_out.value] + np.uint64(ys * W)                      # raster index of the band image -> of the tile
+        truncated = n_out.value < n_tot.value
+        floor_key = int(mine.min()) if truncated and len(mine) else 0     # nothing weaker than this is known from this rank
+        counts = reduce_([len(mine) if r == rank else 0 for r in range(ws)], dist.ReduceOp.SUM, torch.int64)
+        floors = reduce_(np.array([floor_key if r == rank else 0 for r in range(ws)], np.uint64).view(np.int64), dist.ReduceOp.SUM, torch.int64)
+        width = max(1, int(counts.max()))
+        send = torch.zeros(width, dtype=torch.int64)
+        send[:len(mine)] = torch.from_numpy(mine.view(np.int64).copy())
+        if ws > 1:
+            flat = torch.empty(ws * width, dtype=torch.int64, device=coll)
+            dist.all_gather_into_tensor(flat, send.to(coll))
+            recv = flat.view(ws, width)
+            parts = [recv[r, :int(counts[r])].cpu().numpy().view(np.uint64) for r in range(ws)]
+        else:
+            parts = [mine]
+        merged = np.ascontiguousarray(np.concatenate(parts))
+        cut = floors.view(np.uint64).max()
+        merged = np.ascontiguousarray(merged[merged >= cut])               # a rank prefix of the tile's candidate list
+        out_xy = np.empty((cap, 2), np.float32)
+        n = C.c_int()
+        ctx.check(lib.km_select_keys(h, merged.ctypes.data_as(C.c_void_p), len(merged), H, W, max_corners, float(conf.minDistance),
+                                     out_xy.ctypes.data_as(C.c_void_p), cap, C.byref(n)), "km_select_keys")
+        corners = out_xy[:n.value].copy()
+        if not (sliced and k_target and n.value < max_corners and int(cut) > 0):
+            break                                                          # enough corners, or the list was complete
+    if corners is None or len(corners) == 0:
+        return None                                                        # "No features extracted" (klt.py:122-124)
+    # ---- tracks of the corners this rank owns
+    own = (corners[:, 1] >= y0) & (corners[:, 1] < y1)
+    p0_own = np.ascontiguousarray(corners[own])
+    p1_own, p0r_own = np.empty_like(p0_own), np.empty_like(p0_own)
+    left = C.c_int()
+    ctx.check(lib.km_band_track_dev(h, C.c_void_p(lap_ref.ptr), C.c_void_p(lap_mon.ptr), hs, W, ys, H, C.byref(prm), p0_own.ctypes.data_as(C.c_void_p),
+                                    len(p0_own), p1_own.ctypes.data_as(C.c_void_p), p0r_own.ctypes.data_as(C.c_void_p), C.byref(left)),
+              "km_band_track_dev")
+    if int(reduce_([left.value], dist.ReduceOp.MAX, torch.int64)[0]):
+        raise KariosHipError(f"match_tile_banded: a tracked window left its band's {halo}-row halo; use a larger halo")
+    tracks = np.zeros((2, len(corners), 2), np.float32)
+    tracks[0, own], tracks[1, own] = p1_own, p0r_own
+    tracks = reduce_(tracks, dist.ReduceOp.SUM, torch.float32)              # every corner has exactly one owner: the sums are copies
+    cols, n_init = frames.track_columns(corners.reshape(-1, 1, 2), tracks[0].reshape(-1, 1, 2), tracks[1].reshape(-1, 1, 2))
+    frame = frames.assemble(cols)
+    if zncc_threshold is not None:
+        z = np.zeros(len(frame))
+        score_it = frame["score"].to_numpy() >= zncc_threshold
+        mine_rows = score_it & (frame["y0"].to_numpy() >= y0) & (frame["y0"].to_numpy() < y1)
+        outside = 0
+        if mine_rows.any():
+            sub = frame[mine_rows]
+            vals = pair.zncc(sub["x0"].to_numpy(), sub["y0"].to_numpy(), sub["dx"].to_numpy(), sub["dy"].to_numpy())
+            outside = int((np.ascontiguousarray(vals).view(np.uint64) == NAN_OUTSIDE_WINDOW).any())
+            z[mine_rows] = np.where(np.isnan(vals), np.inf, vals)          # (a NaN would poison the sum: it travels as inf)
+        if int(reduce_([outside], dist.ReduceOp.MAX, torch.int64)[0]):     # (decided together: nobody is left waiting in the sum)
+            raise KariosHipError(f"match_tile_banded: a ZNCC chip left its band's {halo}-row halo; use a larger halo")
+        z = reduce_(z, dist.ReduceOp.SUM)
+        z[np.isinf(z)] = np.nan
+        z[~score_it] = np.nan
+        frame["zncc_score"] = z
+    frame.attrs["Ninit"] = n_init
+    return frame

@@ -123,3 +123,83 @@ print("rank", rank, "ok")
             assert (g is None) == (w is None)
             if g is not None:
                 pd.testing.assert_frame_equal(g, w, check_exact=True)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_single_tile_matched_by_several_ranks_exactly(tmp_path, world):
+    """the reference's default single-tile configuration matched by `world` ranks (gloo, sharing GPU 0), each
+    holding only its row band + halo: global min / max and maximum eigenvalue by all-reduce, one ranked selection on the
+    gathered candidate keys, tracks in image coordinates on a virtual row origin.  The frame on every rank must be the
+    single-GPU frame of `ResidentPair.match_tile` - rows, order, index labels, every float32 bit, ZNCC to 1e-12."""
+    script = tmp_path / "band_worker.py"
+    script.write_text(f'''
+import os, sys, pickle
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from karios_amd import synth
+from karios_amd.core import KLTConfiguration, NumpyRasterImage
+from karios_amd.parallel import match_tile_banded, band_rows
+from karios_amd.resident import ResidentPair
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+H, W = 1180, 760
+out = {{}}
+for case, kw in (("wedge", dict(maxCorners=2500, laplacian_kernel_size=7)), ("mask_inv", dict(maxCorners=600, minDistance=14.3, blocksize=7, laplacian_kernel_size={{"mon": 5, "ref": 9}}, laplacian_invert_polarity=True, matching_winsize=31)),
+                 ("all", dict(maxCorners=0, qualityLevel=0.3, laplacian_kernel_size=3))):
+    mon, ref = synth.make_pair(H, W, 0.6, -0.35, seed=77, nodata_wedge=(case == "wedge"))
+    mask = None
+    if case == "mask_inv":
+        mon = (mon.max() - mon).astype(np.uint16)                 # negative radiometry: what laplacian_invert_polarity is for
+        mask = np.full((H, W), 255, np.uint8); mask[300:700, 100:400] = 0; mask[560:640, :] = 0
+    conf = KLTConfiguration(**kw)
+    reads = []
+    class Img(NumpyRasterImage):
+        def read(self, band, x, y, w, h):
+            reads.append((y, h)); return super().read(band, x, y, w, h)
+    frame = match_tile_banded(Img(mon), Img(ref), None if mask is None else Img(mask), conf, zncc_threshold=0.4, device="cpu")
+    edges = band_rows(H, world)
+    assert all(h <= edges[rank + 1] - edges[rank] + 2 * 96 for (_, h) in reads), reads      # only the band and its halo were read
+    if rank == 0 and world == 1:
+        pair = ResidentPair.upload(mon, ref, mask)
+        want = pair.match_tile(conf, zncc_threshold=0.4)
+        out[case + "_single"] = want
+    out[case] = frame
+    if case == "wedge" and world > 1:                              # a halo the 25x25 windows of pyramid level 1 do not fit in
+        try:
+            match_tile_banded(Img(mon), Img(ref), None, conf, halo=32, device="cpu"); out["small_halo"] = "accepted"
+        except Exception as e:
+            out["small_halo"] = f"{{type(e).__name__}}: {{e}}"
+pickle.dump(out, open(os.environ["OUT"], "wb"))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+''')
+    import pandas as pd
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29550 + world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    single = tmp_path / "single.pkl"
+    subprocess.run([sys.executable, str(script)], env=dict(env, RANK="0", WORLD_SIZE="1", OUT=str(single)), check=True, timeout=600)
+    ref = pd.read_pickle(single)
+    for case in ("wedge", "mask_inv", "all"):
+        want, one_band = ref[case + "_single"], ref[case]
+        assert want is not None and len(want) > 100
+        pd.testing.assert_frame_equal(one_band, want, check_exact=False, rtol=0, atol=1e-12)   # one band == the plain single-GPU call
+        assert all(np.array_equal(one_band[c].to_numpy(), want[c].to_numpy()) for c in ("x0", "y0", "dx", "dy", "score"))
+    if world == 1:
+        return
+    outs = [tmp_path / f"r{r}.pkl" for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE=str(world), OUT=str(outs[r])),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    for path in outs:
+        got = pd.read_pickle(path)
+        assert got["small_halo"].startswith("KariosHipError") and "halo" in got["small_halo"], got["small_halo"]   # on EVERY rank
+        for case in ("wedge", "mask_inv", "all"):
+            want = ref[case + "_single"]
+            g = got[case]
+            assert g is not None and len(g) == len(want)
+            assert np.array_equal(g.index.to_numpy(), want.index.to_numpy())
+            for c in ("x0", "y0", "dx", "dy", "score"):
+                np.testing.assert_array_equal(g[c].to_numpy(), want[c].to_numpy(), err_msg=f"{case} {c}")
+            gz, wz = g["zncc_score"].to_numpy(), want["zncc_score"].to_numpy()
+            assert np.array_equal(np.isnan(gz), np.isnan(wz)) and np.nanmax(np.abs(gz - wz)) <= 1e-12
