@@ -108,6 +108,8 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
  *                  float32 correlation peak is not at least 1 % above every other sample
+ *   "profile_stage" with km_set_profiling(1): time only stage i of km_stage_name (every timed span records two events on the
+ *                  library stream and the kernels either side no longer overlap: ~6 us per span); -1 (default): every stage
  * Returns KM_E_ARG for an unknown name. */
 int km_set_option(km_ctx *ctx, const char *name, int value);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */

@@ -120,6 +120,7 @@ int km_ctx_create(int device, km_ctx **out)
         return rc;
     }
     if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
+    if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
@@ -174,6 +175,8 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
+    if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
+    if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
     if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }

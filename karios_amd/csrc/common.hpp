@@ -156,6 +156,8 @@ struct km_ctx {
     int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
     int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
     bool opt_speculative = false;  // "speculative" 1: corners through the synchronisation-free, sort-free path (k_select2.hip); 0 (default): the exact path (k_select.hip)
+    bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
+    int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
     int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)
     bool spec_used = false;        // the running call went through the speculative corner path
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
@@ -238,6 +240,7 @@ struct km_stage_timer {
     int s;
     km_stage_timer(km_ctx *ctx, int stage) : c(ctx), s(stage)
     {
+        if (c->opt_profile_stage >= 0 && stage != c->opt_profile_stage) { s = -1; return; }
         if (c->profiling && c->ev_ready && !c->evs_used[c->ev_cur][s]) {
             (void)hipEventRecord(c->evs[c->ev_cur][s][0], c->stream);
         } else if (c->profiling && c->ev_ready) {
@@ -298,6 +301,9 @@ int kf_dn_keep(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H
 int k2_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, float *d_eig, unsigned *d_max_key);
 int k2_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
                       unsigned long long *d_keys, size_t cap, bool rezero);
+// k_eig3.hip
+int k3_eig_candidates(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, int W, int block, double quality, km_scalars *sc,
+                      unsigned long long *d_keys, size_t cap);
 int kd_candidates(km_ctx *c, const float *d_eig, const uint8_t *d_mask, int H, int W,
                   double quality, km_scalars *d_sc, unsigned long long *d_keys, size_t cap, bool rezero);
 int kd_pyrdown_u8(km_ctx *c, const uint8_t *d_src, int H, int W, uint8_t *d_dst);

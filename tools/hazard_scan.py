@@ -89,9 +89,51 @@ def scan(path):
     return hazards
 
 
+DPP_CTRL = re.compile(r"\b(quad_perm|row_shl|row_shr|row_ror|wave_shl|wave_shr|wave_rol|wave_ror|row_mirror|row_half_mirror|row_bcast|row_newbcast|row_share|row_xmask)\b")
+
+
+def scan_dpp(path):
+    """A VGPR written by a VALU instruction must not be read as the DPP operand (src0) of a DPP instruction within the next
+    2 wait states (LLVM GCNHazardRecognizer::checkDPPHazards).  The compiler pads for writers it emitted; a writer inside
+    inline asm is invisible to it.  -> list of (function, writer line, writer text, reader line, reader text, wait states)."""
+    out = []
+    func = "?"
+    window = []   # [wait states since the write, dst regs, line, text]
+    inline = False
+    with open(path) as f:
+        for ln, raw in enumerate(f, 1):
+            s = raw.strip()
+            if s.endswith(":") and not s.startswith(".") and not s.startswith(";"):
+                func, window = s[:-1], []
+            if ";;#ASMSTART" in raw:
+                inline = True
+            if ";;#ASMEND" in raw:
+                inline = False
+            p = parse(raw)
+            if p is None:
+                continue
+            op, ops = p
+            op = norm(op)
+            if op.startswith("v_") and DPP_CTRL.search(raw) and len(ops) > 1:
+                src0 = vregs(ops[1].split()[0])
+                for (since, dst, dln, dtxt) in window:
+                    if src0 & dst and since < 2:
+                        out.append((func, dln, dtxt, ln, s, since))
+            ws = int(ops[0], 0) + 1 if op == "s_nop" else 1
+            window = [[w[0] + ws] + w[1:] for w in window if w[0] + ws < 2]
+            if inline and op.startswith("v_") and ops:
+                window.append([0, vregs(ops[0]), ln, s])
+    return out
+
+
 if __name__ == "__main__":
     bad = 0
     for p in sys.argv[1:]:
+        dz = scan_dpp(p)
+        for (func, dln, dtxt, ln, s, since) in dz:
+            print(f"{p}:{dln}: [inline-asm VALU write read through DPP after {since} wait states] {dtxt}\n   -> {ln}: {s}\n   in {func}")
+        print(f"{p}: {len(dz)} potential DPP hazards behind inline asm")
+        bad += len(dz)
         hz = scan(p)
         for (func, dln, dtxt, ln, s, kind, inl) in hz:
             print(f"{p}:{dln}: [{kind}{' inline-asm' if inl else ''}] {dtxt}\n   -> {ln}: {s}\n   in {func}")
