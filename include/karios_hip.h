@@ -92,6 +92,8 @@ int km_set_profiling(km_ctx *ctx, int enable);
 /* Knobs (no counterpart in the reference; results NEVER depend on them - tests/test_gpu_forced_paths.py):
  *   "fused_eig"    1 (default) = GFTT's minimum-eigenvalue + candidate detection fused in one pass (no eig map);
  *                  0 = eig map + candidate scan.  Initial value from the environment variable KARIOS_HIP_FUSED_EIG.
+ *   "eig3"         1 (default) = the fused pass runs 8 pixels per lane (k_eig3.hip) on images at least 512 columns wide;
+ *                  0 = always the 2-pixels-per-lane kernel (k_eig2.hip).  Initial value from KARIOS_HIP_EIG3.
  *   Test knobs that shrink internal capacities so that the corner detector's retry paths run on every call
  *   (0 restores the default):
  *   "key_cap"      candidate keys per shard of the first attempt          -> key-buffer overflow + regrow
@@ -99,11 +101,11 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "topk_factor"  top-K pre-filter keeps factor * maxCorners keys (8)    -> second selection pass on all candidates
  *   "select_first" first ranked prefix of the selection sweeps (3 * maxCorners) -> prefix growth
  *   "defer"        0: pyramid jobs run after the selection's read-back waits instead of under them
- *   "speculative"  1: the tile entry points detect corners without a host synchronisation and without library sorts (fixed
- *                  capacities, k_select2.hip); a tile that does not fit is flagged (frame header word 2) and repeated through
- *                  the exact path.  0 (default): always the exact path - on one GPU both take the same time per pair, the
- *                  waits of the exact path being filled with independent work.  Initial value from
- *                  the environment variable KARIOS_HIP_SPECULATIVE.
+ *   "speculative"  1 (default): the tile entry points detect corners without a host synchronisation and without library sorts
+ *                  (fixed capacities, k_select2.hip); a tile that does not fit is flagged (frame header word 2) and repeated
+ *                  through the exact path - inside the call for the blocking entry points, by the caller of km_frame_wait for
+ *                  submitted frames (PendingFrame.result()).  0: always the exact path (two scalar read-backs per tile, rocPRIM
+ *                  sorts).  Initial value from the environment variable KARIOS_HIP_SPECULATIVE.
  *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the

@@ -155,7 +155,7 @@ struct km_ctx {
     int opt_stage_cap = 0;     // "stage_cap": usable slots of the fused kernel's per-wave LDS stage (forces the two-kernel fallback)
     int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
     int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
-    bool opt_speculative = false;  // "speculative" 1: corners through the synchronisation-free, sort-free path (k_select2.hip); 0 (default): the exact path (k_select.hip)
+    bool opt_speculative = true;   // "speculative" 1 (default): corners through the synchronisation-free, sort-free path (k_select2.hip) where a tile entry point can repeat a flagged tile; 0: always the exact path (k_select.hip)
     bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
     int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
     int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)

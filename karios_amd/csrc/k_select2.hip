@@ -21,7 +21,8 @@
 #define KF_NB KM_TK_NB
 #define KF_SHIFT 14
 #define KF_CELL 64            // candidates a grid cell can hold (a 10 x 10 cell of a textured image holds up to ~25 local maxima)
-#define KF_SWEEPS 4
+#define KF_SWEEPS 4            // sweeps per launch of the cell-walking form (more neighbours than KF_NBR)
+#define KF_POLLS 32           // state polls per launch of the register form: a poll is one round of <= KF_NBR parallel loads
 #define KF_SLICE 4u           // the ranked top slice holds (at least) KF_SLICE * maxCorners keys (the exact path starts from 8x and can grow)
 
 namespace {
@@ -135,9 +136,11 @@ __global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long lon
     }
 }
 
-// ranked candidates -> their grid cell (fixed capacity), state undecided
+// ranked candidates -> their grid cell (fixed capacity), state undecided.  A cell's record holds its population AND its first
+// candidate: nearly every occupied cell holds exactly one (160 000 candidates on 1.2 million cells), and the sweeps then reach a
+// neighbour's key with two dependent loads instead of three.
 __global__ __launch_bounds__(256) void f_cells_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw,
-                                                      unsigned *__restrict__ cell_cnt, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
+                                                      uint2 *__restrict__ cell_rec, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
                                                       unsigned kept_cap)
 {
     const unsigned n = kf_count(sc, kept_cap);
@@ -147,13 +150,19 @@ __global__ __launch_bounds__(256) void f_cells_kernel(const unsigned long long *
     int x, y;
     kf_xy(keys[i], W, x, y);
     const unsigned g = (unsigned)(y / cell) * (unsigned)gw + (unsigned)(x / cell);
-    const unsigned slot = atomicAdd(&cell_cnt[g], 1u);
-    if (slot < KF_CELL) cell_items[(size_t)g * KF_CELL + slot] = i;
+    const unsigned slot = atomicAdd(&cell_rec[g].x, 1u);
+    if (slot == 0) cell_rec[g].y = i;
+    else if (slot < KF_CELL) cell_items[(size_t)g * KF_CELL + slot] = i;
     else atomicOr(&sc->flags, KM_FLAG_CELL_OVERFLOW);
 }
 
+// One launch = up to KF_SWEEPS relaxation sweeps of every undecided candidate.  The launch is bound by the LATENCY of dependent
+// loads (2.4 waves per SIMD, every load a cache miss somewhere in a 10 MB grid), so a thread first fetches the nine cell records
+// of its neighbourhood at once, then the keys of their first candidates at once, keeps the few higher-ranked neighbours within the
+// minimum distance (0.2 on average) in registers, and the sweeps only poll those neighbours' states.
+#define KF_NBR 6
 __global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw, int gh,
-                                                      double md2, const unsigned *__restrict__ cell_cnt, const unsigned *__restrict__ cell_items,
+                                                      double md2, const uint2 *__restrict__ cell_rec, const unsigned *__restrict__ cell_items,
                                                       unsigned *state, unsigned *n_undecided, unsigned kept_cap)
 {
     const unsigned n = kf_count(sc, kept_cap);
@@ -164,29 +173,82 @@ __global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *
         const unsigned long long ki = keys[i];
         kf_xy(ki, W, x, y);
         const int xc = x / cell, yc = y / cell;
-        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+        unsigned nb[KF_NBR];
+        int nnb = 0;
+        bool overflow = false;
+        auto consider = [&](unsigned j, unsigned long long kj) {
+            if (kj <= ki) return;                              // only higher-ranked candidates matter (rank = key order)
+            int xj, yj;
+            kf_xy(kj, W, xj, yj);
+            const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
+            if (!((double)(dx * dx + dy * dy) < md2)) return;
+#pragma unroll
+            for (int t = 0; t < KF_NBR; t++) if (nnb == t) nb[t] = j;
+            overflow |= nnb >= KF_NBR;
+            nnb += 1;
+        };
+        uint2 rec[9];
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) {
+            const int yy = yc - 1 + c9 / 3, xx = xc - 1 + c9 % 3;
+            const bool in = yy >= 0 && yy < gh && xx >= 0 && xx < gw;
+            rec[c9] = in ? cell_rec[(unsigned)yy * (unsigned)gw + (unsigned)xx] : make_uint2(0u, 0u);
+        }
+        unsigned long long k0[9];
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) k0[c9] = rec[c9].x ? keys[rec[c9].y] : 0ull;
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) if (rec[c9].x) consider(rec[c9].y, k0[c9]);
+#pragma unroll
+        for (int c9 = 0; c9 < 9; c9++) {
+            const unsigned cnt = min(rec[c9].x, (unsigned)KF_CELL);
+            if (cnt > 1) {                                     // rare: the cell's further candidates
+                const int yy = yc - 1 + c9 / 3, xx = xc - 1 + c9 % 3;
+                const size_t base = ((size_t)yy * (size_t)gw + (size_t)xx) * KF_CELL;
+                for (unsigned k = 1; k < cnt; k++) {
+                    const unsigned j = cell_items[base + k];
+                    consider(j, keys[j]);
+                }
+            }
+        }
         undecided = true;
-        for (int sweep = 0; sweep < KF_SWEEPS && undecided; sweep++) {
-            bool blocked = false, rejected = false;
-            for (int yy = y1; yy <= y2 && !rejected; yy++)
-                for (int xx = x1; xx <= x2 && !rejected; xx++) {
-                    const unsigned g = (unsigned)yy * (unsigned)gw + (unsigned)xx;
-                    const unsigned cnt = min(cell_cnt[g], (unsigned)KF_CELL);
+        if (!overflow) {
+            for (int sweep = 0; sweep < KF_POLLS && undecided; sweep++) {
+                unsigned sj[KF_NBR];
+#pragma unroll
+                for (int t = 0; t < KF_NBR; t++)
+                    sj[t] = t < nnb ? __hip_atomic_load(&state[nb[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)S_REJECT;
+                bool blocked = false, rejected = false;
+#pragma unroll
+                for (int t = 0; t < KF_NBR; t++) { rejected |= sj[t] == S_ACCEPT; blocked |= sj[t] == S_UNDECIDED; }
+                if (rejected) { __hip_atomic_store(&state[i], (unsigned)S_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+                else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)S_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+            }
+        } else {
+            // more higher-ranked neighbours than registers: walk the cells every sweep
+            for (int sweep = 0; sweep < KF_SWEEPS && undecided; sweep++) {
+                bool blocked = false, rejected = false;
+                for (int c9 = 0; c9 < 9 && !rejected; c9++) {
+                    const int yy = yc - 1 + c9 / 3, xx = xc - 1 + c9 % 3;
+                    if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
+                    const size_t g = (size_t)yy * (size_t)gw + (size_t)xx;
+                    const unsigned cnt = min(cell_rec[g].x, (unsigned)KF_CELL);
                     for (unsigned k = 0; k < cnt; k++) {
-                        const unsigned j = cell_items[(size_t)g * KF_CELL + k];
+                        const unsigned j = k == 0 ? cell_rec[g].y : cell_items[g * KF_CELL + k];
                         const unsigned long long kj = keys[j];
-                        if (kj <= ki) continue;               // only higher-ranked candidates matter (rank = key order)
+                        if (kj <= ki) continue;
                         int xj, yj;
                         kf_xy(kj, W, xj, yj);
                         const float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
                         if (!((double)(dx * dx + dy * dy) < md2)) continue;
-                        const unsigned sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (sj == S_ACCEPT) { rejected = true; break; }
-                        if (sj == S_UNDECIDED) blocked = true;
+                        const unsigned s2 = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (s2 == S_ACCEPT) { rejected = true; break; }
+                        if (s2 == S_UNDECIDED) blocked = true;
                     }
                 }
-            if (rejected) { __hip_atomic_store(&state[i], (unsigned)S_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
-            else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)S_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+                if (rejected) { __hip_atomic_store(&state[i], (unsigned)S_REJECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+                else if (!blocked) { __hip_atomic_store(&state[i], (unsigned)S_ACCEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); undecided = false; }
+            }
         }
     }
     const unsigned long long bal = __ballot(undecided);
@@ -272,13 +334,16 @@ __global__ __launch_bounds__(1024) void f_acc_fill_kernel(const unsigned long lo
 }
 
 // Position of an accepted corner in OpenCV's output order = accepted corners in stronger bins + accepted corners of its own bin
-// with a larger key; the first maxCorners positions are the result.  One wavefront per chunk of 64 corners of ONE bin: the keys
-// it compares against then sit at wave-uniform addresses (scalar loads, eight keys per instruction).
-__global__ __launch_bounds__(256) void f_acc_emit_kernel(const unsigned long long *__restrict__ acc_keys, const unsigned *__restrict__ acc_off,
-                                                         const unsigned *__restrict__ chunk_off, int W, int max_corners, int cap,
-                                                         float *__restrict__ out_xy)
+// with a larger key; the first maxCorners positions are the result.  One WORKGROUP per chunk of 64 corners of ONE bin: each of
+// its 16 wavefronts compares the 64 corners (one per lane) with a sixteenth of the bin - keys at wave-uniform addresses, scalar
+// loads, eight per instruction - and the partial counts meet in LDS.  (One wavefront walking a 10 000-corner bin alone - equal
+// eigenvalues are common in a quantised Laplacian image - took 73 us.)
+__global__ __launch_bounds__(1024) void f_acc_emit_kernel(const unsigned long long *__restrict__ acc_keys, const unsigned *__restrict__ acc_off,
+                                                          const unsigned *__restrict__ chunk_off, int W, int max_corners, int cap,
+                                                          float *__restrict__ out_xy)
 {
-    const unsigned chunk = blockIdx.x * 4 + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ unsigned s_part[16][64];
+    const unsigned chunk = blockIdx.x;
     if (chunk >= chunk_off[KF_NB]) return;
     unsigned lo_b = 0, hi_b = KF_NB;                           // bin of this chunk: last b with chunk_off[b] <= chunk
     while (hi_b - lo_b > 1) {
@@ -288,16 +353,26 @@ __global__ __launch_bounds__(256) void f_acc_emit_kernel(const unsigned long lon
     const unsigned b = lo_b;
     const unsigned lo = acc_off[b], hi = acc_off[b + 1];
     if (lo >= (unsigned)max_corners) return;                 // the whole bin lies behind the cut
-    const unsigned s = lo + (chunk - chunk_off[b]) * 64 + (threadIdx.x & 63);
+    const unsigned lane = threadIdx.x & 63, wv = (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned s = lo + (chunk - chunk_off[b]) * 64 + lane;
     const bool live = s < hi;
     const unsigned long long k = live ? acc_keys[s] : 0ull;
-    unsigned p = lo;
-    for (unsigned t = lo; t < hi; t++) p += acc_keys[t] > k ? 1u : 0u;      // uniform index: scalar loads
-    if (live && p < (unsigned)max_corners && p < (unsigned)cap) {
-        int x, y;
-        kf_xy(k, W, x, y);
-        out_xy[2 * p] = (float)x;
-        out_xy[2 * p + 1] = (float)y;
+    const unsigned len = hi - lo, per = (len + 15) / 16;
+    const unsigned t0 = lo + min(wv * per, len), t1 = lo + min((wv + 1) * per, len);
+    unsigned p = 0;
+    for (unsigned t = t0; t < t1; t++) p += acc_keys[t] > k ? 1u : 0u;      // uniform index: scalar loads
+    s_part[wv][lane] = p;
+    __syncthreads();
+    if (wv == 0) {
+        unsigned pos = lo;
+#pragma unroll
+        for (int w = 0; w < 16; w++) pos += s_part[w][lane];
+        if (live && pos < (unsigned)max_corners && pos < (unsigned)cap) {
+            int x, y;
+            kf_xy(k, W, x, y);
+            out_xy[2 * pos] = (float)x;
+            out_xy[2 * pos + 1] = (float)y;
+        }
     }
 }
 
@@ -311,7 +386,8 @@ size_t kf_kept_capacity(int max_corners) { return (size_t)max_corners * 2 * KF_S
 struct kf_buffers {
     unsigned long long *kept;
     unsigned long long *acc_keys;
-    unsigned *cell_cnt, *cell_items, *state, *acc_cnt, *acc_cur, *acc_off, *chunk_off;
+    uint2 *cell_rec;
+    unsigned *cell_items, *state, *acc_cnt, *acc_cur, *acc_off, *chunk_off;
     unsigned kept_cap;
     int cell, gw, gh;
     size_t cells;
@@ -326,11 +402,11 @@ static int kf_layout(km_ctx *c, int H, int W, int max_corners, double min_distan
     b->cells = (size_t)b->gw * b->gh;
     if (b->cells * KF_CELL > 0x7fffffffull) return KM_E_UNSUPPORTED;
     b->kept = (unsigned long long *)km_ws(c, WS_MISC3, (2 * (size_t)b->kept_cap + 32) * sizeof(unsigned long long));
-    b->cell_cnt = (unsigned *)km_ws(c, WS_GRID, b->cells * (1 + KF_CELL) * sizeof(unsigned));
+    b->cell_rec = (uint2 *)km_ws(c, WS_GRID, b->cells * (2 + KF_CELL) * sizeof(unsigned));
     unsigned *per = (unsigned *)km_ws(c, WS_MISC2, ((size_t)b->kept_cap + 4 * KF_NB + 16) * sizeof(unsigned));
-    if (!b->kept || !b->cell_cnt || !per) return KM_E_NOMEM;
+    if (!b->kept || !b->cell_rec || !per) return KM_E_NOMEM;
     b->acc_keys = b->kept + b->kept_cap + 16;
-    b->cell_items = b->cell_cnt + b->cells; b->state = per;
+    b->cell_items = (unsigned *)(b->cell_rec + b->cells); b->state = per;
     b->acc_cnt = per + b->kept_cap; b->acc_cur = b->acc_cnt + KF_NB; b->acc_off = b->acc_cur + KF_NB;   // acc_off, chunk_off: KF_NB + 1 entries
     b->chunk_off = b->acc_off + KF_NB + 4;
     return KM_OK;
@@ -358,12 +434,12 @@ int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, flo
     int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
     if (rc) return rc;
     const double md2 = min_distance * min_distance;
-    KM_HIP(c, hipMemsetAsync(b.cell_cnt, 0, b.cells * sizeof(unsigned), c->stream));
+    KM_HIP(c, hipMemsetAsync(b.cell_rec, 0, b.cells * sizeof(uint2), c->stream));
     const unsigned g256 = (b.kept_cap + 255) / 256;
-    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_cnt, b.cell_items, b.state, b.kept_cap);
+    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_rec, b.cell_items, b.state, b.kept_cap);
     KM_LAUNCH_CHECK(c);
     for (int g = 0; g < 4; g++) {
-        f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_cnt, b.cell_items, b.state, &sc->und[g], b.kept_cap);
+        f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_rec, b.cell_items, b.state, &sc->und[g], b.kept_cap);
         KM_LAUNCH_CHECK(c);
     }
     KM_HIP(c, hipMemsetAsync(b.acc_cnt, 0, 2 * KF_NB * sizeof(unsigned), c->stream));      // acc_cnt + acc_cur
@@ -374,7 +450,7 @@ int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, flo
     f_acc_fill_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_off, b.acc_cur, b.acc_keys, b.kept_cap);
     KM_LAUNCH_CHECK(c);
     // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
-    f_acc_emit_kernel<<<(b.kept_cap / 64 + KF_NB + 3) / 4, 256, 0, c->stream>>>(b.acc_keys, b.acc_off, b.chunk_off, W, max_corners, cap, d_xy);
+    f_acc_emit_kernel<<<b.kept_cap / 64 + KF_NB, 1024, 0, c->stream>>>(b.acc_keys, b.acc_off, b.chunk_off, W, max_corners, cap, d_xy);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

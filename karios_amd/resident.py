@@ -421,7 +421,7 @@ class ResidentPair:
                                                    self.y_size, self.x_size, self.x_size, self.x_size, float(zncc_threshold or 0.0), cap,
                                                    C.byref(ticket)), "km_klt_tile_frame_submit")
         def exact():
-            before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "0") or 0))
+            before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "1") or 0))
             c.set_option("speculative", 0)
             try:
                 return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off))

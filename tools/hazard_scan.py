@@ -98,7 +98,7 @@ def scan_dpp(path):
     inline asm is invisible to it.  -> list of (function, writer line, writer text, reader line, reader text, wait states)."""
     out = []
     func = "?"
-    window = []   # [wait states since the write, dst regs, line, text]
+    window = []   # [wait states since the write, dst regs, line, text, writer is inline asm]
     inline = False
     with open(path) as f:
         for ln, raw in enumerate(f, 1):
@@ -116,13 +116,13 @@ def scan_dpp(path):
             op = norm(op)
             if op.startswith("v_") and DPP_CTRL.search(raw) and len(ops) > 1:
                 src0 = vregs(ops[1].split()[0])
-                for (since, dst, dln, dtxt) in window:
-                    if src0 & dst and since < 2:
+                for (since, dst, dln, dtxt, winl) in window:
+                    if src0 & dst and since < 2 and (winl or inline):      # writer or reader invisible to the compiler
                         out.append((func, dln, dtxt, ln, s, since))
             ws = int(ops[0], 0) + 1 if op == "s_nop" else 1
             window = [[w[0] + ws] + w[1:] for w in window if w[0] + ws < 2]
-            if inline and op.startswith("v_") and ops:
-                window.append([0, vregs(ops[0]), ln, s])
+            if op.startswith("v_") and ops and not op.startswith("v_cmp"):
+                window.append([0, vregs(ops[0]), ln, s, inline])
     return out
 
 
@@ -131,7 +131,7 @@ if __name__ == "__main__":
     for p in sys.argv[1:]:
         dz = scan_dpp(p)
         for (func, dln, dtxt, ln, s, since) in dz:
-            print(f"{p}:{dln}: [inline-asm VALU write read through DPP after {since} wait states] {dtxt}\n   -> {ln}: {s}\n   in {func}")
+            print(f"{p}:{dln}: [VALU write read through DPP after {since} wait states, one of them inline asm] {dtxt}\n   -> {ln}: {s}\n   in {func}")
         print(f"{p}: {len(dz)} potential DPP hazards behind inline asm")
         bad += len(dz)
         hz = scan(p)
