@@ -167,38 +167,45 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
         }
     };
     // horizontal box sums: window of pixel p = strip pixels p - L .. p + Rr, indices < 0 / > 7 live in the neighbouring lanes
-    auto windows = [&](auto q_tag, int (&Wd)[8]) {
-        constexpr int q = decltype(q_tag)::value;
-        // w +/- the vertical sum of strip pixel k of this lane's window (k < 0: left neighbour's pixel k + 8, k > 7: right neighbour's k - 8)
-        auto add_ext = [&](int w, auto kt) -> int {
-            constexpr int k = decltype(kt)::value;
+    // (the three products advance in lockstep: three independent dependency chains for the scheduler instead of one)
+    auto windows = [&](int (&Wd)[3][8]) {
+        // w + the vertical sum of strip pixel k of this lane's window (k < 0: left neighbour's pixel k + 8, k > 7: right neighbour's k - 8)
+        auto add_ext = [&](int w, auto q_tag, auto kt) -> int {
+            constexpr int q = decltype(q_tag)::value, k = decltype(kt)::value;
             if constexpr (k < 0) return e3_add_prev(w, V[q][k + 8]);
             else if constexpr (k > 7) return e3_add_next(w, V[q][k - 8]);
             else return w + V[q][k];
         };
         // vext(k) - w
-        auto ext_minus = [&](auto kt, int w) -> int {
-            constexpr int k = decltype(kt)::value;
+        auto ext_minus = [&](auto q_tag, auto kt, int w) -> int {
+            constexpr int q = decltype(q_tag)::value, k = decltype(kt)::value;
             if constexpr (k < 0) return e3_prev_minus(V[q][k + 8], w);
             else if constexpr (k > 7) return e3_next_minus(V[q][k - 8], w);
             else return V[q][k] - w;
         };
-        int w;
-        if constexpr (L == 7 && Rr == 7) {
-            // the window of pixel 0 = the whole lane + pixels 1..7 of the left neighbour
-            const int T = ((V[q][0] + V[q][1]) + (V[q][2] + V[q][3])) + ((V[q][4] + V[q][5]) + (V[q][6] + V[q][7]));
-            w = T + e2_lane_m1(T - V[q][0]);
-        } else {
-            w = 0;
-            e3_for<BLOCK>([&](auto kt) { w = add_ext(w, std::integral_constant<int, decltype(kt)::value - L>{}); });
-        }
-        Wd[0] = w;
+        int w[3];
+        e3_for<3>([&](auto qt) {
+            constexpr int q = decltype(qt)::value;
+            if constexpr (L == 7 && Rr == 7) {
+                // the window of pixel 0 = the whole lane + pixels 1..7 of the left neighbour
+                const int T = ((V[q][0] + V[q][1]) + (V[q][2] + V[q][3])) + ((V[q][4] + V[q][5]) + (V[q][6] + V[q][7]));
+                w[q] = T + e2_lane_m1(T - V[q][0]);
+            } else {
+                w[q] = 0;
+                e3_for<BLOCK>([&](auto kt) { w[q] = add_ext(w[q], qt, std::integral_constant<int, decltype(kt)::value - L>{}); });
+            }
+            Wd[q][0] = w[q];
+        });
         e3_for<7>([&](auto pt) {
             constexpr int P = decltype(pt)::value;
             // w + entering - leaving as two "operand minus accumulator" steps: leaving - w, then entering - (leaving - w)
-            const int t = ext_minus(std::integral_constant<int, P - L>{}, w);
-            w = ext_minus(std::integral_constant<int, P + 1 + Rr>{}, t);
-            Wd[P + 1] = w;
+            int t[3];
+            e3_for<3>([&](auto qt) { t[decltype(qt)::value] = ext_minus(qt, std::integral_constant<int, P - L>{}, w[decltype(qt)::value]); });
+            e3_for<3>([&](auto qt) {
+                constexpr int q = decltype(qt)::value;
+                w[q] = ext_minus(qt, std::integral_constant<int, P + 1 + Rr>{}, t[q]);
+                Wd[q][P + 1] = w[q];
+            });
         });
     };
     auto lambda_min = [&](int sxx, int sxy, int syy) {
@@ -268,17 +275,15 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
         const int y = m - Rr;                        // lambda row completed by this step
         constexpr int C = PH, P1 = (PH + 2) % 3, P2 = (PH + 1) % 3;    // lambda slots: row y, y-1, y-2
         {
-            int Wxx[8], Wxy[8], Wyy[8];
+            int Wd[3][8];
             // the vertical sums were written by inline assembly (v_mad_i32_i16) and are read through DPP - also inline assembly -
             // below: 2 wait states after a VALU write of the operand, 5 after a VALU write of EXEC
             asm("s_nop 4" : "+v"(V[0][0]), "+v"(V[0][1]), "+v"(V[0][2]), "+v"(V[0][3]), "+v"(V[0][4]), "+v"(V[0][5]), "+v"(V[0][6]), "+v"(V[0][7]),
                             "+v"(V[1][0]), "+v"(V[1][1]), "+v"(V[1][2]), "+v"(V[1][3]), "+v"(V[1][4]), "+v"(V[1][5]), "+v"(V[1][6]), "+v"(V[1][7]),
                             "+v"(V[2][0]), "+v"(V[2][1]), "+v"(V[2][2]), "+v"(V[2][3]), "+v"(V[2][4]), "+v"(V[2][5]), "+v"(V[2][6]), "+v"(V[2][7]));
-            windows(std::integral_constant<int, 0>{}, Wxx);
-            windows(std::integral_constant<int, 1>{}, Wxy);
-            windows(std::integral_constant<int, 2>{}, Wyy);
+            windows(Wd);
 #pragma unroll
-            for (int p = 0; p < 8; p++) E[C][p] = lambda_min(Wxx[p], Wxy[p], Wyy[p]);
+            for (int p = 0; p < 8; p++) E[C][p] = lambda_min(Wd[0][p], Wd[1][p], Wd[2][p]);
         }
         if (cand) {
             // candidate test of row y-1: own value >= the 3x3 maximum (itself included)
@@ -364,16 +369,33 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
             flush_if(EIG3_FLUSH_AT);
         }
     };
-    // interior: rows m-1 .. m+1 and m-BLOCK-1 .. m-BLOCK+1 plain, trail / output / candidates all active, 3 rows prefetched
-    const int mi_lo = max(m_first + BLOCK + 1, BLOCK + 1), mi_hi = min(m_last, H - 2 - 3);
+    // interior: rows m-1 .. m+1 (and m-BLOCK-1 .. m-BLOCK+1 once the trailing window is in use) plain, 3 rows prefetched.  An item
+    // whose rows all lie below the top border enters the sliding march after three steps and runs its warm-up there (the
+    // general steps wait for their loads one by one: sixteen of them cost a tenth of a 96-row item)
+    const bool early = m_first >= 1 && BLOCK >= 5;   // every trailing row inside the image; the trail slides in before its first use
+    const int mi_lo = early ? m_first + 1 : max(m_first + BLOCK + 1, BLOCK + 1), mi_hi = min(m_last, H - 2 - 3);
     general_until(min(mi_lo - 1, m_last), true);
     if (m <= mi_hi && m + 2 <= mi_hi) {
         uint2 ql[3], qt[3], qm[3];                   // static FIFO slots: slot k serves step m + k, refilled for m + k + 3
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             ql[k] = load8(src, m + k + 1);
-            qt[k] = load8(src, m + k - BLOCK + 1);
-            qm[k] = load8(mptr, m + k - Rr);
+            qt[k] = load8(src, max(m + k - BLOCK + 1, 0));      // (clamped rows are loaded before the trail / the mask are in use)
+            qm[k] = load8(mptr, max(m + k - Rr, 0));
+        }
+        // warm-up groups: not every part of a step is active yet
+        while (m + 2 <= mi_hi && m - m_first < BLOCK + 1) {
+            e3_for<3>([&](auto kt) {
+                constexpr int K = decltype(kt)::value;
+                const int step = m + K - m_first;
+                LW[(K + 2) % 3] = unpack(ql[K]);
+                TW[(K + 2) % 3] = unpack(qt[K]);
+                compute(kt, m + K, qm[K], step >= BLOCK, step >= BLOCK - 1, step >= BLOCK - 1 && m + K - Rr >= ye0 + 2);
+                ql[K] = load8(src, m + K + 3 + 1);
+                qt[K] = load8(src, max(m + K + 3 - BLOCK + 1, 0));
+                qm[K] = load8(mptr, max(m + K + 3 - Rr, 0));
+            });
+            m += 3;
         }
         while (m + 2 <= mi_hi) {
             flush_if(EIG3_FLUSH_AT);
