@@ -51,8 +51,8 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config of the headline line")
     ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

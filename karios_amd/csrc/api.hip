@@ -121,6 +121,7 @@ int km_ctx_create(int device, km_ctx **out)
     }
     if (const char *e = getenv("KARIOS_HIP_FUSED_EIG")) c->fused_eig = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
+    if (const char *e = getenv("KARIOS_HIP_AUX_PYRAMID")) c->opt_aux_pyramid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
@@ -147,6 +148,9 @@ int km_ctx_destroy(km_ctx *c)
             for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->evs[k][i][0]); (void)hipEventDestroy(c->evs[k][i][1]); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t e : c->upload_marks) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->free_marks) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -175,6 +179,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
     if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
@@ -566,9 +571,31 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             km_stage_timer t(c, ST_EIGEN);
             rc = k2_eig_candidates(c, d_ref_lap, d_mask, H, W, prm->block_size, prm->quality_level, sc, keys, capk, false);
         }
+        bool forked = false;
         if (rc == KM_E_UNSUPPORTED) spec = false;
         else if (rc) return rc;
         else {
+            // The pyramids depend on the Laplacians only: they run on a second stream next to the ranking / selection chain
+            // (a dozen small latency-bound kernels that leave the GPU nearly empty) and are joined before LK.
+            if (c->opt_aux_pyramid) {
+                if (!c->aux_stream) {
+                    KM_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                    KM_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                    KM_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                }
+                KM_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // behind the fused eigenvalue pass
+                KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+                hipStream_t main_stream = c->stream;
+                c->stream = c->aux_stream;
+                {
+                    km_stage_timer t(c, ST_PYRAMID);
+                    rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B);
+                }
+                if (rc == KM_OK && hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(join)");
+                c->stream = main_stream;
+                if (rc) return rc;
+                forked = true;
+            }
             {
                 km_stage_timer t(c, ST_SORT);
                 rc = kf_rank(c, keys, capk, H, W, prm->max_corners, prm->quality_level, prm->min_distance, sc);
@@ -577,6 +604,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
                 km_stage_timer t(c, ST_SELECT);
                 rc = kf_select(c, H, W, prm->max_corners, prm->min_distance, d_p0, cap, sc);
             }
+            if (forked) KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));   // (whatever happens next reuses the pyramid buffers)
             if (rc == KM_E_UNSUPPORTED) {   // (grid too large for the fixed-slot cells: nothing irreversible was enqueued)
                 spec = false;
                 KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
@@ -584,8 +612,10 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         }
         if (spec) {
             c->spec_used = true;
-            km_stage_timer t(c, ST_PYRAMID);
-            if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
+            if (!forked) {
+                km_stage_timer t(c, ST_PYRAMID);
+                if ((rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B))) return rc;
+            }
         }
     }
     if (spec) {

@@ -134,6 +134,8 @@ struct km_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // km_upload_async: uploads of the next pair / tile under the compute of the current one
     hipEvent_t ev_copy = nullptr;
+    hipStream_t aux_stream = nullptr;    // sync-free tile path: the pyramids (they depend on the Laplacians only) run here next to the
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // chain of small corner-selection kernels on `stream`, joined before LK
     bool copy_pending = false;           // uploads queued since the compute stream last waited for the whole copy stream
     std::vector<hipEvent_t> upload_marks;   // km_upload_mark tickets: events on the copy stream, nullptr = ticket consumed
     std::vector<hipEvent_t> free_marks;
@@ -156,6 +158,7 @@ struct km_ctx {
     int opt_topk_factor = 0;   // "topk_factor": the top-K pre-filter keeps factor * maxCorners keys (default 8; 1 forces the second selection pass)
     int opt_select_first = 0;  // "select_first": first prefix of the selection sweeps = value candidates (default 3 * maxCorners; small values force prefix growth)
     bool opt_speculative = true;   // "speculative" 1 (default): corners through the synchronisation-free, sort-free path (k_select2.hip) where a tile entry point can repeat a flagged tile; 0: always the exact path (k_select.hip)
+    bool opt_aux_pyramid = true;   // "aux_pyramid": sync-free tile path builds the pyramids on a second stream, next to the corner selection
     bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
     int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
     int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)
