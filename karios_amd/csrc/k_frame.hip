@@ -13,7 +13,9 @@
 
 #include "common.hpp"
 
+#include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
+
 
 #define FB_T 1024
 
@@ -76,6 +78,77 @@ __global__ __launch_bounds__(256) void fb_gather_kernel(const unsigned *__restri
     }
 }
 
+// Row order of the frame without a library sort (eight launches + a gather for 20 000 rows: ~50 us of mostly launch latency).
+// Every workgroup buckets ALL kept rows by their x0 (a few columns per bucket; counting sort in LDS: histogram, scan, fill - the
+// same in every workgroup, 160 KB of keys from L2, each thread's keys loaded in one batch) and then places its own slice of the
+// rows: position = rows in lower buckets + rows of the same bucket with a smaller (x0, y0) key - ties (possible only with
+// caller-supplied points) by their position in the kept list, like pandas' stable multi-column sort.  Corners keep a minimum
+// distance, so a bucket holds a handful of rows.  One launch, no global synchronisation.
+#define FBP_T 1024
+template <int RPT>
+__global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long long *__restrict__ keys, const float *__restrict__ tmp, int cap,
+                                                         const int *__restrict__ hdr, float *__restrict__ out /* 6*cap */, int shift, int nbins)
+{
+    extern __shared__ unsigned fbp_smem[];
+    unsigned *cnt = fbp_smem, *start = fbp_smem + nbins;          // start: nbins + 1 entries
+    unsigned short *items = (unsigned short *)(start + nbins + 1);
+    __shared__ unsigned s_wave[FBP_T / 64];
+    const int m = hdr[0], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slice = (m + (int)gridDim.x - 1) / (int)gridDim.x;      // rows this workgroup places: [r0, r1), at most one per thread
+    const int r0 = blockIdx.x * slice, r1 = min(r0 + slice, m);
+    if (r0 >= m) return;
+    unsigned long long k[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) k[u] = keys[min(u * FBP_T + tid, m - 1)];
+    const int mine_r = r0 + tid;
+    const unsigned long long my_key = keys[min(mine_r, m - 1)];
+    float col[5];
+#pragma unroll
+    for (int c2 = 0; c2 < 5; c2++) col[c2] = tmp[(size_t)c2 * cap + min(mine_r, m - 1)];
+    for (int b = tid; b < nbins; b += FBP_T) cnt[b] = 0u;
+    __syncthreads();
+    // 1. histogram of the buckets
+#pragma unroll
+    for (int u = 0; u < RPT; u++)
+        if (u * FBP_T + tid < m) atomicAdd(&cnt[(unsigned)(k[u] >> 32) >> shift], 1u);
+    __syncthreads();
+    // 2. exclusive scan: every thread owns a run of consecutive buckets
+    const int per = (nbins + FBP_T - 1) / FBP_T, b0 = min(tid * per, nbins), b1 = min(b0 + per, nbins);
+    unsigned mine = 0;
+    for (int b = b0; b < b1; b++) mine += cnt[b];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (int w = 0; w < wv; w++) run += s_wave[w];
+    for (int b = b0; b < b1; b++) { const unsigned c2 = cnt[b]; start[b] = run; cnt[b] = run; run += c2; }   // cnt becomes the fill cursor
+    if (tid == FBP_T - 1) start[nbins] = run;
+    __syncthreads();
+    // 3. fill the buckets
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        const int r = u * FBP_T + tid;
+        if (r < m) items[atomicAdd(&cnt[(unsigned)(k[u] >> 32) >> shift], 1u)] = (unsigned short)r;
+    }
+    __syncthreads();
+    // 4. rank inside the bucket, write the row to its place
+    if (mine_r < r1) {
+        const unsigned b = (unsigned)(my_key >> 32) >> shift;
+        const unsigned lo = start[b], hi = start[b + 1];
+        unsigned pos = lo;
+        for (unsigned t = lo; t < hi; t++) {
+            const int j = (int)items[t];
+            const unsigned long long kj = keys[j];
+            pos += (kj < my_key || (kj == my_key && j < mine_r)) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 5; c2++) out[(size_t)c2 * cap + pos] = col[c2];
+        out[(size_t)5 * cap + pos] = __uint_as_float((unsigned)mine_r);   // index label, bit pattern of the int
+    }
+}
+
 // d_out: [header 4 ints: n_rows, n_init, 0, 0][6 * cap floats: x0 | y0 | dx | dy | score | index bits]
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
              float x_off, float y_off, void *d_out)
@@ -87,8 +160,6 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     unsigned *ranks = (unsigned *)km_ws(c, WS_MISC1, (size_t)cap * 2 * sizeof(unsigned));
     float *tmp = (float *)km_ws(c, WS_MISC2, (size_t)cap * 5 * sizeof(float));
     if (!keys || !ranks || !tmp) return KM_E_NOMEM;
-    unsigned long long *keys_alt = keys + cap;
-    unsigned *ranks_alt = ranks + cap;
     const int nblk = (n_max + FB_T - 1) / FB_T;
     const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);   // fixed sort length: sentinel keys behind the kept rows
     unsigned *counts = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)nblk * sizeof(unsigned));
@@ -97,6 +168,36 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     KM_LAUNCH_CHECK(c);
     fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort);
     KM_LAUNCH_CHECK(c);
+    if (n_sort <= 32768u) {
+        // up to a few 10^4 rows (maxCorners of a tile): one workgroup, buckets of x0 in LDS (<= 64 KB of buckets + 2 B per row)
+        const unsigned x_max = (unsigned)fmaxf(x_off, 0.f) + 70000u;          // x0 = corner column + tile offset, columns < 65536
+        int shift = 0;
+        while (((x_max >> shift) + 1u) > 8192u) shift++;
+        const int nbins = (int)(x_max >> shift) + 1;
+        const size_t smem = ((size_t)2 * nbins + 1) * sizeof(unsigned) + (size_t)n_sort * sizeof(unsigned short);
+        const int rpt = (int)((n_sort + FBP_T - 1) / FBP_T);
+        auto launch = [&](auto rpt_tag) -> int {
+            constexpr int RPT = decltype(rpt_tag)::value;
+            static size_t opted = 0;
+            if (smem > 48 * 1024 && smem > opted) {
+                KM_HIP(c, hipFuncSetAttribute((const void *)fb_place_kernel<RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                opted = 144 * 1024;
+            }
+            fb_place_kernel<RPT><<<32, FBP_T, smem, c->stream>>>(keys, tmp, cap, hdr, out, shift, nbins);
+            return KM_OK;
+        };
+        int rl;
+        if (rpt <= 8) rl = launch(std::integral_constant<int, 8>{});
+        else if (rpt <= 16) rl = launch(std::integral_constant<int, 16>{});
+        else if (rpt <= 24) rl = launch(std::integral_constant<int, 24>{});
+        else rl = launch(std::integral_constant<int, 32>{});
+        if (rl) return rl;
+        KM_LAUNCH_CHECK(c);
+        return KM_OK;
+    }
+    // maxCorners = 0 on a large tile: hundreds of thousands of rows - library radix sort of (key, rank) pairs + gather
+    unsigned long long *keys_alt = keys + cap;
+    unsigned *ranks_alt = ranks + cap;
     size_t tmp_bytes = 0;
     KM_HIP(c, rocprim::radix_sort_pairs((void *)nullptr, tmp_bytes, keys, keys_alt, ranks, ranks_alt, n_sort, 0, 64, c->stream));
     void *stmp = km_ws(c, WS_SORT_TMP, tmp_bytes ? tmp_bytes : 16);
