@@ -387,7 +387,7 @@ def main():
     def host_half(pend):
         raw = pend.wait()
         spans = pend.stage_ms()
-        frame = None if raw.flags else raw.to_frame()
+        frame = None if raw.flags else raw.to_frame(radial=True)       # (radial error / angle built with the frame: one DataFrame construction)
         return pend, raw, spans, (None if frame is None else pair.score_frame(frame, 0.4))
 
     def collect(pending):

@@ -65,24 +65,36 @@ def assemble(cols: dict[str, np.ndarray], x_off=0, y_off=0, clip_outliers: bool 
     return DataFrame(data, index=order, copy=False)
 
 
-def block_to_frame(block: np.ndarray, cap: int, with_zncc: bool = False) -> DataFrame | None:
+def block_to_frame(block: np.ndarray, cap: int, with_zncc: bool = False, radial: bool = False, own: bool = False) -> DataFrame | None:
     """Frame block of the device pipeline (km_klt_tile_frame[_zncc]_dev: 4 int32 {rows, Ninit, 0, 0}, then `cap` float32 per
-    column x0 | y0 | dx | dy | score | index bits, then `cap` float64 zncc) -> DataFrame; None when no corner was found."""
+    column x0 | y0 | dx | dy | score | index bits, then `cap` float64 zncc) -> DataFrame; None when no corner was found.
+    `radial`: with the `radial error` / `angle` columns of `radial_angle_columns` already in place (one DataFrame construction
+    instead of two column insertions, which cost more than every array operation of the host stage together).  `own`: the block
+    belongs to the frame from now on (the columns become views of it instead of copies)."""
     rows, n_init = (int(v) for v in block[:2].view(np.int32))
     if n_init == 0:
         return None
     body = block[4:]
-    data = {name: body[i * cap:i * cap + rows].copy() for i, name in enumerate(COLUMNS)}
+    take = (lambda a: a) if own else (lambda a: a.copy())
+    data = {name: take(body[i * cap:i * cap + rows]) for i, name in enumerate(COLUMNS)}
     if with_zncc:
-        data["zncc_score"] = body[6 * cap:8 * cap].view(np.float64)[:rows].copy()
+        data["zncc_score"] = take(body[6 * cap:8 * cap].view(np.float64)[:rows])
+    if radial:
+        data["radial error"], data["angle"] = _radial_angle(data["dx"], data["dy"])
     labels = body[5 * cap:5 * cap + rows].view(np.int32).astype(np.int64)
     return DataFrame(data, index=labels, copy=False)
+
+
+def _radial_angle(dx: np.ndarray, dy: np.ndarray):
+    """|(dx, dy)| and atan2(dy, dx) in degrees, float32 like the displacement columns they are computed from (core.py:872-873).
+    numpy on the host: a device atan2 would not reproduce numpy's last bit."""
+    return np.sqrt(dx ** 2 + dy ** 2), np.degrees(np.arctan2(dy, dx))
 
 
 def radial_angle_columns(frame: DataFrame) -> DataFrame:
     """Adds `radial error` = |(dx, dy)| and `angle` = atan2(dy, dx) in degrees, float32 like the displacement columns they are
     computed from (core.py:872-873).  numpy on the host: a device atan2 would not reproduce numpy's last bit."""
-    dx, dy = frame["dx"].to_numpy(), frame["dy"].to_numpy()
-    frame["radial error"] = np.sqrt(dx ** 2 + dy ** 2)
-    frame["angle"] = np.degrees(np.arctan2(dy, dx))
+    if "radial error" in frame.columns and "angle" in frame.columns:      # built with block_to_frame(..., radial=True)
+        return frame
+    frame["radial error"], frame["angle"] = _radial_angle(frame["dx"].to_numpy(), frame["dy"].to_numpy())
     return frame

@@ -86,8 +86,9 @@ class RawFrame:
     def n_candidates(self) -> int:
         return int(self.block[3:4].view(np.int32)[0])
 
-    def to_frame(self) -> DataFrame | None:
-        return ResidentPair._frame_from_block(self.block, self.cap, self.with_zncc)
+    def to_frame(self, radial: bool = False) -> DataFrame | None:
+        """The tile's DataFrame; `radial`: with the `radial error` / `angle` columns of `score_frame` already in place."""
+        return ResidentPair._frame_from_block(self.block, self.cap, self.with_zncc, radial, own=True)   # (the block is this frame's private copy)
 
 
 class PendingFrame:
