@@ -106,6 +106,9 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *                  through the exact path - inside the call for the blocking entry points, by the caller of km_frame_wait for
  *                  submitted frames (PendingFrame.result()).  0: always the exact path (two scalar read-backs per tile, rocPRIM
  *                  sorts).  Initial value from the environment variable KARIOS_HIP_SPECULATIVE.
+ *   "aux_pyramid"  1 (default): on the synchronisation-free path the two pyramids are built on a second stream next to the
+ *                  corner-selection chain and joined before LK; 0: on the library's stream.  Initial value from
+ *                  KARIOS_HIP_AUX_PYRAMID.
  *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the

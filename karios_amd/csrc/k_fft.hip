@@ -23,7 +23,7 @@
 #include <vector>
 
 #define FFT_NMAX 12288
-#define FFT_T 256
+#define FFT_T 768            // 12 wavefronts: 3 per SIMD (one workgroup per CU: the row fills LDS)
 
 namespace {
 
@@ -65,16 +65,20 @@ template <int R> __device__ __forceinline__ void dft_small(float2 (&x)[R], const
 // complete (the caller stores them to LDS).
 __constant__ float2 c_t61[30 * 30];
 
-template <typename Put> __device__ __forceinline__ void dft61(const float2 (&x)[61], Put put)
+// `part` (0..3, wave-uniform) selects the outputs this call produces: k = 8 part + 1 .. min(8 part + 8, 30) and their mirrors
+// 61 - k (+ X[0] from part 0) - four wavefronts share the 61-point transform of the same 64 butterflies, each paying a quarter
+// of the 3 600 FMAs (with one thread per butterfly only 180 of a workgroup's threads were busy, for 3 600 FMAs each).
+template <typename Put> __device__ __forceinline__ void dft61(const float2 (&x)[61], int part, Put put)
 {
     float2 a[31], b[31];
     float2 sum = x[0];
 #pragma unroll
     for (int j = 1; j <= 30; j++) { a[j] = cadd(x[j], x[61 - j]); b[j] = csub(x[j], x[61 - j]); sum = cadd(sum, a[j]); }
     const float2 x0 = x[0];
-    put(0, sum);
+    if (part == 0) put(0, sum);
+    const int k_lo = 8 * part + 1, k_hi = min(8 * part + 8, 30);
 #pragma unroll 1
-    for (int k = 1; k <= 30; k++) {
+    for (int k = k_lo; k <= k_hi; k++) {
         float cr = 0.f, ci = 0.f, sr = 0.f, si = 0.f;
 #pragma unroll
         for (int j = 1; j <= 30; j++) {
@@ -92,10 +96,10 @@ template <typename Put> __device__ __forceinline__ void dft61(const float2 (&x)[
 // branch-free (surplus butterflies re-read the last one, only their stores are predicated): every twiddle gather of the stage
 // is in flight before the first one is used - with a branch per butterfly each gather's latency (~1 us under load) was paid
 // separately, which made a 10980-point transform take 125 us.
-template <int R> __device__ __forceinline__ void stage(float2 *row, int N, int Ns, const float2 *__restrict__ tw)
+template <int R> __device__ __forceinline__ void stage(float2 *row, int N, int Ns, const float2 *__restrict__ tw, int tid)
 {
     constexpr int MAXB = (FFT_NMAX / R + FFT_T - 1) / FFT_T;
-    const int nb = N / R, tid = threadIdx.x;
+    const int nb = N / R;
     const int stride = N / (Ns * R);                 // twiddle exponent step: W_N^(t k stride), t < R, k < Ns
     constexpr bool NEEDS_ROOTS = R != 2 && R != 4;      // radix 2 / 4 butterflies are additions only
     float2 root[NEEDS_ROOTS ? R : 1];
@@ -137,25 +141,32 @@ template <int R> __device__ __forceinline__ void stage(float2 *row, int N, int N
     __syncthreads();
 }
 
-__device__ __forceinline__ void stage61(float2 *row, int N, int Ns, const float2 *__restrict__ tw)
+__device__ __forceinline__ void stage61(float2 *row, int N, int Ns, const float2 *__restrict__ tw, int tid)
 {
     const int nb = N / 61, stride = N / (Ns * 61);
-    for (int base = 0; base < nb; base += FFT_T) {          // nb = 180 for 10980: one butterfly per thread
-        const int j = base + (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int part = wave & 3;                              // which quarter of the outputs (wave-uniform: coefficient loads stay scalar)
+    constexpr int PER = (FFT_T / 64 / 4) * 64;              // butterflies per trip: 192 (nb = 180 for 10980)
+    if (Ns > 1) {
+        // a second radix-61 stage (N a multiple of 3721): its twiddles are applied in place first, so that the butterfly below
+        // never holds 60 twiddles next to its 61 inputs (61 is the first radix of every plan: normally Ns = 1 and this is skipped)
+        for (int idx = nb + tid; idx < N; idx += FFT_T) {
+            const int t = idx / nb, j = idx - t * nb;
+            row[idx] = cmul(row[idx], tw[t * (j % Ns) * stride]);
+        }
+        __syncthreads();
+    }
+    for (int base = 0; base < nb; base += PER) {
+        const int j = base + (wave >> 2) * 64 + lane;
         float2 v[61];
         if (j < nb) {
-            const int k = j % Ns;
 #pragma unroll
-            for (int t = 0; t < 61; t++) {
-                float2 x = row[j + t * nb];
-                if (Ns > 1 && t > 0) x = cmul(x, tw[t * k * stride]);
-                v[t] = x;
-            }
+            for (int t = 0; t < 61; t++) v[t] = row[j + t * nb];
         }
         __syncthreads();
         if (j < nb) {
             const int k = j % Ns, j0 = (j / Ns) * Ns * 61 + k;
-            dft61(v, [&](int t, float2 val) { row[j0 + t * Ns] = val; });   // every thread's inputs are in registers: in-place stores are safe
+            dft61(v, part, [&](int t, float2 val) { row[j0 + t * Ns] = val; });   // every thread's inputs are in registers: in-place stores are safe
         }
         __syncthreads();
     }
@@ -208,13 +219,17 @@ __global__ __launch_bounds__(FFT_T) void fft_rows_kernel(const T *__restrict__ i
         int Ns = 1;
         for (int s = 0; s < plan.n_stages; s++) {
             const int R = plan.radix[s];
+            // the thread index is made opaque per stage: otherwise every stage's row-invariant index arithmetic is hoisted out of
+            // the row loop and held in registers through all the other stages (hundreds of values: the kernel spilled)
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
             switch (R) {
-            case 61: stage61(row, N, Ns, tw); break;
-            case 7: stage<7>(row, N, Ns, tw); break;
-            case 5: stage<5>(row, N, Ns, tw); break;
-            case 4: stage<4>(row, N, Ns, tw); break;
-            case 3: stage<3>(row, N, Ns, tw); break;
-            default: stage<2>(row, N, Ns, tw); break;
+            case 61: stage61(row, N, Ns, tw, tid); break;
+            case 7: stage<7>(row, N, Ns, tw, tid); break;
+            case 5: stage<5>(row, N, Ns, tw, tid); break;
+            case 4: stage<4>(row, N, Ns, tw, tid); break;
+            case 3: stage<3>(row, N, Ns, tw, tid); break;
+            default: stage<2>(row, N, Ns, tw, tid); break;
             }
             Ns *= R;
         }
