@@ -683,8 +683,7 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
     }
     if (dtype != KM_U8) {
         km_stage_timer t(c, ST_MINMAX);
-        if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0]))) return rc;
-        if ((rc = kd_minmax(c, d_mon, dtype, H, W, smon, &sc->mm[2]))) return rc;
+        if ((rc = kd_minmax_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, &sc->mm[0]))) return rc;
     }   // (u8 input: mm stays 0 from the scalar block the entry point zeroed)
     {
         km_stage_timer t(c, ST_LAPLACIAN);

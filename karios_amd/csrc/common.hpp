@@ -279,6 +279,8 @@ static inline size_t km_any_dtype_size(int dtype)
 // k_dense.hip
 int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
               double *d_mm /* [2] */);
+int kd_minmax_pair(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb,
+                   double *d_mm /* [4]: min_a, max_a, min_b, max_b */);
 int kd_to_uint8(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
                 const double *d_mm, int invert, uint8_t *d_out);
 int kd_auto_mask(km_ctx *c, const void *d_mon, const void *d_ref, int dtype, int H, int W,

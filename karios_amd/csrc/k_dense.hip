@@ -75,10 +75,14 @@ __device__ __forceinline__ unsigned stretch_u8(T v, double mn, double range, boo
 }
 
 // ------------------------------------------------------------------ K1 min/max
+// blockIdx.y selects the image (kd_minmax_pair: both rasters of a pair in one launch); partials of image y start at 2 * gridDim.x * y
 template <typename T>
-__global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict__ img, int H, int W,
-                                                             ptrdiff_t stride, double *partial)
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                                             ptrdiff_t stride0, ptrdiff_t stride1, double *partial)
 {
+    const T *__restrict__ img = blockIdx.y ? img1 : img0;
+    const ptrdiff_t stride = blockIdx.y ? stride1 : stride0;
+    partial += (size_t)2 * gridDim.x * blockIdx.y;
     using A = typename px_traits<T>::acc;
     A mn, mx;
     if constexpr (px_traits<T>::code == KM_F32) { mn = INFINITY; mx = -INFINITY; }
@@ -127,6 +131,8 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict
 
 __global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial, int nb, double *out)
 {
+    partial += (size_t)2 * nb * blockIdx.x;     // (one block per image)
+    out += 2 * blockIdx.x;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         mn = fmin(mn, partial[2 * i]);
@@ -143,22 +149,35 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial
     }
 }
 
-int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, double *d_mm)
+// min / max of one image (d_b == nullptr) or of the two rasters of a pair in one launch: d_mm[0..1] (and d_mm[2..3])
+static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm)
 {
-    const int nb = 2048;
-    double *partial = (double *)km_ws(c, WS_PARTIAL, 2 * nb * sizeof(double));
+    const int nb = 2048, ni = d_b ? 2 : 1;
+    double *partial = (double *)km_ws(c, WS_PARTIAL, (size_t)2 * nb * ni * sizeof(double));
     if (!partial) return KM_E_NOMEM;
+    const dim3 grid(nb, ni);
     switch (dtype) {
-    case KM_U8: minmax_partial_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_img, H, W, stride, partial); break;
-    case KM_U16: minmax_partial_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_img, H, W, stride, partial); break;
-    case KM_I16: minmax_partial_kernel<int16_t><<<nb, 256, 0, c->stream>>>((const int16_t *)d_img, H, W, stride, partial); break;
-    case KM_F32: minmax_partial_kernel<float><<<nb, 256, 0, c->stream>>>((const float *)d_img, H, W, stride, partial); break;
+    case KM_U8: minmax_partial_kernel<uint8_t><<<grid, 256, 0, c->stream>>>((const uint8_t *)d_a, (const uint8_t *)d_b, H, W, sa, sb, partial); break;
+    case KM_U16: minmax_partial_kernel<uint16_t><<<grid, 256, 0, c->stream>>>((const uint16_t *)d_a, (const uint16_t *)d_b, H, W, sa, sb, partial); break;
+    case KM_I16: minmax_partial_kernel<int16_t><<<grid, 256, 0, c->stream>>>((const int16_t *)d_a, (const int16_t *)d_b, H, W, sa, sb, partial); break;
+    case KM_F32: minmax_partial_kernel<float><<<grid, 256, 0, c->stream>>>((const float *)d_a, (const float *)d_b, H, W, sa, sb, partial); break;
     default: return km_fail(c, KM_E_ARG, "minmax: bad dtype %d", dtype);
     }
     KM_LAUNCH_CHECK(c);
-    minmax_final_kernel<<<1, 256, 0, c->stream>>>(partial, nb, d_mm);
+    minmax_final_kernel<<<ni, 256, 0, c->stream>>>(partial, nb, d_mm);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
+}
+
+int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, double *d_mm)
+{
+    return minmax_launch(c, d_img, nullptr, dtype, H, W, stride, 0, d_mm);
+}
+
+// both rasters of a pair: d_mm = {min_a, max_a, min_b, max_b}
+int kd_minmax_pair(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm)
+{
+    return minmax_launch(c, d_a, d_b, dtype, H, W, sa, sb, d_mm);
 }
 
 // ------------------------------------------------------------------ standalone stretch / mask

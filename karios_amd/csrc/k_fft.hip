@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256) void argmax_f32_kernel(const float *__restrict
 bool factorize(int N, fft_plan *p)
 {
     if (N < 2 || N > FFT_NMAX) return false;
+    // radix 61 works in place with every butterfly's inputs in registers: all N / 61 butterflies must fit ONE trip of the
+    // workgroup (192 butterflies); longer rows (61 x 193 .. 61 x 201) take the double-precision path
+    if (N % 61 == 0 && N / 61 > (FFT_T / 64 / 4) * 64) return false;
     p->n_stages = 0;
     int n = N;
     // the big radix first: its inputs then need no twiddles (Ns = 1)

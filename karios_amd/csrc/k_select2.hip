@@ -102,10 +102,13 @@ __global__ __launch_bounds__(1024) void f_cut_kernel(km_scalars *sc, unsigned k_
 // kept keys -> their bin's range of `out` (order inside a bin is fixed by the sort that follows).  A workgroup first counts
 // its keys per bin in LDS, reserves one range per non-empty bin (a device-scope atomic with return costs microseconds and
 // same-address ones serialise: one per key made this the slowest kernel of the stage) and then places the keys.
+// (side job: the selection's cell records are zeroed here - a separate memset is one more launch on a latency-bound chain)
 __global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
-                                                         unsigned long long *__restrict__ out, unsigned kept_cap)
+                                                         unsigned long long *__restrict__ out, unsigned kept_cap, uint4 *__restrict__ zero16, size_t n_zero16)
 {
     __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
+    for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x; i < n_zero16; i += (size_t)gridDim.x * gridDim.y * 1024)
+        zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     const unsigned cap_s = cap / KM_NSHARD;
     const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
     keys += (size_t)blockIdx.y * cap_s;
@@ -141,10 +144,11 @@ __global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long lon
 // neighbour's key with two dependent loads instead of three.
 __global__ __launch_bounds__(256) void f_cells_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw,
                                                       uint2 *__restrict__ cell_rec, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
-                                                      unsigned kept_cap)
+                                                      unsigned kept_cap, unsigned *__restrict__ acc_zero)
 {
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    for (unsigned t = i; t < 2 * KF_NB; t += gridDim.x * 256) acc_zero[t] = 0u;      // acc_cnt + acc_cur of the ranking behind the sweeps
     if (i >= n) return;
     state[i] = S_UNDECIDED;
     int x, y;
@@ -422,7 +426,9 @@ int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H,
     if ((rc = ks_topk_hist(c, d_keys, cap_keys, sc, quality))) return rc;
     f_cut_kernel<<<1, 1024, 0, c->stream>>>(sc, (unsigned)max_corners * KF_SLICE, quality, (unsigned)cap_keys, b.kept_cap, (unsigned)c->opt_spec_flag);
     KM_LAUNCH_CHECK(c);
-    f_scatter_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap);
+    // (cell records of 8 bytes in a 16-byte aligned buffer; with an odd cell count the first two item slots behind them are zeroed too - they are written later)
+    f_scatter_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap, (uint4 *)b.cell_rec,
+                                                                  (b.cells + 1) / 2);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -434,15 +440,13 @@ int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, flo
     int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
     if (rc) return rc;
     const double md2 = min_distance * min_distance;
-    KM_HIP(c, hipMemsetAsync(b.cell_rec, 0, b.cells * sizeof(uint2), c->stream));
     const unsigned g256 = (b.kept_cap + 255) / 256;
-    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_rec, b.cell_items, b.state, b.kept_cap);
+    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_rec, b.cell_items, b.state, b.kept_cap, b.acc_cnt);
     KM_LAUNCH_CHECK(c);
     for (int g = 0; g < 4; g++) {
         f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_rec, b.cell_items, b.state, &sc->und[g], b.kept_cap);
         KM_LAUNCH_CHECK(c);
     }
-    KM_HIP(c, hipMemsetAsync(b.acc_cnt, 0, 2 * KF_NB * sizeof(unsigned), c->stream));      // acc_cnt + acc_cur
     f_acc_count_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_cnt, b.kept_cap);
     KM_LAUNCH_CHECK(c);
     f_acc_scan_kernel<<<1, 1024, 0, c->stream>>>(b.acc_cnt, b.acc_off, b.chunk_off, sc, max_corners, 3u);

@@ -171,7 +171,7 @@ def test_kernel_search_with_inverted_and_searched_polarity_on_uint16(ops, O, pol
 
 
 # ---------------------------------------------------------------------------- hand-written float32 phase correlation
-@pytest.mark.parametrize("shape", [(244, 183), (420, 360), (1098, 1220), (96, 250), (366, 366), (61, 122), (1830, 700)])
+@pytest.mark.parametrize("shape", [(244, 183), (420, 360), (1098, 1220), (96, 250), (366, 366), (61, 122), (1830, 700), (122, 3721)])
 def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape):
     """k_fft.hip (float32, radices 2/3/4/5/7/61) against the double-precision rocFFT path and the oracle: same integer shifts
     on shifted copies (clear peak -> fast path is trusted), and the double path takes over when the peak is split evenly."""

@@ -301,6 +301,8 @@ def main():
         except Exception as e:   # noqa: BLE001 - a crash in one case must not hide the others
             fails = [f"exception {type(e).__name__}: {e}"]
         done += 1
+        if done % 5000 == 0:      # a killed soak still leaves its count behind
+            print(f"progress: {done} cases, {bad} failing, {time.time() - t0:.0f} s", flush=True)
         if fails:
             bad += 1
             if LAST:
