@@ -14,7 +14,7 @@ The same JSON line carries
                 1-thread figure on a bounded sample (rank 0, N = 1 only);
   end_to_end    the drop-in path a KARIOS user gets: page-locked host rasters -> `karios_amd.matcher.KLT.match` ->
                 DataFrame + ZNCC column per pair, upload of pair i+1 under the compute of pair i (PCIe-inclusive; never `value`);
-  in_flight     the same workload with THREE independent pairs in flight on the one GPU (a library context = stream + workspace
+  in_flight     (with --in-flight) the same workload with THREE independent pairs in flight on the one GPU (a library context = stream + workspace
                 each): the latency-bound stretches of one pair are filled by the others (N = 1 only).  The headline keeps one pair
                 in flight so that the kernel durations behind `roofline` are those of the kernels alone;
   config4       BASELINE config 4 as a FIXED workload (4 bands x tile_size 5490 = 16 units) split over the N ranks -
@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-in-flight", action="store_true", help="skip the 3-pairs-in-flight throughput object (N=1 only)")
+    ap.add_argument("--in-flight", action="store_true", help="add the 3-pairs-in-flight throughput object (N=1 only; off by default: a "
+                    "profile of the default command then shows every kernel running alone, like the events behind `roofline`)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config of the headline line")
     ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -593,7 +594,7 @@ def main():
         out["end_to_end"] = end_to_end(host_pair[0], host_pair[1], ctx, max(4, min(12, a.steps)))
     del mon_t, ref_t
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not a.no_in_flight:
+    if rank == 0 and world == 1 and a.in_flight:
         out["in_flight"] = in_flight(dev, conf, S)
         torch.cuda.empty_cache()
     if not a.no_config4 and S == 10980:
