@@ -29,8 +29,8 @@ void *km_ws(km_ctx *c, int slot, size_t bytes)
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return b.p;
     if (b.p) {
-        // the stream may still use the old buffer
-        (void)hipStreamSynchronize(c->stream);
+        // the library's streams (compute, second stream of the sync-free tile path) may still use the old buffer
+        (void)hipDeviceSynchronize();
         (void)hipFree(b.p);
         b.p = nullptr; b.cap = 0;
     }
