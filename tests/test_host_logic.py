@@ -269,3 +269,35 @@ def test_oracle_thread_team_respects_the_cpu_quota(O):
     except AttributeError:
         pass
     assert 1 <= O.max_threads() <= max(n, 1) or O.max_threads() == 1
+
+
+def test_block_to_frame_with_radial_columns_equals_the_two_step_construction():
+    """`frames.block_to_frame(..., radial=True, own=True)` - the host half of the pipelined bench: one DataFrame construction, columns
+    as views of the block - gives the frame of `block_to_frame` + `radial_angle_columns` (reference api/core.py:872-873), bit for bit,
+    index labels included; `radial_angle_columns` leaves such a frame alone."""
+    import pandas as pd
+    from karios_amd import frames
+    cap, rows = 500, 321
+    rng = np.random.default_rng(7)
+    block = np.zeros(4 + 8 * cap, np.float32)
+    block[:4].view(np.int32)[:] = (rows, 400, 0, 0)
+    body = block[4:]
+    body[0:cap] = rng.integers(0, 3000, cap)
+    body[cap:2 * cap] = rng.integers(0, 3000, cap)
+    body[2 * cap:3 * cap] = rng.normal(0.5, 2.0, cap)
+    body[3 * cap:4 * cap] = rng.normal(-0.25, 2.0, cap)
+    body[4 * cap:5 * cap] = rng.uniform(0, 1, cap)
+    body[5 * cap:6 * cap].view(np.int32)[:] = rng.permutation(cap)
+    z = rng.uniform(-1, 1, cap)
+    z[::7] = np.nan
+    body[6 * cap:8 * cap].view(np.float64)[:] = z
+    two_step = frames.radial_angle_columns(frames.block_to_frame(block, cap, True))
+    private = block.copy()
+    one_step = frames.block_to_frame(private, cap, True, radial=True, own=True)
+    pd.testing.assert_frame_equal(one_step, two_step, check_exact=True)
+    assert list(one_step.columns) == ["x0", "y0", "dx", "dy", "score", "zncc_score", "radial error", "angle"]
+    assert one_step["radial error"].dtype == np.float32 and one_step["angle"].dtype == np.float32
+    assert frames.radial_angle_columns(one_step) is one_step
+    assert len(one_step) == rows and one_step.index.dtype == np.int64
+    block[:2].view(np.int32)[:] = (0, 0)
+    assert frames.block_to_frame(block, cap, True, radial=True) is None
