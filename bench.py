@@ -47,6 +47,7 @@ STAGE_BYTES_PER_PX = {
     "pyramid": 2.5,                  # read 1+1, write 1/4+1/4
 }
 PHASE_BYTES_PER_PX_F64 = 116.0       # SURVEY 8(d) large-shift model executed in fp64 (reference precision)
+PHASE_BYTES_PER_PX_F32 = 60.0        # SURVEY 8(d) large-shift model in float32 (28 forward + 12 cross power + 16 inverse + 4 arg-max)
 SHIFT_BYTES_PER_PX = 4.0
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
 
@@ -377,19 +378,25 @@ def config3_line(a, ctx, dev):
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
     phase_ms /= a.steps
-    algo = PHASE_BYTES_PER_PX_F64 * S * S
+    # 60 B/px for a float32 transform, twice the FFT terms (116 B/px) when the transform runs in the reference's fp64 -
+    # priced on the path the library actually took (km_phase_info: 1 = hand-written float32 FFT, 2 = fp64 fallback)
+    path, margin = ctx.phase_info()
+    algo = (PHASE_BYTES_PER_PX_F32 if path == 1 else PHASE_BYTES_PER_PX_F64) * S * S
     achieved = algo / (phase_ms * 1e-3) / 1e9
     return {
         "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, large-shift pre-alignment + KLT",
         "value": S * S / 1e6 / (dt / a.steps), "unit": "Mpx/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 FFT (reference precision), u8/int32 stencils, f32 LK solve", "data": "synthetic",
+        "dtype": ("f32 FFT (integer shift accepted on a clear peak, fp64 otherwise)" if path == 1 else "f64 FFT (reference precision)")
+                 + ", u8/int32 stencils, f32 LK solve", "data": "synthetic",
         "config": {"workload": f"BASELINE config 3: synthetic Sentinel-2 pair {S}x{S} uint16 shifted by (37.25, -20.75) px, phase correlation -> "
                                "shift_image -> KLT (one tile, maxCorners 20000) -> offsets added back; inputs resident in HBM", "pairs_per_step": 1},
         "detected_offset_row_col": [float(off[0]), float(off[1])],
         "matched_keypoints_per_pair": len(frame), "median_dx_dy": [float(np.median(frame["dx"])), float(np.median(frame["dy"]))],
         "stage_ms": {"phase_correlation": round(phase_ms, 3)},
-        "roofline": {"bound": "hbm", "kernel": "phase_correlation (2x D2Z FFT, cross-power, Z2D FFT, arg-max)", "achieved": achieved,
+        "phase_path": {"path": "float32 hand-written FFT" if path == 1 else "fp64 rocFFT", "peak_margin": margin},
+        "roofline": {"bound": "hbm", "kernel": "phase_correlation (2-D FFT of ref + i mon, cross-power, inverse 2-D FFT, arg-max)" if path == 1
+                     else "phase_correlation (2x D2Z FFT, cross-power, Z2D FFT, arg-max)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo, "kernel_ms": phase_ms},
         "cpu_baseline": None,
