@@ -11,7 +11,9 @@ per-band key-point blocks are all-gathered over RCCL inside the timed region.
 The same JSON line carries
   roofline      dominant dense kernel: algorithmic bytes (SURVEY 8d) / hipEvent stage time on the library's stream;
   cpu_baseline  the CPU oracle (a port of the reference path) on the same pair: median of 5 runs with all usable cores and a
-                1-thread figure on a bounded sample (rank 0, N = 1 only);
+                1-thread figure on a bounded sample (rank 0, N = 1 only); its `parity` object is SURVEY 8(d)'s gate on the measured
+                pair: the GPU frame of the timed loop against the oracle's result (key points identical and in order, |d dx|, |d dy|
+                <= 1e-3 px, score <= 1e-2, ZNCC <= 1e-9);
   end_to_end    the drop-in path a KARIOS user gets: page-locked host rasters -> `karios_amd.matcher.KLT.match` ->
                 DataFrame + ZNCC column per pair, upload of pair i+1 under the compute of pair i (PCIe-inclusive; never `value`);
   in_flight     (with --in-flight) the same workload with THREE independent pairs in flight on the one GPU (a library context = stream + workspace
@@ -69,7 +71,32 @@ def parse():
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(mon, ref, conf_kw, runs):
+def parity_gate(frame, res, zncc_oracle):
+    """SURVEY 8(d) parity gates on the pair that was measured: the GPU frame of the timed loop against the oracle's result for the
+    same full-size pair - key points identical and in the same order, displacements within 1e-3 px, score within 1e-2, ZNCC within 1e-9."""
+    if frame is None or res is None:
+        return {"checked": False}
+    gx, gy = frame["x0"].to_numpy(), frame["y0"].to_numpy()
+    same = len(gx) == len(res["x0"]) and bool(np.array_equal(gx, res["x0"]) and np.array_equal(gy, res["y0"]))
+    out = {"checked": True, "rows_gpu": int(len(gx)), "rows_oracle": int(len(res["x0"])), "keypoints_identical_and_in_order": same}
+    if same:
+        out["max_abs_ddx_px"] = float(np.abs(frame["dx"].to_numpy() - res["dx"]).max())
+        out["max_abs_ddy_px"] = float(np.abs(frame["dy"].to_numpy() - res["dy"]).max())
+        out["max_abs_dscore"] = float(np.abs(frame["score"].to_numpy() - res["score"]).max())
+        if zncc_oracle is not None and "zncc_score" in frame.columns:
+            keep = res["score"] >= 0.4
+            z = frame["zncc_score"].to_numpy()[keep]
+            out["zncc_nan_pattern_identical"] = bool(np.array_equal(np.isnan(z), np.isnan(zncc_oracle)))
+            both = ~np.isnan(z) & ~np.isnan(zncc_oracle)
+            out["max_abs_dzncc"] = float(np.abs(z[both] - zncc_oracle[both]).max()) if both.any() else 0.0
+        out["passed"] = bool(out["max_abs_ddx_px"] <= 1e-3 and out["max_abs_ddy_px"] <= 1e-3 and out["max_abs_dscore"] <= 1e-2
+                             and out.get("zncc_nan_pattern_identical", True) and out.get("max_abs_dzncc", 0.0) <= 1e-9)
+    else:
+        out["passed"] = False
+    return out
+
+
+def cpu_baseline(mon, ref, conf_kw, runs, gpu_frame=None):
     """Oracle (kind 'port') on the SAME full pair, all usable cores: median of `runs` timed passes after one warm-up;
     plus a 1-thread figure on the top tenth of the image (maxCorners scaled to the same corner density)."""
     from oracle import oracle as O
@@ -84,7 +111,7 @@ def cpu_baseline(mon, ref, conf_kw, runs):
         n = 0
         if res is not None:
             keep = res["score"] >= 0.4
-            O.zncc_batch(r, m, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
+            res["_zncc_kept"] = O.zncc_batch(r, m, res["x0"][keep], res["y0"][keep], res["dx"][keep], res["dy"][keep])
             n = len(res["x0"])
         return time.perf_counter() - t0, n, res
 
@@ -105,6 +132,7 @@ def cpu_baseline(mon, ref, conf_kw, runs):
            "keypoints_per_s": n / med,
            "single_thread": {"value": rows1 * S / 1e6 / t1, "unit": "Mpx/s", "cores": 1,
                              "sample": f"top {rows1} rows, maxCorners {conf1.maxCorners}, median of 3 passes, {t1:.2f} s"}}
+    out["parity"] = parity_gate(gpu_frame, res, None if res is None else res.get("_zncc_kept"))
     live = cv2_live(mon, ref, dict(maxCorners=conf.maxCorners), res)
     if live is not None:
         out["opencv_live"] = live
@@ -526,6 +554,7 @@ def main():
     dt = time.perf_counter() - t0
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"]
+    last_frame = frame                # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
     timed_eig_ms = stage_sum.get("min_eigen", 0.0) / a.steps
     # untimed pass: every stage bracketed
     ctx.set_option("profile_stage", -1)
@@ -622,7 +651,7 @@ def main():
         if rank == 0:
             out["config4"] = c4
     if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
-        cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs)
+        cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs, gpu_frame=last_frame)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]
     elif rank == 0:
