@@ -1,30 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the KARIOS matching hot path on MI355X (BASELINE.json metric).
 
-Default (`--config 2`): one "step" = one pass of the hot path over one synthetic Sentinel-2-sized pair that is already
-resident in HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK forward/backward ->
-forward-backward score -> per-key-point ZNCC of the rows with score >= 0.4 (BASELINE config 2: "Sentinel-2 10 m band pair
-(10980x10980), KLT only, 1 MI355X"; default processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000).
-With N > 1 every rank matches its own band pair (weak scaling: the reference's tiles / bands are independent) and the
-per-band key-point blocks are all-gathered over RCCL inside the timed region.
+`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.  With N > 1 and no launcher environment the process
+SPAWNS N ranks itself (before anything touches the GPU), relays rank 0's line and fails if any rank fails; under an external
+launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) WORLD_SIZE must equal --gpus.
 
-The same JSON line carries
-  roofline      dominant dense kernel: algorithmic bytes / hipEvent stage time on the library's stream;
-  cpu_baseline  the CPU oracle (a port of the reference path) on the same pair: median of 5 runs with all usable cores and a
-                1-thread figure on a bounded sample (rank 0, N = 1 only); its `parity` object is SURVEY 8(d)'s gate on the measured
-                pair: the GPU frame of the timed loop against the oracle's result (key points identical and in order, |d dx|, |d dy|
-                <= 1e-3 px, score <= 1e-2, ZNCC <= 1e-9);
-  end_to_end    the drop-in path a KARIOS user gets: page-locked host rasters -> `karios_amd.matcher.KLT.match` ->
-                DataFrame + ZNCC column per pair, upload of pair i+1 under the compute of pair i (PCIe-inclusive; never `value`);
-  in_flight     (with --in-flight) the same workload with THREE independent pairs in flight on the one GPU (a library context = stream + workspace
-                each): the latency-bound stretches of one pair are filled by the others (N = 1 only).  The headline keeps one pair
-                in flight so that the kernel durations behind `roofline` are those of the kernels alone;
-  config4       BASELINE config 4 as a FIXED workload (4 bands x tile_size 5490 = 16 units) split over the N ranks -
-                strong scaling; at N = 1 one GPU runs all 16 units;
-  oracle_sensitivity  how far the two defensible roundings of the OpenCV-defined arithmetic can move the result
-                (profiles/r02_oracle_sensitivity.json, produced by tools/oracle_sensitivity.py).
+Headline (`value`): one "step" = one pass of the hot path over one synthetic Sentinel-2-sized pair that is already resident in
+HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK forward/backward -> forward-backward
+score -> per-key-point ZNCC of the rows with score >= 0.4 (BASELINE config 2: "Sentinel-2 10 m band pair (10980x10980), KLT
+only, 1 MI355X"; default processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000), driven through the product's
+`karios_amd.stream.FrameStream` (one pair in flight behind the one being submitted).  With N > 1 every rank matches its own
+band pair (weak scaling: the reference's tiles / bands are independent) and the per-band key-point blocks are all-gathered over
+RCCL inside the timed region.
 
-`--config 3` prints the line of BASELINE config 3 instead (large-shift pre-alignment: phase correlation + shift_image + KLT).
+Objects on the same line
+  roofline      the largest kernel of the step: bytes it must move / its hipEvent span on the library's stream (see `roofline_of`);
+  cpu_baseline  the CPU oracle (a port of the reference path) on the same pair, all usable cores + a 1-thread sample (rank 0,
+                N = 1); its `parity` object is SURVEY 8(d)'s gate on the measured pair (GPU frame of the timed loop vs the oracle);
+  end_to_end    the drop-in path: page-locked host rasters -> `karios_amd.matcher.KLT.match` -> DataFrame + ZNCC
+                (PCIe-inclusive; never `value`);
+  in_flight     the same workload with THREE independent pairs in flight on the one GPU (one library context each);
+  config3       BASELINE config 3 (large-shift pre-alignment: phase correlation + shift_image + KLT) at 10980^2 with its own
+                roofline, the path the transform took and a gate (offset == generator truth == oracle on a 1098^2 crop);
+  config4       BASELINE config 4 as a FIXED workload (4 bands x tile_size 5490 = 16 units) split over the N ranks - strong
+                scaling; each rank's units run over up to three contexts in flight;
+  config5       BASELINE config 5 stand-in at 10980^2 (cross-sensor look + user mask), one GPU;
+  oracle_sensitivity  precomputed (labelled): how far the two defensible roundings of the OpenCV-defined arithmetic move the result.
+`--config 3` prints the config-3 object as the line of its own.
 """
 from __future__ import annotations
 
@@ -32,6 +34,7 @@ import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -44,30 +47,86 @@ sys.path.insert(0, ROOT)
 STAGE_BYTES_PER_PX = {
     "minmax": 4.0,                   # read mon 2 + ref 2
     "stretch_laplacian_mask": 7.0,   # read 2+2, write lap_mon 1 + lap_ref 1 + mask 1
-    "min_eigen": 5.0,                # read lap_ref 1, write eig 4
-    "candidates": 5.0,               # read eig 4 + mask 1
+    "min_eigen": 5.0,                # read lap_ref 1, write eig 4            (two-kernel path only)
+    "candidates": 5.0,               # read eig 4 + mask 1                    (two-kernel path only)
     "pyramid": 2.5,                  # read 1+1, write 1/4+1/4
 }
+FUSED_EIG_BYTES_PER_PX = 2.0         # fused K3+K4: read lap_ref 1 + mask 1; the eig map is never written (+ 8 B per emitted key)
+LK_BYTES_PER_POINT = 6272.0          # 2 directions x 2 levels x (28x28 I-patch + 28x28 J-patch), u8
+ZNCC_BYTES_PER_POINT = 7396.0        # 2 x 43x43 x 2 B
+SELECT_BYTES_PER_CANDIDATE = 16.0    # candidate ranking
 PHASE_BYTES_PER_PX_F64 = 116.0       # SURVEY 8(d) large-shift model executed in fp64 (reference precision)
 PHASE_BYTES_PER_PX_F32 = 60.0        # SURVEY 8(d) large-shift model in float32 (28 forward + 12 cross power + 16 inverse + 4 arg-max)
 SHIFT_BYTES_PER_PX = 4.0
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
+PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
+SENS_FILE = os.path.join("profiles", "r02_oracle_sensitivity.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--in-flight", action="store_true", help="add the 3-pairs-in-flight throughput object (N=1 only; off by default: a "
-                    "profile of the default command then shows every kernel running alone, like the events behind `roofline`)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config of the headline line")
     ap.add_argument("--size", type=int, default=10980, help="image side (BASELINE: 10980)")
+    ap.add_argument("--share-gpu", action="store_true", help="development: the N ranks share the visible GPU(s) round-robin and the "
+                    "collectives run on gloo / host memory (RCCL wants one device per rank)")
+    ap.add_argument("--in-flight", action="store_true", help="(kept for compatibility: the in_flight object is part of the default line)")
+    ap.add_argument("--no-in-flight", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
-    ap.add_argument("--cpu-runs", type=int, default=5)
-    return ap.parse_args()
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in their environment), relay rank 0's JSON line, fail when any rank fails.  This parent never imports torch or touches
+    HIP: a process that has initialised the GPU must not be replaced or forked on this pool."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KARIOS_BENCH_LAUNCHER="bench.py (spawned ranks)")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0 = ""
+    failed = None
+    try:
+        out0, _ = procs[0].communicate()
+        for r, p in enumerate(procs):
+            rc = p.wait()
+            if rc != 0 and failed is None:
+                failed = (r, rc)
+    except BaseException:
+        failed = failed or (-1, 1)
+        raise
+    finally:
+        if failed is not None:
+            for p in procs:                      # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    for ln in out0.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with status {failed[1]}", file=sys.stderr)
+        return failed[1] or 1
+    if not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[-1])
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
@@ -227,67 +286,56 @@ def end_to_end(mon, ref, ctx, steps):
             "pageable_numpy_ms_per_pair": dt_plain * 1e3}
 
 
-# ---------------------------------------------------------------------------------------------------- config 4
-def in_flight(dev, conf, S, n_ctx=3, pairs=48):
+# ---------------------------------------------------------------------------------------------------- in flight
+def in_flight(dev, conf, S, first_pair, n_ctx=3, pairs=60):
     """Throughput with `n_ctx` independent band pairs in flight on ONE GPU: one library context (stream + workspace) per pair,
-    submitted round-robin by one thread, the host halves on one worker.  The latency-bound stretches of one pair (the corner-selection
-    chain, the frame ordering, ZNCC) are filled by the dense stages of the others.  Reported next to the headline, whose timed region
+    submitted round-robin through ONE `FrameStream`.  The latency-bound stretches of one pair (the corner-selection chain, the
+    frame ordering, ZNCC) are filled by the dense stages of the others.  Reported next to the headline, whose timed region
     keeps ONE pair in flight so that its kernel durations - the roofline - are those of the kernels alone."""
     import torch
-    from concurrent.futures import ThreadPoolExecutor
     from karios_amd import synth
     from karios_amd._lib import Context
     from karios_amd.resident import ResidentPair
-    data = [synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * i, device=dev) for i in range(n_ctx)]
+    from karios_amd.stream import FrameStream
+    data = [first_pair] + [synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * i, device=dev) for i in range(1, n_ctx)]
     torch.cuda.synchronize()
     ctxs = [Context(dev.index or 0) for _ in range(n_ctx)]
     prs = [ResidentPair.from_device_pointers(m.data_ptr(), r.data_ptr(), np.uint16, S, S, ctx=c, keepalive=(m, r)) for (m, r), c in zip(data, ctxs)]
-    pool = ThreadPoolExecutor(max_workers=1)
 
-    def host_half(pair, pend):
-        raw = pend.wait()
-        if raw.flags:
-            return None
-        return pair.score_frame(raw.to_frame(radial=True), 0.4)
-
-    def run(n):
-        futs, rows, redo = [], 0, 0
-        def take(item):
-            nonlocal rows, redo
-            pair, pend, fut = item
-            frame = fut.result()
-            if frame is None:                    # flagged by the sync-free corner path: exact repeat on the submitting thread
-                redo += 1
-                frame = pair.score_frame(pend.redo().to_frame(radial=True), 0.4)
-            rows += len(frame)
+    def run(stream, n):
+        rows = 0
         for i in range(n):
-            pr = prs[i % n_ctx]
-            pend = pr.submit_tile(conf, zncc_threshold=0.4)
-            futs.append((pr, pend, pool.submit(host_half, pr, pend)))
-            if len(futs) > 2 * n_ctx:
-                take(futs.pop(0))
-        for item in futs:
-            take(item)
+            rows += sum(len(d.frame) for d in stream.submit(prs[i % n_ctx], conf) if d.frame is not None)
+        rows += sum(len(d.frame) for d in stream.drain() if d.frame is not None)
         for c in ctxs:
             c.sync()
-        return rows, redo
+        return rows
 
-    run(4 * n_ctx)
-    t0 = time.perf_counter()
-    rows, redo = run(pairs)
-    dt = time.perf_counter() - t0
-    pool.shutdown()
+    with FrameStream(0.4, depth=2 * n_ctx) as stream:
+        run(stream, 4 * n_ctx)
+        redone0 = stream.units_redone
+        t0 = time.perf_counter()
+        rows = run(stream, pairs)
+        dt = time.perf_counter() - t0
+        redone = stream.units_redone - redone0
+    del prs, data
+    for c in ctxs:
+        c.close()
     return {"pairs_in_flight": n_ctx, "pairs": pairs, "ms_per_pair": dt / pairs * 1e3, "Mpx_per_s": S * S / 1e6 * pairs / dt,
-            "matched_keypoints_per_sec": rows / dt, "tiles_redone": redo,
-            "note": "independent pairs on separate HIP streams of one GPU; the headline value / roofline keep one pair in flight"}
+            "matched_keypoints_per_sec": rows / dt, "tiles_redone": redone,
+            "note": "independent pairs on separate library contexts (HIP streams) of one GPU through karios_amd.stream.FrameStream; "
+                    "the headline value / roofline keep one pair in flight"}
 
 
-def config4(ctx, dev, rank, world, coll_dev, steps):
+# ---------------------------------------------------------------------------------------------------- config 4
+def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3):
     """4 bands x tile_size 5490 = 16 work units of 10980^2 pairs (seeds 20260101 + 10 b), split round-robin over the ranks;
-    every rank keeps only its units' regions (box + ZNCC halo) resident; a step = all 16 units + ONE all-gather of their blocks."""
+    every rank keeps only its units' regions (box + ZNCC halo) resident and deals them to up to three library contexts (units in
+    flight fill each other's latency-bound stretches); a step = all 16 units + ONE all-gather of their blocks."""
     import torch
     import torch.distributed as dist
     from karios_amd import synth
+    from karios_amd._lib import Context
     from karios_amd.core import KLTConfiguration
     from karios_amd.parallel import DEFAULT_HALO, block_len, enumerate_units, gather_block_tensor, units_of_rank
     from karios_amd.resident import ResidentPair
@@ -298,6 +346,8 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
     per_rank = (len(units) + world - 1) // world
     send = torch.zeros((per_rank, 1 + L), dtype=torch.float32, device=dev)
     send[:, 0] = -1
+    n_ctx = max(1, min(n_ctx_max, len(mine)))
+    ctxs = [Context(dev.index or 0) for _ in range(n_ctx)]
     resident = []
     for b in sorted({u.band for u in mine}):
         mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * b, device=dev)
@@ -305,7 +355,8 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
             rx, ry = max(0, u.x_off - DEFAULT_HALO), max(0, u.y_off - DEFAULT_HALO)
             rw, rh = min(S, u.x_off + u.x_size + DEFAULT_HALO) - rx, min(S, u.y_off + u.y_size + DEFAULT_HALO) - ry
             m, r = mon_t[ry:ry + rh, rx:rx + rw].contiguous(), ref_t[ry:ry + rh, rx:rx + rw].contiguous()
-            pair = ResidentPair.from_device_pointers(m.data_ptr(), r.data_ptr(), np.uint16, rh, rw, ctx=ctx, keepalive=(m, r))
+            c = ctxs[len(resident) % n_ctx]
+            pair = ResidentPair.from_device_pointers(m.data_ptr(), r.data_ptr(), np.uint16, rh, rw, ctx=c, keepalive=(m, r))
             pair.window = (rx, ry, S, S)
             resident.append((u, pair, (u.x_off - rx, u.y_off - ry, u.x_size, u.y_size)))
         del mon_t, ref_t
@@ -316,24 +367,31 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
 
     redone = [0]
 
+    def sink(c, slot):
+        c.check(c.lib.km_set_frame_sink(c.handle, None if slot is None else send[slot, 1:].data_ptr(), 0 if slot is None else L * 4), "km_set_frame_sink")
+
     def step():
         pend = []
         for slot, (u, pair, box) in enumerate(resident):
-            ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, send[slot, 1:].data_ptr(), L * 4), "km_set_frame_sink")
+            sink(pair.ctx, slot)
             pend.append(pair.submit_tile(conf, box=box, zncc_threshold=0.4, origin=(u.x_off, u.y_off)))
-        ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, None, 0), "km_set_frame_sink")
-        ctx.sync()
+            sink(pair.ctx, None)
+        for c in ctxs:
+            c.sync()
         # a unit outside the fixed capacities of the sync-free corner path comes back flagged (header word 2): exact repeat, into the
         # same slot of the send buffer (never seen on a GPU of its own; two development ranks time-slicing ONE GPU do raise it)
         if resident:
             flags = send[:len(resident), 3].contiguous().view(torch.int32).cpu()
-            for slot in (int(i) for i in torch.nonzero(flags).flatten()):
-                ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, send[slot, 1:].data_ptr(), L * 4), "km_set_frame_sink")
+            again = [int(i) for i in torch.nonzero(flags).flatten()]
+            for slot in again:
+                c = resident[slot][1].ctx
+                sink(c, slot)
                 pend[slot].redo()
-                ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, None, 0), "km_set_frame_sink")
+                sink(c, None)
                 redone[0] += 1
-            if len(flags) and int(flags.count_nonzero()):
-                ctx.sync()
+            if again:
+                for c in ctxs:
+                    c.sync()
         if coll_dev.type == "cuda":
             blocks = gather_block_tensor(send, len(units))
         else:                                  # development: several gloo ranks share one GPU
@@ -341,21 +399,23 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
         flagged = int((blocks[:, 2].contiguous().view(torch.int32) != 0).sum().item())
         if flagged:       # (cannot happen: flagged units were repeated through the exact path above)
             raise SystemExit(f"config 4: {flagged} unit(s) still flagged after the exact repeat")
-        return int(blocks[:, 0].contiguous().view(torch.int32).sum().item())
+        got = int((blocks[:, 1].contiguous().view(torch.int32) != 0).sum().item())      # header word 1 = Ninit: units that arrived
+        return int(blocks[:, 0].contiguous().view(torch.int32).sum().item()), got
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(2):
-        rows = step()
+        rows, got = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        rows = step()
+        rows, got = step()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -363,22 +423,24 @@ def config4(ctx, dev, rank, world, coll_dev, steps):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     del resident
+    for c in ctxs:
+        c.close()
     return {"workload": "BASELINE config 4: 4 synthetic band pairs 10980x10980 uint16 (seeds 20260101+10b), tile_size 5490 -> 16 units, KLT + ZNCC, "
                         "each rank holds only its units' regions (box + 128 px halo); one all-gather of the 16 frame blocks per step",
-            "scaling": "strong", "units": len(units), "units_per_rank": [len(units_of_rank(units, r, world)) for r in range(world)],
+            "scaling": "strong", "n_gpus": world, "units": len(units), "units_gathered": got,
+            "units_per_rank": [len(units_of_rank(units, r, world)) for r in range(world)], "contexts_in_flight_per_rank": n_ctx,
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": 4 * S * S / 1e6 / (dt / steps), "unit": "Mpx/s",
             "matched_keypoints_per_step": rows, "matched_keypoints_per_sec": rows / (dt / steps), "units_repeated_exactly_on_this_rank": redone[0]}
 
 
 # ---------------------------------------------------------------------------------------------------- config 3
-def config3_line(a, ctx, dev):
+def config3_object(ctx, dev, S, steps, warmup, with_gate=True):
     """BASELINE config 3: the same pair shifted by (37.25, -20.75) px with --enable-large-shift-detection: phase correlation
-    (LargeOffsetMatcher.match) -> integer shift_image -> KLT on the shifted pair -> offsets added back (core.py:233-252)."""
+    (LargeOffsetMatcher.match) -> integer shift_image -> KLT on the shifted pair -> offsets added back (core.py:233-252, 739-786)."""
     import torch
     from karios_amd import synth
     from karios_amd.core import KLTConfiguration
     from karios_amd.resident import ResidentPair
-    S = a.size
     conf = KLTConfiguration()
     mon_t, ref_t = synth.make_pair_torch(S, S, 37.25, -20.75, device=dev)
     torch.cuda.synchronize()
@@ -393,82 +455,238 @@ def config3_line(a, ctx, dev):
         frame["dy"] = frame["dy"] + np.float32(off[0])
         return off, frame, t_phase
 
-    for _ in range(max(1, a.warmup)):
+    for _ in range(max(1, warmup)):
         step()
+    ctx.set_option("profile_stage", -1)
     ctx.set_profiling(True)
     ctx.sync()
     t0 = time.perf_counter()
     phase_ms = 0.0
-    for _ in range(a.steps):
+    for _ in range(steps):
         off, frame, tp = step()
         phase_ms += tp
     ctx.sync()
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
-    phase_ms /= a.steps
+    phase_ms /= steps
     # 60 B/px for a float32 transform, twice the FFT terms (116 B/px) when the transform runs in the reference's fp64 -
     # priced on the path the library actually took (km_phase_info: 1 = hand-written float32 FFT, 2 = fp64 fallback)
     path, margin = ctx.phase_info()
     algo = (PHASE_BYTES_PER_PX_F32 if path == 1 else PHASE_BYTES_PER_PX_F64) * S * S
     achieved = algo / (phase_ms * 1e-3) / 1e9
-    return {
-        "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, large-shift pre-alignment + KLT",
-        "value": S * S / 1e6 / (dt / a.steps), "unit": "Mpx/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    kname = "phase_correlation_f32" if path == 1 else "phase_correlation_f64"
+    out = {
+        "workload": f"BASELINE config 3: synthetic Sentinel-2 pair {S}x{S} uint16 shifted by (37.25, -20.75) px, phase correlation -> "
+                    "shift_image -> KLT (one tile, maxCorners 20000) -> offsets added back; inputs resident in HBM",
+        "value": S * S / 1e6 / (dt / steps), "unit": "Mpx/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
         "dtype": ("f32 FFT (integer shift accepted on a clear peak, fp64 otherwise)" if path == 1 else "f64 FFT (reference precision)")
-                 + ", u8/int32 stencils, f32 LK solve", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3: synthetic Sentinel-2 pair {S}x{S} uint16 shifted by (37.25, -20.75) px, phase correlation -> "
-                               "shift_image -> KLT (one tile, maxCorners 20000) -> offsets added back; inputs resident in HBM", "pairs_per_step": 1},
+                 + ", u8/int32 stencils, f32 LK solve",
         "detected_offset_row_col": [float(off[0]), float(off[1])],
         "matched_keypoints_per_pair": len(frame), "median_dx_dy": [float(np.median(frame["dx"])), float(np.median(frame["dy"]))],
         "stage_ms": {"phase_correlation": round(phase_ms, 3)},
         "phase_path": {"path": "float32 hand-written FFT" if path == 1 else "fp64 rocFFT", "peak_margin": margin},
         "roofline": {"bound": "hbm", "kernel": "phase_correlation (2-D FFT of ref + i mon, cross-power, inverse 2-D FFT, arg-max)" if path == 1
                      else "phase_correlation (2x D2Z FFT, cross-power, Z2D FFT, arg-max)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(kname, S),
                      "algorithmic_bytes_per_launch": algo, "kernel_ms": phase_ms},
-        "cpu_baseline": None,
     }
+    if with_gate:
+        # gate: the detected offset equals the generator's truth, and - on a 1098^2 crop of the SAME pair, small enough for the
+        # fp64 numpy oracle - the GPU's answer equals the oracle's
+        from oracle import oracle as O
+        c = min(S, 1098)
+        mon_c, ref_c = mon_t[:c, :c].contiguous(), ref_t[:c, :c].contiguous()
+        torch.cuda.synchronize()
+        crop = ResidentPair.from_device_pointers(mon_c.data_ptr(), ref_c.data_ptr(), np.uint16, c, c, ctx=ctx, keepalive=(mon_c, ref_c))
+        gpu_crop = crop.phase_offset()
+        crop_path, _ = ctx.phase_info()
+        ora_crop = O.phase_cross_correlation(mon_c.cpu().numpy().view(np.uint16), ref_c.cpu().numpy().view(np.uint16))
+        truth = [-21.0, 37.0]
+        out["gate"] = {"truth_row_col": truth, "full_size_equals_truth": [float(off[0]), float(off[1])] == truth,
+                       "crop": c, "gpu_crop_row_col": [float(v) for v in gpu_crop], "oracle_crop_row_col": [float(v) for v in ora_crop],
+                       "crop_path": "float32" if crop_path == 1 else "fp64",
+                       "gpu_crop_equals_oracle": bool(np.array_equal(gpu_crop, ora_crop)),
+                       "median_dx_dy_within_0.05_px": bool(abs(np.median(frame["dx"]) - 37.25) < 0.05 and abs(np.median(frame["dy"]) + 20.75) < 0.05)}
+        g = out["gate"]
+        g["passed"] = bool(g["full_size_equals_truth"] and g["gpu_crop_equals_oracle"] and g["median_dx_dy_within_0.05_px"])
+    return out
+
+
+def config5_object(ctx, dev, S, steps):
+    """BASELINE config 5 stand-in at full size on ONE GPU: cross-sensor look (mon 3x3 block-averaged and nearest-upsampled, gamma 0.8
+    radiometry, shift (0.4, -0.3)) with a user mask zeroing ~20 % of the pixels (the DEM is never read by the matcher)."""
+    import torch
+    from karios_amd import synth
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    from karios_amd.stream import FrameStream
+    conf = KLTConfiguration()
+    mon_t, ref_t, mask_t = synth.make_cross_sensor_pair_torch(S, S, device=dev)
+    torch.cuda.synchronize()
+    pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, mask_ptr=mask_t.data_ptr(),
+                                             keepalive=(mon_t, ref_t, mask_t))
+    last = [None]
+
+    def run(stream, n):
+        rows = 0
+        for _ in range(n):
+            for d in stream.submit(pair, conf):
+                rows += 0 if d.frame is None else len(d.frame)
+                last[0] = d.frame if d.frame is not None else last[0]
+        for d in stream.drain():
+            rows += 0 if d.frame is None else len(d.frame)
+            last[0] = d.frame if d.frame is not None else last[0]
+        ctx.sync()
+        return rows
+
+    with FrameStream(0.4, depth=1) as stream:
+        run(stream, 3)
+        t0 = time.perf_counter()
+        rows = run(stream, steps)
+        dt = time.perf_counter() - t0
+        redone = stream.units_redone
+    f = last[0]
+    masked = float((mask_t == 0).float().mean().item())
+    return {"workload": f"BASELINE config 5 stand-in: {S}x{S} uint16 pair, monitored image with a 30 m look (3x3 block mean, nearest x3), gamma 0.8, "
+                        "shift (0.4, -0.3) px, user mask, KLT + ZNCC on one GPU; inputs resident in HBM",
+            "value": S * S / 1e6 / (dt / steps), "unit": "Mpx/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "masked_fraction": round(masked, 4), "matched_keypoints_per_pair": rows // steps, "tiles_redone": redone,
+            "median_dx_dy": None if f is None or not len(f) else [float(np.median(f["dx"])), float(np.median(f["dy"]))]}
+
+
+# ---------------------------------------------------------------------------------------------------- roofline helpers
+def pmc_traffic(kernel: str, S: int) -> dict:
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: separate --pmc runs, gfx950
+    correction 2 * FETCH_SIZE + WRITE_SIZE).  PRECOMPUTED - measured with rocprofv3 on an earlier run of the same command, not by
+    this process - and labelled so."""
+    path = os.path.join(ROOT, PMC_FILE)
+    try:
+        db = json.load(open(path))
+    except Exception:
+        return {"traffic": None}
+    ent = db.get(kernel)
+    if not isinstance(ent, dict) or str(S) not in ent:
+        return {"traffic": None}
+    return {"traffic": ent[str(S)], "traffic_source": f"precomputed: {PMC_FILE}"
+            + (f" (measured at commit {ent['measured_at']})" if ent.get("measured_at") else " (round-1 counters)")}
+
+
+def roofline_of(stage_ms: dict, S: int, n_init: int, n_cand: int, n_zncc: int, timed_stage: str | None) -> dict:
+    """Every stage's bytes-it-must-move / span, and the object for the LARGEST one.  Dense stages: SURVEY 8(d)'s per-pixel figures;
+    the fused minimum-eigenvalue + candidate kernel is priced on what IT moves (source 1 B/px + mask 1 B/px + 8 B per emitted key) -
+    SURVEY's 10 B/px for the two unfused steps counts an eigenvalue-map round trip the fusion removed and is reported next to it as
+    `unfused_model`; LK 6272 B per corner, ZNCC 7396 B per scored row, corner ranking + selection 16 B per candidate."""
+    px = float(S) * S
+    model = {"minmax": STAGE_BYTES_PER_PX["minmax"] * px, "stretch_laplacian_mask": STAGE_BYTES_PER_PX["stretch_laplacian_mask"] * px,
+             "pyramid": STAGE_BYTES_PER_PX["pyramid"] * px, "lk_fwd_bwd": LK_BYTES_PER_POINT * n_init, "zncc": ZNCC_BYTES_PER_POINT * n_zncc}
+    fused = stage_ms.get("candidates", 0) == 0 and stage_ms.get("min_eigen", 0) > 0
+    eig_name = "min_eigen_candidates_fused" if fused else "min_eigen"
+    if fused:
+        model[eig_name] = FUSED_EIG_BYTES_PER_PX * px + 8.0 * n_cand
+    else:
+        model["min_eigen"] = STAGE_BYTES_PER_PX["min_eigen"] * px
+        model["candidates"] = STAGE_BYTES_PER_PX["candidates"] * px
+    ms = dict(stage_ms)
+    if fused:
+        ms[eig_name] = ms.pop("min_eigen")
+        ms.pop("candidates", None)
+    if "sort" in ms or "select" in ms:
+        ms["rank_select"] = ms.pop("sort", 0.0) + ms.pop("select", 0.0)
+        model["rank_select"] = SELECT_BYTES_PER_CANDIDATE * n_cand
+    table = {}
+    for k, b in model.items():
+        t = ms.get(k, 0.0)
+        if t > 0 and b > 0:
+            table[k] = {"ms": round(t, 4), "bytes": b, "achieved": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    dom = max(table, key=lambda k: table[k]["ms"])
+    d = table[dom]
+    out = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+           **pmc_traffic(dom, S), "algorithmic_bytes_per_launch": d["bytes"], "kernel_ms": d["ms"],
+           "kernel_ms_source": ("HIP events over the timed steps" if dom == timed_stage else "HIP events over an untimed pass of the same loop")}
+    if fused and eig_name in table:
+        unf = (STAGE_BYTES_PER_PX["min_eigen"] + STAGE_BYTES_PER_PX["candidates"]) * px
+        e = table[eig_name]
+        e["unfused_model"] = {"bytes": unf, "achieved": unf / (e["ms"] * 1e-3) / 1e9, "frac": unf / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "SURVEY 8(d) P3 + P4 = 10 B/px: what the two unfused steps would move (eig map written and read back)"}
+    out["kernels"] = table
+    dense = [k for k in ("minmax", "stretch_laplacian_mask", eig_name, "candidates", "pyramid") if k in table]
+    db, dm = sum(table[k]["bytes"] for k in dense), sum(table[k]["ms"] for k in dense)
+    out["dense_path"] = {"bytes": db, "ms": dm, "achieved": db / (dm * 1e-3) / 1e9, "frac": db / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    tb, tm = sum(v["bytes"] for v in table.values()), sum(v["ms"] for v in table.values())
+    out["all_stages"] = {"bytes": tb, "ms_serial_sum": tm, "achieved": tb / (tm * 1e-3) / 1e9, "frac": tb / (tm * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
 
+    n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X: karios_amd has no CPU path")
+    share = a.share_gpu or os.environ.get("KARIOS_BENCH_SHARE_GPU") == "1"
+    if local_rank >= n_dev and not share:
+        print(f"bench.py: rank {rank} wants GPU {local_rank} but only {n_dev} are visible (--share-gpu: development runs on fewer GPUs)", file=sys.stderr)
+        sys.exit(3)
+    dev_index = local_rank % n_dev
+    backend = "gloo" if share else os.environ.get("KARIOS_BENCH_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: karios_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    coll_dev = dev if os.environ.get("KARIOS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    ranks_seen, devices = 1, [{"rank": 0, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)}]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl" on ROCm) in production; KARIOS_BENCH_BACKEND=gloo lets the multi-rank logic be exercised with several
-        # ranks sharing one GPU (development box) - the collectives then run on CPU tensors
-        backend = os.environ.get("KARIOS_BENCH_BACKEND", "nccl")
+        # RCCL ("nccl" on ROCm) in production; gloo lets the multi-rank logic be exercised with several ranks sharing one GPU
+        # (development box) - the collectives then run on CPU tensors
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        one = torch.ones(1, device=coll_dev, dtype=torch.int64)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        mine = torch.tensor([rank, dev_index], device=coll_dev, dtype=torch.int64)
+        allr = torch.empty(2 * world, device=coll_dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(allr, mine)
+        devices = [{"rank": int(r), "device": int(d)} for r, d in allr.view(world, 2).tolist()]
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: the all-reduce saw {ranks_seen} ranks, expected {world}")
 
     from karios_amd import synth
     from karios_amd._lib import Context
     from karios_amd.core import KLTConfiguration
     from karios_amd.parallel import gather_rank_blocks
     from karios_amd.resident import ResidentPair
+    from karios_amd.stream import FrameStream
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
+    S = a.size
     if a.config == 3:
         if world > 1:
             raise SystemExit("config 3 (a global 2-D FFT) does not shard: replicas only, run it with --gpus 1")
-        print(json.dumps(config3_line(a, ctx, dev)))
+        o = config3_object(ctx, dev, S, a.steps, a.warmup)
+        line = {"metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, large-shift pre-alignment + KLT",
+                "value": o["value"], "unit": "Mpx/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": o["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": o["dtype"], "data": "synthetic",
+                "config": {"workload": o["workload"], "pairs_per_step": 1}, "cpu_baseline": None}
+        line.update({k: v for k, v in o.items() if k not in ("value", "unit", "steps", "ms_per_step", "dtype", "workload")})
+        print(json.dumps(line))
         return
 
-    S = a.size
     conf = KLTConfiguration()  # processing_configuration.json defaults: one tile, k=7, maxCorners 20000
     t_gen = time.perf_counter()
     mon_t, ref_t = synth.make_pair_torch(S, S, 0.5, 0.25, seed=20260101 + 10 * rank, device=dev)
@@ -476,51 +694,29 @@ def main():
     t_gen = time.perf_counter() - t_gen
     pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
 
-    # One step = one band pair through the whole hot path.  The main thread SUBMITS the pair (km_klt_tile_frame_submit: the
-    # call returns when the pair's last kernel and the copy of its frame block are enqueued, so the next pair's dense
-    # stages queue right behind them); a worker thread waits for the block and runs the host half (frame block -> pandas
-    # DataFrame + radial error / angle columns, numpy as in the reference) while the device already works on the next
-    # pair (ctypes releases the GIL inside the library).  Every frame is complete before the closing fence, so K timed
-    # steps are K finished pairs.
-    from concurrent.futures import ThreadPoolExecutor
-    # the submitting thread now spends ~0.1 ms per pair inside the library (no host synchronisation in the corner path) and the
-    # rest in Python next to the worker: with CPython's default 5 ms switch interval a thread that needs the GIL can wait that
-    # long for the other to yield it
-    sys.setswitchinterval(1e-4)
-    pool = ThreadPoolExecutor(max_workers=1)
+    # One step = one band pair through the whole hot path, driven by the product's FrameStream: the main thread SUBMITS the pair
+    # (km_klt_tile_frame_submit returns when the pair's last kernel and the copy of its frame block are enqueued, so the next
+    # pair's dense stages queue right behind them); the stream's worker thread waits for the block and runs the host half (frame
+    # block -> pandas DataFrame + radial error / angle columns, numpy as in the reference) while the device already works on the
+    # next pair.  Every frame is complete before the closing fence, so K timed steps are K finished pairs.
     stage_sum = {}
-    totals = {"rows": 0, "frames": 0, "n_init": 0}
+    totals = {"rows": 0, "frames": 0, "n_init": 0, "redone": 0, "last": None}
 
-    def host_half(pend):
-        raw = pend.wait()
-        spans = pend.stage_ms()
-        frame = None if raw.flags else raw.to_frame(radial=True)       # (radial error / angle built with the frame: one DataFrame construction)
-        return pend, raw, spans, (None if frame is None else pair.score_frame(frame, 0.4))
-
-    def collect(pending):
-        """Result of an earlier step: its frame, and - the path's only exchange step - the all-gather of every rank's
-        key-point block (device pipeline layout) over RCCL; the gathered blocks stay in HBM."""
-        pend, raw, spans, frame = pending.result()
-        if raw.flags:                       # the tile did not fit the synchronisation-free corner path: exact repeat (counted in the step)
-            totals["redone"] = totals.get("redone", 0) + 1
-            raw = pend.redo()
-            frame = raw.to_frame()
-            frame = None if frame is None else pair.score_frame(frame, 0.4)
-        n_rows = raw.n_rows
-        if world > 1:
-            _, n_rows = gather_rank_blocks(raw.block, conf.maxCorners, True, device=coll_dev)
-        totals["rows"] += n_rows
-        totals["frames"] += 1
-        totals["n_init"] = int(raw.block[:4].view(np.int32)[1])
-        totals["n_candidates"] = raw.n_candidates
-        for k, v in spans.items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-        return frame
-
-    def step(pending):
-        nxt = pool.submit(host_half, pair.submit_tile(conf, zncc_threshold=0.4))
-        frame = collect(pending) if pending is not None else None
-        return nxt, frame
+    def take(results):
+        """Finished steps: their frames, and - the path's only exchange step - the all-gather of every rank's key-point block
+        (device pipeline layout) over RCCL; the gathered blocks stay in HBM."""
+        for d in results:
+            n_rows = d.raw.n_rows
+            if world > 1:
+                _, n_rows = gather_rank_blocks(d.raw.block, conf.maxCorners, True, device=coll_dev)
+            totals["rows"] += n_rows
+            totals["frames"] += 1
+            totals["n_init"] = int(d.raw.block[:4].view(np.int32)[1])
+            totals["n_candidates"] = d.raw.n_candidates
+            totals["redone"] += int(d.redone)
+            totals["last"] = d.frame
+            for k, v in d.spans.items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
 
     def fence():
         ctx.sync()
@@ -529,45 +725,51 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    pending = None
+    stream = FrameStream(0.4, depth=1, want_spans=True)
     for _ in range(a.warmup):
-        pending, _ = step(pending)
-    if pending is not None:
-        collect(pending)
-        pending = None
-    # HIP events on the library stream bracket ONE stage inside the timed region - the dominant dense kernel the roofline is
-    # quoted on (the fused minimum-eigenvalue + candidate pass, stage "min_eigen"): a timed span is two event records, i.e. two
-    # points where consecutive kernels may not overlap, and timing all ten stages costs ~0.07 ms per pair.  The full stage
-    # table comes from a second, untimed pass of the same loop right after.
-    eig_stage = [ctx.lib.km_stage_name(i).decode() for i in range(16)].index("min_eigen")
-    ctx.set_option("profile_stage", eig_stage)
+        take(stream.submit(pair, conf))
+    take(stream.drain())
+    # HIP events on the library stream bracket ONE stage inside the timed region - the one the roofline is quoted on: a timed span
+    # is two event records, i.e. two points where consecutive kernels may not overlap, and timing all ten stages costs ~0.07 ms
+    # per pair.  The stage is the largest of the warm-up's full table; the full stage table of the line comes from a second,
+    # untimed pass of the same loop right after.
+    stage_names = [ctx.lib.km_stage_name(i).decode() for i in range(16)]
+    ctx.set_option("profile_stage", -1)
     ctx.set_profiling(True)
     stage_sum.clear()
-    totals.update(rows=0, frames=0)
+    for _ in range(3):
+        take(stream.submit(pair, conf))
+    take(stream.drain())
+    fence()
+    probe = {k: v for k, v in stage_sum.items() if k in ("stretch_laplacian_mask", "min_eigen", "lk_fwd_bwd") and v > 0}
+    timed_stage = max(probe, key=probe.get) if probe else "min_eigen"
+    ctx.set_option("profile_stage", stage_names.index(timed_stage))
+    stage_sum.clear()
+    totals.update(rows=0, frames=0, redone=0)
     fence()
     t0 = time.perf_counter()
-    frame = None
     for _ in range(a.steps):
-        pending, _ = step(pending)
-    frame = collect(pending)          # the last pair's frame: part of the timed region
+        take(stream.submit(pair, conf))
+    take(stream.drain())              # the last pair's frame: part of the timed region
     fence()
     dt = time.perf_counter() - t0
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"]
-    last_frame = frame                # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
-    timed_eig_ms = stage_sum.get("min_eigen", 0.0) / a.steps
+    frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
+    timed_ms = stage_sum.get(timed_stage, 0.0) / a.steps
+    redone_timed = totals["redone"]
     # untimed pass: every stage bracketed
     ctx.set_option("profile_stage", -1)
     stage_steps = max(3, min(a.steps, 12))
     stage_sum.clear()
     keep = dict(totals)
-    pending = None
     for _ in range(stage_steps):
-        pending, _ = step(pending)
-    collect(pending)
+        take(stream.submit(pair, conf))
+    take(stream.drain())
     fence()
     totals.update(keep)
     ctx.set_profiling(False)
+    stream.close()
     if world > 1:
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -580,29 +782,11 @@ def main():
     out = None
     if rank == 0:
         stage_ms = {k: v / stage_steps for k, v in stage_sum.items()}
-        if timed_eig_ms > 0:
-            stage_ms["min_eigen"] = timed_eig_ms      # the roofline kernel: its average over the TIMED region
-        bytes_per_px = dict(STAGE_BYTES_PER_PX)
-        if stage_ms.get("candidates", 0) == 0 and stage_ms.get("min_eigen", 0) > 0:
-            # default path: K3 + K4 fused in ONE kernel (no eig map) timed under "min_eigen"; the yardstick stays the
-            # algorithmic figure of SURVEY 8(d) for the two steps it performs (P3 5 B/px + P4 5 B/px)
-            bytes_per_px["min_eigen_candidates_fused"] = bytes_per_px.pop("min_eigen") + bytes_per_px.pop("candidates")
-            stage_ms["min_eigen_candidates_fused"] = stage_ms.pop("min_eigen")
-            stage_ms.pop("candidates", None)
-        dense = {k: stage_ms[k] for k in bytes_per_px if stage_ms.get(k, 0) > 0}
-        dom = max(dense, key=dense.get)
-        # minmax runs as 2 launch pairs and the pyramid as 2 launches; the stage span is the unit that is timed
-        algo_bytes = bytes_per_px[dom] * S * S
-        achieved = algo_bytes / (dense[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dom, {}).get(str(S))
-            except Exception:
-                traffic = None
-        dense_ms = sum(dense.values())
-        dense_bytes = sum(bytes_per_px[k] for k in dense) * S * S
+        if timed_ms > 0:
+            stage_ms[timed_stage] = timed_ms      # the roofline kernel: its average over the TIMED region
+        n_cand = int(totals.get("n_candidates", 0) or stats.n_candidates)
+        n_zncc = 0 if frame is None else int((frame["score"].to_numpy() >= 0.4).sum())
+        roof = roofline_of(stage_ms, S, int(stats.n_init), n_cand, n_zncc, "min_eigen_candidates_fused" if timed_stage == "min_eigen" else timed_stage)
         out = {
             "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, KLT + ZNCC",
             "value": mpx_per_s, "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -610,47 +794,52 @@ def main():
             "dtype": "u8/int32 stencils, f32 LK solve, f64 stretch+ZNCC", "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: synthetic Sentinel-2 10 m band pair {S}x{S} uint16, shift (0.5, 0.25) px, "
                                    "KLT only (Laplacian k=7, maxCorners 20000, one tile), ZNCC of rows with score>=0.4, "
-                                   "inputs resident in HBM; host DataFrame stage of pair i overlaps the device stage of pair i+1", "pairs_per_step": world,
+                                   "inputs resident in HBM; host DataFrame stage of pair i overlaps the device stage of pair i+1 "
+                                   "(karios_amd.stream.FrameStream, depth 1)", "pairs_per_step": world,
                        "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
+            "world": world, "launcher": os.environ.get("KARIOS_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "single process"),
+            "backend": (backend if world > 1 else None), "rccl_ranks_seen": ranks_seen, "devices": devices,
             "matched_keypoints_per_sec": n_kp_total / dt,
             "matched_keypoints_per_pair": (0 if frame is None else len(frame)),
-            "n_init": int(stats.n_init), "n_candidates": int(totals.get("n_candidates", 0) or stats.n_candidates),
-            "speculative_tiles_redone": int(totals.get("redone", 0)),
+            "n_init": int(stats.n_init), "n_candidates": n_cand,
+            "speculative_tiles_redone": int(redone_timed),
             "median_dx_dy": (None if frame is None else [float(np.median(frame["dx"])), float(np.median(frame["dy"]))]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_note": f"min_eigen(_candidates_fused): HIP events over the {a.steps} timed steps; the other stages: an untimed pass of "
+            "stage_ms_note": f"{timed_stage}: HIP events over the {a.steps} timed steps; the other stages: an untimed pass of "
                              f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": dense[dom],
-                         "dense_path": {"bytes": dense_bytes, "ms": dense_ms, "achieved": dense_bytes / (dense_ms * 1e-3) / 1e9,
-                                        "frac": dense_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "roofline": roof,
             "synth_seconds": round(t_gen, 2),
         }
-        sens = os.path.join(ROOT, "profiles", "r02_oracle_sensitivity.json")
+        sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):
             try:
-                out["oracle_sensitivity"] = json.load(open(sens))
+                out["oracle_sensitivity"] = dict(json.load(open(sens)), source=f"precomputed: {SENS_FILE} (tools/oracle_sensitivity.py, round 2; "
+                                                 "its `seconds` are that tool's run time, not this process's)")
             except Exception:
                 pass
-    pool.shutdown()
 
+    solo = rank == 0 and world == 1
     host_pair = None
-    if rank == 0 and world == 1 and not (a.no_cpu_baseline and a.no_end_to_end):
+    if solo and not (a.no_cpu_baseline and a.no_end_to_end):
         host_pair = (mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16))
     del pair
-    if rank == 0 and world == 1 and not a.no_end_to_end:
+    if solo and not a.no_end_to_end:
         out["end_to_end"] = end_to_end(host_pair[0], host_pair[1], ctx, max(4, min(12, a.steps)))
+    if solo and not a.no_in_flight:
+        out["in_flight"] = in_flight(dev, conf, S, (mon_t, ref_t))
     del mon_t, ref_t
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and a.in_flight:
-        out["in_flight"] = in_flight(dev, conf, S)
+    if solo and not a.no_config3:
+        out["config3"] = config3_object(ctx, dev, S, max(3, min(6, a.steps // 3)), 2)
+        torch.cuda.empty_cache()
+    if solo and not a.no_config5 and hasattr(synth, "make_cross_sensor_pair_torch"):
+        out["config5"] = config5_object(ctx, dev, S, max(4, min(10, a.steps // 2)))
         torch.cuda.empty_cache()
     if not a.no_config4 and S == 10980:
-        c4 = config4(ctx, dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)))
+        c4 = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)))
         if rank == 0:
             out["config4"] = c4
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
+    if solo and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
         cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs, gpu_frame=last_frame)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]

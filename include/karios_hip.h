@@ -130,7 +130,7 @@ int km_d2h(km_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 /* Page-locked host memory for image buffers that GDAL (or numpy) fills and the GPU fetches: an upload from such a buffer
  * runs at full PCIe rate and asynchronously (a pageable source is staged chunk by chunk and blocks the caller). */
 int km_host_alloc(km_ctx *ctx, size_t bytes, void **hptr);
-int km_host_free(km_ctx *ctx, void *hptr);
+int km_host_free(km_ctx *ctx /* may be NULL: the block outlived its context */, void *hptr);
 /* Asynchronous strided upload on the context's COPY stream: `rows` rows of `width_bytes` bytes, pitches in bytes.  Returns
  * at once when `src_host` is page-locked; every later call on the context that launches kernels waits (on the device, not
  * on the host) for the uploads queued so far, so pair / tile i+1 can travel while pair / tile i computes.  The caller keeps

@@ -206,6 +206,7 @@ class Context:
             raise KariosHipError(f"km_ctx_create(device={device}) failed ({rc}): {msg.decode() if msg else ''}")
         self.handle = h
         self.device = device
+        self._alive = [True]      # shared with the finalizers of this context's page-locked arrays (`pinned_empty`)
 
     # ---- device buffers are recycled: a tile loop would otherwise pay a hipMalloc / hipFree pair (and their implicit device
     # synchronisations) per image and tile
@@ -253,6 +254,10 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            # page-locked arrays that outlive the context are released without it (km_host_free(NULL, p)); the staging area the
+            # context itself owns goes first, while its streams still exist
+            self.__dict__.pop("_kp_staging", None)
+            self._alive[0] = False
             self.trim_pool()
             self.lib.km_ctx_destroy(self.handle)
             self.handle = None
@@ -308,7 +313,10 @@ def pinned_empty(shape, dtype, ctx: "Context | None" = None) -> np.ndarray:
     p = C.c_void_p()
     ctx.check(ctx.lib.km_host_alloc(ctx.handle, max(n, 1), C.byref(p)), "km_host_alloc")
     raw = (C.c_char * max(n, 1)).from_address(p.value)
-    weakref.finalize(raw, lambda lib=ctx.lib, h=ctx.handle, q=p.value: lib.km_host_free(h, C.c_void_p(q)))
+    # the finalizer may run after the context is gone (interpreter shutdown, an explicit close()): then the block is released
+    # without touching the destroyed context
+    weakref.finalize(raw, lambda lib=ctx.lib, h=ctx.handle, alive=ctx._alive, q=p.value:
+                     lib.km_host_free(h if alive[0] else None, C.c_void_p(q)))
     return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 

@@ -267,7 +267,10 @@ int km_host_alloc(km_ctx *c, size_t bytes, void **hptr)
 }
 int km_host_free(km_ctx *c, void *hptr)
 {
-    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    // The block may outlive the context it was allocated through (a numpy array over it is released by the garbage
+    // collector): with a null context hipHostFree alone decides - it waits for the copies that still read the block.
+    if (!hptr) return KM_OK;
+    if (!c) return hipHostFree(hptr) == hipSuccess ? KM_OK : KM_E_HIP;
     if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
     KM_HIP(c, hipHostFree(hptr));
     return KM_OK;
@@ -1640,9 +1643,11 @@ int km_band_track_dev(km_ctx *c, const uint8_t *d_lap_ref, const uint8_t *d_lap_
             off += ((size_t)wf[l] * hr[l] + 255) & ~(size_t)255;
         }
     }
+    int trim[5] = {0};   // rows of level l next to an artificial band edge that the 5-tap pyrDown computed from mirrored (not the image's) rows:
+    for (int l = 1; l <= levels; l++) trim[l] = (trim[l - 1] + 2 + 1) / 2;   // output row r reads rows 2r-2 .. 2r+2: trim_l = ceil((trim_{l-1} + 2) / 2) = 1, 2, 2, 2
     for (int l = 0; l <= levels; l++) {
-        // rows of level l computed from rows that an artificial band edge mirrored are not the image's: they are declared absent
-        const int o = oy >> l, trim_top = (l > 0 && oy > 0) ? 1 : 0, trim_bot = (l > 0 && oy + H < H_image) ? 1 : 0;
+        // ... they are declared absent
+        const int o = oy >> l, trim_top = oy > 0 ? trim[l] : 0, trim_bot = oy + H < H_image ? trim[l] : 0;
         A.H[l] = B.H[l] = hf[l]; A.W[l] = B.W[l] = wf[l];
         A.oy[l] = B.oy[l] = o + trim_top;
         A.Hres[l] = B.Hres[l] = hr[l] - trim_top - trim_bot;

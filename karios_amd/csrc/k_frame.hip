@@ -110,7 +110,7 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long lon
     // 1. histogram of the buckets
 #pragma unroll
     for (int u = 0; u < RPT; u++)
-        if (u * FBP_T + tid < m) atomicAdd(&cnt[(unsigned)(k[u] >> 32) >> shift], 1u);
+        if (u * FBP_T + tid < m) atomicAdd(&cnt[min((unsigned)(k[u] >> 32) >> shift, (unsigned)nbins - 1u)], 1u);   // (clamped: a monotonic bucket map keeps the order exact for any column)
     __syncthreads();
     // 2. exclusive scan: every thread owns a run of consecutive buckets
     const int per = (nbins + FBP_T - 1) / FBP_T, b0 = min(tid * per, nbins), b1 = min(b0 + per, nbins);
@@ -130,12 +130,12 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long lon
 #pragma unroll
     for (int u = 0; u < RPT; u++) {
         const int r = u * FBP_T + tid;
-        if (r < m) items[atomicAdd(&cnt[(unsigned)(k[u] >> 32) >> shift], 1u)] = (unsigned short)r;
+        if (r < m) items[atomicAdd(&cnt[min((unsigned)(k[u] >> 32) >> shift, (unsigned)nbins - 1u)], 1u)] = (unsigned short)r;
     }
     __syncthreads();
     // 4. rank inside the bucket, write the row to its place
     if (mine_r < r1) {
-        const unsigned b = (unsigned)(my_key >> 32) >> shift;
+        const unsigned b = min((unsigned)(my_key >> 32) >> shift, (unsigned)nbins - 1u);
         const unsigned lo = start[b], hi = start[b + 1];
         unsigned pos = lo;
         for (unsigned t = lo; t < hi; t++) {
@@ -154,6 +154,10 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
              float x_off, float y_off, void *d_out)
 {
     if (cap <= 0 || n_max <= 0) return km_fail(c, KM_E_ARG, "frame: empty capacity");
+    // the tile origin is added to the corner coordinates and the sum becomes the (x0, y0) ordering key: a pair of non-negative
+    // integers.  The reference's origins are tile offsets (klt.py:341-342); anything else is refused instead of mis-ordered.
+    if (!(x_off >= 0.f && x_off <= 1073741824.f && y_off >= 0.f && y_off <= 1073741824.f))
+        return km_fail(c, KM_E_ARG, "frame: tile origin (%g, %g) must be finite and within [0, 2^30]", (double)x_off, (double)y_off);
     int *hdr = (int *)d_out;
     float *out = (float *)((char *)d_out + 16);
     unsigned long long *keys = (unsigned long long *)km_ws(c, WS_MISC0, (size_t)cap * 2 * sizeof(unsigned long long));

@@ -153,6 +153,15 @@ class ResidentPair:
         self._out = None
         self._host_frame = None
 
+    def __del__(self):
+        # a pair that was uploaded (e.g. prefetched) but never used still holds an upload ticket: give its slot and event back
+        try:
+            t = self.__dict__.pop("_upload_ticket", -1)
+            if t >= 0 and getattr(self.ctx, "handle", None):
+                self.ctx.lib.km_upload_join(self.ctx.handle, t)
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
     @classmethod
     def upload(cls, mon: np.ndarray, ref: np.ndarray, mask: np.ndarray | None = None, ctx: Context | None = None,
                no_data_mon=None, no_data_ref=None) -> "ResidentPair":
@@ -431,39 +440,23 @@ class ResidentPair:
         return PendingFrame(c, ticket.value, cap, with_zncc, redo=exact)
 
     def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
-        """`match` as a pipeline: tile i+1 is submitted to the device (`submit_tile`) while a worker thread waits for tile i
-        and builds its DataFrame.  `host_stage(frame)` (e.g. `score_frame`) runs on the CALLING thread when the frame is
-        collected: a context is not thread-safe, and a stage that calls back into the library (ZNCC / MI of rows the device
-        call did not score) must not run beside `submit_tile`.  Yields the frames in tile order, like `KLT.match`."""
-        from concurrent.futures import ThreadPoolExecutor
+        """`match` as a pipeline (`karios_amd.stream.FrameStream`): tile i+1 is submitted to the device (`submit_tile`) while a
+        worker thread waits for tile i and builds its DataFrame.  `host_stage(frame)` (e.g. `score_frame`) runs on the CALLING
+        thread when the frame is collected: a context is not thread-safe, and a stage that calls back into the library (ZNCC /
+        MI of rows the device call did not score) must not run beside `submit_tile`.  Yields the frames in tile order, like
+        `KLT.match`."""
+        from .stream import FrameStream
         if boxes is None:
             boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
-
-        def host_half(pend):     # touches the frame slot only (km_frame_wait) + numpy / pandas
-            raw = pend.wait() if isinstance(pend, PendingFrame) else pend
-            return pend, (None if raw.flags else raw.to_frame())
-
-        def collect(future):
-            pend, frame = future.result()
-            if isinstance(pend, PendingFrame) and pend.wait().flags:     # did not fit the synchronisation-free corner path: exact repeat, here
-                frame = pend.redo().to_frame()
-            return host_stage(frame) if frame is not None and host_stage is not None else frame
-
-        # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
-        submit = self.submit_tile if conf.maxCorners > 0 else self.match_tile_raw
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = None
+        stage = None if host_stage is None else (lambda frame, _pair: host_stage(frame))
+        with FrameStream(zncc_threshold, depth=1, host_stage=stage, score_columns=False) as stream:
             for box in boxes:
-                nxt = pool.submit(host_half, submit(conf, box, zncc_threshold))   # (match_tile_raw repeats a flagged tile itself)
-                if pending is not None:
-                    frame = collect(pending)
-                    if frame is not None:
-                        yield frame
-                pending = nxt
-            if pending is not None:
-                frame = collect(pending)
-                if frame is not None:
-                    yield frame
+                for done in stream.submit(self, conf, box):
+                    if done.frame is not None:
+                        yield done.frame
+            for done in stream.drain():
+                if done.frame is not None:
+                    yield done.frame
 
     _frame_from_block = staticmethod(frames.block_to_frame)
 
@@ -600,7 +593,14 @@ def _identity(arr: np.ndarray) -> tuple:
 def shared_pair(mon: np.ndarray, ref: np.ndarray, ctx: Context | None = None, publish: "ResidentPair | None" = None) -> "ResidentPair":
     """The resident copy of (mon, ref) on `ctx`: a pair published earlier for the same two host arrays (e.g. by `KLT.match` for
     a tile that covers the whole image), else a fresh upload that is remembered for the next service.  `publish` registers
-    an existing pair instead of looking one up."""
+    an existing pair instead of looking one up.
+
+    Contract: between the call that published a pair and the last service that looks it up the two host arrays must not be
+    modified in place - the fingerprint samples ~4 000 pixels per image, an edit that misses all of them would be scored
+    against the stale resident copy.  The reference's flow satisfies it (the rasters are read once, `core.py:845-907`, and
+    `clear_cache()` after scoring drops them); a caller that does edit in place calls `forget_shared_pairs()` first.  Likewise
+    an upload from page-locked memory is asynchronous: the source must stay untouched until the pair's first device call
+    (`ResidentPair._ready`) or `Context.sync()`."""
     ctx = ctx if ctx is not None else default_context()
     key = (id(ctx), _identity(mon), _identity(ref))
     if publish is None:

@@ -1,0 +1,130 @@
+"""Pipelined matching of a stream of tiles / band pairs: the device half of tile i+1 runs while a worker thread turns the
+finished block of tile i into its DataFrame.
+
+`KariosAPI._compute_matches` (reference `karios/api/core.py:845-921`) consumes `KLT.match` one frame at a time and post-processes
+each (`_handle_klt_results`: radial error, angle, ZNCC of the confident rows) before asking for the next; the device would idle
+during that host work.  `FrameStream` is the product-side form of that loop: the caller SUBMITS work units (any `ResidentPair`,
+any box, on any number of library contexts) and receives finished, scored frames in submission order.  Everything timing-
+related lives here - the bounded number of units in flight, the worker thread, the interpreter's switch interval while the
+stream is open, the exact repeat of a unit the synchronisation-free corner path flagged - so that `bench.py`, `KLT.match`
+callers and `ResidentPair.match_pipelined` share one implementation.
+"""
+from __future__ import annotations
+
+import sys
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+
+from pandas import DataFrame
+
+from .resident import PendingFrame, RawFrame, ResidentPair
+
+
+@dataclass
+class StreamResult:
+    """One finished work unit."""
+    frame: DataFrame | None      # None: no valid pixel / no corner in the unit (the reference yields nothing for such a tile)
+    raw: RawFrame                # the unit's frame block (the unit of the multi-GPU gather)
+    tag: object = None           # whatever the caller passed to `submit`
+    redone: bool = False         # the unit was repeated through the exact corner path
+    spans: dict = field(default_factory=dict)   # stage -> ms (only with `Context.set_profiling(True)` and `want_spans`)
+
+
+class FrameStream:
+    """`with FrameStream(confidence_threshold=0.4) as s: for ...: done += s.submit(pair, conf)`; `done += s.drain()`.
+
+    depth               units still pending when `submit` returns (1: classic two-stage pipeline - the host half of unit i runs
+                        beside the device half of unit i+1; 0: synchronous; 2 x contexts when the pairs sit on several contexts
+                        of one GPU - a context holds at most three frames in flight)
+    confidence_threshold  rows with score >= threshold get their ZNCC in the SAME device call (`zncc_score` column); None: bare frames
+    score_columns       the frame also carries the `radial error` / `angle` columns of `_handle_klt_results` (core.py:872-893);
+                        default: whenever a threshold is given
+    host_stage          optional callable(frame, pair) -> frame run on the CALLING thread when a frame is collected (a stage that
+                        calls back into the library - mutual information, ZNCC of rows the device did not score - must not run
+                        beside `submit`: a context is not thread-safe)
+    gil_switch_interval the submitting thread spends ~0.1 ms per unit inside the library and the rest in Python next to the worker;
+                        with CPython's default 5 ms switch interval a thread that needs the GIL can wait that long for the other to
+                        yield it.  The stream lowers the interval while it is open and restores it on close; None leaves it alone.
+    """
+
+    def __init__(self, confidence_threshold: float | None = None, depth: int = 1, host_stage=None, want_spans: bool = False,
+                 gil_switch_interval: float | None = 1e-4, score_columns: bool | None = None):
+        self.threshold, self.depth, self.host_stage, self.want_spans = confidence_threshold, max(0, int(depth)), host_stage, want_spans
+        self.score_columns = (confidence_threshold is not None) if score_columns is None else bool(score_columns)
+        self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="karios-frame")
+        self._pending: deque = deque()
+        self._old_interval = None
+        if gil_switch_interval is not None:
+            self._old_interval = sys.getswitchinterval()
+            sys.setswitchinterval(gil_switch_interval)
+        self.units_redone = 0
+
+    # ------------------------------------------------------------------ context manager
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        if self._old_interval is not None:
+            sys.setswitchinterval(self._old_interval)
+            self._old_interval = None
+
+    # ------------------------------------------------------------------ the two halves
+    def _host_half(self, pair: ResidentPair, pend):
+        """Worker thread: touches the frame slot (km_frame_wait) and numpy / pandas only."""
+        raw = pend.wait() if isinstance(pend, PendingFrame) else pend
+        spans = pend.stage_ms() if self.want_spans and isinstance(pend, PendingFrame) else {}
+        frame = None
+        if not raw.flags:
+            frame = raw.to_frame(radial=self.score_columns)
+            if frame is not None and self.score_columns and raw.with_zncc:
+                frame = pair.score_frame(frame, self.threshold)     # every column is in place: pure numpy, no library call
+        return raw, spans, frame
+
+    def _collect(self, item) -> StreamResult:
+        pair, pend, tag, fut = item
+        raw, spans, frame = fut.result()
+        redone = False
+        if raw.flags:                      # did not fit the fixed capacities of the synchronisation-free corner path: exact repeat, here
+            raw = pend.redo()
+            frame = raw.to_frame(radial=self.score_columns)
+            if frame is not None and self.score_columns and self.threshold is not None:
+                frame = pair.score_frame(frame, self.threshold)
+            redone = True
+            self.units_redone += 1
+        if frame is not None and self.host_stage is not None:
+            frame = self.host_stage(frame, pair)
+        return StreamResult(frame, raw, tag, redone, spans)
+
+    # ------------------------------------------------------------------ API
+    def submit(self, pair: ResidentPair, conf, box=None, origin=None, tag=None) -> list[StreamResult]:
+        """Queue one unit on `pair`'s context; returns the units collected to keep at most `depth` pending (oldest first -
+        possibly none)."""
+        if self._pool is None:
+            raise RuntimeError("FrameStream is closed")
+        # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
+        if conf.maxCorners > 0:
+            pend = pair.submit_tile(conf, box, self.threshold, origin)
+        else:
+            pend = pair.match_tile_raw(conf, box, self.threshold, origin)    # (blocking; repeats a flagged tile itself)
+        self._pending.append((pair, pend, tag, self._pool.submit(self._host_half, pair, pend)))
+        out = []
+        while len(self._pending) > self.depth:
+            out.append(self._collect(self._pending.popleft()))
+        return out
+
+    def drain(self) -> list[StreamResult]:
+        out = []
+        while self._pending:
+            out.append(self._collect(self._pending.popleft()))
+        return out
+
+
+__all__ = ["FrameStream", "StreamResult"]

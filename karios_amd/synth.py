@@ -113,12 +113,8 @@ def make_cross_sensor_pair(H: int, W: int, sx: float = 0.4, sy: float = -0.3, se
     return mon, ref, mask
 
 
-def make_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int = 20260101, noise_sigma: float = 15.0,
-                    device="cuda"):
-    """GPU version of `make_pair` for full-size bench inputs (same construction -- three box-blurred
-    noise scales, bilinear sub-pixel shift, additive noise, uint16 quantisation -- generated by torch on
-    the device; NOT bit-identical to the numpy generator, which the parity tests use).
-    -> (mon, ref) int16-storage torch tensors holding uint16 bit patterns, dense (H, W)."""
+def _base_torch(H: int, W: int, seed: int, device):
+    """Device version of `make_base`: float32 texture field of shape (H + 2 PAD, W + 2 PAD)."""
     import torch
 
     g = torch.Generator(device=device)
@@ -156,11 +152,15 @@ def make_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int
         base += gain * t
         del t
     del n
+    return base
 
-    def quant(a):
-        return torch.clamp(torch.round(a), 1, 16000).to(torch.int32).to(torch.int16)  # values < 32768: same bits as uint16
 
-    ref = quant(base[PAD:PAD + H, PAD:PAD + W]).contiguous()
+def _quant_torch(a):
+    import torch
+    return torch.clamp(torch.round(a), 1, 16000).to(torch.int32).to(torch.int16)  # values < 32768: same bits as uint16
+
+
+def _sample_shifted_torch(base, H: int, W: int, sx: float, sy: float):
     fy, fx = PAD - sy, PAD - sx
     iy, ix = int(np.floor(fy)), int(np.floor(fx))
     ay, ax = float(fy - iy), float(fx - ix)
@@ -168,10 +168,48 @@ def make_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int
     b01 = base[iy:iy + H, ix + 1:ix + W + 1]
     b10 = base[iy + 1:iy + H + 1, ix:ix + W]
     b11 = base[iy + 1:iy + H + 1, ix + 1:ix + W + 1]
-    mon_f = (1 - ay) * ((1 - ax) * b00 + ax * b01) + ay * ((1 - ax) * b10 + ax * b11)
+    return (1 - ay) * ((1 - ax) * b00 + ax * b01) + ay * ((1 - ax) * b10 + ax * b11)
+
+
+def make_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int = 20260101, noise_sigma: float = 15.0,
+                    device="cuda"):
+    """GPU version of `make_pair` for full-size bench inputs (same construction -- three box-blurred
+    noise scales, bilinear sub-pixel shift, additive noise, uint16 quantisation -- generated by torch on
+    the device; NOT bit-identical to the numpy generator, which the parity tests use).
+    -> (mon, ref) int16-storage torch tensors holding uint16 bit patterns, dense (H, W)."""
+    import torch
+
+    base = _base_torch(H, W, seed, device)
+    ref = _quant_torch(base[PAD:PAD + H, PAD:PAD + W]).contiguous()
+    mon_f = _sample_shifted_torch(base, H, W, sx, sy)
     if noise_sigma > 0:
         g2 = torch.Generator(device=device)
         g2.manual_seed(seed + 1)
         mon_f = mon_f + noise_sigma * torch.randn((H, W), generator=g2, device=device, dtype=torch.float32)
-    mon = quant(mon_f).contiguous()
+    mon = _quant_torch(mon_f).contiguous()
     return mon, ref
+
+
+def make_cross_sensor_pair_torch(H: int, W: int, sx: float = 0.4, sy: float = -0.3, seed: int = 20260101, device="cuda"):
+    """GPU version of `make_cross_sensor_pair` (BASELINE config 5 stand-in) for full-size bench inputs: the monitored image is the
+    shifted texture 3x3 block-averaged and nearest-upsampled x3 (a 30 m sensor on the 10 m grid) with gamma-0.8 radiometry; the
+    user mask zeroes ~20 % of the pixels in seeded random rectangles.  -> (mon, ref, mask): int16-storage uint16 bit patterns, uint8."""
+    import torch
+
+    base = _base_torch(H, W, seed, device)
+    ref = _quant_torch(base[PAD:PAD + H, PAD:PAD + W]).contiguous()
+    m = _sample_shifted_torch(base, H, W, sx, sy).contiguous()
+    del base
+    h3, w3 = (H // 3) * 3, (W // 3) * 3
+    blk = m[:h3, :w3].reshape(h3 // 3, 3, w3 // 3, 3).mean(dim=(1, 3))
+    m[:h3, :w3] = blk.repeat_interleave(3, dim=0).repeat_interleave(3, dim=1)
+    m = 16000.0 * torch.pow(torch.clamp(m, 1, 16000) / 16000.0, 0.8)
+    mon = _quant_torch(m).contiguous()
+    rng = np.random.default_rng(seed + 2)
+    mask = torch.ones((H, W), dtype=torch.uint8, device=device)
+    target = 0.2 * H * W
+    while int((mask == 0).sum().item()) < target:
+        h, w = rng.integers(H // 16 + 1, H // 4 + 2), rng.integers(W // 16 + 1, W // 4 + 2)
+        y, x = rng.integers(0, H), rng.integers(0, W)
+        mask[y:y + h, x:x + w] = 0
+    return mon, ref, mask

@@ -301,3 +301,79 @@ def test_block_to_frame_with_radial_columns_equals_the_two_step_construction():
     assert len(one_step) == rows and one_step.index.dtype == np.int64
     block[:2].view(np.int32)[:] = (0, 0)
     assert frames.block_to_frame(block, cap, True, radial=True) is None
+
+
+# ---------------------------------------------------------------------------- bench.py launcher
+def _run_bench(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_spawns_n_ranks_and_fails_when_a_rank_fails():
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks itself; without a GPU each of them refuses to run
+    (no CPU path) and the parent must report the failure with a non-zero status instead of printing a one-rank line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench.py")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""                                  # no JSON line from a failed job
+    assert r.stderr.count("needs an MI355X") == 2, r.stderr        # both ranks were started
+    assert "rank 0 exited with status" in r.stderr or "rank 1 exited with status" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
+
+
+# ---------------------------------------------------------------------------- FrameStream (host logic with a stand-in pair)
+class _FakePair:
+    """Duck type of ResidentPair for the stream's host logic: `match_tile_raw` hands back a finished block at once."""
+
+    def __init__(self, cap=8):
+        self.cap, self.calls, self.ctx = cap, [], None
+
+    def match_tile_raw(self, conf, box=None, zncc_threshold=None, origin=None):
+        from karios_amd.parallel import pack_frame
+        from karios_amd.resident import RawFrame
+        k = len(self.calls)
+        self.calls.append((box, zncc_threshold, origin))
+        n = 1 + k % 3
+        f = pd.DataFrame({c: np.full(n, float(k), np.float32) for c in ("x0", "y0", "dx", "dy", "score")})
+        f["zncc_score"] = np.linspace(0.0, 1.0, n)
+        return RawFrame(pack_frame(f, self.cap, zncc_threshold is not None), self.cap, zncc_threshold is not None)
+
+    def score_frame(self, frame, thr, mutual_info=False):
+        from karios_amd import frames
+        return frames.radial_angle_columns(frame)
+
+
+def test_frame_stream_orders_results_bounds_depth_and_restores_the_switch_interval():
+    from types import SimpleNamespace
+    from karios_amd.stream import FrameStream
+    conf = SimpleNamespace(maxCorners=0)
+    before = sys.getswitchinterval()
+    pair = _FakePair()
+    seen = []
+    with FrameStream(0.4, depth=2, host_stage=lambda f, p: f.assign(stage=1)) as s:
+        assert sys.getswitchinterval() == pytest.approx(1e-4)
+        got = []
+        for k in range(7):
+            done = s.submit(pair, conf, box=(k, 0, 1, 1), tag=k)
+            seen.append(len(done))
+            got += done
+        got += s.drain()
+    assert sys.getswitchinterval() == pytest.approx(before)
+    assert seen == [0, 0, 1, 1, 1, 1, 1]                              # two units stay pending behind each submission
+    assert [d.tag for d in got] == list(range(7))                     # submission order
+    assert [len(d.frame) for d in got] == [1 + k % 3 for k in range(7)]
+    assert all({"radial error", "angle", "zncc_score", "stage"} <= set(d.frame.columns) for d in got)
+    assert all(float(d.frame["x0"].iloc[0]) == d.tag and not d.redone for d in got)
+    with pytest.raises(RuntimeError):
+        s.submit(pair, conf)
+    # bare frames: no threshold -> no ZNCC call, no score columns
+    with FrameStream(None, depth=0, gil_switch_interval=None) as s0:
+        d = s0.submit(_FakePair(), conf)
+        assert len(d) == 1 and list(d[0].frame.columns) == ["x0", "y0", "dx", "dy", "score"]
