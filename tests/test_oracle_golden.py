@@ -317,3 +317,99 @@ def test_opencv_literal_second_opinion_stays_close(O):
     assert len(set(map(tuple, p0.reshape(-1, 2))) ^ set(map(tuple, p1.reshape(-1, 2)))) <= 4
     a, b = O.pyr_lk(lap_ref, lap_mon, p0), O.pyr_lk_cv(lap_ref, lap_mon, p0)
     assert np.abs(a - b).max() < 5e-3 and np.median(np.abs(a - b)) < 1e-5
+
+
+# ------------------------------------------------------------------ (c) what REAL OpenCV output confirms
+# The reference tree holds one genuine output of cv2 + the reference's glue: the golden CSV of its end-to-end test (inputs
+# stripped).  tests/golden/make_golden_csv_facts.py mines it in the build container; the facts below hold without the images.
+def _csv_facts():
+    import json
+    g = load("e2e_csv_facts.npz")
+    return json.loads(str(g["facts"])), g
+
+
+def test_real_opencv_min_distance_is_strict_and_grid_border_rule(O):
+    facts, _ = _csv_facts()
+    assert facts["corners_are_integers"] and facts["tile_sequence_in_file"] == [0, 1, 2, 3]        # tiles x-outer / y-inner (klt.py:220-232)
+    for t in facts["tiles"]:
+        assert t["rows"] <= facts["max_corners"] and t["sorted_by_x0_y0"]                           # per-tile maxCorners, (x0, y0) order (klt.py:348)
+        # goodFeaturesToTrack rejects a candidate only when dx^2 + dy^2 < minDistance^2: pairs at EXACTLY 10 px exist, none closer
+        assert t["nearest_neighbour_min"] == 10.0 and t["nearest_neighbour_below_min_distance"] == 0
+        assert t["nearest_neighbour_equal_min_distance"] > 0
+        assert t["smallest_distances"][:3] == pytest.approx([10.0, 101 ** 0.5, 104 ** 0.5])
+        # corners never sit on the 1-px border of their TILE (the detector runs per tile box), and reach right up to it
+        (w, h), (x_lo, x_hi), (y_lo, y_hi) = t["size"], t["local_x_range"], t["local_y_range"]
+        assert 1 <= x_lo and x_hi <= w - 2 and 1 <= y_lo and y_hi <= h - 2
+    full = facts["tiles"][0]
+    assert full["local_x_range"] == [1.0, 5998.0] and full["local_y_range"] == [1.0, 5998.0]
+    # the oracle's selection has exactly that rule: a peak 10 px from a stronger one survives, one at sqrt(98) px does not
+    eig = np.zeros((64, 64), np.float32)
+    eig[20, 20], eig[28, 26], eig[27, 27 + 20] = 3.0, 2.0, 1.0                 # (26,28) is exactly 10 px from (20,20); (47,27) is far
+    eig[27, 27] = 1.5                                                          # sqrt(98) px from (20,20), and < 10 px from (26,28)
+    got = O.select_corners(eig, None, 0, 0.01, 10).reshape(-1, 2).tolist()
+    assert got == [[20.0, 20.0], [26.0, 28.0], [47.0, 27.0]]
+
+
+def test_real_opencv_tracks_are_float32_in_tile_coordinates():
+    """dx = x1 - x0 and d = max|p0 - p0r| are float32 operations on TILE-LOCAL coordinates (the tile offset is added afterwards,
+    klt.py:341-342): x0_local + dx is exactly representable in float32 for every row, x0_global + dx is not; every score is
+    1 - d / float32(0.1) for a d on the float32 grid of the local coordinate - reproduced through karios_amd.frames."""
+    from karios_amd import frames
+    facts, g = _csv_facts()
+    x, y, dx, dy, score, tile = (g[k] for k in ("x0", "y0", "dx", "dy", "score", "tile"))
+    T = facts["tile_size"]
+    xl, yl = x - (tile // 2) * np.float32(T), y - (tile % 2) * np.float32(T)
+
+    def representable(a64):
+        return a64.astype(np.float32).astype(np.float64) == a64
+    assert representable(xl.astype(np.float64) + dx).all() and representable(yl.astype(np.float64) + dy).all()
+    off = tile >= 2
+    assert representable(x[off].astype(np.float64) + dx[off]).mean() < 0.5       # not so in image coordinates
+    # score lattice: search the float32 grid of the local coordinates for the forward-backward distance behind each score
+    limit = frames.FB_LIMIT
+    found = np.zeros(len(score), bool)
+    p0 = np.stack([xl, yl], 1)
+    p0r = p0.copy()
+    for axis, coord in enumerate((xl, yl)):
+        for fine in (1.0, 0.5):                                                # just below a power of two the grid is twice as fine
+            u = np.spacing(coord.astype(np.float32)).astype(np.float64) * fine
+            k0 = np.round((1.0 - score.astype(np.float64)) * 0.1 / u)
+            for dk in (-2, -1, 0, 1, 2):
+                back = (coord.astype(np.float64) + (k0 + dk) * u * (1 if fine == 1.0 else -1)).astype(np.float32)   # a return point on that grid
+                d = np.abs(coord - back)
+                hit = ((np.float32(1) - d / limit) == score) & (d < limit) & ~found
+                p0r[hit, axis], found = back[hit], found | hit
+    assert found.all()
+    # ... and the product's own track -> frame arithmetic returns the CSV's columns from such tracks
+    p1 = np.stack([xl + dx, yl + dy], 1).astype(np.float32)
+    cols, n = frames.track_columns(p0.reshape(-1, 1, 2), p1.reshape(-1, 1, 2), p0r.reshape(-1, 1, 2))
+    assert n == len(score) and len(cols["score"]) == len(score)                 # all pass the FB test (they are in the CSV)
+    np.testing.assert_array_equal(cols["score"], score)
+    np.testing.assert_array_equal(cols["dx"], dx)
+    np.testing.assert_array_equal(cols["dy"], dy)
+    for t in range(4):
+        m = tile == t
+        f = frames.assemble({k: v[m] for k, v in cols.items()}, (t // 2) * T, (t % 2) * T)
+        assert f["x0"].dtype == np.float32 and np.array_equal(np.sort(f["x0"].to_numpy()), np.sort(x[m]))
+
+
+def test_real_opencv_result_columns_and_zncc_bounds_rule():
+    """`radial error` recomputes bit-exactly and `angle` to numpy's arctan2 accuracy from the float32 dx, dy (core.py:872-873);
+    the NaN pattern of `zncc_score` is exactly {score < 0.4} + the chip bounds rule - with ONE documented difference: the run
+    that wrote the CSV predates the `>=` of zncc_service.py:212-215 and scored the two rows at y0 == size - 28."""
+    import pandas as pd
+    from karios_amd import frames
+    from karios_amd.matcher.zncc_service import CHIP_SIZE, _chip_centres
+    facts, g = _csv_facts()
+    frame = pd.DataFrame({k: g[k] for k in ("x0", "y0", "dx", "dy", "score")})
+    out = frames.radial_angle_columns(frame.copy())
+    np.testing.assert_array_equal(out["radial error"].to_numpy(), g["radial_error"])
+    assert out["angle"].dtype == np.float32
+    assert (np.abs(out["angle"].to_numpy() - g["angle"]) <= 4 * np.spacing(np.abs(g["angle"]))).all()
+    S = facts["image_size"]
+    *_, inside = _chip_centres(frame, (CHIP_SIZE - 1) // 2, (S, S), (S, S))
+    expect_nan = (g["score"] < np.float32(0.4)) | ~inside
+    csv_nan = np.isnan(g["zncc_score"])
+    differ = np.flatnonzero(expect_nan != csv_nan)
+    assert len(differ) == 2 and (g["y0"][differ] == S - 28).all() and not csv_nan[differ].any()
+    assert not (csv_nan & ~expect_nan).any()                                     # no NaN the rule does not explain (e.g. flat windows)
