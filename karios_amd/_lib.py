@@ -207,6 +207,10 @@ class Context:
         self.handle = h
         self.device = device
         self._alive = [True]      # shared with the finalizers of this context's page-locked arrays (`pinned_empty`)
+        # development / A-B measurements: KARIOS_HIP_OPTIONS="lk2=0,eig3=0" applies `set_option` to every new context
+        for item in filter(None, os.environ.get("KARIOS_HIP_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            self.set_option(name.strip(), int(value or 1))
 
     # ---- device buffers are recycled: a tile loop would otherwise pay a hipMalloc / hipFree pair (and their implicit device
     # synchronisations) per image and tile

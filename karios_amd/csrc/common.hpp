@@ -166,6 +166,7 @@ struct km_ctx {
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
+    bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
     // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)

@@ -402,6 +402,287 @@ __global__ __launch_bounds__(64 * LK_WPB) KM_LK_OCC void lk_kernel(lk_args g, in
     if (left_band && g.left_band && (threadIdx.x & 63) == 0) atomicOr(g.left_band, 1);
 }
 
+
+// ================================================================================================================
+// K7, second form (two-level pyramids = the reference's maxLevel 1, klt.py:128-140; whole levels resident).
+//
+// What the first form pays per key point besides the window arithmetic: FOUR round trips to HBM (template + search
+// neighbourhood per level and direction - the backward pass stages exactly the neighbourhoods the forward pass just had,
+// with the roles of the two images swapped), a Scharr pass that writes two int16 planes to LDS through byte reads
+// (two thirds of the kernel's LDS instructions) and reads them back, and index arithmetic on run-time sizes.
+// Here every wavefront stages ONE (win + 7)^2 neighbourhood per image and level around its key point - four patches, all
+// loads of the key point in flight together - and both directions work on them: the forward search patch of J is the
+// backward template patch, the forward template patch of I is the backward search patch.  A lane evaluates the Scharr
+// derivative of its own runs straight from the patch bytes in packed 16-bit arithmetic (4 unaligned 8-byte LDS reads per
+// run, no derivative planes, no LDS write / barrier / read-back), so a patch is never modified and stays valid for the
+// other direction.  A patch is re-centred (re-read from HBM) only when a window leaves its margin (displacements > 2 px
+// per level; the reference's data is pre-aligned to less).  The arithmetic is the first form's, bit for bit.
+#define LK2_M 3                       // margin (px) of a patch around the window it was centred on
+#define LK2_INVALID (-(1 << 28))      // origin of a patch that holds nothing yet
+
+template <int WIN> struct lk2_geo {
+    int win;
+    __device__ __host__ explicit lk2_geo(int w) : win(WIN ? WIN : w) {}
+    __device__ __host__ int ps() const { return (WIN ? WIN : win) + 1 + 2 * LK2_M; }          // rows = columns of a patch
+    __device__ __host__ int pp() const { return (ps() + 4 + 3) & ~3; }                       // row pitch (8-byte run reads end <= 4 bytes behind a row)
+    __device__ __host__ int bytes() const { return (ps() * pp() + 16 + 15) & ~15; }          // + slack behind the last row
+};
+
+typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lk_us2 lk_as_us2(uint32_t v) { return __builtin_bit_cast(lk_us2, v); }
+__device__ __forceinline__ uint32_t lk_us_as_u(lk_us2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// (re)load the patch of image level (img, IW, IH) with origin (ox, oy); caller brackets with LK_WAVE_SYNC
+template <int MAXIT, int WIN>
+__device__ __forceinline__ void lk2_restage(const uint8_t *__restrict__ img, int IW, int IH, int ox, int oy, const lk2_geo<WIN> &geo, uint8_t *patch)
+{
+    stage_patch<MAXIT>(img, IW, IH, ox, oy, geo.ps(), geo.ps(), patch, geo.pp());
+}
+
+// One direction of the tracker on the resident patches.  X = template image (patches px[0..1] = level 0, 1), Y = search
+// image.  ox/oy: patch origins per (image slot, level), updated when a patch is re-centred.
+template <int NR, int WIN, int MAXIT>
+__device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
+                                const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], float &outx, float &outy)
+{
+    const int win = geo.win;
+    const float half = (float)(win - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int PP = geo.pp(), PB = geo.bytes();
+    float resx = px, resy = py;
+#pragma unroll 1
+    for (int level = 1; level >= 0; level--) {
+        const int IW = I.W[level], IH = I.H[level], JW = J.W[level], JH = J.H[level];
+        const float sc = level ? 0.5f : 1.f;
+        float prx = px * sc, pry = py * sc;
+        float nx, ny;
+        if (level == 1) { nx = prx; ny = pry; }
+        else { nx = resx * 2.f; ny = resy * 2.f; }
+        resx = nx; resy = ny;
+        prx -= half; pry -= half;
+        const int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
+        if (ipx < -win || ipx >= IW || ipy < -win || ipy >= IH) continue;
+        float a = prx - (float)ipx, b = pry - (float)ipy;
+        int w00, w01, w10, w11;
+        lk_weights(a, b, w00, w01, w10, w11);
+        uint8_t *X = pI + level * PB, *Y = pJ + level * PB;
+        // the template needs patch rows / columns [t - 1, t + win + 1] with t = window origin - patch origin: 1 <= t <= 2 M - 1
+        int tx = ipx - oI[level][0], ty = ipy - oI[level][1];
+        if (tx < 1 || tx > 2 * LK2_M - 1 || ty < 1 || ty > 2 * LK2_M - 1) {
+            LK_WAVE_SYNC();
+            oI[level][0] = ipx - LK2_M; oI[level][1] = ipy - LK2_M;
+            lk2_restage<MAXIT>(I.img[level], IW, IH, oI[level][0], oI[level][1], geo, X);
+            LK_WAVE_SYNC();
+            tx = ty = LK2_M;
+        }
+        // derivatives are zero outside the image (OpenCV pads the derivative image with zeros, the intensities with REFLECT_101)
+        const bool need_mask = !(ipx >= 0 && ipy >= 0 && ipx + win <= IW - 1 && ipy + win <= IH - 1);
+        uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
+        int sA11 = 0, sA12 = 0, sA22 = 0;
+        {
+            const lk_s2 wt0 = lk_as_s2(lk_pack16(w00, w01)), wt1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
+            const uint8_t *xb = X + (ty - 1) * PP + (tx - 1);
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                int rd = run_desc[t];
+                asm volatile("" : "+v"(rd));
+                const int y = rd & 0xff, x0 = (rd >> 8) & 0xff, n = rd >> 16;
+                // patch rows y-1 .. y+2 (window coordinates), bytes x0-1 .. x0+6
+                const uint8_t *pr = xb + y * PP + x0;
+                uint2 R[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) __builtin_memcpy(&R[k], pr + k * PP, 8);
+                // columns as 16-bit pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7)
+                lk_us2 E[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        E[k][j] = lk_as_us2(__builtin_amdgcn_perm(R[k].y, R[k].x, 0x0c000c00u | (uint32_t)(2 * j) | ((uint32_t)(2 * j + 1) << 16)));
+                uint32_t gx[2][3], gy[2][3];      // derivative pairs of the two bilinear rows: positions (0,1) (2,3) (4,5)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    lk_us2 S[4], V[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        S[j] = (E[d][j] + E[d + 2][j]) * (unsigned short)3 + E[d + 1][j] * (unsigned short)10;   // [3 10 3] down the column
+                        V[j] = E[d + 2][j] - E[d][j];                                                               // [-1 0 1] down the column
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        gx[d][q] = lk_us_as_u(S[q + 1] - S[q]);                                                     // s(c+1) - s(c-1)
+                        const lk_us2 vo = lk_as_us2(__builtin_amdgcn_alignbyte(lk_us_as_u(V[q + 1]), lk_us_as_u(V[q]), 2));   // (v(c), v(c+1)) of the odd columns
+                        gy[d][q] = lk_us_as_u((V[q] + V[q + 1]) * (unsigned short)3 + vo * (unsigned short)10);     // 3 (v(c-1) + v(c+1)) + 10 v(c)
+                    }
+                }
+                if (need_mask) {
+                    const int gy0 = ipy + y, gx0 = ipx + x0;
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const uint32_t mrow = (unsigned)(gy0 + d) < (unsigned)IH ? 0xffffffffu : 0u;
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            const uint32_t m = (((unsigned)(gx0 + 2 * q) < (unsigned)IW ? 0x0000ffffu : 0u) |
+                                                ((unsigned)(gx0 + 2 * q + 1) < (unsigned)IW ? 0xffff0000u : 0u)) & mrow;
+                            gx[d][q] &= m; gy[d][q] &= m;
+                        }
+                    }
+                }
+                int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
+                iv[LK_RUN] = 0; ixv[LK_RUN] = 0; iyv[LK_RUN] = 0;
+#pragma unroll
+                for (int k = 0; k < LK_RUN; k++) {
+                    // intensities: bytes k+1, k+2 of patch rows y, y+1
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)(k + 1) | ((uint32_t)(k + 2) << 16);
+                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(R[1].y, R[1].x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(R[2].y, R[2].x, sel));
+                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, __builtin_amdgcn_sdot2(c1, wt1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                    auto pair = [&](const uint32_t (&g)[3]) -> lk_s2 {
+                        return lk_as_s2((k & 1) ? __builtin_amdgcn_alignbyte(g[(k + 1) / 2], g[k / 2], 2) : g[k / 2]);
+                    };
+                    ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, __builtin_amdgcn_sdot2(pair(gx[1]), wt1, 1 << 13, false), false) >> 14;
+                    iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, __builtin_amdgcn_sdot2(pair(gy[1]), wt1, 1 << 13, false), false) >> 14;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const uint32_t pm = n >= 2 * q + 2 ? 0xffffffffu : (n == 2 * q + 1 ? 0x0000ffffu : 0u);
+                    IvP[t][q] = lk_pack16(iv[2 * q], iv[2 * q + 1]) & pm;
+                    IxP[t][q] = lk_pack16(ixv[2 * q], ixv[2 * q + 1]) & pm;
+                    IyP[t][q] = lk_pack16(iyv[2 * q], iyv[2 * q + 1]) & pm;
+                    sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
+                    sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
+                    sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
+                }
+            }
+        }
+        const long long iA11 = wave_sum_split(sA11), iA12 = wave_sum_split(sA12), iA22 = wave_sum_split(sA22);
+        const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float dA = A11 - A22;
+        const float q = dA * dA + 4.f * A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf(q)) / (float)(2 * win * win);
+        if (minEig < 1e-4f || D < FLT_EPSILON) continue;
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        int jx0 = oJ[level][0], jy0 = oJ[level][1];
+        for (int j = 0; j < max_count; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= JW || iny < -win || iny >= JH) break;
+            if (inx < jx0 || iny < jy0 || inx > jx0 + 2 * LK2_M || iny > jy0 + 2 * LK2_M) {
+                // the window left the cached neighbourhood: re-centre it
+                LK_WAVE_SYNC();
+                jx0 = inx - LK2_M; jy0 = iny - LK2_M;
+                lk2_restage<MAXIT>(J.img[level], JW, JH, jx0, jy0, geo, Y);
+                LK_WAVE_SYNC();
+            }
+            a = nx - (float)inx; b = ny - (float)iny;
+            lk_weights(a, b, w00, w01, w10, w11);
+            const lk_s2 wr0 = lk_as_s2(lk_pack16(w00, w01)), wr1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
+            const uint8_t *jb = Y + (iny - jy0) * PP + (inx - jx0);
+            int sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
+                const uint8_t *p0 = jb + y * PP + x0;
+                uint2 r0, r1;                         // bytes x0 .. x0+7 of the two patch rows (unaligned LDS reads)
+                __builtin_memcpy(&r0, p0, 8);
+                __builtin_memcpy(&r1, p0 + PP, 8);
+                int val[LK_RUN + 1];
+                val[LK_RUN] = 0;
+#pragma unroll
+                for (int k = 0; k < LK_RUN; k++) {
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);   // (byte k, byte k+1) as 16-bit values
+                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
+                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, __builtin_amdgcn_sdot2(c1, wr1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 3; q2++) {
+                    const lk_s2 diff = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1])) - lk_as_s2(IvP[t][q2]);
+                    sb1 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IxP[t][q2]), sb1, false);
+                    sb2 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IyP[t][q2]), sb2, false);
+                }
+            }
+            const long long ib1 = wave_sum_split(sb1), ib2 = wave_sum_split(sb2);
+            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            const float ddx = (A12 * b2 - A22 * b1) * D;
+            const float ddy = (A12 * b1 - A11 * b2) * D;
+            nx += ddx; ny += ddy;
+            resx = nx + half; resy = ny + half;
+            if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= epsilon) break;
+            if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+                resx -= ddx * 0.5f; resy -= ddy * 0.5f;
+                break;
+            }
+            pdx = ddx; pdy = ddy;
+        }
+        oJ[level][0] = jx0; oJ[level][1] = jy0;
+    }
+    outx = resx; outy = resy;
+}
+
+template <int NR, int WIN, int MAXIT>
+__global__ __launch_bounds__(64) KM_LK_OCC void lk2_kernel(lk_args g, const int *__restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
+    // workgroup w runs on XCD w % 8: every XCD takes one contiguous eighth of the (spatially ordered) point list
+    const unsigned per = ((unsigned)n + KM_XCDS - 1) / KM_XCDS, slot = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
+    if (blockIdx.x / KM_XCDS >= per || slot >= (unsigned)n) return;
+    const int p = order ? order[slot] : (int)slot;
+    const lk2_geo<WIN> geo(g.win);
+    const int win = geo.win, PS = geo.ps(), PP = geo.pp(), PB = geo.bytes();
+    uint8_t *pA = smem_all, *pB = smem_all + 2 * PB;      // patches: [image][level]
+    const int rpr = (win + LK_RUN - 1) / LK_RUN, total = win * rpr;
+    int run_desc[NR];
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        const int r = t * 64 + (int)(threadIdx.x & 63);
+        const int y = r / rpr, x0 = (r - y * rpr) * LK_RUN;
+        run_desc[t] = r < total ? (y | (x0 << 8) | (min(LK_RUN, win - x0) << 16)) : 0;
+    }
+    const float px = g.pts_in[2 * p], py = g.pts_in[2 * p + 1];
+    const float half = (float)(win - 1) * 0.5f;
+    // one neighbourhood per image and level, centred on the key point's window: all loads of the key point in flight together
+    int oA[2][2], oB[2][2];
+    bool want[2], inside = true;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const float sc = l ? 0.5f : 1.f;
+        const int ipx = (int)floorf(px * sc - half), ipy = (int)floorf(py * sc - half);
+        want[l] = !(ipx < -win || ipx >= g.A.W[l] || ipy < -win || ipy >= g.A.H[l]);      // (else the level is skipped: nothing to stage)
+        oA[l][0] = oB[l][0] = want[l] ? ipx - LK2_M : LK2_INVALID;
+        oA[l][1] = oB[l][1] = want[l] ? ipy - LK2_M : LK2_INVALID;
+        inside = inside && want[l] && lk_patch_inside(g.A.W[l], g.A.H[l], oA[l][0], oA[l][1], PS, PS, MAXIT);
+    }
+    if (inside) {
+        lk_patch_regs<MAXIT> r0, r1, r2, r3;
+        stage_patch_issue<MAXIT>(g.A.img[1], g.A.W[1], oA[1][0], oA[1][1], PS, PS, r0);
+        stage_patch_issue<MAXIT>(g.B.img[1], g.B.W[1], oB[1][0], oB[1][1], PS, PS, r1);
+        stage_patch_issue<MAXIT>(g.A.img[0], g.A.W[0], oA[0][0], oA[0][1], PS, PS, r2);
+        stage_patch_issue<MAXIT>(g.B.img[0], g.B.W[0], oB[0][0], oB[0][1], PS, PS, r3);
+        stage_patch_commit<MAXIT>(PS, PS, pA + PB, PP, r0);
+        stage_patch_commit<MAXIT>(PS, PS, pB + PB, PP, r1);
+        stage_patch_commit<MAXIT>(PS, PS, pA, PP, r2);
+        stage_patch_commit<MAXIT>(PS, PS, pB, PP, r3);
+    } else {
+#pragma unroll 1
+        for (int l = 1; l >= 0; l--)
+            if (want[l]) {
+                lk2_restage<MAXIT>(g.A.img[l], g.A.W[l], g.A.H[l], oA[l][0], oA[l][1], geo, pA + l * PB);
+                lk2_restage<MAXIT>(g.B.img[l], g.B.W[l], g.B.H[l], oB[l][0], oB[l][1], geo, pB + l * PB);
+            }
+    }
+    LK_WAVE_SYNC();
+    float fx, fy;
+    lk2_track_point<NR, WIN, MAXIT>(g.A, g.B, pA, pB, oA, oB, px, py, geo, g.max_count, g.epsilon, run_desc, fx, fy);
+    if ((threadIdx.x & 63) == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
+    if (g.backward) {
+        float rx, ry;
+        lk2_track_point<NR, WIN, MAXIT>(g.B, g.A, pB, pA, oB, oA, fx, fy, geo, g.max_count, g.epsilon, run_desc, rx, ry);
+        if ((threadIdx.x & 63) == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
+    }
+}
+
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
              double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {
@@ -415,11 +696,28 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
     g.epsilon = e * e;
     g.p1 = d_p1; g.p0r = d_p0r; g.left_band = d_left_band;
+    const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;   // runs per lane (win <= 40: <= 5)
+    if (c->opt_lk2 && A.levels == 1 && B.levels == 1 && A.Hres[0] == 0 && B.Hres[0] == 0 && !d_left_band) {
+        // second form: four resident patches per key point, both directions on them
+        const lk2_geo<0> geo(win);
+        const size_t sm2 = (size_t)4 * geo.bytes();
+        const unsigned nblk2 = km_xcd_grid((unsigned)n_max);
+        const int *order = nullptr;
+        if (win == 25) lk2_kernel<2, 25, 4><<<nblk2, 64, sm2, c->stream>>>(g, order);
+        else switch (nr) {
+        case 1: lk2_kernel<1, 0, 3><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
+        case 2: lk2_kernel<2, 0, 4><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
+        case 3: lk2_kernel<3, 0, 6><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
+        case 4: lk2_kernel<4, 0, 8><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
+        default: lk2_kernel<5, 0, 9><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
+        }
+        KM_LAUNCH_CHECK(c);
+        return KM_OK;
+    }
     const int RP = (win + 3 + 3 + 3) & ~3, JS = win + 1 + 2 * LK_M, JP = (JS + 3 + 3) & ~3;
     const size_t sm = (((size_t)(win + 3) * RP + 15) & ~(size_t)15) + (((size_t)JS * JP + 15) & ~(size_t)15) + ((size_t)(win + 1) * (win + 1) + 8) * 2 * sizeof(short) + 16;
     const size_t smw = (sm + 15) & ~(size_t)15, sm_all = smw * LK_WPB;
     const int nblk = (n_max + LK_WPB - 1) / LK_WPB;
-    const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;   // runs per lane (win <= 40: <= 5)
     switch (nr) {
     case 1: lk_kernel<1><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
     case 2: lk_kernel<2><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;

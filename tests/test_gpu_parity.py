@@ -227,8 +227,18 @@ def test_good_features_flat_image_is_none(ops):
     assert ops.good_features_to_track(np.zeros((2, 2), np.uint8), 100, 0.1, 10, blockSize=3) is None
 
 
-@pytest.mark.parametrize("win", [25, 9, 31, 15])
-def test_pyrlk_matches_oracle(ops, O, win):
+@pytest.fixture(params=[1, 0], ids=["lk_resident_patches", "lk_first_form"])
+def lk_form(request, ops):
+    """Both forms of the LK kernel (k_lk.hip): four resident patches per key point (default for two-level pyramids) and the
+    first form (per-level staging + derivative planes; deeper pyramids, row bands)."""
+    ctx = ops._lib.default_context()
+    ctx.set_option("lk2", request.param)
+    yield request.param
+    ctx.set_option("lk2", 1)
+
+
+@pytest.mark.parametrize("win", [25, 9, 31, 15, 21, 38])
+def test_pyrlk_matches_oracle(ops, O, win, lk_form):
     lap_mon, lap_ref, _, _ = _lap_pair(O, 260, 330, sx=0.6, sy=-0.35)
     p0 = O.good_features(lap_ref, None, 800, 0.05, 7, 9)
     got = ops.calc_optical_flow_pyr_lk(lap_ref, lap_mon, p0, winSize=(win, win))
@@ -242,6 +252,28 @@ def test_pyrlk_matches_oracle(ops, O, win):
     eb = O.pyr_lk(lap_mon, lap_ref, p1, win)
     assert np.abs(gb - eb).max() <= 1e-3
     assert np.array_equal(gb, eb)
+
+
+@pytest.mark.parametrize("shift", [(0.5, 0.25), (2.6, -1.7), (4.4, 5.3), (-7.2, 3.1)])
+def test_lk_forward_backward_in_one_launch_with_displacements_beyond_the_patch_margin(ops, O, shift, lk_form):
+    """Forward + backward pass of the fused tracker launch (`km_klt_track` with given corners) against the oracle's two calls:
+    displacements within the 3-px margin of the resident patches, and beyond it per level (patches re-centred for the search and
+    for the backward template), plus corners whose windows overhang or leave the image."""
+    lap_mon, lap_ref, _, _ = _lap_pair(O, 300, 360, sx=shift[0], sy=shift[1], seed=20260107)
+    p0 = O.good_features(lap_ref, None, 600, 0.05, 7, 9)
+    extra = np.array([[[0.0, 0.0]], [[359.0, 299.0]], [[3.0, 150.0]], [[356.0, 7.0]], [[180.0, 297.0]], [[12.0, 12.0]], [[-20.0, 40.0]],
+                      [[500.0, 100.0]], [[100.0, -13.0]], [[13.0, 286.0]]], np.float32)
+    p0 = np.concatenate([p0, extra])
+    conf = O.default_conf(maxCorners=len(p0))
+    got = ops.klt_track(lap_ref, lap_mon, None, conf, p0=p0)
+    p1 = O.pyr_lk(lap_ref, lap_mon, p0, 25)
+    p0r = O.pyr_lk(lap_mon, lap_ref, p1, 25)
+    np.testing.assert_array_equal(got[0], p0)
+    np.testing.assert_array_equal(got[1], p1)
+    np.testing.assert_array_equal(got[2], p0r)
+    moved = np.abs(p1 - p0).reshape(-1, 2).max(1)
+    if max(abs(shift[0]), abs(shift[1])) > 4:
+        assert (moved > 3).mean() > 0.5          # (the case really leaves the margin)
 
 
 def test_pyrlk_small_image_no_pyramid_and_identity(ops, O):
