@@ -729,6 +729,25 @@ def main():
     for _ in range(a.warmup):
         take(stream.submit(pair, conf))
     take(stream.drain())
+    # settle (untimed, on top of the W warm-up steps): a fresh box ramps its clocks over the first few hundred milliseconds of
+    # load - windows of 20 steps are repeated until two consecutive ones agree within 2 % (at least 0.3 s, at most 2 s of work)
+    settle = {"windows": 0, "seconds": 0.0}
+    t_settle, prev = time.perf_counter(), None
+    while True:
+        fence()
+        t_w = time.perf_counter()
+        for _ in range(20):
+            take(stream.submit(pair, conf))
+        take(stream.drain())
+        fence()
+        cur = time.perf_counter() - t_w
+        settle["windows"] += 1
+        elapsed = time.perf_counter() - t_settle
+        if (prev is not None and abs(cur - prev) <= 0.02 * prev and elapsed >= 0.3) or elapsed >= 2.0:
+            break
+        prev = cur
+    settle["seconds"] = round(time.perf_counter() - t_settle, 3)
+    settle["last_window_ms_per_step"] = round(cur / 20 * 1e3, 4)
     # HIP events on the library stream bracket ONE stage inside the timed region - the one the roofline is quoted on: a timed span
     # is two event records, i.e. two points where consecutive kernels may not overlap, and timing all ten stages costs ~0.07 ms
     # per pair.  The stage is the largest of the warm-up's full table; the full stage table of the line comes from a second,
@@ -808,7 +827,7 @@ def main():
             "stage_ms_note": f"{timed_stage}: HIP events over the {a.steps} timed steps; the other stages: an untimed pass of "
                              f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
             "roofline": roof,
-            "synth_seconds": round(t_gen, 2),
+            "synth_seconds": round(t_gen, 2), "settle": settle,
         }
         sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):

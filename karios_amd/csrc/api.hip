@@ -182,6 +182,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
+    if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
     if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);

@@ -78,6 +78,7 @@ enum km_slot {
     WS_FFT_WORK,
     WS_FRAME,
     WS_AUTO,        // batched auto-ksize search: all Laplacians, pyramids, tracks
+    WS_LK_ORDER,    // spatial processing order of the key points of one LK launch
     WS_COUNT
 };
 
@@ -167,6 +168,7 @@ struct km_ctx {
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
+    bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
     // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)

@@ -441,6 +441,16 @@ __device__ __forceinline__ void lk2_restage(const uint8_t *__restrict__ img, int
 
 // One direction of the tracker on the resident patches.  X = template image (patches px[0..1] = level 0, 1), Y = search
 // image.  ox/oy: patch origins per (image slot, level), updated when a patch is re-centred.
+// a * b (two int16 products) + k with the addend in a register that stays live: VOP3P form, no copy of the constant.  The result
+// is only ever the accumulator (src C) of the next dot of the same family, which the hardware forwards (tools/hazard_scan.py
+// checks the generated code: the compiler cannot see a DOT behind inline assembly).
+__device__ __forceinline__ int lk_dot2_k(lk_s2 a, lk_s2 b, int k)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
+    return d;
+}
+
 template <int NR, int WIN, int MAXIT>
 __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
                                 const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], float &outx, float &outy)
@@ -450,6 +460,10 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
     const float FLT_SCALE = 1.f / (1 << 20);
     const int PP = geo.pp(), PB = geo.bytes();
     float resx = px, resy = py;
+    // rounding constants live in registers: the three-operand v_dot2_i32_i16 (lk_dot2_k) takes them as its addend, where the
+    // compiler's accumulating v_dot2c needs a v_mov of the literal in front of every interpolated value
+    int k_half9 = 1 << (14 - 5 - 1), k_half14 = 1 << 13;
+    asm volatile("" : "+v"(k_half9), "+v"(k_half14));
 #pragma unroll 1
     for (int level = 1; level >= 0; level--) {
         const int IW = I.W[level], IH = I.H[level], JW = J.W[level], JH = J.H[level];
@@ -535,12 +549,12 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                     // intensities: bytes k+1, k+2 of patch rows y, y+1
                     const uint32_t sel = 0x0c000c00u | (uint32_t)(k + 1) | ((uint32_t)(k + 2) << 16);
                     const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(R[1].y, R[1].x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(R[2].y, R[2].x, sel));
-                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, __builtin_amdgcn_sdot2(c1, wt1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, lk_dot2_k(c1, wt1, k_half9), false) >> (14 - 5);
                     auto pair = [&](const uint32_t (&g)[3]) -> lk_s2 {
                         return lk_as_s2((k & 1) ? __builtin_amdgcn_alignbyte(g[(k + 1) / 2], g[k / 2], 2) : g[k / 2]);
                     };
-                    ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, __builtin_amdgcn_sdot2(pair(gx[1]), wt1, 1 << 13, false), false) >> 14;
-                    iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, __builtin_amdgcn_sdot2(pair(gy[1]), wt1, 1 << 13, false), false) >> 14;
+                    ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, lk_dot2_k(pair(gx[1]), wt1, k_half14), false) >> 14;
+                    iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, lk_dot2_k(pair(gy[1]), wt1, k_half14), false) >> 14;
                 }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -593,7 +607,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                 for (int k = 0; k < LK_RUN; k++) {
                     const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);   // (byte k, byte k+1) as 16-bit values
                     const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
-                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, __builtin_amdgcn_sdot2(c1, wr1, 1 << (14 - 5 - 1), false), false) >> (14 - 5);
+                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, lk_dot2_k(c1, wr1, k_half9), false) >> (14 - 5);
                 }
 #pragma unroll
                 for (int q2 = 0; q2 < 3; q2++) {
@@ -621,7 +635,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
 }
 
 template <int NR, int WIN, int MAXIT>
-__global__ __launch_bounds__(64) KM_LK_OCC void lk2_kernel(lk_args g, const int *__restrict__ order)
+__device__ __forceinline__ void lk2_body(const lk_args &g, const int *__restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
@@ -683,6 +697,74 @@ __global__ __launch_bounds__(64) KM_LK_OCC void lk2_kernel(lk_args g, const int 
     }
 }
 
+template <int NR, int WIN, int MAXIT>
+__global__ __launch_bounds__(64) KM_LK_OCC void lk2_kernel(lk_args g, const int *__restrict__ order)
+{
+    lk2_body<NR, WIN, MAXIT>(g, order);
+}
+
+// the reference's window (matching_winsize 25, processing_configuration.json:14) with every size a compile-time constant.
+// 6 waves per SIMD: the register allocator would take 82 VGPRs (5 waves) for two fewer copies.
+#ifndef LK2_25_WAVES
+#define LK2_25_WAVES 6
+#endif
+#if LK2_25_WAVES
+#define LK2_25_OCC __attribute__((amdgpu_waves_per_eu(LK2_25_WAVES, LK2_25_WAVES)))
+#else
+#define LK2_25_OCC
+#endif
+__global__ __launch_bounds__(64) LK2_25_OCC void lk2_kernel_win25(lk_args g, const int *__restrict__ order)
+{
+    lk2_body<2, 25, 4>(g, order);
+}
+
+// Processing order of one launch's key points: counting sort by 2^shift-px cell (row-major), one workgroup.  Corners arrive in
+// strength order, i.e. scattered over the image: neighbouring wavefronts then share no cache line, and every 32-byte patch row
+// costs a 128-byte line from HBM.  In cell order the patches of neighbouring key points overlap in L2 (workgroup w runs on XCD
+// w % 8, so lk2_kernel hands every XCD one contiguous eighth of this list).  The order inside a cell is whatever the LDS
+// atomics produce: it only decides WHEN a key point is tracked, its result is written by index.
+#define LKO_T 1024
+template <int RPT>
+__global__ __launch_bounds__(LKO_T) void lk_order_kernel(const float *__restrict__ pts, const int *__restrict__ d_n, int n_max, int W, int H, int shift,
+                                                         int ncx, int ncells, int *__restrict__ order)
+{
+    extern __shared__ unsigned lko_cnt[];
+    __shared__ unsigned s_wave[LKO_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = d_n ? min(*d_n, n_max) : n_max;
+    // every thread's key points in ONE batch of loads (a loop that loads and bins per trip pays the memory latency per trip)
+    float2 pt[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) pt[u] = ((const float2 *)pts)[min(u * LKO_T + tid, max(n - 1, 0))];
+    for (int b = tid; b < ncells; b += LKO_T) lko_cnt[b] = 0u;
+    int cell[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        const int cx = min(max((int)pt[u].x, 0), W - 1) >> shift, cy = min(max((int)pt[u].y, 0), H - 1) >> shift;   // (points outside the image: clamped)
+        cell[u] = cy * ncx + cx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; u++)
+        if (u * LKO_T + tid < n) atomicAdd(&lko_cnt[cell[u]], 1u);
+    __syncthreads();
+    const int per = (ncells + LKO_T - 1) / LKO_T, b0 = min(tid * per, ncells), b1 = min(b0 + per, ncells);
+    unsigned mine = 0;
+    for (int b = b0; b < b1; b++) mine += lko_cnt[b];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (int w = 0; w < wv; w++) run += s_wave[w];
+    for (int b = b0; b < b1; b++) { const unsigned c2 = lko_cnt[b]; lko_cnt[b] = run; run += c2; }   // counts become fill cursors
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPT; u++)
+        if (u * LKO_T + tid < n) order[atomicAdd(&lko_cnt[cell[u]], 1u)] = u * LKO_T + tid;
+}
+
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
              double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {
@@ -703,7 +785,20 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
         const size_t sm2 = (size_t)4 * geo.bytes();
         const unsigned nblk2 = km_xcd_grid((unsigned)n_max);
         const int *order = nullptr;
-        if (win == 25) lk2_kernel<2, 25, 4><<<nblk2, 64, sm2, c->stream>>>(g, order);
+        if (c->opt_lk_order && n_max >= 2048 && n_max <= 32 * LKO_T) {
+            int shift = 7;
+            while ((((A.W[0] - 1) >> shift) + 1) * (((A.H[0] - 1) >> shift) + 1) > 8192) shift++;
+            const int ncx = ((A.W[0] - 1) >> shift) + 1, ncells = ncx * (((A.H[0] - 1) >> shift) + 1);
+            int *d_order = (int *)km_ws(c, WS_LK_ORDER, (size_t)n_max * sizeof(int));
+            if (!d_order) return KM_E_NOMEM;
+            const size_t lds = (size_t)ncells * sizeof(unsigned);
+            if (n_max <= 8 * LKO_T) lk_order_kernel<8><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
+            else if (n_max <= 20 * LKO_T) lk_order_kernel<20><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
+            else lk_order_kernel<32><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
+            KM_LAUNCH_CHECK(c);
+            order = d_order;
+        }
+        if (win == 25) lk2_kernel_win25<<<nblk2, 64, sm2, c->stream>>>(g, order);
         else switch (nr) {
         case 1: lk2_kernel<1, 0, 3><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
         case 2: lk2_kernel<2, 0, 4><<<nblk2, 64, sm2, c->stream>>>(g, order); break;

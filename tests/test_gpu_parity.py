@@ -276,6 +276,29 @@ def test_lk_forward_backward_in_one_launch_with_displacements_beyond_the_patch_m
         assert (moved > 3).mean() > 0.5          # (the case really leaves the margin)
 
 
+def test_lk_many_points_are_tracked_in_spatial_order_with_identical_results(ops, O):
+    """>= 2048 key points: the launch processes them in 128-px cell order (lk_order_kernel), one contiguous eighth per XCD.  The
+    order is an implementation detail: results are written by index and equal the oracle's, with the ordering on and off; points
+    outside the image are binned into the border cells."""
+    lap_mon, lap_ref, _, _ = _lap_pair(O, 420, 520, sx=0.8, sy=-0.6, seed=20260109)
+    yy, xx = np.mgrid[3:417:6, 2:518:6]
+    p0 = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float32)
+    p0 = np.concatenate([p0, np.array([[-30.0, 5.0], [600.0, 100.0], [100.0, 500.0], [-1e6, 1e6]], np.float32)]).reshape(-1, 1, 2)
+    assert len(p0) >= 2048
+    conf = O.default_conf(maxCorners=len(p0))
+    p1 = O.pyr_lk(lap_ref, lap_mon, p0, 25)
+    p0r = O.pyr_lk(lap_mon, lap_ref, p1, 25)
+    ctx = ops._lib.default_context()
+    try:
+        for flag in (1, 0):
+            ctx.set_option("lk_order", flag)
+            got = ops.klt_track(lap_ref, lap_mon, None, conf, p0=p0)
+            np.testing.assert_array_equal(got[1], p1)
+            np.testing.assert_array_equal(got[2], p0r)
+    finally:
+        ctx.set_option("lk_order", 1)
+
+
 def test_pyrlk_small_image_no_pyramid_and_identity(ops, O):
     img = rand_u8((40, 44), seed=77)  # (w+1)/2 <= winSize: level 1 is dropped
     pts = np.array([[[10.0, 12.0]], [[30.5, 20.25]], [[0.0, 0.0]], [[43.0, 39.0]]], np.float32)
