@@ -80,6 +80,7 @@ def parse(argv=None):
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--timed-stage", default="auto", help="stage bracketed by HIP events inside the timed region (auto: the largest kernel; none)")
     return ap.parse_args(argv)
 
 
@@ -743,7 +744,12 @@ def main():
         cur = time.perf_counter() - t_w
         settle["windows"] += 1
         elapsed = time.perf_counter() - t_settle
-        if (prev is not None and abs(cur - prev) <= 0.02 * prev and elapsed >= 0.3) or elapsed >= 2.0:
+        done = (prev is not None and abs(cur - prev) <= 0.02 * prev and elapsed >= 0.3) or elapsed >= 2.0
+        if world > 1:                      # every rank must leave the loop in the same round (the fence is a barrier)
+            flag = torch.tensor([1 if done else 0], device=coll_dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item()) or settle["windows"] >= 12
+        if done:
             break
         prev = cur
     settle["seconds"] = round(time.perf_counter() - t_settle, 3)
@@ -762,7 +768,11 @@ def main():
     fence()
     probe = {k: v for k, v in stage_sum.items() if k in ("stretch_laplacian_mask", "min_eigen", "lk_fwd_bwd") and v > 0}
     timed_stage = max(probe, key=probe.get) if probe else "min_eigen"
+    if a.timed_stage not in ("auto", "none"):
+        timed_stage = a.timed_stage
     ctx.set_option("profile_stage", stage_names.index(timed_stage))
+    if a.timed_stage == "none":
+        ctx.set_profiling(False)
     stage_sum.clear()
     totals.update(rows=0, frames=0, redone=0)
     fence()

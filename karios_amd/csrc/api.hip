@@ -180,6 +180,8 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_early") == 0) { c->opt_aux_early = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
@@ -572,35 +574,48 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         const size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
         if (!keys) return KM_E_NOMEM;
+        // The pyramids depend on the Laplacians only: they run on a second stream, joined before LK.  Forked BEFORE the fused
+        // eigenvalue pass ("aux_early", default): that kernel is bound by instruction issue at 3 waves per SIMD and leaves the
+        // memory system idle, and the ranking / selection chain behind it (small latency-bound kernels) then has the GPU to itself;
+        // forked behind it (round 2) the pyramids stretched the chain's one-workgroup kernels from 8 to 36 us.
+        bool forked = false;
+        auto fork_pyramids = [&]() -> int {
+            if (!c->aux_stream) {
+                // lowest priority: when a kernel of the main stream and a pyramid kernel become ready together (both wait for the
+                // Laplacians), the main stream's takes the compute units first and the pyramids fill what it leaves
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                KM_HIP(c, hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, c->opt_aux_priority ? prio_lo : 0));
+                KM_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                KM_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            KM_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            hipStream_t main_stream = c->stream;
+            c->stream = c->aux_stream;
+            int r;
+            {
+                km_stage_timer t(c, ST_PYRAMID);
+                r = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B);
+            }
+            if (r == KM_OK && hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess) r = km_fail(c, KM_E_HIP, "hipEventRecord(join)");
+            c->stream = main_stream;
+            forked = r == KM_OK;
+            return r;
+        };
         {
+            // (the stage's start event sits in front of the fork: recorded between the fork and the kernel it would let the pyramid
+            // kernels take the compute units first, and the bracketed kernel would measure 0.48 instead of 0.33 ms)
             km_stage_timer t(c, ST_EIGEN);
+            if (c->opt_aux_pyramid && c->opt_aux_early && (rc = fork_pyramids())) return rc;
             rc = k2_eig_candidates(c, d_ref_lap, d_mask, H, W, prm->block_size, prm->quality_level, sc, keys, capk, false);
         }
-        bool forked = false;
-        if (rc == KM_E_UNSUPPORTED) spec = false;
-        else if (rc) return rc;
+        if (rc == KM_E_UNSUPPORTED) {
+            spec = false;
+            if (forked) { KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); forked = false; }   // (the general path builds its own pyramids in the same buffers)
+        } else if (rc) return rc;
         else {
-            // The pyramids depend on the Laplacians only: they run on a second stream next to the ranking / selection chain
-            // (a dozen small latency-bound kernels that leave the GPU nearly empty) and are joined before LK.
-            if (c->opt_aux_pyramid) {
-                if (!c->aux_stream) {
-                    KM_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                    KM_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                    KM_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-                }
-                KM_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // behind the fused eigenvalue pass
-                KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-                hipStream_t main_stream = c->stream;
-                c->stream = c->aux_stream;
-                {
-                    km_stage_timer t(c, ST_PYRAMID);
-                    rc = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B);
-                }
-                if (rc == KM_OK && hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(join)");
-                c->stream = main_stream;
-                if (rc) return rc;
-                forked = true;
-            }
+            if (c->opt_aux_pyramid && !forked && (rc = fork_pyramids())) return rc;
             {
                 km_stage_timer t(c, ST_SORT);
                 rc = kf_rank(c, keys, capk, H, W, prm->max_corners, prm->quality_level, prm->min_distance, sc);
