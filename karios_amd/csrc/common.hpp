@@ -136,6 +136,8 @@ struct km_ctx {
     hipStream_t copy_stream = nullptr;   // km_upload_async: uploads of the next pair / tile under the compute of the current one
     hipEvent_t ev_copy = nullptr;
     hipStream_t aux_stream = nullptr;    // sync-free tile path: the pyramids (they depend on the Laplacians only) run here next to the
+    hipStream_t d2h_stream = nullptr;    // km_klt_tile_frame_submit: the finished frame block travels to the host here
+    hipEvent_t ev_tail = nullptr, frame_copy = nullptr;   // frame_copy: completion of the last block copy (WS_FRAME must not be rewritten before)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // chain of small corner-selection kernels on `stream`, joined before LK
     bool copy_pending = false;           // uploads queued since the compute stream last waited for the whole copy stream
     std::vector<hipEvent_t> upload_marks;   // km_upload_mark tickets: events on the copy stream, nullptr = ticket consumed
