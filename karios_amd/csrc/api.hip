@@ -189,6 +189,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
+    if (strcmp(name, "stash_cap") == 0) { c->opt_stash_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
 }
@@ -611,7 +612,9 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             // kernels take the compute units first, and the bracketed kernel would measure 0.48 instead of 0.33 ms)
             km_stage_timer t(c, ST_EIGEN);
             if (c->opt_aux_pyramid && c->opt_aux_early && (rc = fork_pyramids())) return rc;
+            c->eig_defer_max = true; c->eig_partial = nullptr; c->eig_npartial = 0;   // the ranking's first launch reduces the per-wave maxima itself
             rc = k2_eig_candidates(c, d_ref_lap, d_mask, H, W, prm->block_size, prm->quality_level, sc, keys, capk, false);
+            c->eig_defer_max = false;
         }
         if (rc == KM_E_UNSUPPORTED) {
             spec = false;
@@ -1064,8 +1067,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if ((rc = frame_block_free(c))) return rc;
     {
         km_stage_timer t(c, ST_FRAME);
-        if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out))) return rc;
-        if (c->spec_used && (rc = kf_stamp_header(c, d_out, sc))) return rc;
+        if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out, c->spec_used ? sc : nullptr))) return rc;
     }
     if (with_zncc) {
         km_stage_timer t(c, ST_ZNCC);

@@ -101,7 +101,7 @@ struct km_scalars {
     unsigned int hist[KM_TK_NB];   // top-K pre-filter histogram (zeroed with the block at the start of a call)
     unsigned int run_max_shard[64]; // sharded running max-eig keys of the 2-px fused kernel (same-address device-scope traffic serialises)
     unsigned int flags;            // KM_FLAG_*: the speculative (no host sync) corner path could not complete, repeat through the exact path
-    unsigned int pad1[3];
+    unsigned int tickets[3];       // "last workgroup finishes the job" counters of the merged launches of k_select2.hip (zeroed with the block)
     unsigned int bin_off[KM_TK_NB]; // k_select2.hip: first slot of every value bin in the kept list
     unsigned int bin_cur[KM_TK_NB]; //                fill cursors of the bins
 };
@@ -166,7 +166,11 @@ struct km_ctx {
     bool opt_aux_priority = true;  // "aux_priority": the second stream has the lowest priority
     bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
     int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
+    int opt_stash_cap = 0;         // "stash_cap": kept keys a workgroup of the scatter launch stashes in LDS (small values force its second read of the keys)
     int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)
+    const unsigned *eig_partial = nullptr;   // speculative path: per-wave maxima the fused eigenvalue pass left for the ranking's first launch
+    unsigned eig_npartial = 0;               //   (the one-workgroup reduction launch in between is skipped), consumed by kf_rank
+    bool eig_defer_max = false;
     bool spec_used = false;        // the running call went through the speculative corner path
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
@@ -333,7 +337,6 @@ size_t kf_kept_capacity(int max_corners);
 int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H, int W, int max_corners, double quality, double min_distance,
             km_scalars *sc);
 int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc);
-int kf_stamp_header(km_ctx *c, void *d_block, const km_scalars *sc);
 // k_lk.hip
 struct km_pyr {
     const uint8_t *img[5];
@@ -348,7 +351,7 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
              float *d_p0r, int *d_left_band = nullptr);
 // k_frame.hip
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
-             float x_off, float y_off, void *d_out);
+             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header = nullptr);   // d_sc_header: header words 2 / 3 = flags, candidate count
 // k_zncc.hip
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
             int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,

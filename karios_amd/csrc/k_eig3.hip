@@ -490,6 +490,10 @@ int launch_eig3(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
     eig3_kernel<BLOCK><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, partial, n_border, rows2, nstrips, rows3, nitems, quality, sc,
                                                                    d_keys, cap, cap2, cap3);
     KM_LAUNCH_CHECK(c);
+    if (c->eig_defer_max) {          // speculative corner path: kf_rank's first launch takes the maximum of the partials itself
+        c->eig_partial = partial; c->eig_npartial = ntiles * 4;
+        return KM_OK;
+    }
     eig3_max_kernel<<<1, 1024, 0, c->stream>>>(partial, ntiles * 4, &sc->max_eig_key);
     KM_LAUNCH_CHECK(c);
     return KM_OK;

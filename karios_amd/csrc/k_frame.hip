@@ -25,7 +25,8 @@ __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restric
                                                           const float *__restrict__ p0r, const int *__restrict__ d_n, int n_max,
                                                           float back_thr, float x_off, float y_off, unsigned long long *__restrict__ keys,
                                                           unsigned *__restrict__ ranks, float *__restrict__ tmp /* 5*cap */, int cap,
-                                                          int *__restrict__ hdr, unsigned *__restrict__ counts, int n_sort)
+                                                          int *__restrict__ hdr, unsigned *__restrict__ counts, int n_sort,
+                                                          const km_scalars *__restrict__ sc_hdr)
 {
     __shared__ int s_wave[FB_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -63,7 +64,12 @@ __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restric
             ranks[r] = (unsigned)r;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) { hdr[0] = min(base + tot, cap); hdr[1] = n; hdr[2] = 0; hdr[3] = 0; }
+    // header words 2 / 3 of a tile that went through the synchronisation-free corner path: its flags and the exact candidate count
+    // (the host sees them with the frame block)
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        hdr[0] = min(base + tot, cap); hdr[1] = n;
+        hdr[2] = sc_hdr ? (int)sc_hdr->flags : 0; hdr[3] = sc_hdr ? (int)sc_hdr->cut[3] : 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void fb_gather_kernel(const unsigned *__restrict__ order, const float *__restrict__ tmp, int cap,
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long lon
 
 // d_out: [header 4 ints: n_rows, n_init, 0, 0][6 * cap floats: x0 | y0 | dx | dy | score | index bits]
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
-             float x_off, float y_off, void *d_out)
+             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header)
 {
     if (cap <= 0 || n_max <= 0) return km_fail(c, KM_E_ARG, "frame: empty capacity");
     // the tile origin is added to the corner coordinates and the sum becomes the (x0, y0) ordering key: a pair of non-negative
@@ -168,9 +174,9 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);   // fixed sort length: sentinel keys behind the kept rows
     unsigned *counts = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)nblk * sizeof(unsigned));
     if (!counts) return KM_E_NOMEM;
-    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort);
+    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort, d_sc_header);
     KM_LAUNCH_CHECK(c);
-    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort);
+    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort, d_sc_header);
     KM_LAUNCH_CHECK(c);
     if (n_sort <= 32768u) {
         // up to a few 10^4 rows (maxCorners of a tile): one workgroup, buckets of x0 in LDS (<= 64 KB of buckets + 2 B per row)

@@ -52,21 +52,93 @@ __device__ __forceinline__ void kf_xy(unsigned long long key, int W, int &x, int
     x = (int)(idx - (unsigned)y * (unsigned)W);
 }
 
-// hist[KF_NB] (filled by tk_hist_kernel) -> cut[0] = D (last kept bin), cut[1] = kept keys, cut[3] = exact candidate count,
-// bin_off[b] = first slot of bin b in the kept list; overflow flags of the emission stage
-__global__ __launch_bounds__(1024) void f_cut_kernel(km_scalars *sc, unsigned k_target, double quality, unsigned cap_keys, unsigned kept_cap, unsigned test_flags)
+// "Last workgroup finishes the job": every workgroup of a launch takes a ticket when its contribution has been performed; the one
+// that draws the last ticket runs the one-workgroup step that used to be the next launch (a launch of a 3-us kernel costs a
+// pipeline drain + dispatch on a chain where nothing overlaps).  The contributions are device-scope ATOMICS (performed at the
+// memory side, beyond the per-XCD L2s) and the last workgroup reads them with device-scope atomic loads, so the hand-over needs
+// no cache maintenance: only "my atomics are done" (s_waitcnt) before the ticket.  (A __threadfence() here writes back every
+// dirty line of the XCD's L2 - the pyramid levels the second stream is producing at that moment included: + 90 us.)
+__device__ __forceinline__ bool kf_last_workgroup(unsigned *ticket, unsigned n_workgroups)
 {
+    __shared__ unsigned s_ticket;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    return s_ticket == n_workgroups - 1;
+}
+
+// Launch 1 of the ranking.  Every workgroup: (side jobs) zero its share of the selection's cell records and of the accepted-corner
+// counters; reduce the per-wave maxima of the fused eigenvalue pass (a few thousand words from L2 - cheaper than a launch in
+// between; workgroup 0 publishes the result); histogram of its keys by value bin.  The LAST workgroup then cuts:
+// hist[KF_NB] -> cut[0] = D (last kept bin), cut[1] = kept keys, cut[3] = exact candidate count, bin_off[b] = first slot of
+// bin b in the kept list; overflow flags of the emission stage.
+__global__ __launch_bounds__(1024) void f_hist_cut_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
+                                                          const unsigned *__restrict__ max_partial, unsigned n_partial, unsigned k_target,
+                                                          unsigned kept_cap, unsigned test_flags, uint4 *__restrict__ zero16, size_t n_zero16,
+                                                          unsigned *__restrict__ acc_zero)
+{
+    __shared__ unsigned h[KF_NB];
     __shared__ unsigned s_wave[16];
-    __shared__ unsigned s_first;
+    __shared__ unsigned s_first, s_maxkey;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned a = sc->hist[2 * t], b = sc->hist[2 * t + 1];
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+    for (size_t i = (size_t)wg * 1024 + t; i < n_zero16; i += (size_t)n_wg * 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (unsigned i = wg * 1024 + t; i < 2 * KF_NB; i += n_wg * 1024) acc_zero[i] = 0u;      // acc_cnt + acc_cur of the ranking behind the sweeps
+    for (int i = t; i < KF_NB; i += 1024) h[i] = 0;
+    unsigned maxkey;
+    if (max_partial) {
+        unsigned m = 0;
+        for (unsigned i = t; i < n_partial; i += 1024) m = max(m, max_partial[i]);
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) s_wave[wv] = m;
+        __syncthreads();
+        if (t == 0) {
+            unsigned mm = 0;
+            for (int i = 0; i < 16; i++) mm = max(mm, s_wave[i]);
+            s_maxkey = mm;
+            if (wg == 0) sc->max_eig_key = mm;         // for the launches that follow (every workgroup here has its own copy)
+        }
+        __syncthreads();
+        maxkey = s_maxkey;
+    } else {
+        maxkey = sc->max_eig_key;
+        __syncthreads();
+    }
+    const unsigned bm = (maxkey & 0x80000000u) ? (maxkey & 0x7fffffffu) : ~maxkey;
+    const float maxv = maxkey ? __uint_as_float(bm) : 0.f;
+    const float thr = (float)__dmul_rn((double)maxv, quality);
+    const unsigned top = (maxkey & 0x7fffffffu) >> KF_SHIFT;   // max eig > 0: ordered key = bits | 0x80000000
+    // the key buffer is KM_NSHARD regions of cap / KM_NSHARD slots; blockIdx.y selects the region
+    {
+        const unsigned cap_s = cap / KM_NSHARD;
+        const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
+        const unsigned long long *kk = keys + (size_t)blockIdx.y * cap_s;
+        unsigned tail = 0;                              // the clamp bin collects the bulk of the (weak) candidates: counted per wave
+        for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
+            const unsigned i = b + t;
+            unsigned d = 0xffffffffu;
+            if (i < n) { const unsigned long long k = kk[i]; if (kf_above(k, thr)) d = kf_bin(k, top); }
+            tail += (unsigned)__popcll(__ballot(d == KF_NB - 1));
+            if (d < KF_NB - 1) atomicAdd(&h[d], 1u);
+        }
+        if (lane == 0 && tail) atomicAdd(&h[KF_NB - 1], tail);
+    }
+    __syncthreads();
+    for (int i = t; i < KF_NB; i += 1024)
+        if (h[i]) atomicAdd(&sc->hist[i], h[i]);
+    if (!kf_last_workgroup(&sc->tickets[0], n_wg)) return;
+    // ---- the cut (one workgroup, every histogram complete)
+    const unsigned a = __hip_atomic_load(&sc->hist[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = __hip_atomic_load(&sc->hist[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned v = a + b;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = __shfl_up(v, o);
         if (lane >= o) v += u;
     }
-    if (lane == 63) s_wave[wv] = v;
+    if (lane == 63) s_wave[wv] = v;                     // (the maximum's use of s_wave ended two barriers ago)
     if (t == 0) s_first = 0xffffffffu;
     __syncthreads();
     unsigned base = 0, total = 0;
@@ -89,26 +161,31 @@ __global__ __launch_bounds__(1024) void f_cut_kernel(km_scalars *sc, unsigned k_
     }
     if (t == 0) {
         sc->cut[3] = total;
-        sc->thr = kf_threshold(sc, quality);
-        const unsigned mk = sc->max_eig_key;
-        const unsigned bb = (mk & 0x80000000u) ? (mk & 0x7fffffffu) : ~mk;
-        sc->max_eig = mk ? __uint_as_float(bb) : 0.f;
+        sc->thr = thr;
+        sc->max_eig = maxv;
         unsigned fl = (sc->pad0 ? KM_FLAG_STAGE_OVERFLOW : 0u) | test_flags;
-        for (int s = 0; s < KM_NSHARD; s++) if (sc->shard_cnt[s] > cap_keys / KM_NSHARD) fl |= KM_FLAG_SHARD_OVERFLOW;
+        for (int s2 = 0; s2 < KM_NSHARD; s2++) if (sc->shard_cnt[s2] > cap / KM_NSHARD) fl |= KM_FLAG_SHARD_OVERFLOW;
         if (fl) atomicOr(&sc->flags, fl);
     }
 }
 
-// kept keys -> their bin's range of `out` (order inside a bin is fixed by the sort that follows).  A workgroup first counts
-// its keys per bin in LDS, reserves one range per non-empty bin (a device-scope atomic with return costs microseconds and
-// same-address ones serialise: one per key made this the slowest kernel of the stage) and then places the keys.
-// (side job: the selection's cell records are zeroed here - a separate memset is one more launch on a latency-bound chain)
-__global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
-                                                         unsigned long long *__restrict__ out, unsigned kept_cap, uint4 *__restrict__ zero16, size_t n_zero16)
+// Launch 2: kept keys -> their bin's range of `out` (order inside a bin is irrelevant: the selection compares keys) AND into their
+// cell of the minimum-distance grid (fixed capacity), state undecided.  A workgroup reads its ~14 000 keys ONCE: the ~4 % above the
+// cut are counted per bin and stashed in LDS; it then reserves one range per non-empty bin (a device-scope atomic with return costs
+// microseconds and same-address ones serialise: one per key made this the slowest kernel of the stage) and places the stashed keys
+// one per thread - the cell insertion is a device-scope atomic WITH return, and inside the key loop its latency was paid per trip
+// (+ 90 us).  A cell's record holds its population AND its first candidate: nearly every occupied cell holds exactly one (160 000
+// candidates on 1.2 million cells), and the sweeps then reach a neighbour's key with two dependent loads instead of three.
+// (The cell records were zeroed by launch 1.)
+#define KF_STASH 3072
+__global__ __launch_bounds__(1024) void f_scatter_cells_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
+                                                               unsigned long long *__restrict__ out, unsigned kept_cap, int W, int cell, int gw,
+                                                               uint2 *__restrict__ cell_rec, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
+                                                               unsigned stash_cap /* <= KF_STASH (test knob: small values force the second read) */)
 {
     __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
-    for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024 + threadIdx.x; i < n_zero16; i += (size_t)gridDim.x * gridDim.y * 1024)
-        zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    __shared__ unsigned long long s_stash[KF_STASH];
+    __shared__ unsigned s_n;
     const unsigned cap_s = cap / KM_NSHARD;
     const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
     keys += (size_t)blockIdx.y * cap_s;
@@ -117,12 +194,16 @@ __global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long lon
     const unsigned D = sc->cut[0];
     if (sc->cut[1] > kept_cap) return;                   // flagged: the exact path takes over
     for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
         const unsigned long long k = keys[i];
         if (!kf_above(k, thr)) continue;
         const unsigned b = kf_bin(k, top);
-        if (b <= D) atomicAdd(&s_cnt[b], 1u);
+        if (b > D) continue;
+        atomicAdd(&s_cnt[b], 1u);
+        const unsigned e = atomicAdd(&s_n, 1u);
+        if (e < stash_cap) s_stash[e] = k;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < KF_NB; i += 1024) {
@@ -131,33 +212,28 @@ __global__ __launch_bounds__(1024) void f_scatter_kernel(const unsigned long lon
         s_cnt[i] = 0;
     }
     __syncthreads();
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
-        const unsigned long long k = keys[i];               // second read: from L2
-        if (!kf_above(k, thr)) continue;
-        const unsigned b = kf_bin(k, top);
-        if (b <= D) out[s_base[b] + atomicAdd(&s_cnt[b], 1u)] = k;
+    auto place = [&](unsigned long long k) {
+        const unsigned pos = s_base[kf_bin(k, top)] + atomicAdd(&s_cnt[kf_bin(k, top)], 1u);
+        out[pos] = k;
+        state[pos] = S_UNDECIDED;
+        int x, y;
+        kf_xy(k, W, x, y);
+        const unsigned g = (unsigned)(y / cell) * (unsigned)gw + (unsigned)(x / cell);
+        const unsigned slot = atomicAdd(&cell_rec[g].x, 1u);
+        if (slot == 0) cell_rec[g].y = pos;
+        else if (slot < KF_CELL) cell_items[(size_t)g * KF_CELL + slot] = pos;
+        else atomicOr(&sc->flags, KM_FLAG_CELL_OVERFLOW);
+    };
+    const unsigned kept_here = s_n;
+    if (kept_here <= stash_cap) {
+        for (unsigned e = threadIdx.x; e < kept_here; e += 1024) place(s_stash[e]);
+    } else {
+        // more keys above the cut than the stash holds (a tile whose strong corners crowd into one part of the key buffer): second read
+        for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+            const unsigned long long k = keys[i];
+            if (kf_above(k, thr) && kf_bin(k, top) <= D) place(k);
+        }
     }
-}
-
-// ranked candidates -> their grid cell (fixed capacity), state undecided.  A cell's record holds its population AND its first
-// candidate: nearly every occupied cell holds exactly one (160 000 candidates on 1.2 million cells), and the sweeps then reach a
-// neighbour's key with two dependent loads instead of three.
-__global__ __launch_bounds__(256) void f_cells_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw,
-                                                      uint2 *__restrict__ cell_rec, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
-                                                      unsigned kept_cap, unsigned *__restrict__ acc_zero)
-{
-    const unsigned n = kf_count(sc, kept_cap);
-    const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    for (unsigned t = i; t < 2 * KF_NB; t += gridDim.x * 256) acc_zero[t] = 0u;      // acc_cnt + acc_cur of the ranking behind the sweeps
-    if (i >= n) return;
-    state[i] = S_UNDECIDED;
-    int x, y;
-    kf_xy(keys[i], W, x, y);
-    const unsigned g = (unsigned)(y / cell) * (unsigned)gw + (unsigned)(x / cell);
-    const unsigned slot = atomicAdd(&cell_rec[g].x, 1u);
-    if (slot == 0) cell_rec[g].y = i;
-    else if (slot < KF_CELL) cell_items[(size_t)g * KF_CELL + slot] = i;
-    else atomicOr(&sc->flags, KM_FLAG_CELL_OVERFLOW);
 }
 
 // One launch = up to KF_SWEEPS relaxation sweeps of every undecided candidate.  The launch is bound by the LATENCY of dependent
@@ -260,11 +336,15 @@ __global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *
 }
 
 // accepted corners per value bin.  Workgroup-aggregated like the scatter: thousands of accepted corners share a handful of bins
-// (equal eigenvalues), and one device-scope atomic per corner on the same address took 300 us.
-__global__ __launch_bounds__(1024) void f_acc_count_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
-                                                           const km_scalars *sc, unsigned *__restrict__ acc_cnt, unsigned kept_cap)
+// (equal eigenvalues), and one device-scope atomic per corner on the same address took 300 us.  The LAST workgroup then scans:
+// acc_off = exclusive scan of acc_cnt, chunk_off = exclusive scan of the bins' 64-corner chunks; corner count, flags.
+__global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
+                                                                km_scalars *sc, unsigned *__restrict__ acc_cnt, unsigned kept_cap,
+                                                                unsigned *__restrict__ acc_off, unsigned *__restrict__ chunk_off, int max_corners,
+                                                                unsigned und_slot)
 {
     __shared__ unsigned s_cnt[KF_NB];
+    __shared__ unsigned s_wave[16], s_wave2[16];
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
     for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
@@ -274,15 +354,10 @@ __global__ __launch_bounds__(1024) void f_acc_count_kernel(const unsigned long l
     __syncthreads();
     for (int i = threadIdx.x; i < KF_NB; i += 1024)
         if (s_cnt[i]) atomicAdd(&acc_cnt[i], s_cnt[i]);
-}
-
-// acc_off = exclusive scan of acc_cnt, chunk_off = exclusive scan of the bins' 64-corner chunks; corner count, flags
-__global__ __launch_bounds__(1024) void f_acc_scan_kernel(const unsigned *__restrict__ acc_cnt, unsigned *__restrict__ acc_off,
-                                                          unsigned *__restrict__ chunk_off, km_scalars *sc, int max_corners, unsigned und_slot)
-{
-    __shared__ unsigned s_wave[16], s_wave2[16];
+    if (!kf_last_workgroup(&sc->tickets[1], gridDim.x)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned a = acc_cnt[2 * t], b = acc_cnt[2 * t + 1];
+    const unsigned a = __hip_atomic_load(&acc_cnt[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = __hip_atomic_load(&acc_cnt[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned ca = (a + 63) / 64, cb = (b + 63) / 64;
     unsigned v = a + b, w = ca + cb;
 #pragma unroll
@@ -382,9 +457,6 @@ __global__ __launch_bounds__(1024) void f_acc_emit_kernel(const unsigned long lo
 
 }  // namespace
 
-// Histogram kernel of the pre-filter lives in k_select.hip
-int ks_topk_hist(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, km_scalars *d_sc, double quality);
-
 size_t kf_kept_capacity(int max_corners) { return (size_t)max_corners * 2 * KF_SLICE; }
 
 struct kf_buffers {
@@ -416,24 +488,29 @@ static int kf_layout(km_ctx *c, int H, int W, int max_corners, double min_distan
     return KM_OK;
 }
 
-// Ranking of the keys the fused kernel emitted: histogram -> cut -> scatter by bin -> per-bin sort.  Everything is enqueued;
-// nothing is read back.  Requires max_corners > 0, min_distance >= 1 and a scalar block zeroed at the start of the call.
+// Ranking of the keys the fused kernel emitted: (maximum, histogram, cut) -> (scatter by value bin + grid cells).  Two launches;
+// everything is enqueued, nothing is read back.  Requires max_corners > 0, min_distance >= 1 and a scalar block zeroed at the
+// start of the call.
 int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H, int W, int max_corners, double quality, double min_distance, km_scalars *sc)
 {
     kf_buffers b;
     int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
     if (rc) return rc;
-    if ((rc = ks_topk_hist(c, d_keys, cap_keys, sc, quality))) return rc;
-    f_cut_kernel<<<1, 1024, 0, c->stream>>>(sc, (unsigned)max_corners * KF_SLICE, quality, (unsigned)cap_keys, b.kept_cap, (unsigned)c->opt_spec_flag);
-    KM_LAUNCH_CHECK(c);
     // (cell records of 8 bytes in a 16-byte aligned buffer; with an odd cell count the first two item slots behind them are zeroed too - they are written later)
-    f_scatter_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap, (uint4 *)b.cell_rec,
-                                                                  (b.cells + 1) / 2);
+    f_hist_cut_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, c->eig_partial, c->eig_npartial,
+                                                                   (unsigned)max_corners * KF_SLICE, b.kept_cap, (unsigned)c->opt_spec_flag,
+                                                                   (uint4 *)b.cell_rec, (b.cells + 1) / 2, b.acc_cnt);
+    KM_LAUNCH_CHECK(c);
+    c->eig_partial = nullptr; c->eig_npartial = 0;
+    f_scatter_cells_kernel<<<dim3(16, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap, W, b.cell, b.gw,
+                                                                        b.cell_rec, b.cell_items, b.state,
+                                                                        c->opt_stash_cap > 0 && c->opt_stash_cap < KF_STASH ? (unsigned)c->opt_stash_cap : (unsigned)KF_STASH);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
 // Greedy minimum-distance selection on the ranked keys of kf_rank: corners in d_xy, their count in sc->n_corners.
+#define KF_LAUNCHES 3          // sweep launches (the third finds nothing left to do on ordinary images: 42 + 6 + 2 us)
 int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc)
 {
     kf_buffers b;
@@ -441,30 +518,17 @@ int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, flo
     if (rc) return rc;
     const double md2 = min_distance * min_distance;
     const unsigned g256 = (b.kept_cap + 255) / 256;
-    f_cells_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.cell_rec, b.cell_items, b.state, b.kept_cap, b.acc_cnt);
-    KM_LAUNCH_CHECK(c);
-    for (int g = 0; g < 4; g++) {
+    for (int g = 0; g < KF_LAUNCHES; g++) {
         f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_rec, b.cell_items, b.state, &sc->und[g], b.kept_cap);
         KM_LAUNCH_CHECK(c);
     }
-    f_acc_count_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_cnt, b.kept_cap);
-    KM_LAUNCH_CHECK(c);
-    f_acc_scan_kernel<<<1, 1024, 0, c->stream>>>(b.acc_cnt, b.acc_off, b.chunk_off, sc, max_corners, 3u);
+    f_acc_count_scan_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_cnt, b.kept_cap, b.acc_off, b.chunk_off, max_corners,
+                                                        (unsigned)(KF_LAUNCHES - 1));
     KM_LAUNCH_CHECK(c);
     f_acc_fill_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_off, b.acc_cur, b.acc_keys, b.kept_cap);
     KM_LAUNCH_CHECK(c);
     // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
     f_acc_emit_kernel<<<b.kept_cap / 64 + KF_NB, 1024, 0, c->stream>>>(b.acc_keys, b.acc_off, b.chunk_off, W, max_corners, cap, d_xy);
-    KM_LAUNCH_CHECK(c);
-    return KM_OK;
-}
-
-// frame header words 2 / 3: speculation flags and the exact candidate count (the host sees them with the frame block)
-__global__ void kf_header_kernel(int *hdr, const km_scalars *sc) { hdr[2] = (int)sc->flags; hdr[3] = (int)sc->cut[3]; }
-
-int kf_stamp_header(km_ctx *c, void *d_block, const km_scalars *sc)
-{
-    kf_header_kernel<<<1, 1, 0, c->stream>>>((int *)d_block, sc);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

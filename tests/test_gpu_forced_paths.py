@@ -112,3 +112,25 @@ def test_speculative_corner_path_flags_and_repeats(ops, O):
         for col in ("x0", "y0", "dx", "dy", "score", "zncc_score"):
             np.testing.assert_array_equal(f3[col].to_numpy(), frame[col].to_numpy())
         ctx.set_option("spec_flag", 0)
+
+
+def test_scatter_launch_second_read_when_the_stash_is_too_small(ops, O):
+    """Launch 2 of the synchronisation-free ranking stashes a workgroup's kept keys in LDS (3072 slots) and reads the key buffer a
+    second time when they do not fit.  "stash_cap" shrinks the stash so that every workgroup with kept keys takes the second read:
+    same corners, same tracks, no flag."""
+    from karios_amd._lib import default_context
+    mon, ref = synth.make_pair(420, 500, 0.4, 0.2, seed=3)
+    ctx = default_context()
+    conf = O.default_conf(maxCorners=700, laplacian_kernel_size=5)
+    exp = O.klt_tile(mon, ref, conf)
+    try:
+        for stash in (1, 7, 0):
+            ctx.set_option("speculative", 1)
+            ctx.set_option("stash_cap", stash)
+            status, tracks = ops.klt_tile(ref, mon, conf, mon_ksize=5, ref_ksize=5)
+            assert status == "ok" and not ctx.stats().path_flags & 16          # went through the speculative path, not repeated
+            p0 = O.good_features(exp["lap_ref"], exp["mask"], 700, 0.1, 10, 15)
+            np.testing.assert_array_equal(tracks[0], p0)
+            np.testing.assert_array_equal(tracks[1], O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0, 25))
+    finally:
+        ctx.set_option("stash_cap", 0)
