@@ -180,6 +180,8 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "topk_factor") == 0) { c->opt_topk_factor = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
+    if (strcmp(name, "fft_dbg") == 0) { c->opt_fft_dbg = value; return KM_OK; }
+    if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }

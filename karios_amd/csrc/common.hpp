@@ -79,6 +79,9 @@ enum km_slot {
     WS_FRAME,
     WS_AUTO,        // batched auto-ksize search: all Laplacians, pyramids, tracks
     WS_LK_ORDER,    // spatial processing order of the key points of one LK launch
+    WS_FFT_TW0,     // twiddle tables of the float32 FFT (row length of the first / second dimension), kept between calls
+    WS_FFT_TW1,
+    WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
     WS_COUNT
 };
 
@@ -174,6 +177,8 @@ struct km_ctx {
     bool spec_used = false;        // the running call went through the speculative corner path
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
+    int opt_fft_dbg = 0;           // development: bits that skip phases of the 61 M row kernel (timing experiments; results are then wrong)
+    bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
     bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
@@ -195,6 +200,7 @@ struct km_ctx {
     double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
+    int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
     size_t fft_work_bytes = 0;
 };
 

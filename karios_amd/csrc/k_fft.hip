@@ -20,6 +20,8 @@
 #include <cmath>
 #include <cstring>
 #include <string.h>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #define FFT_NMAX 12288
@@ -297,6 +299,321 @@ __global__ __launch_bounds__(256) void argmax_f32_kernel(const float *__restrict
     if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
 }
 
+// ================================================================================================================
+// Rows of length N = 61 * M (M <= 192 with prime factors in {2, 3, 5, 7}; Sentinel-2: 10980 = 61 * 180, 5490 = 61 * 90,
+// 1830 = 61 * 30), second form.
+//
+// What the Stockham kernel above pays per row besides its arithmetic (44 us per 10980-point row, one 88-KB workgroup per CU):
+// a dozen workgroup barriers with a global twiddle gather in front of most of them, a radix-61 butterfly whose 3 600
+// coefficients arrive through scalar loads that are waited for at every k, and a row load that nothing overlaps.  Here
+//   * the 61-point transforms (stride M) run first, with the coefficients as INSTRUCTION LITERALS: v_fmamk_f32 d, a, K, d -
+//     no loads, no waits, four independent accumulator chains per output pair (fft61_coef.inc, tools/gen_fft61.py);
+//   * what remains are 61 INDEPENDENT transforms of length M (X[t + 61 m] = sum_j Y[j][t] W_N^(j t) W_M^(j m)): each is done
+//     by ONE wavefront on its own 61-strided elements of the row - wave-synchronous Stockham stages, no workgroup barrier,
+//     the length-M twiddles from a 1.5-KB LDS table, the inter-step twiddles W_N^(j t) from a table laid out [t][j] so that
+//     the lanes of a wavefront read consecutive words; the twelve wavefronts drift apart and hide each other's latencies;
+//   * the next row travels from HBM into registers while the wavefronts work on the current one;
+//   * the last inverse pass never writes |cc|: every row reports its largest and second-largest sample (fft61 mode 3), a
+//     one-workgroup kernel finds the arg-max and the margin - two passes over a 482-MB plane and its store are gone.
+#include "fft61_coef.inc"
+
+template <class F, int... I> __device__ __forceinline__ void f61_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void e3_style_for(F &&f) { f61_for_impl(f, std::make_integer_sequence<int, N>{}); }   // f(0_c) .. f((N-1)_c)
+
+#define F61_T 768
+#define F61_MMAX 192
+
+template <int K, int J> __device__ __forceinline__ void f61_mac(float &cr, float &ci, float &sr, float &si, const float2 &a, const float2 &b)
+{
+    asm("v_fmamk_f32 %0, %1, %2, %0" : "+v"(cr) : "v"(a.x), "n"(F61_C[K][J]));
+    asm("v_fmamk_f32 %0, %1, %2, %0" : "+v"(ci) : "v"(a.y), "n"(F61_C[K][J]));
+    asm("v_fmamk_f32 %0, %1, %2, %0" : "+v"(sr) : "v"(b.x), "n"(F61_S[K][J]));
+    asm("v_fmamk_f32 %0, %1, %2, %0" : "+v"(si) : "v"(b.y), "n"(F61_S[K][J]));
+}
+
+// accumulators of one wavefront's share of the 61-point transform: up to 8 consecutive k (k = K0 + 1 .. K0 + NK)
+struct f61_acc {
+    float cr[8], ci[8], sr[8], si[8];
+};
+
+template <int K0, int J, int... I>
+__device__ __forceinline__ void f61_step(f61_acc &s, const float2 &a, const float2 &b, std::integer_sequence<int, I...>)
+{
+    (f61_mac<K0 + I, J>(s.cr[I], s.ci[I], s.sr[I], s.si[I], a, b), ...);
+}
+
+// One wavefront's share of the 61-point transforms of 64 butterflies (lane = butterfly j): outputs k = K0 + 1 .. K0 + NK and their
+// mirrors 61 - k (+ X[0] when K0 == 0).  The inputs stream from LDS in j order - x[j] and x[61 - j] are read, folded into their sum
+// and difference, and fed to the NK x 4 accumulator chains at once (32 independent FMAs per j: no chain ever waits) - so a lane
+// holds 4 NK accumulators and a few inputs instead of all 61 inputs: ~90 registers instead of ~250 (which spilled, next-row
+// prefetch included).  Nothing is written here: the outputs overwrite other butterflies' inputs, so they wait in the accumulators
+// for the workgroup barrier (`f61_emit`).
+template <int K0, int NK>
+__device__ __forceinline__ void f61_accumulate(const float2 *__restrict__ in /* row + j */, int M, f61_acc &s, float2 &x0, float2 &sum)
+{
+#pragma unroll
+    for (int i = 0; i < NK; i++) s.cr[i] = s.ci[i] = s.sr[i] = s.si[i] = 0.f;
+    x0 = in[0];
+    sum = x0;
+    e3_style_for<30>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;              // coefficient column J <-> input pair (J + 1, 60 - J)
+        const float2 p = in[(J + 1) * M], q = in[(60 - J) * M];
+        const float2 a = cadd(p, q), b = csub(p, q);
+        sum = cadd(sum, a);
+        f61_step<K0, J>(s, a, b, std::make_integer_sequence<int, NK>{});
+    });
+}
+
+template <int K0, int NK, typename Put> __device__ __forceinline__ void f61_emit(const f61_acc &s, float2 x0, float2 sum, Put put)
+{
+    if (K0 == 0) put(0, sum);
+#pragma unroll
+    for (int i = 0; i < NK; i++) {
+        // X[k] = x0 + C_k - i S_k,  X[61 - k] = x0 + C_k + i S_k   (k = K0 + i + 1;  -i (sr + i si) = si - i sr)
+        put(K0 + i + 1, make_float2(x0.x + s.cr[i] + s.si[i], x0.y + s.ci[i] - s.sr[i]));
+        put(60 - K0 - i, make_float2(x0.x + s.cr[i] - s.si[i], x0.y + s.ci[i] + s.sr[i]));
+    }
+}
+
+// every wavefront works on its own elements of the row: only the compiler must be kept from moving LDS traffic across the phases
+#define F61_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// One Stockham stage (radix R, Ns = product of the radices done) of the length-M transform whose element i lives at row[i * 61 + tp];
+// one wavefront, in place: every input is in registers before the first output is written.  `big` (first stage only): the
+// inter-step twiddles W_N^(i tp) of this sub-transform, consecutive in i.
+template <int R>
+__device__ __forceinline__ void f61_wave_stage(float2 *row, int tp, int M, int Ns, const float2 *__restrict__ twM, const float2 *__restrict__ big, int lane)
+{
+    constexpr int TRIPS = R == 2 ? 2 : 1;                 // M / R butterflies, <= 64 per trip (M <= 192)
+    const int nb = M / R, step = M / (Ns * R);
+    const unsigned rcp_ns = (1u << 20) / (unsigned)Ns + 1u;      // b / Ns == (b * rcp_ns) >> 20 for b < 256, Ns <= 192 (checked exhaustively)
+    constexpr bool NEEDS_ROOTS = R != 2 && R != 4;
+    float2 root[NEEDS_ROOTS ? R : 1];
+    if constexpr (NEEDS_ROOTS) {
+#pragma unroll
+        for (int n = 0; n < R; n++) root[n] = twM[n * (M / R)];
+    }
+    float2 v[TRIPS][R];
+#pragma unroll
+    for (int u = 0; u < TRIPS; u++) {
+        const int b = min(lane + 64 * u, nb - 1);
+        const int k = b - (int)(((unsigned)b * rcp_ns) >> 20) * Ns;
+#pragma unroll
+        for (int t = 0; t < R; t++) v[u][t] = row[(b + t * nb) * 61 + tp];
+        if (big) {
+#pragma unroll
+            for (int t = 0; t < R; t++) v[u][t] = cmul(v[u][t], big[b + t * nb]);
+        }
+        if (Ns > 1) {
+#pragma unroll
+            for (int t = 1; t < R; t++) v[u][t] = cmul(v[u][t], twM[t * k * step]);
+        }
+    }
+    F61_WAVE_SYNC();
+#pragma unroll
+    for (int u = 0; u < TRIPS; u++) {
+        const int b = lane + 64 * u;
+        dft_small<R>(v[u], root);
+        if (b < nb) {
+            const int q = (int)(((unsigned)b * rcp_ns) >> 20), k = b - q * Ns, j0 = q * Ns * R + k;
+#pragma unroll
+            for (int t = 0; t < R; t++) row[(j0 + t * Ns) * 61 + tp] = v[u][t];
+        }
+    }
+    F61_WAVE_SYNC();
+}
+
+struct f61_plan {
+    int M, n_stages;
+    int radix[8];
+};
+
+// per-row result of mode 3: key of the largest |cc| (value bits << 32 | ~flat index) and the second-largest value's bits
+struct f61_top2 {
+    unsigned long long best;
+    unsigned second, pad;
+};
+
+// MODE 0: rows of two real images -> z = a + i b;  1: complex rows in place;  2: complex rows, inverse (conjugate in, conjugate out);
+// 3: like 2 without an output plane: top2[r] = largest / second-largest |cc| of row r
+template <typename T, int MC /* M at compile time (0: run time): the 61 strided reads of a butterfly then carry immediate offsets */, int mode>
+__global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__ img_a, const T *__restrict__ img_b, ptrdiff_t sa, ptrdiff_t sb,
+                                                           float2 *__restrict__ data, f61_top2 *__restrict__ top2, int N, int nrows, f61_plan plan,
+                                                           const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *row = (float2 *)smem;
+    float2 *twM = row + N;                                  // exp(-2 pi i n / M), n < M
+    __shared__ unsigned long long s_best[F61_T / 64];
+    __shared__ unsigned s_second[F61_T / 64];
+    const int M = MC ? MC : plan.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PF = (FFT_NMAX + F61_T - 1) / F61_T;      // elements of a row per thread (16)
+    for (int i = tid; i < M; i += F61_T) twM[i] = twM_g[i];
+
+    // the row a thread holds in flight: elements tid + F61_T * u, exactly as loaded (conversions and the conjugation wait for
+    // `commit`: an instruction that consumes a load would stall the wavefront until the data has arrived)
+    float2 pf[PF];
+    auto fetch = [&](int r) {
+        if (mode == 0) {
+            const T *pa = img_a + (size_t)r * sa, *pb = img_b + (size_t)r * sb;
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int i = min(tid + F61_T * u, N - 1);
+                if constexpr (std::is_same<T, float>::value) { pf[u].x = pa[i]; pf[u].y = pb[i]; }
+                else { pf[u].x = __uint_as_float((unsigned)(int)pa[i]); pf[u].y = __uint_as_float((unsigned)(int)pb[i]); }   // (the load itself extends)
+            }
+        } else {
+            const float2 *src = data + (size_t)r * N;
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = src[min(tid + F61_T * u, N - 1)];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = tid + F61_T * u;
+            float2 x = pf[u];
+            if (mode == 0) {
+                if constexpr (!std::is_same<T, float>::value)
+                    x = make_float2((float)(T)(int)__float_as_uint(pf[u].x), (float)(T)(int)__float_as_uint(pf[u].y));
+            } else if (mode >= 2) {
+                x.y = -x.y;
+            }
+            if (i < N) row[i] = x;
+        }
+    };
+    int r = blockIdx.x;
+    if (r < nrows) { fetch(r); commit(); }
+    __syncthreads();
+    for (; r < nrows; r += gridDim.x) {
+        // ---- phase A: 61-point transforms of the M butterflies (inputs at stride M, outputs contiguous: Y[j][t] -> row[61 j + t])
+        {
+            const int part = wave & 3, j = (wave >> 2) * 64 + lane;
+            f61_acc acc;                                    // (part 3 uses 6 of the 8)
+            float2 x0 = make_float2(0.f, 0.f), sum = x0;
+            if (j < M && !(dbg & 1)) {
+                switch (part) {
+                case 0: f61_accumulate<0, 8>(row + j, M, acc, x0, sum); break;
+                case 1: f61_accumulate<8, 8>(row + j, M, acc, x0, sum); break;
+                case 2: f61_accumulate<16, 8>(row + j, M, acc, x0, sum); break;
+                default: f61_accumulate<24, 6>(row + j, M, acc, x0, sum); break;
+                }
+            }
+            __syncthreads();
+            if (j < M && !(dbg & 1)) {
+                auto put = [&](int t, float2 val) { row[j * 61 + t] = val; };
+                switch (part) {
+                case 0: f61_emit<0, 8>(acc, x0, sum, put); break;
+                case 1: f61_emit<8, 8>(acc, x0, sum, put); break;
+                case 2: f61_emit<16, 8>(acc, x0, sum, put); break;
+                default: f61_emit<24, 6>(acc, x0, sum, put); break;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the next row starts its way from HBM (consumed after the store below)
+        const int rn = r + gridDim.x;
+        if (rn < nrows && !(dbg & 4)) fetch(rn);
+        // ---- phase B: 61 independent length-M transforms, one wavefront each
+        for (int tp = wave; tp < ((dbg & 2) ? 0 : 61); tp += F61_T / 64) {
+            int Ns = 1;
+            for (int s = 0; s < plan.n_stages; s++) {
+                const int R = plan.radix[s];
+                const float2 *big = s == 0 ? big_g + (size_t)tp * M : nullptr;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                // (keeps each stage's index arithmetic local)
+                switch (R) {
+                case 7: f61_wave_stage<7>(row, tp, M, Ns, twM, big, ln); break;
+                case 5: f61_wave_stage<5>(row, tp, M, Ns, twM, big, ln); break;
+                case 4: f61_wave_stage<4>(row, tp, M, Ns, twM, big, ln); break;
+                case 3: f61_wave_stage<3>(row, tp, M, Ns, twM, big, ln); break;
+                default: f61_wave_stage<2>(row, tp, M, Ns, twM, big, ln); break;
+                }
+                Ns *= R;
+            }
+        }
+        __syncthreads();
+        // ---- the finished row leaves (natural order: X[t + 61 m] at row[t + 61 m])
+        if (mode == 3) {
+            unsigned long long best = 0;
+            unsigned second = 0;
+            for (int i = tid; i < N; i += F61_T) {
+                const float2 x = row[i];
+                const float a = sqrtf(x.x * x.x + x.y * x.y);
+                if (a == a) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(a) << 32) | (0xffffffffull - ((unsigned long long)r * (unsigned)N + (unsigned)i));
+                    if (key > best) { second = max(second, (unsigned)(best >> 32)); best = key; }
+                    else second = max(second, __float_as_uint(a));
+                }
+            }
+            // wave: largest key; second = largest value among everything that is not that sample
+            unsigned long long wb = wmax_u64(best);
+            unsigned cand = best == wb ? second : (unsigned)(best >> 32);
+            cand = max(cand, second);
+            for (int o = 32; o > 0; o >>= 1) cand = max(cand, (unsigned)__shfl_xor((int)cand, o));
+            if (lane == 0) { s_best[wave] = wb; s_second[wave] = cand; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long rb = 0;
+                for (int w = 0; w < F61_T / 64; w++) rb = s_best[w] > rb ? s_best[w] : rb;
+                unsigned rs = 0;
+                for (int w = 0; w < F61_T / 64; w++) rs = max(rs, s_best[w] == rb ? s_second[w] : max(s_second[w], (unsigned)(s_best[w] >> 32)));
+                top2[r].best = rb; top2[r].second = rs; top2[r].pad = 0;
+            }
+        } else {
+            float2 *dst = data + (size_t)r * N;
+            if (!(dbg & 8)) for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2) x.y = -x.y; dst[i] = x; }
+        }
+        __syncthreads();
+        if (rn < nrows && !(dbg & 4)) commit();
+        __syncthreads();
+    }
+}
+
+// rows' (largest key, second-largest value) -> overall: out[0] = key of the arg-max, out[1] = bits of the second-largest sample
+__global__ __launch_bounds__(1024) void f61_top2_reduce_kernel(const f61_top2 *__restrict__ top2, int nrows, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long s_b[16];
+    __shared__ unsigned s_s[16];
+    unsigned long long best = 0;
+    for (int i = threadIdx.x; i < nrows; i += 1024) best = top2[i].best > best ? top2[i].best : best;
+    unsigned long long wb = wmax_u64(best);
+    if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = wb;
+    __syncthreads();
+    unsigned long long gb = 0;
+    for (int w = 0; w < 16; w++) gb = s_b[w] > gb ? s_b[w] : gb;
+    unsigned sec = 0;
+    for (int i = threadIdx.x; i < nrows; i += 1024) sec = max(sec, top2[i].best == gb ? top2[i].second : max(top2[i].second, (unsigned)(top2[i].best >> 32)));
+    for (int o = 32; o > 0; o >>= 1) sec = max(sec, (unsigned)__shfl_xor((int)sec, o));
+    if ((threadIdx.x & 63) == 0) s_s[threadIdx.x >> 6] = sec;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned gs = 0;
+        for (int w = 0; w < 16; w++) gs = max(gs, s_s[w]);
+        out[0] = gb; out[1] = (unsigned long long)gs;
+    }
+}
+
+bool factorize61(int N, f61_plan *p)
+{
+    if (N < 122 || N > FFT_NMAX || N % 61) return false;
+    int m = N / 61;
+    if (m > F61_MMAX || m % 61 == 0) return false;
+    p->M = m; p->n_stages = 0;
+    static const int radices[] = {7, 5, 4, 3, 2};
+    for (int r : radices)
+        while (m % r == 0) {
+            if (p->n_stages == 8) return false;
+            p->radix[p->n_stages++] = r;
+            m /= r;
+        }
+    return m == 1 && p->n_stages > 0;
+}
+
 bool factorize(int N, fft_plan *p)
 {
     if (N < 2 || N > FFT_NMAX) return false;
@@ -316,9 +633,16 @@ bool factorize(int N, fft_plan *p)
     return n == 1;
 }
 
-int upload_twiddles(km_ctx *c, int slot, int N, float2 **out)
+// Twiddle tables of one row length, kept in a workspace slot of their own between calls (a Sentinel-2 product is a stack of bands
+// of the same size): tw[n] = exp(-2 pi i n / N), n < N; for N = 61 M also twM[n] = exp(-2 pi i n / M), n < M, and
+// big[t][j] = exp(-2 pi i j t / N), t < 61, j < M (the inter-step twiddles, consecutive in j).  Computed in double on the host.
+struct fft_tables {
+    const float2 *tw = nullptr, *twM = nullptr, *big = nullptr;
+};
+
+int upload_twiddles(km_ctx *c, int which, int N, const f61_plan *p61, fft_tables *out)
 {
-    static bool t61_ready = false;            // (cos, sin)(2 pi j k / 61), j, k = 1 .. 30, for the radix-61 butterfly
+    static bool t61_ready = false;            // (cos, sin)(2 pi j k / 61), j, k = 1 .. 30, for the first form's radix-61 butterfly
     if (!t61_ready) {
         std::vector<float2> h(900);
         for (int k = 1; k <= 30; k++)
@@ -329,16 +653,31 @@ int upload_twiddles(km_ctx *c, int slot, int N, float2 **out)
         KM_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_t61), h.data(), 900 * sizeof(float2)));
         t61_ready = true;
     }
-    float2 *d = (float2 *)km_ws(c, slot, (size_t)N * sizeof(float2));
+    const int M = p61 ? p61->M : 0;
+    const size_t total = (size_t)N + (size_t)M + (p61 ? (size_t)N : 0);
+    float2 *d = (float2 *)km_ws(c, which ? WS_FFT_TW1 : WS_FFT_TW0, (size_t)(2 * FFT_NMAX + F61_MMAX) * sizeof(float2));
     if (!d) return KM_E_NOMEM;
-    std::vector<float2> h((size_t)N);
+    out->tw = d; out->twM = p61 ? d + N : nullptr; out->big = p61 ? d + N + M : nullptr;
+    if (c->fft_tw_n[which] == N) return KM_OK;
+    std::vector<float2> h(total);
     for (int n = 0; n < N; n++) {
         const double a = -2.0 * M_PI * (double)n / (double)N;
         h[(size_t)n] = make_float2((float)cos(a), (float)sin(a));
     }
-    KM_HIP(c, hipMemcpyAsync(d, h.data(), (size_t)N * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    if (p61) {
+        for (int n = 0; n < M; n++) {
+            const double a = -2.0 * M_PI * (double)n / (double)M;
+            h[(size_t)N + n] = make_float2((float)cos(a), (float)sin(a));
+        }
+        for (int t = 0; t < 61; t++)
+            for (int j = 0; j < M; j++) {
+                const double a = -2.0 * M_PI * (double)((long long)j * t) / (double)N;
+                h[(size_t)N + M + (size_t)t * M + j] = make_float2((float)cos(a), (float)sin(a));
+            }
+    }
+    KM_HIP(c, hipMemcpyAsync(d, h.data(), total * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));          // `h` goes out of scope
-    *out = d;
+    c->fft_tw_n[which] = N;
     return KM_OK;
 }
 
@@ -358,13 +697,49 @@ int launch_rows(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, f
     return KM_OK;
 }
 
+template <typename T, int MC, int MODE>
+int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
+                     const fft_tables &tb)
+{
+    const size_t lds = ((size_t)N + (size_t)plan.M) * sizeof(float2);
+    static bool opted = false;
+    if (!opted) {
+        KM_HIP(c, hipFuncSetAttribute((const void *)fft61_rows_kernel<T, MC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((FFT_NMAX + F61_MMAX) * sizeof(float2))));
+        opted = true;   // per instantiation (static local of the template)
+    }
+    const int grid = nrows < c->n_cu ? nrows : c->n_cu;      // one 88-KB workgroup per CU: each walks its rows with the next one in flight
+    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// mode 0 reads two images of pixel type T; modes 1 .. 3 work on the complex plane (T = float).  Sentinel-2's 10 m bands
+// (10980 = 61 * 180) run with M as a compile-time constant.
+template <typename T>
+int launch_rows61(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
+                  const fft_tables &tb, int mode)
+{
+    const bool m180 = plan.M == 180;
+    if (mode == 0) return m180 ? launch_rows61_as<T, 180, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<T, 0, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    if constexpr (std::is_same<T, float>::value) {
+        switch (mode) {
+        case 1: return m180 ? launch_rows61_as<float, 180, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        case 2: return m180 ? launch_rows61_as<float, 180, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        default: return m180 ? launch_rows61_as<float, 180, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        }
+    }
+    return km_fail(c, KM_E_INTERNAL, "fft61: complex passes run on float planes");
+}
+
 }  // namespace
 
 // True when the float32 fast path covers this shape.
 bool kp_fast_supported(int H, int W)
 {
     fft_plan p;
-    return H >= 2 && W >= 2 && factorize(H, &p) && factorize(W, &p) && (size_t)H * W <= 0x7fffffffull;
+    f61_plan q;
+    return H >= 2 && W >= 2 && (factorize(H, &p) || factorize61(H, &q)) && (factorize(W, &p) || factorize61(W, &q)) && (size_t)H * W <= 0x7fffffffull;
 }
 
 // Phase correlation in float32.  out_rc = integer shift as skimage reports it; *margin = (max - second largest) / max of |cc|:
@@ -373,19 +748,31 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
                         double out_rc[2], double *margin)
 {
     fft_plan pw, ph;
-    if (!factorize(W, &pw) || !factorize(H, &ph)) return KM_E_UNSUPPORTED;
+    f61_plan qw, qh;
+    const bool w61 = c->opt_fft61 && factorize61(W, &qw), h61 = c->opt_fft61 && factorize61(H, &qh);
+    if ((!w61 && !factorize(W, &pw)) || (!h61 && !factorize(H, &ph))) return KM_E_UNSUPPORTED;
     const size_t n = (size_t)H * W;
     float2 *A = (float2 *)km_ws(c, WS_FFT_A, n * sizeof(float2)), *B = (float2 *)km_ws(c, WS_FFT_B, n * sizeof(float2));
     km_scalars *sc = (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars));
-    if (!A || !B || !sc) return KM_E_NOMEM;
-    float2 *tw_w = nullptr, *tw_h = nullptr;
+    f61_top2 *top2 = (f61_top2 *)km_ws(c, WS_FFT_TOP2, (size_t)H * sizeof(f61_top2));
+    if (!A || !B || !sc || !top2) return KM_E_NOMEM;
+    fft_tables tw_w, tw_h;
     int rc;
-    if ((rc = upload_twiddles(c, WS_MISC0, W, &tw_w))) return rc;
+    if ((rc = upload_twiddles(c, 0, W, w61 ? &qw : nullptr, &tw_w))) return rc;
     if (H == W) tw_h = tw_w;
-    else if ((rc = upload_twiddles(c, WS_MISC1, H, &tw_h))) return rc;
+    else if ((rc = upload_twiddles(c, 1, H, h61 ? &qh : nullptr, &tw_h))) return rc;
+    // complex rows of length N (in place; mode 3: no output plane when the 61 M form runs, |cc| into `mag` otherwise)
+    auto rows = [&](float2 *data, float *mag, int N, int nrows, bool is_w, int mode) -> int {
+        if (is_w ? w61 : h61) return launch_rows61<float>(c, nullptr, nullptr, 0, 0, data, top2, N, nrows, is_w ? qw : qh, is_w ? tw_w : tw_h, mode);
+        return launch_rows<float>(c, nullptr, nullptr, 0, 0, data, mag, N, nrows, is_w ? pw : ph, (is_w ? tw_w : tw_h).tw, mode);
+    };
     // forward: rows (length W) of z = a + i b -> A; transpose -> B (W x H); rows (length H) in place
     switch (dtype) {
-#define KM_ROWS(CODE, T) case CODE: rc = launch_rows<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, A, nullptr, W, H, pw, tw_w, 0); break;
+#define KM_ROWS(CODE, T)                                                                                                                    \
+    case CODE:                                                                                                                              \
+        rc = w61 ? launch_rows61<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, A, nullptr, W, H, qw, tw_w, 0)                   \
+                 : launch_rows<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, A, nullptr, W, H, pw, tw_w.tw, 0);                 \
+        break;
         KM_ROWS(KM_U8, uint8_t) KM_ROWS(KM_U16, uint16_t) KM_ROWS(KM_I16, int16_t) KM_ROWS(KM_F32, float)
 #undef KM_ROWS
     default: return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d", dtype);
@@ -394,31 +781,46 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
     const dim3 tg((W + 63) / 64, (H + 63) / 64), tg2((H + 63) / 64, (W + 63) / 64);
     transpose_kernel<<<tg, 256, 0, c->stream>>>(A, B, H, W);
     KM_LAUNCH_CHECK(c);
-    if ((rc = launch_rows<float>(c, nullptr, nullptr, 0, 0, B, nullptr, H, W, ph, tw_h, 1))) return rc;
+    if ((rc = rows(B, nullptr, H, W, false, 1))) return rc;
     cross_power_f32_kernel<<<c->n_cu * 16, 256, 0, c->stream>>>(B, A, W, H);
     KM_LAUNCH_CHECK(c);
     // inverse: rows (length H) of the transposed spectrum in place; transpose -> B (H x W); rows (length W) -> |cc|
-    if ((rc = launch_rows<float>(c, nullptr, nullptr, 0, 0, A, nullptr, H, W, ph, tw_h, 2))) return rc;
+    if ((rc = rows(A, nullptr, H, W, false, 2))) return rc;
     transpose_kernel<<<tg2, 256, 0, c->stream>>>(A, B, W, H);
     KM_LAUNCH_CHECK(c);
     float *cc = (float *)A;
-    if ((rc = launch_rows<float>(c, nullptr, nullptr, 0, 0, B, cc, W, H, pw, tw_w, 3))) return rc;
+    if ((rc = rows(B, cc, W, H, true, 3))) return rc;
     // largest and second-largest |cc|
     unsigned long long *k1 = &sc->argmax_key, *k2 = (unsigned long long *)&sc->valid;
-    KM_HIP(c, hipMemsetAsync(k1, 0, sizeof *k1, c->stream));
-    KM_HIP(c, hipMemsetAsync(k2, 0, sizeof *k2, c->stream));
-    argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, ~0ull, k1);
-    KM_LAUNCH_CHECK(c);
     unsigned long long h1 = 0, h2 = 0;
-    KM_HIP(c, hipMemcpyAsync(&h1, k1, sizeof h1, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
-    const unsigned long long flat = h1 ? 0xffffffffull - (h1 & 0xffffffffull) : 0ull;
-    argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, flat, k2);
-    KM_LAUNCH_CHECK(c);
-    KM_HIP(c, hipMemcpyAsync(&h2, k2, sizeof h2, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long flat;
+    unsigned b1, b2;
+    if (w61) {
+        // the rows reported their two largest samples: one small launch, one read-back
+        unsigned long long *d_res = (unsigned long long *)&sc->hist[0];
+        f61_top2_reduce_kernel<<<1, 1024, 0, c->stream>>>(top2, H, d_res);
+        KM_LAUNCH_CHECK(c);
+        unsigned long long res[2] = {0, 0};
+        KM_HIP(c, hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+        h1 = res[0];
+        flat = h1 ? 0xffffffffull - (h1 & 0xffffffffull) : 0ull;
+        b1 = (unsigned)(h1 >> 32); b2 = (unsigned)res[1];
+    } else {
+        KM_HIP(c, hipMemsetAsync(k1, 0, sizeof *k1, c->stream));
+        KM_HIP(c, hipMemsetAsync(k2, 0, sizeof *k2, c->stream));
+        argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, ~0ull, k1);
+        KM_LAUNCH_CHECK(c);
+        KM_HIP(c, hipMemcpyAsync(&h1, k1, sizeof h1, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+        flat = h1 ? 0xffffffffull - (h1 & 0xffffffffull) : 0ull;
+        argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, flat, k2);
+        KM_LAUNCH_CHECK(c);
+        KM_HIP(c, hipMemcpyAsync(&h2, k2, sizeof h2, hipMemcpyDeviceToHost, c->stream));
+        KM_HIP(c, hipStreamSynchronize(c->stream));
+        b1 = (unsigned)(h1 >> 32); b2 = (unsigned)(h2 >> 32);
+    }
     float v1, v2;
-    const unsigned b1 = (unsigned)(h1 >> 32), b2 = (unsigned)(h2 >> 32);
     __builtin_memcpy(&v1, &b1, 4); __builtin_memcpy(&v2, &b2, 4);
     *margin = (h1 && v1 > 0.f) ? (double)(v1 - v2) / (double)v1 : 0.0;
     double r = (double)(flat / (unsigned long long)W), col = (double)(flat % (unsigned long long)W);

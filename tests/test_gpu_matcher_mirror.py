@@ -171,10 +171,22 @@ def test_kernel_search_with_inverted_and_searched_polarity_on_uint16(ops, O, pol
 
 
 # ---------------------------------------------------------------------------- hand-written float32 phase correlation
-@pytest.mark.parametrize("shape", [(244, 183), (420, 360), (1098, 1220), (96, 250), (366, 366), (61, 122), (1830, 700), (122, 3721)])
-def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape):
-    """k_fft.hip (float32, radices 2/3/4/5/7/61) against the double-precision rocFFT path and the oracle: same integer shifts
-    on shifted copies (clear peak -> fast path is trusted), and the double path takes over when the peak is split evenly."""
+@pytest.fixture(params=[1, 0], ids=["rows_61xM_wave_local", "rows_stockham"])
+def fft_form(request, ops):
+    """Both row kernels of k_fft.hip for lengths 61 * M: the wave-local form (default) and the workgroup-wide Stockham kernel
+    (every other length, and 61 * M with M > 192)."""
+    ctx = ops._lib.default_context()
+    ctx.set_option("fft61", request.param)
+    yield request.param
+    ctx.set_option("fft61", 1)
+
+
+@pytest.mark.parametrize("shape", [(244, 183), (420, 360), (1098, 1220), (96, 250), (366, 366), (61, 122), (1830, 700), (122, 3721),
+                                   (427, 915), (2135, 128), (64, 5490), (10980, 61), (3660, 854)])
+def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape, fft_form):
+    """k_fft.hip (float32, radices 2/3/4/5/7/61; rows of length 61 * M as 61-point transforms + M-point transforms per wavefront)
+    against the double-precision rocFFT path and the oracle: same integer shifts on shifted copies (clear peak -> fast path is
+    trusted), and the double path takes over when the peak is split evenly."""
     from karios_amd._lib import default_context
     H, W = shape
     ctx = default_context()
