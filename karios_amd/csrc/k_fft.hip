@@ -43,6 +43,22 @@ template <int R> __device__ __forceinline__ void dft_small(float2 (&x)[R], const
         const float2 a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d = csub(x[1], x[3]);
         const float2 md = make_float2(d.y, -d.x);          // -i * d
         x[0] = cadd(a, c); x[2] = csub(a, c); x[1] = cadd(b, md); x[3] = csub(b, md);
+    } else if constexpr (R == 3) {
+        // W = exp(-2 pi i / 3) = -1/2 - i sqrt(3)/2:  X1,2 = x0 - (x1 + x2) / 2 -+ i (sqrt(3)/2) (x1 - x2)
+        const float c = 0.86602540378443864676f;
+        const float2 t = cadd(x[1], x[2]), d = csub(x[1], x[2]);
+        const float2 m = make_float2(x[0].x - 0.5f * t.x, x[0].y - 0.5f * t.y), r = make_float2(c * d.y, -c * d.x);   // r = -i c d
+        x[0] = cadd(x[0], t); x[1] = cadd(m, r); x[2] = csub(m, r);
+    } else if constexpr (R == 5) {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        const float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
+        const float2 m1 = make_float2(x[0].x + c1 * a1.x + c2 * a2.x, x[0].y + c1 * a1.y + c2 * a2.y);
+        const float2 m2 = make_float2(x[0].x + c2 * a1.x + c1 * a2.x, x[0].y + c2 * a1.y + c1 * a2.y);
+        const float2 n1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y), n2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+        // X1,4 = m1 -+ i n1, X2,3 = m2 -+ i n2   (-i n = (n.y, -n.x))
+        x[0] = make_float2(x[0].x + a1.x + a2.x, x[0].y + a1.y + a2.y);
+        x[1] = make_float2(m1.x + n1.y, m1.y - n1.x); x[4] = make_float2(m1.x - n1.y, m1.y + n1.x);
+        x[2] = make_float2(m2.x + n2.y, m2.y - n2.x); x[3] = make_float2(m2.x - n2.y, m2.y + n2.x);
     } else {
         float2 y[R];
 #pragma unroll
@@ -103,7 +119,7 @@ template <int R> __device__ __forceinline__ void stage(float2 *row, int N, int N
     constexpr int MAXB = (FFT_NMAX / R + FFT_T - 1) / FFT_T;
     const int nb = N / R;
     const int stride = N / (Ns * R);                 // twiddle exponent step: W_N^(t k stride), t < R, k < Ns
-    constexpr bool NEEDS_ROOTS = R != 2 && R != 4;      // radix 2 / 4 butterflies are additions only
+    constexpr bool NEEDS_ROOTS = R == 7;                 // radix 2 .. 5 butterflies carry their constants
     float2 root[NEEDS_ROOTS ? R : 1];
     if constexpr (NEEDS_ROOTS) {
 #pragma unroll
@@ -390,7 +406,7 @@ __device__ __forceinline__ void f61_wave_stage(float2 *row, int tp, int M, int N
     constexpr int TRIPS = R == 2 ? 2 : 1;                 // M / R butterflies, <= 64 per trip (M <= 192)
     const int nb = M / R, step = M / (Ns * R);
     const unsigned rcp_ns = (1u << 20) / (unsigned)Ns + 1u;      // b / Ns == (b * rcp_ns) >> 20 for b < 256, Ns <= 192 (checked exhaustively)
-    constexpr bool NEEDS_ROOTS = R != 2 && R != 4;
+    constexpr bool NEEDS_ROOTS = R == 7;
     float2 root[NEEDS_ROOTS ? R : 1];
     if constexpr (NEEDS_ROOTS) {
 #pragma unroll
