@@ -3,6 +3,8 @@
 // ends in HIP kernels on the context stream; there is no fallback path.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -181,6 +183,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     if (strcmp(name, "fft_dbg") == 0) { c->opt_fft_dbg = value; return KM_OK; }
+    if (strcmp(name, "roctx") == 0) { c->opt_roctx = value != 0; return KM_OK; }
     if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
@@ -212,6 +215,39 @@ static const char *const kStageNames[ST_COUNT] = {"minmax", "stretch_laplacian_m
                                                   "select", "pyramid", "lk_fwd_bwd", "zncc", "fb_frame", "mutual_info", "phase_correlation"};
 
 const char *km_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+// ---- roctx ranges (tracing): resolved lazily with dlopen, a no-op when no roctx library is present
+extern "C++" {
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static bool g_roctx_tried = false;
+static void roctx_resolve()
+{
+    if (g_roctx_tried) return;
+    g_roctx_tried = true;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return;
+        g_roctx_push = nullptr; g_roctx_pop = nullptr;
+    }
+}
+void km_roctx_push(int stage)
+{
+    roctx_resolve();
+    if (g_roctx_push) {
+        char name[64];
+        snprintf(name, sizeof name, "karios:%s", km_stage_name(stage));
+        g_roctx_push(name);
+    }
+}
+void km_roctx_pop()
+{
+    if (g_roctx_pop) g_roctx_pop();
+}
+}  // extern "C++"
 
 int km_get_stage_ms(km_ctx *c, float *out, int cap, int *n)
 {

@@ -178,6 +178,7 @@ struct km_ctx {
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
     int opt_fft_dbg = 0;           // development: bits that skip phases of the 61 M row kernel (timing experiments; results are then wrong)
+    bool opt_roctx = false;        // "roctx": roctx ranges around the stages
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
@@ -205,6 +206,10 @@ struct km_ctx {
 };
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
+// km_set_option("roctx", 1): every stage's host-side enqueue span becomes a roctx range (rocprofv3 --marker-trace); the library
+// is looked up at run time (librocprofiler-sdk-roctx.so / libroctx64.so), nothing is linked
+void km_roctx_push(int stage);
+void km_roctx_pop();
 void *km_pinned_rb(km_ctx *c, size_t bytes);   // >= bytes of pinned host memory owned by the context (nullptr on failure)
 
 // MI355X dispatches workgroup w of a grid to XCD w % 8, and every XCD has its own L2.  The marching kernels therefore
@@ -258,8 +263,10 @@ int km_run_deferred(km_ctx *ctx);   // runs every job still pending (call before
 struct km_stage_timer {
     km_ctx *c;
     int s;
+    bool marked = false;
     km_stage_timer(km_ctx *ctx, int stage) : c(ctx), s(stage)
     {
+        if (c->opt_roctx) { km_roctx_push(stage); marked = true; }
         if (c->opt_profile_stage >= 0 && stage != c->opt_profile_stage) { s = -1; return; }
         if (c->profiling && c->ev_ready && !c->evs_used[c->ev_cur][s]) {
             (void)hipEventRecord(c->evs[c->ev_cur][s][0], c->stream);
@@ -269,6 +276,7 @@ struct km_stage_timer {
     }
     ~km_stage_timer()
     {
+        if (marked) km_roctx_pop();
         if (s >= 0 && c->profiling && c->ev_ready) {
             (void)hipEventRecord(c->evs[c->ev_cur][s][1], c->stream);
             c->evs_used[c->ev_cur][s] = true;
