@@ -24,9 +24,15 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
                                                    const float *__restrict__ dy, int n, const int *__restrict__ d_n,
                                                    const float *__restrict__ score, float score_thr, double *__restrict__ out, km_window win)
 {
-    const int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // key point of this wave: uniform, scalar addressing
+    // Workgroup w runs on XCD w % 8 (an L2 each).  The rows of a frame are ordered by (x0, y0): handing every XCD one CONTIGUOUS
+    // eighth of them makes the ~1000 key points an XCD works on at a time a band of ~70 image columns, whose 43 x 43 chips overlap
+    // in L2 - dealt round-robin, neighbouring chips sat in eight different L2s and every 86-byte chip row cost its own 128-byte lines.
+    // (the eighths are cut from the rows the frame really has: the launch is sized for the capacity)
+    const int n_rows = d_n ? min(*d_n, n) : n;
+    const unsigned per = ((unsigned)(n_rows + 3) / 4 + KM_XCDS - 1) / KM_XCDS, blk = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
+    const int k = (int)blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // key point of this wave: uniform, scalar addressing
     const int lane = threadIdx.x & 63;
-    if (k >= (d_n ? min(*d_n, n) : n)) return;
+    if (blockIdx.x / KM_XCDS >= per || k >= n_rows) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // rows below the confidence threshold are not scored (core.py:878-893): NaN, like the reference's column
     if (score && !(score[k] >= score_thr)) { if (lane == 0) out[k] = nan; return; }
@@ -90,7 +96,7 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
                      const float *d_score, float score_thr, double *d_out)
 {
     if (n <= 0) return KM_OK;
-    const int nb = (n + 3) / 4;
+    const int nb = (int)km_xcd_grid((unsigned)((n + 3) / 4));
 #define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
     switch (dtype) {
     case KM_U8: KM_Z(uint8_t); break;
