@@ -599,21 +599,32 @@ def roofline_of(stage_ms: dict, S: int, n_init: int, n_cand: int, n_zncc: int, t
         t = ms.get(k, 0.0)
         if t > 0 and b > 0:
             table[k] = {"ms": round(t, 4), "bytes": b, "achieved": b / (t * 1e-3) / 1e9, "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    dom = max(table, key=lambda k: table[k]["ms"])
+    # the pyramids run on the library's second stream beside the fused eigenvalue pass (they fill what that issue-bound kernel leaves):
+    # their span is stretched by the sharing and is not on the critical path - never the "largest kernel"
+    if "pyramid" in table:
+        table["pyramid"]["overlapped"] = "second stream, beside min_eigen: the span is stretched by the sharing (0.10 ms alone)"
+    dom = max((k for k in table if k != "pyramid"), key=lambda k: table[k]["ms"])
     d = table[dom]
     out = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
            **pmc_traffic(dom, S), "algorithmic_bytes_per_launch": d["bytes"], "kernel_ms": d["ms"],
            "kernel_ms_source": ("HIP events over the timed steps" if dom == timed_stage else "HIP events over an untimed pass of the same loop")}
+    t = out.get("traffic")
+    if t:
+        out["frac_of_measured_traffic"] = t / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS      # what the kernel really moved (PMC, precomputed) / time / peak
     if fused and eig_name in table:
         unf = (STAGE_BYTES_PER_PX["min_eigen"] + STAGE_BYTES_PER_PX["candidates"]) * px
         e = table[eig_name]
         e["unfused_model"] = {"bytes": unf, "achieved": unf / (e["ms"] * 1e-3) / 1e9, "frac": unf / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "note": "SURVEY 8(d) P3 + P4 = 10 B/px: what the two unfused steps would move (eig map written and read back)"}
     out["kernels"] = table
-    dense = [k for k in ("minmax", "stretch_laplacian_mask", eig_name, "candidates", "pyramid") if k in table]
+    dense = [k for k in ("minmax", "stretch_laplacian_mask", eig_name, "candidates") if k in table]
     db, dm = sum(table[k]["bytes"] for k in dense), sum(table[k]["ms"] for k in dense)
-    out["dense_path"] = {"bytes": db, "ms": dm, "achieved": db / (dm * 1e-3) / 1e9, "frac": db / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    tb, tm = sum(v["bytes"] for v in table.values()), sum(v["ms"] for v in table.values())
+    if "pyramid" in table:
+        db += table["pyramid"]["bytes"]            # (their bytes count, their time hides under the eigenvalue pass)
+    out["dense_path"] = {"bytes": db, "ms": dm, "achieved": db / (dm * 1e-3) / 1e9, "frac": db / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "minmax + stretch/Laplacian/mask + fused eigenvalue pass (+ the pyramids' bytes, hidden beside it)"}
+    tb = sum(v["bytes"] for v in table.values())
+    tm = sum(v["ms"] for k, v in table.items() if k != "pyramid")
     out["all_stages"] = {"bytes": tb, "ms_serial_sum": tm, "achieved": tb / (tm * 1e-3) / 1e9, "frac": tb / (tm * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return out
 
@@ -852,10 +863,10 @@ def main():
     if solo and not (a.no_cpu_baseline and a.no_end_to_end):
         host_pair = (mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16))
     del pair
-    if solo and not a.no_end_to_end:
-        out["end_to_end"] = end_to_end(host_pair[0], host_pair[1], ctx, max(4, min(12, a.steps)))
     if solo and not a.no_in_flight:
         out["in_flight"] = in_flight(dev, conf, S, (mon_t, ref_t))
+    if solo and not a.no_end_to_end:
+        out["end_to_end"] = end_to_end(host_pair[0], host_pair[1], ctx, max(4, min(12, a.steps)))
     del mon_t, ref_t
     torch.cuda.empty_cache()
     if solo and not a.no_config3:

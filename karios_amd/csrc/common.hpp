@@ -166,7 +166,9 @@ struct km_ctx {
     bool opt_speculative = true;   // "speculative" 1 (default): corners through the synchronisation-free, sort-free path (k_select2.hip) where a tile entry point can repeat a flagged tile; 0: always the exact path (k_select.hip)
     bool opt_aux_pyramid = true;   // "aux_pyramid": sync-free tile path builds the pyramids on a second stream, next to the corner selection
     bool opt_aux_early = true;     // "aux_early": ... forked before the fused eigenvalue pass (0: behind it, next to the selection chain only)
-    bool opt_aux_priority = true;  // "aux_priority": the second stream has the lowest priority
+    bool opt_aux_priority = false; // "aux_priority" 1: the second stream gets the lowest priority.  Off: it bought nothing for one context (the start event in
+                                   // front of the fork already lets the main stream's kernel go first) and with several contexts on one GPU it made the
+                                   // selection sweeps of one context wait on the others (tiles flagged as unconverged and repeated)
     bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
     int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
     int opt_stash_cap = 0;         // "stash_cap": kept keys a workgroup of the scatter launch stashes in LDS (small values force its second read of the keys)

@@ -510,7 +510,8 @@ int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H,
 }
 
 // Greedy minimum-distance selection on the ranked keys of kf_rank: corners in d_xy, their count in sc->n_corners.
-#define KF_LAUNCHES 3          // sweep launches (the third finds nothing left to do on ordinary images: 42 + 6 + 2 us)
+#define KF_LAUNCHES 4          // sweep launches (42 + 6 + 2 + 2 us: the last two find nothing left to do on a GPU of their own; with several
+                               // contexts sharing the GPU the polling sweeps give up earlier and three launches left tiles unconverged - flagged, repeated)
 int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc)
 {
     kf_buffers b;

@@ -134,3 +134,87 @@ def test_scatter_launch_second_read_when_the_stash_is_too_small(ops, O):
             np.testing.assert_array_equal(tracks[1], O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0, 25))
     finally:
         ctx.set_option("stash_cap", 0)
+
+
+def test_page_locked_array_may_outlive_its_context(ops):
+    """A `pinned_empty` array released after its context is gone (advisor, round 2): the finalizer then frees the block without
+    touching the destroyed context (km_host_free(NULL, p)); the staging area a context owns is dropped before the context."""
+    import gc
+    from karios_amd._lib import Context, pinned_empty
+    from karios_amd.resident import ResidentPair
+    ctx = Context(0)
+    keep = pinned_empty((300, 400), np.uint16, ctx)
+    keep[:] = 7
+    mon, ref = synth.make_pair(300, 400, 0.5, 0.25)
+    pair = ResidentPair.upload(mon, ref, ctx=ctx)
+    z = pair.zncc(np.array([100.0], np.float32), np.array([100.0], np.float32), np.array([0.5], np.float32), np.array([0.25], np.float32))
+    assert z.shape == (1,) and "_kp_staging" in ctx.__dict__          # the context now owns page-locked staging
+    del pair
+    ctx.close()
+    assert "_kp_staging" not in ctx.__dict__ and ctx.handle is None
+    assert int(keep.sum()) == 7 * 300 * 400                            # still readable
+    del keep
+    gc.collect()                                                       # finalizer runs with the context closed: must not crash
+    ctx2 = Context(0)                                                  # the device is still usable
+    ctx2.sync()
+    ctx2.close()
+
+
+def test_frame_origin_must_be_a_tile_offset(ops, O):
+    """The (x0, y0) ordering key of the device frame is built from corner + tile origin as non-negative integers (advisor, round 2):
+    a negative or non-finite origin is refused, a large one is ordered exactly (bucket index clamped, order decided by the keys)."""
+    from karios_amd._lib import KariosHipError
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(300, 420, 0.4, 0.2, seed=11)
+    conf = O.default_conf(maxCorners=500)
+    pair = ResidentPair.upload(mon, ref)
+    base = pair.match_tile(conf)
+    for bad in ((-1.0, 0.0), (0.0, float("nan")), (float("inf"), 0.0), (3e9, 0.0)):
+        with pytest.raises(KariosHipError, match="tile origin"):
+            pair.match_tile(conf, origin=bad)
+    far = pair.match_tile(conf, origin=(1 << 20, 1 << 21))             # beyond the bucket range of the placement kernel
+    np.testing.assert_array_equal(far["x0"].to_numpy(), base["x0"].to_numpy() + np.float32(1 << 20))
+    np.testing.assert_array_equal(far["y0"].to_numpy(), base["y0"].to_numpy() + np.float32(1 << 21))
+    for col in ("dx", "dy", "score"):
+        np.testing.assert_array_equal(far[col].to_numpy(), base[col].to_numpy())
+    assert (np.diff(far["x0"].to_numpy()) >= 0).all()
+
+
+def test_band_tracker_with_a_three_level_pyramid_equals_the_full_image(ops, O):
+    """km_band_track_dev on a row band with maxLevel 2 (the matcher itself uses 1): the rows of level l that the 5-tap pyrDown
+    computed from a mirrored band edge are declared absent with the recurrence trim_l = ceil((trim_{l-1} + 2) / 2) = 1, 2, 2
+    (advisor, round 2: one row per level was too few from level 2 on) - tracks inside the band equal the full image's, a window that
+    reaches the trimmed rows raises the flag instead of reading them."""
+    import ctypes as C
+    from karios_amd._lib import default_context
+    from karios_amd.ops import make_params
+    from karios_amd.resident import DeviceBuffer
+    H, W, ys, hs = 600, 500, 104, 392
+    mon, ref = synth.make_pair(H, W, 0.7, -0.4, seed=21)
+    lap_ref, lap_mon = O.laplacian_u8(O.to_uint8(ref), 7), O.laplacian_u8(O.to_uint8(mon), 7)
+    ctx = default_context()
+    d_ref, d_mon = DeviceBuffer(ctx, hs * W), DeviceBuffer(ctx, hs * W)
+    d_ref.upload(lap_ref[ys:ys + hs])
+    d_mon.upload(lap_mon[ys:ys + hs])
+    prm = make_params(O.default_conf(maxCorners=100))
+    prm.max_level = 2
+    p0 = O.good_features(lap_ref, None, 4000, 0.02, 6, 9).reshape(-1, 2)
+    inside = p0[(p0[:, 1] >= 230) & (p0[:, 1] <= 370)][:300].copy()
+    assert len(inside) > 50
+
+    def band_track(pts):
+        p1, p0r, left = np.empty_like(pts), np.empty_like(pts), C.c_int()
+        ctx.check(ctx.lib.km_band_track_dev(ctx.handle, C.c_void_p(d_ref.ptr), C.c_void_p(d_mon.ptr), hs, W, ys, H, C.byref(prm),
+                                            pts.ctypes.data_as(C.c_void_p), len(pts), p1.ctypes.data_as(C.c_void_p), p0r.ctypes.data_as(C.c_void_p),
+                                            C.byref(left)), "km_band_track_dev")
+        return p1, p0r, left.value
+
+    p1, p0r, left = band_track(inside)
+    e1 = O.pyr_lk(lap_ref, lap_mon, inside, 25, max_level=2)
+    e0r = O.pyr_lk(lap_mon, lap_ref, e1, 25, max_level=2)
+    assert left == 0
+    np.testing.assert_array_equal(p1, e1.reshape(-1, 2))
+    np.testing.assert_array_equal(p0r, e0r.reshape(-1, 2))
+    # a point whose level-2 window needs the rows next to the band edge
+    edge = np.array([[250.0, ys + 44.0]], np.float32)
+    assert band_track(edge)[2] == 1
