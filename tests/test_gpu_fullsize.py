@@ -112,3 +112,28 @@ def test_config5_cross_sensor_with_user_mask(ops, O):
     np.testing.assert_array_equal(frames[1]["x0"].to_numpy(), exp["x0"])
     np.testing.assert_array_equal(frames[1]["y0"].to_numpy(), exp["y0"])
     assert np.abs(frames[1]["dx"].to_numpy() - exp["dx"]).max() <= 1e-3
+
+
+def test_config2_unbounded_corners_full_size(ops, torch_dev):
+    """maxCorners = 0 at 10980 x 10980: every corner the greedy minimum-distance selection accepts (hundreds of thousands) - the exact
+    ranking path (all candidates ranked by the library sort), the frame ordering beyond 32 768 rows, LK on several 10^5 key points.
+    Properties: order, borders, minimum distance; and the prefix property of the greedy selection - the 20 000 corners of the default
+    configuration are exactly the 20 000 strongest of the unbounded run, with identical tracks."""
+    from karios_amd.core import KLTConfiguration
+    pair, _, _ = _pair(torch_dev, 0.5, 0.25)
+    conf_all, conf_top = KLTConfiguration(maxCorners=0), KLTConfiguration()
+    full = pair.match_tile(conf_all)
+    assert len(full) > 200000
+    _check_frame(full, conf_all)
+    assert abs(np.median(full["dx"]) - 0.5) < 0.02 and abs(np.median(full["dy"]) - 0.25) < 0.02
+    top = pair.match_tile(conf_top)
+    key_full = full["x0"].to_numpy().astype(np.int64) * 65536 + full["y0"].to_numpy().astype(np.int64)
+    key_top = top["x0"].to_numpy().astype(np.int64) * 65536 + top["y0"].to_numpy().astype(np.int64)
+    pos = np.searchsorted(key_full, key_top)                     # both frames are ordered by (x0, y0)
+    assert (pos < len(key_full)).all() and (key_full[pos] == key_top).all()     # every default corner is in the unbounded set
+    for col in ("dx", "dy", "score"):
+        np.testing.assert_array_equal(full[col].to_numpy()[pos], top[col].to_numpy())
+    # the index labels are positions in strength order: the default run's corners are the first 20 000 of the unbounded list.
+    # (Only corners that pass the forward-backward test have a row: compare through the labels of the rows both frames hold.)
+    assert full.index.to_numpy()[pos].max() < len(full) and np.array_equal(np.argsort(full.index.to_numpy()[pos], kind="stable"),
+                                                                           np.argsort(top.index.to_numpy(), kind="stable"))
