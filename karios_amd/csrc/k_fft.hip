@@ -400,10 +400,11 @@ template <int K0, int NK, typename Put> __device__ __forceinline__ void f61_emit
 // One Stockham stage (radix R, Ns = product of the radices done) of the length-M transform whose element i lives at row[i * 61 + tp];
 // one wavefront, in place: every input is in registers before the first output is written.  `big` (first stage only): the
 // inter-step twiddles W_N^(i tp) of this sub-transform, consecutive in i.
-template <int R>
-__device__ __forceinline__ void f61_wave_stage(float2 *row, int tp, int M, int Ns, const float2 *__restrict__ twM, const float2 *__restrict__ big, int lane)
+template <int R, int MC = 0, int NSC = 0 /* M and Ns at compile time (0: run time): every index of the stage folds into constants */>
+__device__ __forceinline__ void f61_wave_stage(float2 *row, int tp, int M_rt, int Ns_rt, const float2 *__restrict__ twM, const float2 *__restrict__ big, int lane)
 {
     constexpr int TRIPS = R == 2 ? 2 : 1;                 // M / R butterflies, <= 64 per trip (M <= 192)
+    const int M = MC ? MC : M_rt, Ns = NSC ? NSC : Ns_rt;
     const int nb = M / R, step = M / (Ns * R);
     const unsigned rcp_ns = (1u << 20) / (unsigned)Ns + 1u;      // b / Ns == (b * rcp_ns) >> 20 for b < 256, Ns <= 192 (checked exhaustively)
     constexpr bool NEEDS_ROOTS = R == 7;
@@ -440,6 +441,21 @@ __device__ __forceinline__ void f61_wave_stage(float2 *row, int tp, int M, int N
         }
     }
     F61_WAVE_SYNC();
+}
+
+// the stages of a length-MC transform with everything a constant: radices in `factorize61`'s order (7s, 5s, 4s, 3s, 2s)
+template <int MC, int NS>
+__device__ __forceinline__ void f61_stages_c(float2 *row, int tp, const float2 *__restrict__ twM, const float2 *__restrict__ big, int lane)
+{
+    if constexpr (NS < MC) {
+        constexpr int REM = MC / NS;
+        constexpr int R = REM % 7 == 0 ? 7 : REM % 5 == 0 ? 5 : REM % 4 == 0 ? 4 : REM % 3 == 0 ? 3 : 2;
+        static_assert(REM % R == 0, "M must factor into 2, 3, 5, 7");
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                    // (keeps each stage's index arithmetic local)
+        f61_wave_stage<R, MC, NS>(row, tp, MC, NS, twM, NS == 1 ? big : nullptr, ln);
+        f61_stages_c<MC, NS * R>(row, tp, twM, big, lane);
+    }
 }
 
 struct f61_plan {
@@ -536,6 +552,12 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
         if (rn < nrows && !(dbg & 4)) fetch(rn);
         // ---- phase B: 61 independent length-M transforms, one wavefront each
         for (int tp = wave; tp < ((dbg & 2) ? 0 : 61); tp += F61_T / 64) {
+            if constexpr (MC != 0) {
+                // radix, Ns and M as constants: the stage sequence `factorize61` produces, unrolled at compile time - with run-time
+                // sizes the index arithmetic of a stage (quotients, strides, twiddle steps) cost more than its butterflies
+                f61_stages_c<MC, 1>(row, tp, twM, big_g + (size_t)tp * M, lane);
+                continue;
+            }
             int Ns = 1;
             for (int s = 0; s < plan.n_stages; s++) {
                 const int R = plan.radix[s];
@@ -730,19 +752,30 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
     return KM_OK;
 }
 
-// mode 0 reads two images of pixel type T; modes 1 .. 3 work on the complex plane (T = float).  Sentinel-2's 10 m bands
-// (10980 = 61 * 180) run with M as a compile-time constant.
+// mode 0 reads two images of pixel type T; modes 1 .. 3 work on the complex plane (T = float).  Sentinel-2's band sizes run with M
+// as a compile-time constant: 10980 = 61 * 180 (10 m), 5490 = 61 * 90 (20 m), 1830 = 61 * 30 (60 m).
+template <typename T, int MODE>
+int launch_rows61_m(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
+                    const fft_tables &tb)
+{
+    switch (plan.M) {
+    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    }
+}
+
 template <typename T>
 int launch_rows61(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
                   const fft_tables &tb, int mode)
 {
-    const bool m180 = plan.M == 180;
-    if (mode == 0) return m180 ? launch_rows61_as<T, 180, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<T, 0, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
     if constexpr (std::is_same<T, float>::value) {
         switch (mode) {
-        case 1: return m180 ? launch_rows61_as<float, 180, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-        case 2: return m180 ? launch_rows61_as<float, 180, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-        default: return m180 ? launch_rows61_as<float, 180, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb) : launch_rows61_as<float, 0, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        case 1: return launch_rows61_m<float, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        case 2: return launch_rows61_m<float, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        default: return launch_rows61_m<float, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
         }
     }
     return km_fail(c, KM_E_INTERNAL, "fft61: complex passes run on float planes");
