@@ -184,6 +184,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
     if (strcmp(name, "fft_dbg") == 0) { c->opt_fft_dbg = value; return KM_OK; }
     if (strcmp(name, "roctx") == 0) { c->opt_roctx = value != 0; return KM_OK; }
+    if (strcmp(name, "fft_cross") == 0) { c->opt_fft_cross_fused = value != 0; return KM_OK; }
     if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }

@@ -181,6 +181,7 @@ struct km_ctx {
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
     int opt_fft_dbg = 0;           // development: bits that skip phases of the 61 M row kernel (timing experiments; results are then wrong)
     bool opt_roctx = false;        // "roctx": roctx ranges around the stages
+    bool opt_fft_cross_fused = true;   // "fft_cross": the cross-power step fused into the first inverse pass's row load (61 M rows)
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form

@@ -274,22 +274,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float2 *__restrict
         if (bx + i < cols && by + tx < rows) out[(size_t)(bx + i) * rows + by + tx] = tile[tx][i];
 }
 
-// Zt = transposed spectrum of z (W rows kx, H columns ky).  P(k) = F conj(G) normalised, written in the same layout.
+// P(k) = F conj(G) / max(|F conj(G)|, floor) from z = Z(k) and zm = Z(-k) of the packed transform Z = FFT2(a + i b):
+// F = (z + conj zm) / 2,  G = (z - conj zm) / (2 i)   (the common factor 1/4 cancels in the normalisation)
+__device__ __forceinline__ float2 cross_power_of(float2 z, float2 zm)
+{
+    const float floor_ = 100.0f * 2.220446049250313e-16f;
+    const float2 f = make_float2(z.x + zm.x, z.y - zm.y);
+    const float2 d = make_float2(z.x - zm.x, z.y + zm.y);
+    const float2 g = make_float2(d.y, -d.x);             // d / i
+    const float re = f.x * g.x + f.y * g.y, im = f.y * g.x - f.x * g.y;   // f * conj(g)
+    const float mag = fmaxf(hypotf(re, im) * 0.25f, floor_);
+    return make_float2(re * 0.25f / mag, im * 0.25f / mag);
+}
+
+// Zt = transposed spectrum of z (W rows kx, H columns ky).  P(k) written in the same layout.
 __global__ __launch_bounds__(256) void cross_power_f32_kernel(const float2 *__restrict__ Z, float2 *__restrict__ P, int W, int H)
 {
     const size_t n = (size_t)W * H;
-    const float floor_ = 100.0f * 2.220446049250313e-16f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int kx = (int)(i / H), ky = (int)(i - (size_t)kx * H);
         const int mx = kx ? W - kx : 0, my = ky ? H - ky : 0;
-        const float2 z = Z[i], zm = Z[(size_t)mx * H + my];
-        // F = (z + conj zm) / 2,  G = (z - conj zm) / (2 i)   (the common factor 1/4 cancels in the normalisation)
-        const float2 f = make_float2(z.x + zm.x, z.y - zm.y);
-        const float2 d = make_float2(z.x - zm.x, z.y + zm.y);
-        const float2 g = make_float2(d.y, -d.x);             // d / i
-        const float re = f.x * g.x + f.y * g.y, im = f.y * g.x - f.x * g.y;   // f * conj(g)
-        const float mag = fmaxf(hypotf(re, im) * 0.25f, floor_);
-        P[i] = make_float2(re * 0.25f / mag, im * 0.25f / mag);
+        P[i] = cross_power_of(Z[i], Z[(size_t)mx * H + my]);
     }
 }
 
@@ -470,15 +475,19 @@ struct f61_top2 {
 };
 
 // MODE 0: rows of two real images -> z = a + i b;  1: complex rows in place;  2: complex rows, inverse (conjugate in, conjugate out);
-// 3: like 2 without an output plane: top2[r] = largest / second-largest |cc| of row r
+// 3: like 2 without an output plane: top2[r] = largest / second-largest |cc| of row r;  4: like 2 with the cross-power step fused
+// into the row load: row r of `data` (= Z, transposed spectrum) and its mirror row are read, P(k) is formed on the way into LDS,
+// the inverse transform of the row goes to `out_plane` (a kernel of its own moved 2.9 GB for that)
 template <typename T, int MC /* M at compile time (0: run time): the 61 strided reads of a butterfly then carry immediate offsets */, int mode>
 __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__ img_a, const T *__restrict__ img_b, ptrdiff_t sa, ptrdiff_t sb,
                                                            float2 *__restrict__ data, f61_top2 *__restrict__ top2, int N, int nrows, f61_plan plan,
-                                                           const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g, int dbg)
+                                                           const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g, int dbg,
+                                                           float2 *__restrict__ out_plane)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *row = (float2 *)smem;
     float2 *twM = row + N;                                  // exp(-2 pi i n / M), n < M
+    constexpr bool CROSS = mode == 4;
     __shared__ unsigned long long s_best[F61_T / 64];
     __shared__ unsigned s_second[F61_T / 64];
     const int M = MC ? MC : plan.M;
@@ -488,9 +497,19 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
 
     // the row a thread holds in flight: elements tid + F61_T * u, exactly as loaded (conversions and the conjugation wait for
     // `commit`: an instruction that consumes a load would stall the wavefront until the data has arrived)
-    float2 pf[PF];
+    float2 pf[PF], pg[CROSS ? PF : 1];
     auto fetch = [&](int r) {
-        if (mode == 0) {
+        if constexpr (CROSS) {
+            // Z(kx, ky) and Z(-kx, -ky): row r and its mirror row read backwards (element 0 pairs with element 0)
+            const int mr = r ? nrows - r : 0;
+            const float2 *src = data + (size_t)r * N, *msrc = data + (size_t)mr * N;
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int i = min(tid + F61_T * u, N - 1);
+                pf[u] = src[i];
+                pg[u] = msrc[i ? N - i : 0];
+            }
+        } else if (mode == 0) {
             const T *pa = img_a + (size_t)r * sa, *pb = img_b + (size_t)r * sb;
 #pragma unroll
             for (int u = 0; u < PF; u++) {
@@ -512,6 +531,9 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             if (mode == 0) {
                 if constexpr (!std::is_same<T, float>::value)
                     x = make_float2((float)(T)(int)__float_as_uint(pf[u].x), (float)(T)(int)__float_as_uint(pf[u].y));
+            } else if constexpr (CROSS) {
+                x = cross_power_of(pf[u], pg[u]);
+                x.y = -x.y;
             } else if (mode >= 2) {
                 x.y = -x.y;
             }
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
         __syncthreads();
         // ---- the next row starts its way from HBM (consumed after the store below)
         const int rn = r + gridDim.x;
-        if (rn < nrows && !(dbg & 4)) fetch(rn);
+        if (!CROSS && rn < nrows && !(dbg & 4)) fetch(rn);     // (mode 4 holds two rows: fetched behind the transforms, where the registers are free)
         // ---- phase B: 61 independent length-M transforms, one wavefront each
         for (int tp = wave; tp < ((dbg & 2) ? 0 : 61); tp += F61_T / 64) {
             if constexpr (MC != 0) {
@@ -575,6 +597,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             }
         }
         __syncthreads();
+        if (CROSS && rn < nrows && !(dbg & 4)) fetch(rn);
         // ---- the finished row leaves (natural order: X[t + 61 m] at row[t + 61 m])
         if (mode == 3) {
             unsigned long long best = 0;
@@ -603,8 +626,8 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
                 top2[r].best = rb; top2[r].second = rs; top2[r].pad = 0;
             }
         } else {
-            float2 *dst = data + (size_t)r * N;
-            if (!(dbg & 8)) for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2) x.y = -x.y; dst[i] = x; }
+            float2 *dst = (CROSS ? out_plane : data) + (size_t)r * N;
+            if (!(dbg & 8)) for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2 || CROSS) x.y = -x.y; dst[i] = x; }
         }
         __syncthreads();
         if (rn < nrows && !(dbg & 4)) commit();
@@ -737,7 +760,7 @@ int launch_rows(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, f
 
 template <typename T, int MC, int MODE>
 int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                     const fft_tables &tb)
+                     const fft_tables &tb, float2 *out_plane)
 {
     const size_t lds = ((size_t)N + (size_t)plan.M) * sizeof(float2);
     static bool opted = false;
@@ -747,7 +770,7 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
         opted = true;   // per instantiation (static local of the template)
     }
     const int grid = nrows < c->n_cu ? nrows : c->n_cu;      // one 88-KB workgroup per CU: each walks its rows with the next one in flight
-    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg);
+    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg, out_plane);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -756,26 +779,27 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
 // as a compile-time constant: 10980 = 61 * 180 (10 m), 5490 = 61 * 90 (20 m), 1830 = 61 * 30 (60 m).
 template <typename T, int MODE>
 int launch_rows61_m(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                    const fft_tables &tb)
+                    const fft_tables &tb, float2 *out_plane)
 {
     switch (plan.M) {
-    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane);
+    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane);
+    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane);
+    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane);
     }
 }
 
 template <typename T>
 int launch_rows61(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                  const fft_tables &tb, int mode)
+                  const fft_tables &tb, int mode, float2 *out_plane = nullptr)
 {
-    if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+    if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
     if constexpr (std::is_same<T, float>::value) {
         switch (mode) {
-        case 1: return launch_rows61_m<float, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-        case 2: return launch_rows61_m<float, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
-        default: return launch_rows61_m<float, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb);
+        case 1: return launch_rows61_m<float, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
+        case 2: return launch_rows61_m<float, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
+        case 4: return launch_rows61_m<float, 4>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane);
+        default: return launch_rows61_m<float, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
         }
     }
     return km_fail(c, KM_E_INTERNAL, "fft61: complex passes run on float planes");
@@ -831,10 +855,15 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
     transpose_kernel<<<tg, 256, 0, c->stream>>>(A, B, H, W);
     KM_LAUNCH_CHECK(c);
     if ((rc = rows(B, nullptr, H, W, false, 1))) return rc;
-    cross_power_f32_kernel<<<c->n_cu * 16, 256, 0, c->stream>>>(B, A, W, H);
-    KM_LAUNCH_CHECK(c);
-    // inverse: rows (length H) of the transposed spectrum in place; transpose -> B (H x W); rows (length W) -> |cc|
-    if ((rc = rows(A, nullptr, H, W, false, 2))) return rc;
+    // inverse: rows (length H) of the transposed cross-power spectrum; transpose -> B (H x W); rows (length W) -> |cc|
+    if (h61 && c->opt_fft_cross_fused) {
+        // the cross-power step rides on the row load of the first inverse pass: B (= Z) -> A
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A))) return rc;
+    } else {
+        cross_power_f32_kernel<<<c->n_cu * 16, 256, 0, c->stream>>>(B, A, W, H);
+        KM_LAUNCH_CHECK(c);
+        if ((rc = rows(A, nullptr, H, W, false, 2))) return rc;
+    }
     transpose_kernel<<<tg2, 256, 0, c->stream>>>(A, B, W, H);
     KM_LAUNCH_CHECK(c);
     float *cc = (float *)A;
