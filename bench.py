@@ -729,6 +729,8 @@ def main():
             totals["last"] = d.frame
             for k, v in d.spans.items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
+            if any(v > 0 for v in d.spans.values()):
+                totals["span_samples"] = totals.get("span_samples", 0) + 1
 
     def fence():
         ctx.sync()
@@ -782,10 +784,16 @@ def main():
     if a.timed_stage not in ("auto", "none"):
         timed_stage = a.timed_stage
     ctx.set_option("profile_stage", stage_names.index(timed_stage))
+    ctx.set_option("profile_every", 4)            # the timed steps are SAMPLED: every fourth records the stage's two events
     if a.timed_stage == "none":
         ctx.set_profiling(False)
     stage_sum.clear()
-    totals.update(rows=0, frames=0, redone=0)
+    totals.update(rows=0, frames=0, redone=0, span_samples=0)
+    # the interpreter's cyclic garbage collector stays out of the timed steps: a generation-2 pass over the object graph of torch +
+    # pandas takes 10 - 20 ms - a quarter of a 60-step region - whenever the frames' allocations happen to trigger it
+    import gc
+    gc.collect()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -793,13 +801,16 @@ def main():
     take(stream.drain())              # the last pair's frame: part of the timed region
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"]
     frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
-    timed_ms = stage_sum.get(timed_stage, 0.0) / a.steps
+    timed_samples = totals.get("span_samples", 0)
+    timed_ms = stage_sum.get(timed_stage, 0.0) / max(1, timed_samples)
     redone_timed = totals["redone"]
     # untimed pass: every stage bracketed
     ctx.set_option("profile_stage", -1)
+    ctx.set_option("profile_every", 1)
     stage_steps = max(3, min(a.steps, 12))
     stage_sum.clear()
     keep = dict(totals)
@@ -845,10 +856,11 @@ def main():
             "speculative_tiles_redone": int(redone_timed),
             "median_dx_dy": (None if frame is None else [float(np.median(frame["dx"])), float(np.median(frame["dy"]))]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_note": f"{timed_stage}: HIP events over the {a.steps} timed steps; the other stages: an untimed pass of "
+            "stage_ms_note": f"{timed_stage}: HIP events on {timed_samples} of the {a.steps} timed steps (every fourth: an event record is a point where "
+                             "consecutive kernels may not overlap); the other stages: an untimed pass of "
                              f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
             "roofline": roof,
-            "synth_seconds": round(t_gen, 2), "settle": settle,
+            "synth_seconds": round(t_gen, 2), "settle": settle, "python_gc": "disabled during the timed steps (collected right before)",
         }
         sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):

@@ -194,6 +194,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
+    if (strcmp(name, "profile_every") == 0) { c->opt_profile_every = value < 1 ? 1 : value; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
     if (strcmp(name, "stash_cap") == 0) { c->opt_stash_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
@@ -414,8 +415,14 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     if (poison && reset == RESET_KLT)
         for (int i = 0; i < WS_COUNT; i++)
             if (c->ws[i].p && i != WS_AUTO) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
-    if (reset == RESET_KLT)
-        { for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false; c->evs_used[c->ev_cur][ST_FRAME] = false; }
+    if (reset == RESET_KLT) {
+        for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false;
+        c->evs_used[c->ev_cur][ST_FRAME] = false;
+        // "profile_every" N: only every N-th tile call records its stage events (a sample of the calls: an event record is a point
+        // where consecutive kernels may not overlap, and on some boxes bracketing one stage of EVERY call costs 3 - 5 % of a step)
+        c->profile_tick++;
+        c->profile_skip = c->opt_profile_every > 1 && (c->profile_tick % (unsigned)c->opt_profile_every) != 0;
+    }
     else if (reset == RESET_ZNCC)
         c->evs_used[c->ev_cur][ST_ZNCC] = false;
     return KM_OK;

@@ -170,6 +170,9 @@ struct km_ctx {
                                    // front of the fork already lets the main stream's kernel go first) and with several contexts on one GPU it made the
                                    // selection sweeps of one context wait on the others (tiles flagged as unconverged and repeated)
     bool opt_eig3 = true;          // "eig3": fused eig + candidate pass with 8 pixels per lane where the image is >= 512 wide (0: always the 2-px kernel)
+    int opt_profile_every = 1;     // "profile_every": with profiling on, only every N-th tile call records stage events
+    unsigned profile_tick = 0;
+    bool profile_skip = false;
     int opt_profile_stage = -1;    // "profile_stage": with profiling on, time only this stage (-1: every stage; each timed span costs two events = two pipeline drains)
     int opt_stash_cap = 0;         // "stash_cap": kept keys a workgroup of the scatter launch stashes in LDS (small values force its second read of the keys)
     int opt_spec_flag = 0;         // "spec_flag": KM_FLAG_* bits raised artificially by the speculative path (tests of the repeat logic)
@@ -270,7 +273,7 @@ struct km_stage_timer {
     km_stage_timer(km_ctx *ctx, int stage) : c(ctx), s(stage)
     {
         if (c->opt_roctx) { km_roctx_push(stage); marked = true; }
-        if (c->opt_profile_stage >= 0 && stage != c->opt_profile_stage) { s = -1; return; }
+        if ((c->opt_profile_stage >= 0 && stage != c->opt_profile_stage) || c->profile_skip) { s = -1; return; }
         if (c->profiling && c->ev_ready && !c->evs_used[c->ev_cur][s]) {
             (void)hipEventRecord(c->evs[c->ev_cur][s][0], c->stream);
         } else if (c->profiling && c->ev_ready) {

@@ -26,7 +26,7 @@ STAGES = {   # stage key -> kernel-name fragments
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
 }
-ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "cross_power_f32"}
+ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce"}
 
 
 def load(path):
