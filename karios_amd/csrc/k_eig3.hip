@@ -168,7 +168,7 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
     };
     // horizontal box sums: window of pixel p = strip pixels p - L .. p + Rr, indices < 0 / > 7 live in the neighbouring lanes
     // (the three products advance in lockstep: three independent dependency chains for the scheduler instead of one)
-    auto windows = [&](int (&Wd)[3][8]) {
+    auto windows = [&](auto &&emit /* (pixel, sxx, sxy, syy): called as soon as the three sums of a pixel exist */) {
         // w + the vertical sum of strip pixel k of this lane's window (k < 0: left neighbour's pixel k + 8, k > 7: right neighbour's k - 8)
         auto add_ext = [&](int w, auto q_tag, auto kt) -> int {
             constexpr int q = decltype(q_tag)::value, k = decltype(kt)::value;
@@ -194,8 +194,8 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
                 w[q] = 0;
                 e3_for<BLOCK>([&](auto kt) { w[q] = add_ext(w[q], qt, std::integral_constant<int, decltype(kt)::value - L>{}); });
             }
-            Wd[q][0] = w[q];
         });
+        emit(std::integral_constant<int, 0>{}, w[0], w[1], w[2]);
         e3_for<7>([&](auto pt) {
             constexpr int P = decltype(pt)::value;
             // w + entering - leaving as two "operand minus accumulator" steps: leaving - w, then entering - (leaving - w)
@@ -204,15 +204,17 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
             e3_for<3>([&](auto qt) {
                 constexpr int q = decltype(qt)::value;
                 w[q] = ext_minus(qt, std::integral_constant<int, P + 1 + Rr>{}, t[q]);
-                Wd[q][P + 1] = w[q];
             });
+            emit(std::integral_constant<int, P + 1>{}, w[0], w[1], w[2]);
         });
     };
+    const double scale2h = scale2 * 0.5;              // (exact)
     auto lambda_min = [&](int sxx, int sxy, int syy) {
-        const float cxx = (float)__dmul_rn((double)sxx, scale2);
-        const float cxy = (float)__dmul_rn((double)sxy, scale2);
-        const float cyy = (float)__dmul_rn((double)syy, scale2);
-        const float a = __fmul_rn(cxx, 0.5f), b = cxy, cc = __fmul_rn(cyy, 0.5f);
+        // a = cxx * 0.5f, cc = cyy * 0.5f of the reference formula: halving commutes with both roundings (no value here is
+        // anywhere near the subnormal range: the smallest non-zero product is scale2 ~ 4e-9 / BLOCK^2), so it is folded into the scale
+        const float a = (float)__dmul_rn((double)sxx, scale2h);
+        const float b = (float)__dmul_rn((double)sxy, scale2);
+        const float cc = (float)__dmul_rn((double)syy, scale2h);
         const float t = __fsub_rn(a, cc);
         const float sq = __fadd_rn(__fmul_rn(t, t), __fmul_rn(b, b));
         return __fsub_rn(__fadd_rn(a, cc), e2_sqrt(sq));
@@ -275,15 +277,13 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
         const int y = m - Rr;                        // lambda row completed by this step
         constexpr int C = PH, P1 = (PH + 2) % 3, P2 = (PH + 1) % 3;    // lambda slots: row y, y-1, y-2
         {
-            int Wd[3][8];
             // the vertical sums were written by inline assembly (v_mad_i32_i16) and are read through DPP - also inline assembly -
             // below: 2 wait states after a VALU write of the operand, 5 after a VALU write of EXEC
             asm("s_nop 4" : "+v"(V[0][0]), "+v"(V[0][1]), "+v"(V[0][2]), "+v"(V[0][3]), "+v"(V[0][4]), "+v"(V[0][5]), "+v"(V[0][6]), "+v"(V[0][7]),
                             "+v"(V[1][0]), "+v"(V[1][1]), "+v"(V[1][2]), "+v"(V[1][3]), "+v"(V[1][4]), "+v"(V[1][5]), "+v"(V[1][6]), "+v"(V[1][7]),
                             "+v"(V[2][0]), "+v"(V[2][1]), "+v"(V[2][2]), "+v"(V[2][3]), "+v"(V[2][4]), "+v"(V[2][5]), "+v"(V[2][6]), "+v"(V[2][7]));
-            windows(Wd);
-#pragma unroll
-            for (int p = 0; p < 8; p++) E[C][p] = lambda_min(Wd[0][p], Wd[1][p], Wd[2][p]);
+            // (a pixel's eigenvalue is formed as soon as its three window sums exist: the 24 sums of a row never coexist)
+            windows([&](auto pt, int sxx, int sxy, int syy) { E[C][decltype(pt)::value] = lambda_min(sxx, sxy, syy); });
         }
         if (cand) {
             // candidate test of row y-1: own value >= the 3x3 maximum (itself included)
