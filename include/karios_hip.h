@@ -337,6 +337,12 @@ int km_band_keys_dev(km_ctx *ctx, const uint8_t *d_mask, int H, int W, double qu
 /* goodFeaturesToTrack steps 6-8 (rank, greedy minDistance selection, maxCorners) on candidate keys of an H x W image, any order */
 int km_select_keys(km_ctx *ctx, const unsigned long long *keys, size_t n, int H, int W, int max_corners, double min_distance,
                    float *out_xy, int cap, int *out_n);
+/* The ordering primitives behind the exact paths (k_sort.hip: rank of every candidate in cv::goodFeaturesToTrack's order, row order
+ * of frames beyond 32 768 rows), on host buffers.  km_sort_pairs_u64: stable sort of n 64-bit keys in place, ascending or
+ * descending; vals (NULL or n 32-bit words) travel with their keys.  km_exclusive_scan_u32: out[i] = sum of in[j], j < i;
+ * count_ones != 0: sum of (in[j] == 1) instead. */
+int km_sort_pairs_u64(km_ctx *ctx, unsigned long long *keys, unsigned *vals, size_t n, int descending);
+int km_exclusive_scan_u32(km_ctx *ctx, const unsigned *in, unsigned *out, size_t n, int count_ones);
 /* LK forward + backward of n points in IMAGE coordinates; rows [oy, oy + H) of the H_image-row Laplacian pair are resident.
  * *left_band = 1: a window needed rows outside the band (halo too small for this displacement) */
 int km_band_track_dev(km_ctx *ctx, const uint8_t *d_lap_ref, const uint8_t *d_lap_mon, int H, int W, int oy, int H_image,

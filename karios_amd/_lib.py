@@ -75,6 +75,8 @@ SIGNATURES = {
     "km_band_eigen_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, C.POINTER(C.c_uint)]),
     "km_band_keys_dev": (_i, [_vp, _vp, _i, _i, _d, C.c_uint, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "km_select_keys": (_i, [_vp, _vp, C.c_size_t, _i, _i, _i, _d, _vp, _i, _pi]),
+    "km_sort_pairs_u64": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
+    "km_exclusive_scan_u32": (_i, [_vp, _vp, _vp, C.c_size_t, _i]),
     "km_band_track_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _pi]),
     "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
     "km_auto_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _vp, C.POINTER(C.c_int64)]),

@@ -1664,6 +1664,40 @@ int km_band_keys_dev(km_ctx *c, const uint8_t *d_mask, int H, int W, double qual
     return KM_OK;
 }
 
+// the ordering primitives of the exact paths on host buffers (parity tests; callers that need the library's key order)
+int km_sort_pairs_u64(km_ctx *c, unsigned long long *keys, unsigned *vals, size_t n, int descending)
+{
+    int rc;
+    if ((rc = begin_call(c))) return rc;
+    if (n && !keys) return km_fail(c, KM_E_ARG, "sort_pairs: bad arguments");
+    if (n == 0) return KM_OK;
+    unsigned long long *dk = (unsigned long long *)km_ws(c, WS_KEYS0, 2 * n * sizeof(unsigned long long));
+    unsigned *dv = vals ? (unsigned *)km_ws(c, WS_MISC1, 2 * n * sizeof(unsigned)) : nullptr;
+    if (!dk || (vals && !dv)) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(dk, keys, n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    if (vals) KM_HIP(c, hipMemcpyAsync(dv, vals, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    if ((rc = km_sort_u64(c, dk, dk + n, dv, dv ? dv + n : nullptr, n, descending != 0))) return rc;
+    KM_HIP(c, hipMemcpyAsync(keys, dk, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (vals) KM_HIP(c, hipMemcpyAsync(vals, dv, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
+int km_exclusive_scan_u32(km_ctx *c, const unsigned *in, unsigned *out, size_t n, int count_ones)
+{
+    int rc;
+    if ((rc = begin_call(c))) return rc;
+    if (n && (!in || !out)) return km_fail(c, KM_E_ARG, "exclusive_scan: bad arguments");
+    if (n == 0) return KM_OK;
+    unsigned *d = (unsigned *)km_ws(c, WS_MISC1, 2 * n * sizeof(unsigned));
+    if (!d) return KM_E_NOMEM;
+    KM_HIP(c, hipMemcpyAsync(d, in, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    if ((rc = km_exclusive_scan(c, d, d + n, n, count_ones ? KM_SCAN_IS_ONE : KM_SCAN_PLAIN, WS_SORT_TMP))) return rc;
+    KM_HIP(c, hipMemcpyAsync(out, d + n, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
 // goodFeaturesToTrack steps 6-8 on a GIVEN list of candidate keys (value bits << 32 | raster index of the H x W image), any order
 int km_select_keys(km_ctx *c, const unsigned long long *keys, size_t n, int H, int W, int max_corners, double min_distance, float *out_xy, int cap,
                    int *out_n)

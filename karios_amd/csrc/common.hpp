@@ -62,7 +62,7 @@ enum km_slot {
     WS_PYR_B,
     WS_KEYS0,       // candidate keys
     WS_KEYS1,       // sort double buffer
-    WS_SORT_TMP,    // rocprim temporary storage
+    WS_SORT_TMP,    // k_sort.hip: digit tables of the radix sort / tile sums of the scan
     WS_GRID,        // accepted-point grid of the greedy selection
     WS_PTS0,        // p0
     WS_PTS1,        // p1
@@ -348,6 +348,10 @@ int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, pt
                    int y_off, int x_off, void *d_out);
 // k_select.hip
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted);
+// k_sort.hip: the ordering primitives of the exact fallback paths (hand-written; no library)
+enum { KM_SCAN_PLAIN = 0, KM_SCAN_IS_ONE = 1 };
+int km_sort_u64(km_ctx *c, unsigned long long *keys_a, unsigned long long *keys_b, unsigned *vals_a, unsigned *vals_b, size_t n, bool descending);
+int km_exclusive_scan(km_ctx *c, const unsigned *in, unsigned *out, size_t n, int mode, int tmp_slot);
 int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, int W,
               int max_corners, double min_distance, float *d_xy, int cap, km_scalars *d_sc, int *n_found, bool fresh_scalars);
 int ks_topk_prefilter(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, size_t k_target, km_scalars *d_sc, double quality,

@@ -14,7 +14,6 @@
 #include "common.hpp"
 
 #include <type_traits>
-#include <rocprim/device/device_radix_sort.hpp>
 
 
 #define FB_T 1024
@@ -205,15 +204,9 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
         KM_LAUNCH_CHECK(c);
         return KM_OK;
     }
-    // maxCorners = 0 on a large tile: hundreds of thousands of rows - library radix sort of (key, rank) pairs + gather
-    unsigned long long *keys_alt = keys + cap;
-    unsigned *ranks_alt = ranks + cap;
-    size_t tmp_bytes = 0;
-    KM_HIP(c, rocprim::radix_sort_pairs((void *)nullptr, tmp_bytes, keys, keys_alt, ranks, ranks_alt, n_sort, 0, 64, c->stream));
-    void *stmp = km_ws(c, WS_SORT_TMP, tmp_bytes ? tmp_bytes : 16);
-    if (!stmp) return KM_E_NOMEM;
-    KM_HIP(c, rocprim::radix_sort_pairs(stmp, tmp_bytes, keys, keys_alt, ranks, ranks_alt, n_sort, 0, 64, c->stream));
-    fb_gather_kernel<<<32, 256, 0, c->stream>>>(ranks_alt, tmp, cap, hdr, out);
+    // maxCorners = 0 on a large tile: hundreds of thousands of rows - radix sort of (key, rank) pairs (k_sort.hip) + gather
+    { const int rs = km_sort_u64(c, keys, keys + cap, ranks, ranks + cap, n_sort, false); if (rs) return rs; }
+    fb_gather_kernel<<<32, 256, 0, c->stream>>>(ranks, tmp, cap, hdr, out);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

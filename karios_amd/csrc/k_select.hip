@@ -20,20 +20,13 @@
 
 #include "common.hpp"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 int ks_sort_keys_desc(km_ctx *c, unsigned long long *d_keys, size_t n, unsigned long long **d_sorted)
 {
     unsigned long long *alt = (unsigned long long *)km_ws(c, WS_KEYS1, n * sizeof(unsigned long long));
     if (!alt) return KM_E_NOMEM;
-    size_t tmp_bytes = 0;
-    KM_HIP(c, rocprim::radix_sort_keys_desc((void *)nullptr, tmp_bytes, d_keys, alt, n, 0, 64, c->stream));
-    void *tmp = km_ws(c, WS_SORT_TMP, tmp_bytes ? tmp_bytes : 16);
-    if (!tmp) return KM_E_NOMEM;
-    KM_HIP(c, rocprim::radix_sort_keys_desc(tmp, tmp_bytes, d_keys, alt, n, 0, 64, c->stream));
-    *d_sorted = alt;
+    const int rc = km_sort_u64(c, d_keys, alt, nullptr, nullptr, n, true);   // (in place: the second buffer is scratch)
+    if (rc) return rc;
+    *d_sorted = d_keys;
     return KM_OK;
 }
 
@@ -113,10 +106,6 @@ __global__ __launch_bounds__(256) void sel_sweep_kernel(const unsigned long long
     const unsigned long long bal = __ballot(undecided);
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_undecided, (unsigned)__popcll(bal));
 }
-
-struct sel_is_accept {
-    __host__ __device__ unsigned operator()(unsigned st) const { return st == ST_ACCEPT ? 1u : 0u; }
-};
 
 // pos = exclusive scan of the accept flags = index in OpenCV's output order
 __global__ __launch_bounds__(256) void sel_emit_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
@@ -366,14 +355,6 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
     if (!grid || !per) return KM_E_NOMEM;
     unsigned *cell_cnt = grid, *cell_fill = grid + cells + 1, *cell_off = grid + 2 * cells + 2;
     unsigned *items = per, *state = per + N, *pos = per + 2 * (size_t)N;
-    auto accept_flags = rocprim::make_transform_iterator(state, sel_is_accept());
-    size_t scan_bytes_cells = 0, scan_bytes_k = 0;
-    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_cells, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
-    KM_HIP(c, rocprim::exclusive_scan((void *)nullptr, scan_bytes_k, accept_flags, pos, 0u, (size_t)N, rocprim::plus<unsigned>(), c->stream));
-    const size_t tmp_bytes = (scan_bytes_cells > scan_bytes_k ? scan_bytes_cells : scan_bytes_k) + 256;
-    void *tmp = km_ws(c, WS_SORT_TMP, tmp_bytes);
-    if (!tmp) return KM_E_NOMEM;
-
     KM_HIP(c, hipMemsetAsync(cell_cnt, 0, (2 * cells + 1) * sizeof(unsigned), c->stream));   // counts + fill cursors
     const size_t first = c->opt_select_first > 0 ? (size_t)c->opt_select_first : (size_t)max_corners * 3;
     unsigned k0 = 0, k1 = (max_corners > 0 || c->opt_select_first > 0) ? (unsigned)(first < n ? first : n) : N;
@@ -383,8 +364,7 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
         // (re)build the cell lists for the prefix [0, k1): counts only need the new part [k0, k1)
         sel_count_kernel<<<(k1 - k0 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k0, k1, W, cell, gw, cell_cnt, state);
         KM_LAUNCH_CHECK(c);
-        size_t sb = scan_bytes_cells;
-        KM_HIP(c, rocprim::exclusive_scan(tmp, sb, cell_cnt, cell_off, 0u, cells + 1, rocprim::plus<unsigned>(), c->stream));
+        { const int rs = km_exclusive_scan(c, cell_cnt, cell_off, cells + 1, KM_SCAN_PLAIN, WS_SORT_TMP); if (rs) return rs; }
         if (k0 > 0) KM_HIP(c, hipMemsetAsync(cell_fill, 0, cells * sizeof(unsigned), c->stream));
         sel_fill_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, k1, W, cell, gw, cell_off, cell_fill, items);
         KM_LAUNCH_CHECK(c);
@@ -399,8 +379,7 @@ int ks_select(km_ctx *c, const unsigned long long *d_sorted, size_t n, int H, in
                 rounds++;
             }
             // optimistic tail: rank the accepted corners right away and fetch (undecided, corner count) together
-            size_t sk = scan_bytes_k;
-            KM_HIP(c, rocprim::exclusive_scan(tmp, sk, accept_flags, pos, 0u, (size_t)k1, rocprim::plus<unsigned>(), c->stream));
+            { const int rs = km_exclusive_scan(c, state, pos, (size_t)k1, KM_SCAN_IS_ONE, WS_SORT_TMP); if (rs) return rs; }
             sel_emit_kernel<<<(k1 + 255) / 256, 256, 0, c->stream>>>(d_sorted, state, pos, k1, W, max_corners, cap, d_xy, d_sc, rounds);
             KM_LAUNCH_CHECK(c);
             unsigned *back = (unsigned *)km_pinned_rb(c, sizeof(km_scalars));   // pinned landing zone (see km_pinned_rb)
