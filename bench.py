@@ -796,12 +796,20 @@ def main():
     gc.disable()
     fence()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(a.steps):
         take(stream.submit(pair, conf))
+        marks.append(time.perf_counter())
     take(stream.drain())              # the last pair's frame: part of the timed region
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    # (where the region's time went, step by step: `value` is the whole region; a single slow step - another tenant of the host, a
+    # page fault - shows here as max >> median instead of hiding in the mean)
+    gaps = sorted(1e3 * (b - a_) for a_, b in zip(marks, marks[1:]))
+    step_spread = {"median_ms": round(gaps[len(gaps) // 2], 4), "p90_ms": round(gaps[min(len(gaps) - 1, int(0.9 * len(gaps)))], 4),
+                   "max_ms": round(gaps[-1], 4), "drain_ms": round(1e3 * (dt - (marks[-1] - t0)), 4),
+                   "note": "host-side intervals between consecutive submit() returns inside the timed region (one pair in flight)"}
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"]
     frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
@@ -860,7 +868,7 @@ def main():
                              "consecutive kernels may not overlap); the other stages: an untimed pass of "
                              f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
             "roofline": roof,
-            "synth_seconds": round(t_gen, 2), "settle": settle, "python_gc": "disabled during the timed steps (collected right before)",
+            "synth_seconds": round(t_gen, 2), "settle": settle, "step_spread": step_spread, "python_gc": "disabled during the timed steps (collected right before)",
         }
         sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):
