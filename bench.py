@@ -80,6 +80,7 @@ def parse(argv=None):
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=1, help="units of the headline loop still pending when submit() returns (FrameStream depth; <= 2 on one context)")
     ap.add_argument("--timed-stage", default="auto", help="stage bracketed by HIP events inside the timed region (auto: the largest kernel; none)")
     return ap.parse_args(argv)
 
@@ -739,7 +740,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    stream = FrameStream(0.4, depth=1, want_spans=True)
+    stream = FrameStream(0.4, depth=max(0, min(2, a.depth)), want_spans=True)
     for _ in range(a.warmup):
         take(stream.submit(pair, conf))
     take(stream.drain())
@@ -772,10 +773,18 @@ def main():
     # per pair.  The stage is the largest of the warm-up's full table; the full stage table of the line comes from a second,
     # untimed pass of the same loop right after.
     stage_names = [ctx.lib.km_stage_name(i).decode() for i in range(16)]
+    # the interpreter's cyclic garbage collector stays out of the timed steps: a generation-2 pass over the object graph of torch +
+    # pandas takes 10 - 20 ms - a quarter of a 60-step region - whenever the frames' allocations happen to trigger it.  It is run
+    # HERE, in front of the probe steps, not right in front of the timed region: a full collection walks the whole heap (the hot
+    # interpreter paths leave the CPU caches) and leaves the GPU idle for tens of milliseconds - the first timed steps then ran 5 - 10 %
+    # slow (step_spread.in_order_ms showed it); the probe steps bring both back under load.
+    import gc
+    gc.collect()
+    gc.disable()
     ctx.set_option("profile_stage", -1)
     ctx.set_profiling(True)
     stage_sum.clear()
-    for _ in range(3):
+    for _ in range(8):
         take(stream.submit(pair, conf))
     take(stream.drain())
     fence()
@@ -789,11 +798,6 @@ def main():
         ctx.set_profiling(False)
     stage_sum.clear()
     totals.update(rows=0, frames=0, redone=0, span_samples=0)
-    # the interpreter's cyclic garbage collector stays out of the timed steps: a generation-2 pass over the object graph of torch +
-    # pandas takes 10 - 20 ms - a quarter of a 60-step region - whenever the frames' allocations happen to trigger it
-    import gc
-    gc.collect()
-    gc.disable()
     fence()
     t0 = time.perf_counter()
     marks = [t0]
@@ -806,9 +810,11 @@ def main():
     gc.enable()
     # (where the region's time went, step by step: `value` is the whole region; a single slow step - another tenant of the host, a
     # page fault - shows here as max >> median instead of hiding in the mean)
+    gaps_in_order = [round(1e3 * (b - a_), 3) for a_, b in zip(marks, marks[1:])]
     gaps = sorted(1e3 * (b - a_) for a_, b in zip(marks, marks[1:]))
     step_spread = {"median_ms": round(gaps[len(gaps) // 2], 4), "p90_ms": round(gaps[min(len(gaps) - 1, int(0.9 * len(gaps)))], 4),
                    "max_ms": round(gaps[-1], 4), "drain_ms": round(1e3 * (dt - (marks[-1] - t0)), 4),
+                   "in_order_ms": gaps_in_order,
                    "note": "host-side intervals between consecutive submit() returns inside the timed region (one pair in flight)"}
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"]
@@ -817,6 +823,7 @@ def main():
     timed_ms = stage_sum.get(timed_stage, 0.0) / max(1, timed_samples)
     redone_timed = totals["redone"]
     # untimed pass: every stage bracketed
+    ctx.set_profiling(True)
     ctx.set_option("profile_stage", -1)
     ctx.set_option("profile_every", 1)
     stage_steps = max(3, min(a.steps, 12))
@@ -868,7 +875,7 @@ def main():
                              "consecutive kernels may not overlap); the other stages: an untimed pass of "
                              f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
             "roofline": roof,
-            "synth_seconds": round(t_gen, 2), "settle": settle, "step_spread": step_spread, "python_gc": "disabled during the timed steps (collected right before)",
+            "synth_seconds": round(t_gen, 2), "settle": settle, "step_spread": step_spread, "python_gc": "disabled during the timed steps (collected in front of the 8 untimed probe steps that precede them)",
         }
         sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):
