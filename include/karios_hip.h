@@ -80,6 +80,7 @@ typedef struct km_klt_stats {
 #define KM_PATH_SECOND_PASS 4     /* the top-K slice held too few mutually distant corners: selection on all candidates */
 #define KM_PATH_PREFIX_GROWN 8    /* the selection's first ranked prefix was enlarged */
 #define KM_PATH_SPEC_RETRY 16     /* the speculative (no host synchronisation) corner path flagged the tile: repeated exactly */
+#define KM_PATH_MM_EARLY 32      /* a submitted unit's min / max ran on the second stream beside the previous unit's LK ("mm_early") */
 
 /* ---- context ------------------------------------------------------------ */
 int km_version(void);
@@ -109,6 +110,9 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "aux_pyramid"  1 (default): on the synchronisation-free path the two pyramids are built on a second stream next to the
  *                  corner-selection chain and joined before LK; 0: on the library's stream.  Initial value from
  *                  KARIOS_HIP_AUX_PYRAMID.
+ *   "mm_early"     1 (default): a unit submitted with km_klt_tile_frame_submit directly behind another one starts its min / max
+ *                  on the second stream as soon as the previous unit's LK launch starts, and streams its two rasters beside
+ *                  that instruction-bound kernel (KM_PATH_MM_EARLY); 0: on the library's stream, behind the previous unit's tail
  *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the

@@ -90,6 +90,7 @@ static int join_uploads(km_ctx *c)
     if (c->copy_pending) {
         KM_HIP(c, hipEventRecord(c->ev_copy, c->copy_stream));
         KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        if (c->aux_stream) KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_copy, 0));   // (the early min / max reads the rasters there)
         c->copy_pending = false;
     }
     return KM_OK;
@@ -153,6 +154,8 @@ int km_ctx_destroy(km_ctx *c)
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_lk_start) (void)hipEventDestroy(c->ev_lk_start);
+    if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t e : c->upload_marks) if (e) (void)hipEventDestroy(e);
@@ -193,6 +196,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
+    if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
     if (strcmp(name, "profile_every") == 0) { c->opt_profile_every = value < 1 ? 1 : value; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
@@ -366,6 +370,7 @@ int km_upload_join(km_ctx *c, int ticket)
     if ((size_t)ticket >= c->upload_marks.size() || !c->upload_marks[ticket]) return km_fail(c, KM_E_ARG, "km_upload_join: unknown ticket %d", ticket);
     hipEvent_t ev = c->upload_marks[ticket];
     KM_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));        // device-side wait: the host does not block
+    if (c->aux_stream) KM_HIP(c, hipStreamWaitEvent(c->aux_stream, ev, 0));
     c->upload_marks[ticket] = nullptr;
     c->free_marks.push_back(ev);
     return KM_OK;
@@ -409,12 +414,15 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     KM_HIP(c, hipSetDevice(c->device));
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     c->spec_used = false; c->spec_flags = 0;
+    // early min / max (klt_tile_dev_impl): only a tile call that DIRECTLY follows a tile call may start its K1 beside the previous
+    // unit's LK - any call in between may have produced the rasters on the main stream (km_shift_image_dev ...)
+    c->lk_start_prev = c->lk_start_valid; c->lk_start_valid = false;
     // debugging aid: KARIOS_HIP_POISON_WS=<byte> fills every workspace buffer at the start of a tile call, so a kernel that reads
     // workspace it (or its predecessors in the call) never wrote shows up as a parity failure instead of a once-in-a-while one
     static const char *const poison = getenv("KARIOS_HIP_POISON_WS");
     if (poison && reset == RESET_KLT)
         for (int i = 0; i < WS_COUNT; i++)
-            if (c->ws[i].p && i != WS_AUTO) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
+            if (c->ws[i].p && i != WS_AUTO && i != WS_MM_EARLY && i != WS_MM_PARTIAL) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
     if (reset == RESET_KLT) {
         for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false;
         c->evs_used[c->ev_cur][ST_FRAME] = false;
@@ -718,6 +726,12 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
         km_stage_timer t(c, ST_LK);
+        if (spec) {
+            // (the next unit's early min / max starts here)
+            if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
+            KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
+            c->lk_start_valid = true;
+        }
         if ((rc = kl_track(c, A, B, d_p0, &sc->n_corners, n_max, prm->win_size, prm->max_count, prm->epsilon, true, d_p1, d_p0r)))
             return rc;
     }
@@ -753,14 +767,37 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
         KM_HIP(c, hipMemcpy2DAsync(dense, (size_t)W, d_mask, (size_t)smask, (size_t)W, (size_t)H, hipMemcpyDeviceToDevice, c->stream));
         d_mask = dense;
     }
-    if (dtype != KM_U8) {
+    const double *mm = sc->mm;
+    if (dtype != KM_U8 && c->mm_early_allowed && c->opt_mm_early && c->lk_start_prev && c->aux_stream) {
+        // Early min / max: K1 of THIS unit does not queue behind the tail of the previous one (LK, FB test, ZNCC - instruction-bound
+        // kernels of short-lived waves that leave HBM idle) but starts on the second stream the moment the previous unit's LK launch
+        // starts, and streams the two rasters beside it.  The previous tile call of this context recorded ev_lk_start; if the GPU is
+        // already past it, the kernel simply runs at once.  Result and partials live in slots of their own (the scalar block is
+        // zeroed on the main stream at the start of every call, WS_PARTIAL belongs to the kernels of the unit still running).
+        double *mm_early = (double *)km_ws(c, WS_MM_EARLY, 4 * sizeof(double));
+        if (!mm_early) return KM_E_NOMEM;
+        if (!c->ev_mm) KM_HIP(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
+        KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_lk_start, 0));
+        hipStream_t main_stream = c->stream;
+        c->stream = c->aux_stream;
+        {
+            km_stage_timer t(c, ST_MINMAX);
+            rc = kd_minmax_pair_ws(c, d_ref, d_mon, dtype, H, W, sref, smon, mm_early, WS_MM_PARTIAL);
+        }
+        if (rc == KM_OK && hipEventRecord(c->ev_mm, c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(min/max)");
+        c->stream = main_stream;
+        if (rc) return rc;
+        KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_mm, 0));
+        mm = mm_early;
+        c->stats.path_flags |= KM_PATH_MM_EARLY;
+    } else if (dtype != KM_U8) {
         km_stage_timer t(c, ST_MINMAX);
         if ((rc = kd_minmax_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, &sc->mm[0]))) return rc;
     }   // (u8 input: mm stays 0 from the scalar block the entry point zeroed)
     {
         km_stage_timer t(c, ST_LAPLACIAN);
         if (d_mask) { if ((rc = kd_count_nonzero(c, d_mask, n, &sc->valid))) return rc; }
-        if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, sc->mm, prm->ksize_ref, prm->ksize_mon,
+        if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, mm, prm->ksize_ref, prm->ksize_mon,
                                             prm->invert_mon, nodata_ref, nodata_mon, lap_ref, lap_mon, mask_auto, &sc->valid)))
             return rc;
     }
@@ -1106,8 +1143,9 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     // that speculative path: the synchronous variants repeat a flagged tile right here, a submitted one is repeated by the
     // caller that waits for it (karios_amd.resident)
     c->spec_allowed = attempt == 0; c->spec_used = false; c->spec_flags = 0;
+    c->mm_early_allowed = slot != nullptr;     // (the synchronous forms report min / max in their statistics: scalar block)
     rc = klt_tile_dev_impl(c, d_ref, d_mon, dtype, H, W, sref, smon, d_mask, smask, nodata_ref, nodata_mon, prm, d_p0, d_p1, d_p0r, cap, sc, &no_valid);
-    c->spec_allowed = false;
+    c->spec_allowed = false; c->mm_early_allowed = false;
     if (rc) return rc;
     const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
     if ((rc = frame_block_free(c))) return rc;

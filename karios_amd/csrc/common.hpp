@@ -62,6 +62,8 @@ enum km_slot {
     WS_PYR_B,
     WS_KEYS0,       // candidate keys
     WS_KEYS1,       // sort double buffer
+    WS_MM_PARTIAL,  // partial minima / maxima of the NEXT unit's rasters (early min/max on the second stream, beside LK of the current unit)
+    WS_MM_EARLY,    // ... and their result {min_ref, max_ref, min_mon, max_mon}
     WS_SORT_TMP,    // k_sort.hip: digit tables of the radix sort / tile sums of the scan
     WS_GRID,        // accepted-point grid of the greedy selection
     WS_PTS0,        // p0
@@ -141,6 +143,9 @@ struct km_ctx {
     hipStream_t aux_stream = nullptr;    // sync-free tile path: the pyramids (they depend on the Laplacians only) run here next to the
     hipStream_t d2h_stream = nullptr;    // km_klt_tile_frame_submit: the finished frame block travels to the host here
     hipEvent_t ev_tail = nullptr, frame_copy = nullptr;   // frame_copy: completion of the last block copy (WS_FRAME must not be rewritten before)
+    hipEvent_t ev_lk_start = nullptr, ev_mm = nullptr;   // early min/max: the next unit's K1 starts on aux_stream when this unit's LK launch starts
+    bool lk_start_valid = false, lk_start_prev = false;   //   ... ev_lk_start was recorded by the tile call that directly preceded this one
+    bool mm_early_allowed = false;       //   ... the running entry point reads no min / max statistics back (km_klt_tile_frame_submit)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // chain of small corner-selection kernels on `stream`, joined before LK
     bool copy_pending = false;           // uploads queued since the compute stream last waited for the whole copy stream
     std::vector<hipEvent_t> upload_marks;   // km_upload_mark tickets: events on the copy stream, nullptr = ticket consumed
@@ -188,6 +193,7 @@ struct km_ctx {
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
+    bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
     bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
@@ -310,6 +316,7 @@ static inline size_t km_any_dtype_size(int dtype)
 // k_dense.hip
 int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
               double *d_mm /* [2] */);
+int kd_minmax_pair_ws(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm, int ws_slot);
 int kd_minmax_pair(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb,
                    double *d_mm /* [4]: min_a, max_a, min_b, max_b */);
 int kd_to_uint8(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,

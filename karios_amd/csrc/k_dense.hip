@@ -102,12 +102,38 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict
         if (head > n) head = n;
         const size_t nvec = (n - head) / V;
         const uint4 *vp = (const uint4 *)(img + head);
-        for (size_t i = tid; i < nvec; i += nth) {
-            uint4 q = vp[i];
-            T e[V];
-            __builtin_memcpy(e, &q, 16);
+        // 16-bit pixels: packed minimum / maximum of the dwords as loaded (v_pk_min/max_u16|i16: 2 instructions per pixel pair
+        // where widening each pixel took 6), folded into mn / mx after the loop
+        typedef typename std::conditional<std::is_signed<T>::value, short, unsigned short>::type P16;
+        typedef P16 pk2 __attribute__((ext_vector_type(2)));
+        constexpr bool PACKED = sizeof(T) == 2 && px_traits<T>::code != KM_F32;
+        pk2 pmn, pmx;
+        pmn.x = pmn.y = std::is_signed<T>::value ? (P16)0x7fff : (P16)0xffff;
+        pmx.x = pmx.y = std::is_signed<T>::value ? (P16)0x8000 : (P16)0;
+        auto take = [&](const uint4 &q) {
+            if constexpr (PACKED) {
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int k = 0; k < V; k++) upd(e[k]);
+                for (int k = 0; k < 4; k++) {
+                    pk2 v;
+                    __builtin_memcpy(&v, &w[k], 4);
+                    pmn = __builtin_elementwise_min(pmn, v);
+                    pmx = __builtin_elementwise_max(pmx, v);
+                }
+            } else {
+                T e[V];
+                __builtin_memcpy(e, &q, 16);
+#pragma unroll
+                for (int k = 0; k < V; k++) upd(e[k]);
+            }
+        };
+        size_t i = tid;
+        for (; i < nvec; i += nth) take(vp[i]);
+        if constexpr (PACKED) {
+            if (nvec > 0) {      // (every lane's packed accumulators hold real pixels or their neutral start values)
+                mn = min(mn, min((A)pmn.x, (A)pmn.y));
+                mx = max(mx, max((A)pmx.x, (A)pmx.y));
+            }
         }
         if (tid < head) upd(img[tid]);
         const size_t tail0 = head + nvec * V;
@@ -150,10 +176,13 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial
 }
 
 // min / max of one image (d_b == nullptr) or of the two rasters of a pair in one launch: d_mm[0..1] (and d_mm[2..3])
-static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm)
+static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm, int ws_slot = WS_PARTIAL)
 {
-    const int nb = 2048, ni = d_b ? 2 : 1;
-    double *partial = (double *)km_ws(c, WS_PARTIAL, (size_t)2 * nb * ni * sizeof(double));
+    // workgroups per image.  Beside LK (early min / max: ws_slot != WS_PARTIAL) the kernel is off the critical path and takes
+    // fewer wave slots from the kernel it shares the GPU with
+    static const int nb_early = [] { const char *e = getenv("KARIOS_HIP_MM_EARLY_NB"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 2048 ? v : 2048; }();
+    const int nb = ws_slot == WS_PARTIAL ? 2048 : nb_early, ni = d_b ? 2 : 1;
+    double *partial = (double *)km_ws(c, ws_slot, (size_t)2 * nb * ni * sizeof(double));
     if (!partial) return KM_E_NOMEM;
     const dim3 grid(nb, ni);
     switch (dtype) {
@@ -172,6 +201,12 @@ static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype,
 int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride, double *d_mm)
 {
     return minmax_launch(c, d_img, nullptr, dtype, H, W, stride, 0, d_mm);
+}
+
+// (partials in a workspace slot of the caller's choice: the early min / max of the next unit runs beside kernels that use WS_PARTIAL)
+int kd_minmax_pair_ws(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t sa, ptrdiff_t sb, double *d_mm, int ws_slot)
+{
+    return minmax_launch(c, d_a, d_b, dtype, H, W, sa, sb, d_mm, ws_slot);
 }
 
 // both rasters of a pair: d_mm = {min_a, max_a, min_b, max_b}

@@ -218,3 +218,52 @@ def test_band_tracker_with_a_three_level_pyramid_equals_the_full_image(ops, O):
     # a point whose level-2 window needs the rows next to the band edge
     edge = np.array([[250.0, ys + 44.0]], np.float32)
     assert band_track(edge)[2] == 1
+
+
+def test_early_minmax_of_back_to_back_units_belongs_to_the_right_unit():
+    """A unit submitted directly behind another one computes its min / max on the second stream beside the previous unit's LK
+    (`mm_early`, KM_PATH_MM_EARLY).  Units of different content, size and pixel type, through one context, must each get the
+    stretch of THEIR OWN rasters (`_to_uint8`, klt.py:42-49): frames equal to the blocking call with the feature switched off."""
+    import pandas as pd
+    from karios_amd._lib import Context
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    from karios_amd.stream import FrameStream
+    conf = KLTConfiguration(maxCorners=500)
+    specs = [(520, 640, 1.0, 0, np.uint16), (700, 530, 0.31, 900, np.uint16), (512, 512, 2.5, 40, np.float32), (610, 700, 0.05, 3000, np.uint16),
+             (520, 640, 1.7, -200, np.int16), (530, 520, 1.0, 0, np.uint8), (640, 600, 0.6, 12000, np.uint16)]
+    ctx, plain = Context(0), Context(0)
+    plain.set_option("mm_early", 0)
+    pairs, want, raw = [], [], []
+    for i, (H, W, gain, bias, dt) in enumerate(specs):
+        mon, ref = synth.make_pair(H, W, 0.3 + 0.1 * i, -0.2, seed=40 + i)
+        conv = lambda a: (np.clip(a.astype(np.float64) * gain + bias, 0, 255) if dt == np.uint8 else a.astype(np.float64) * gain + bias).astype(dt)
+        mon, ref = conv(mon // (64 if dt == np.uint8 else 1)), conv(ref // (64 if dt == np.uint8 else 1))
+        raw.append((mon, ref))
+        pairs.append(ResidentPair.upload(mon, ref, ctx=ctx))
+        want.append(ResidentPair.upload(mon, ref, ctx=plain).match_tile(conf, zncc_threshold=0.4))
+    got, early = [], 0
+    with FrameStream(0.4, depth=1, score_columns=False) as s:
+        for p in pairs:
+            got += [r.frame for r in s.submit(p, conf)]
+            early += bool(int(ctx.stats().path_flags) & 32)
+        got += [r.frame for r in s.drain()]
+    assert early >= len(specs) - 2, f"the early min / max path ran for {early} of {len(specs)} units"   # (not the first; not the uint8 unit)
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            pd.testing.assert_frame_equal(a.reset_index(drop=True), b.reset_index(drop=True), check_exact=True, obj=f"unit {i}")
+    # a call in between takes the feature off for the unit that follows it: here the call PRODUCES that unit's raster on the main
+    # stream (km_shift_image_dev), which a kernel on the second stream would not be ordered behind
+    p0 = pairs[0].submit_tile(conf, zncc_threshold=0.4)
+    shifted = pairs[1].shifted_monitored(3, -2)
+    p1 = shifted.submit_tile(conf, zncc_threshold=0.4)
+    assert not int(ctx.stats().path_flags) & 32
+    p3 = pairs[3].submit_tile(conf, zncc_threshold=0.4)
+    assert int(ctx.stats().path_flags) & 32
+    want_shifted = ResidentPair.upload(raw[1][0], raw[1][1], ctx=plain).shifted_monitored(3, -2).match_tile(conf, zncc_threshold=0.4)
+    pd.testing.assert_frame_equal(want_shifted.reset_index(drop=True), p1.result().to_frame().reset_index(drop=True), check_exact=True)
+    pd.testing.assert_frame_equal(want[3].reset_index(drop=True), p3.result().to_frame().reset_index(drop=True), check_exact=True)
+    pd.testing.assert_frame_equal(want[0].reset_index(drop=True), p0.result().to_frame().reset_index(drop=True), check_exact=True)
+    ctx.close(); plain.close()
