@@ -58,6 +58,23 @@ def test_sort_pairs_is_stable(n, distinct, descending):
     np.testing.assert_array_equal(gv, vals[order])
 
 
+def test_sort_large_unbounded_corner_case():
+    """maxCorners = 0 on a full Sentinel-2 tile can leave ~30 million frame rows: 14 700 tiles per pass, positions beyond 2^24."""
+    rng = np.random.default_rng(123)
+    n = 30_140_100 + 13
+    keys = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
+    keys[::5] >>= np.uint64(33)                      # many keys with empty high digits, as (x0, y0) keys have
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = _sort(keys, vals, False)
+    assert np.all(gk[1:] >= gk[:-1])
+    np.testing.assert_array_equal(keys[gv], gk)                 # the payload is the permutation that sorts
+    assert np.array_equal(np.sort(gv[:1000]), np.sort(gv[:1000]))
+    ties = gk[1:] == gk[:-1]
+    assert np.all(gv[1:][ties] > gv[:-1][ties])                 # stable
+    assert len(np.unique(gv[:: max(1, n // 100_000)])) == len(gv[:: max(1, n // 100_000)])
+    assert int(gv.astype(np.uint64).sum()) == n * (n - 1) // 2  # a permutation
+
+
 def test_sort_frame_shaped_pairs():
     """(x0, y0) ordering keys of a frame with sentinel keys behind the kept rows, ranks as payload (k_frame.hip)."""
     rng = np.random.default_rng(9)
