@@ -582,3 +582,22 @@ def test_large_offset_flow_and_gdt_byte_quirk(ops):
     assert q.dtype == np.uint8 and q.max() == 255
     small = np.roll(ref, (1, 1), (0, 1))                                # below bias_correction_min_threshold on both axes
     assert detect_large_offset(NumpyRasterImage(ref), NumpyRasterImage(small)) is None
+
+
+@pytest.mark.parametrize("shape,seed", [((97, 131), 1), ((256, 256), 2), ((333, 517), 3), ((64, 1025), 4)])
+def test_user_mask_valid_pixel_count(ops, shape, seed):
+    """klt.py:266-279: with a user mask the valid pixels are its non-zero bytes (any value, not only 255) - counted 16 bytes at a
+    time on the device; sizes that leave unaligned heads and tails, masks that are all zero / all set."""
+    rng = np.random.default_rng(seed)
+    mon, ref = synth.make_pair(shape[0], shape[1], 0.3, -0.2, seed=seed)
+    conf = __import__("karios_amd.core", fromlist=["KLTConfiguration"]).KLTConfiguration(maxCorners=200)
+    for kind in ("random", "sparse", "zero", "full"):
+        mask = {"random": rng.integers(0, 256, shape).astype(np.uint8) * (rng.random(shape) < 0.7),
+                "sparse": ((rng.random(shape) < 0.01) * rng.integers(1, 256, shape)).astype(np.uint8),
+                "zero": np.zeros(shape, np.uint8), "full": np.full(shape, 255, np.uint8)}[kind].astype(np.uint8)
+        status, _ = ops.klt_tile(ref, mon, conf, mask_box=mask, mon_ksize=7, ref_ksize=7)
+        st = ops._lib.default_context().stats()
+        if kind == "zero":
+            assert status == "no_valid_pixels"
+        else:
+            assert st.valid_pixels == int(np.count_nonzero(mask)), (kind, shape)
