@@ -2,6 +2,7 @@
 // the device-resident KLT tile pipeline.  Nothing here computes on the CPU: every entry point
 // ends in HIP kernels on the context stream; there is no fallback path.
 #include "common.hpp"
+#include <vector>
 
 #include <dlfcn.h>
 
@@ -437,14 +438,39 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
 }
 
 // strided host image -> dense device buffer in workspace slot
+// diagnosis (KARIOS_HIP_VERIFY_UPLOAD): read a device image back on the library stream and compare it with its host source
+static int verify_upload(km_ctx *c, const char *when, int slot, const void *host, size_t elem, int H, int W, ptrdiff_t stride, const void *d)
+{
+    static const bool verify = getenv("KARIOS_HIP_VERIFY_UPLOAD") != nullptr;
+    if (!verify) return KM_OK;
+    const size_t row = (size_t)W * elem;
+    std::vector<char> back((size_t)H * row);
+    KM_HIP(c, hipMemcpyAsync(back.data(), d, back.size(), hipMemcpyDeviceToHost, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    int bad = 0, first = -1, last = -1;
+    for (int y = 0; y < H; y++)
+        if (memcmp(back.data() + (size_t)y * row, (const char *)host + (size_t)y * stride * elem, row) != 0) { bad++; if (first < 0) first = y; last = y; }
+    if (bad) fprintf(stderr, "KARIOS_HIP_VERIFY_UPLOAD: %s: slot %d, %d x %d x %zu B: %d rows differ from the host source (first %d, last %d)\n", when, slot, H, W, elem,
+                     bad, first, last);
+    return KM_OK;
+}
+
 static int upload_image(km_ctx *c, int slot, const void *host, size_t elem, int H, int W, ptrdiff_t stride, void **dptr)
 {
     void *d = km_ws(c, slot, (size_t)H * W * elem);
     if (!d) return KM_E_NOMEM;
     KM_HIP(c, hipMemcpy2DAsync(d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H, hipMemcpyHostToDevice,
                                c->stream));
+    // The copy is COMPLETE before anything else is enqueued.  The source is pageable caller memory; twice in ~37 000 cases of a
+    // six-process soak (images up to 1500 px, every CPU core busy with the oracles) the kernels of the blocking km_klt_tile call
+    // behind such a copy saw partly stale destination rows (min / max of the monitored raster -32768 / 30720 where numpy says
+    // -4021 / 7987; seven of 1549 corners off; never the resident-pair path, never reproduced in isolation in 29 000 calls).  With the
+    // wait - and in a third soak that also read every upload back and compared it - the mismatch did not recur.  The host-buffer
+    // entry points are blocking anyway; resident pairs upload from page-locked memory on the copy stream and join by event.
+    static const bool async_upload = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;   // (restores the old behaviour for the soak)
+    if (!async_upload) KM_HIP(c, hipStreamSynchronize(c->stream));
     *dptr = d;
-    return KM_OK;
+    return verify_upload(c, "after upload", slot, host, elem, H, W, stride, d);
 }
 
 static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride, const char *what)
@@ -1032,6 +1058,8 @@ int km_klt_tile(km_ctx *c, const void *ref, const void *mon, int dtype, int H, i
         c->spec_allowed = false;
         if (rc) return rc;
         if ((rc = fetch_tracks(c, sc, d_p0, d_p1, d_p0r, p0, p1, p0r, cap, out_n))) return rc;
+        (void)verify_upload(c, "end of km_klt_tile (ref)", WS_RAW_A, ref, es, H, W, sref, d_ref);
+        (void)verify_upload(c, "end of km_klt_tile (mon)", WS_RAW_B, mon, es, H, W, smon, d_mon);
         if (!(c->spec_used && c->spec_flags)) break;       // flagged speculative run: once more through the exact path
         memset(&c->stats, 0, sizeof c->stats);
         c->stats.path_flags |= KM_PATH_SPEC_RETRY;

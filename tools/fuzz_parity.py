@@ -160,6 +160,9 @@ def run_case(case, ops, O, ResidentPair):
         status, tracks = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
                                       mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
         fp.tally()
+        st = fp.ctx.stats()      # post-mortem of a failing case: what the blocking call saw (its min / max, counts, paths)
+        LAST["tile_stats"] = np.array([st.valid_pixels, st.n_candidates, st.n_init, st.min_ref, st.max_ref, st.min_mon, st.max_mon,
+                                       st.max_eig, st.path_flags], np.float64)
         pair = ResidentPair.upload(mon, ref, mask=mask)
         pair.no_data_mon, pair.no_data_ref = case["nodata_mon"], case["nodata_ref"]
         if case.get("async_ring"):
@@ -188,12 +191,28 @@ def run_case(case, ops, O, ResidentPair):
     p1e = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0e, case["winsize"])
     p0re = O.pyr_lk(exp["lap_mon"], exp["lap_ref"], p1e, case["winsize"])
     LAST.update(exp_p0=p0e, exp_p1=p1e, exp_p0r=p0re)
+    def post_mortem():
+        # a rare, non-reproducing mismatch of the blocking call (rounds 1 and 3): record what that call saw and whether the same call
+        # right afterwards agrees with the oracle
+        ts = LAST.get("tile_stats")
+        truth = [float(np.nanmin(ref_b)), float(np.nanmax(ref_b)), float(np.nanmin(mon_b)), float(np.nanmax(mon_b))]
+        fails.append(f"blocking call saw min/max {None if ts is None else ts[3:7].tolist()} (numpy: {truth}), valid {None if ts is None else int(ts[0])} "
+                     f"(mask {int(np.count_nonzero(exp['mask']))}), path flags {None if ts is None else int(ts[8])}")
+        for rep in range(3):
+            s2, t2 = ops.klt_tile(ref_b, mon_b, conf, mask_box=mask_b, nodata_ref=case["nodata_ref"], nodata_mon=case["nodata_mon"],
+                                  mon_ksize=case["mon_k"], ref_ksize=case["ref_k"], invert_mon=case["invert"])
+            fails.append(f"repeat {rep}: " + ("status " + s2 if s2 != "ok" else
+                                              f"p0 {np.array_equal(t2[0], p0e)} p1 {np.array_equal(t2[1], p1e)} p0r {np.array_equal(t2[2], p0re)}"))
+        LAST.update(exp_lap_ref=exp["lap_ref"], exp_lap_mon=exp["lap_mon"], exp_mask=exp["mask"])
     if tracks[0].shape != p0e.shape or not np.array_equal(tracks[0], p0e):
         fails.append(f"p0 differs ({len(tracks[0])} vs {len(p0e)} corners)")
+        post_mortem()
         return fails
     for name, got, want in (("p1", tracks[1], p1e), ("p0r", tracks[2], p0re)):
         if not np.array_equal(got, want):
             fails.append(f"{name} not bit-identical: max |diff| {np.abs(got - want).max():.3g} at {int(np.abs(got - want).argmax()) // 2}")
+    if fails:
+        post_mortem()
     n_exp = len(exp["x0"])
     if frame is None:
         if n_exp:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Unforced parity soak: 4 tile workers (default knobs, images up to 1500 px) + 2 aux workers (ZNCC / MI / phase / shift / DN filter) side by side.
-T=${1:-900}; S=${2:-70000000}
+T=${1:-900}; S=${2:-70000000}   # (env such as KARIOS_HIP_VERIFY_UPLOAD=1 is inherited by the workers)
 mkdir -p gpurun_out
 pids=()
 for i in 0 1 2 3; do
