@@ -136,7 +136,8 @@ int km_d2h(km_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int km_host_alloc(km_ctx *ctx, size_t bytes, void **hptr);
 int km_host_free(km_ctx *ctx /* may be NULL: the block outlived its context */, void *hptr);
 /* Asynchronous strided upload on the context's COPY stream: `rows` rows of `width_bytes` bytes, pitches in bytes.  Returns
- * at once when `src_host` is page-locked; every later call on the context that launches kernels waits (on the device, not
+ * at once when `src_host` is page-locked (a pageable source is copied completely before the call returns); every later call on
+ * the context that launches kernels waits (on the device, not
  * on the host) for the uploads queued so far, so pair / tile i+1 can travel while pair / tile i computes.  The caller keeps
  * `src_host` alive and unmodified, and `dst_dev` unused by earlier work, until km_upload_wait or that later call returns. */
 int km_upload_async(km_ctx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch,

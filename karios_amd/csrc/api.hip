@@ -338,10 +338,17 @@ int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, siz
         KM_HIP(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     }
     if (rows == 0 || width_bytes == 0) return KM_OK;
+    // page-locked source (km_host_alloc / hipHostMalloc / hipHostRegister): truly asynchronous.  Pageable source: the copy is
+    // completed before the call returns (see upload_image: a pageable copy that later work merely queues behind was the one
+    // suspect of the stale-input mismatches of the blocking tile call)
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
     if (dst_pitch == width_bytes && src_pitch == width_bytes)
         KM_HIP(c, hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyHostToDevice, c->copy_stream));
     else
         KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
+    if (!pinned) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
     c->copy_pending = true;
     return KM_OK;
 }

@@ -48,7 +48,8 @@ class DeviceBuffer:
     def upload_image_async(self, img: np.ndarray) -> np.ndarray:
         """Queue the upload of a 2-D image (rows may be strided views of a larger array) on the context's copy stream and
         return the array that must stay alive until the context's next call: from page-locked memory (`pinned_empty`) this
-        returns at once and the copy overlaps whatever the device is computing; pageable memory is staged by the runtime."""
+        returns at once and the copy overlaps whatever the device is computing; from pageable memory the library completes the copy
+        before it returns (km_upload_async)."""
         a = as_image(img)
         assert a.shape[0] * a.shape[1] * a.itemsize <= self.nbytes
         w = a.shape[1] * a.itemsize
