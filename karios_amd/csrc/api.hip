@@ -445,6 +445,15 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
 }
 
 // strided host image -> dense device buffer in workspace slot
+// Host -> device copy of caller (pageable) memory on the library stream, COMPLETE on return: see upload_image for why nothing is
+// queued behind such a copy any more.  (Copies from the library's own page-locked buffers stay asynchronous.)
+static int h2d_now(km_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    KM_HIP(c, hipStreamSynchronize(c->stream));
+    return KM_OK;
+}
+
 // diagnosis (KARIOS_HIP_VERIFY_UPLOAD): read a device image back on the library stream and compare it with its host source
 static int verify_upload(km_ctx *c, const char *when, int slot, const void *host, size_t elem, int H, int W, ptrdiff_t stride, const void *d)
 {
@@ -979,7 +988,7 @@ int km_pyrlk(km_ctx *c, const uint8_t *prev, const uint8_t *next, int H, int W, 
     float *d_in = (float *)km_ws(c, WS_PTS0, (size_t)n * 2 * sizeof(float));
     float *d_out = (float *)km_ws(c, WS_PTS1, (size_t)n * 2 * sizeof(float));
     if (!d_in || !d_out) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(d_in, pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d_in, pts, (size_t)n * 2 * sizeof(float)); if (rch) return rch; }
     km_pyr A, B;
     if ((rc = build_pyramid_pair(c, (const uint8_t *)d_prev, (const uint8_t *)d_next, H, W, win, max_level, &A, &B))) return rc;
     if ((rc = kl_track(c, A, B, d_in, nullptr, n, win, max_count, epsilon, false, d_out, nullptr))) return rc;
@@ -1027,7 +1036,7 @@ int km_klt_track(km_ctx *c, const uint8_t *ref_lap, const uint8_t *mon_lap, cons
     const float *d_p0_in = nullptr;
     if (p0_in) {
         if (n_p0 < 0 || n_p0 > cap) return km_fail(c, KM_E_ARG, "klt_track: p0 count %d (capacity %d)", n_p0, cap);
-        if (n_p0 > 0) KM_HIP(c, hipMemcpyAsync(d_p0, p0_in, (size_t)n_p0 * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if (n_p0 > 0) { const int rch = h2d_now(c, d_p0, p0_in, (size_t)n_p0 * 2 * sizeof(float)); if (rch) return rch; }
         d_p0_in = d_p0;
     }
     if ((rc = klt_track_dev(c, (const uint8_t *)d_ref, (const uint8_t *)d_mon, (const uint8_t *)d_mask, H, W, prm, d_p0_in, n_p0, d_p0, d_p1,
@@ -1480,7 +1489,7 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
     double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)n * sizeof(double));
     if (!kp || !d_out) return KM_E_NOMEM;
     const float *src[4] = {x0, y0, dx, dy};
-    for (int i = 0; i < 4; i++) KM_HIP(c, hipMemcpyAsync(kp + (size_t)i * n, src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 4; i++) { const int rch = h2d_now(c, kp + (size_t)i * n, src[i], (size_t)n * sizeof(float)); if (rch) return rch; }
     {
         km_stage_timer t(c, ST_ZNCC);
         if ((rc = kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, d_out)))
@@ -1508,7 +1517,7 @@ int km_zncc_windows(km_ctx *c, const void *img1, const void *img2, int dtype1, i
     double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)count * sizeof(double));
     uint8_t *d_fl = (uint8_t *)km_ws(c, WS_MISC2, (size_t)count);
     if (!d_uv || !d_out || !d_fl) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(d_uv, uv, (size_t)count * 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d_uv, uv, (size_t)count * 4 * sizeof(int)); if (rch) return rch; }
     if ((rc = kz_zncc_windows(c, d1, d2, dtype1, dtype2, H1, W1, H2, W2, W1, W2, d_uv, half_size, count, d_out, d_fl))) return rc;
     KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (out_outside) KM_HIP(c, hipMemcpyAsync(out_outside, d_fl, (size_t)count, hipMemcpyDeviceToHost, c->stream));
@@ -1546,7 +1555,7 @@ int km_mi_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Href
     double *d_out = (double *)km_ws(c, WS_MISC1, (size_t)n * 2 * sizeof(double));
     if (!kp || !d_out) return KM_E_NOMEM;
     const float *src[4] = {x0, y0, dx, dy};
-    for (int i = 0; i < 4; i++) KM_HIP(c, hipMemcpyAsync(kp + (size_t)i * n, src[i], (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 4; i++) { const int rch = h2d_now(c, kp + (size_t)i * n, src[i], (size_t)n * sizeof(float)); if (rch) return rch; }
     if ((rc = kmi_batch(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, nullptr,
                         nullptr, 0.f, out_st ? d_out : nullptr, out_nmi ? d_out + n : nullptr)))
         return rc;
@@ -1592,9 +1601,9 @@ int km_dn_keep_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, i
     double *d_nv = (double *)km_ws(c, WS_MISC1, (size_t)(n_no > 0 ? n_no : 1) * sizeof(double));
     uint8_t *d_keep = (uint8_t *)km_ws(c, WS_MISC2, (size_t)n);
     if (!d_xy || !d_nv || !d_keep) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(d_xy, x0, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    KM_HIP(c, hipMemcpyAsync(d_xy + n, y0, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (n_no > 0) KM_HIP(c, hipMemcpyAsync(d_nv, no_values, (size_t)n_no * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d_xy, x0, (size_t)n * sizeof(float)); if (rch) return rch; }
+    { const int rch = h2d_now(c, d_xy + n, y0, (size_t)n * sizeof(float)); if (rch) return rch; }
+    if (n_no > 0) { const int rch = h2d_now(c, d_nv, no_values, (size_t)n_no * sizeof(double)); if (rch) return rch; }
     if ((rc = kf_dn_keep(c, d_ref, d_mon, dtype, H, W, sref, smon, d_xy, d_xy + n, n, d_nv, n_no, nodata_ref, nodata_mon, d_keep))) return rc;
     KM_HIP(c, hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
@@ -1666,7 +1675,7 @@ int km_band_prefilter_dev(km_ctx *c, const void *d_ref, const void *d_mon, int d
     km_scalars *sc = scalars(c);
     if (!sc) return KM_E_NOMEM;
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
-    KM_HIP(c, hipMemcpyAsync(sc->mm, minmax, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, sc->mm, minmax, 4 * sizeof(double)); if (rch) return rch; }
     if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, sc->mm, ksize_ref, ksize_mon, invert_mon, nodata_ref, nodata_mon,
                                         d_lap_ref, d_lap_mon, d_user_mask ? nullptr : d_mask, &sc->valid)))
         return rc;
@@ -1747,8 +1756,8 @@ int km_sort_pairs_u64(km_ctx *c, unsigned long long *keys, unsigned *vals, size_
     unsigned long long *dk = (unsigned long long *)km_ws(c, WS_KEYS0, 2 * n * sizeof(unsigned long long));
     unsigned *dv = vals ? (unsigned *)km_ws(c, WS_MISC1, 2 * n * sizeof(unsigned)) : nullptr;
     if (!dk || (vals && !dv)) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(dk, keys, n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    if (vals) KM_HIP(c, hipMemcpyAsync(dv, vals, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, dk, keys, n * sizeof(unsigned long long)); if (rch) return rch; }
+    if (vals) { const int rch = h2d_now(c, dv, vals, n * sizeof(unsigned)); if (rch) return rch; }
     if ((rc = km_sort_u64(c, dk, dk + n, dv, dv ? dv + n : nullptr, n, descending != 0))) return rc;
     KM_HIP(c, hipMemcpyAsync(keys, dk, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     if (vals) KM_HIP(c, hipMemcpyAsync(vals, dv, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -1764,7 +1773,7 @@ int km_exclusive_scan_u32(km_ctx *c, const unsigned *in, unsigned *out, size_t n
     if (n == 0) return KM_OK;
     unsigned *d = (unsigned *)km_ws(c, WS_MISC1, 2 * n * sizeof(unsigned));
     if (!d) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(d, in, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d, in, n * sizeof(unsigned)); if (rch) return rch; }
     if ((rc = km_exclusive_scan(c, d, d + n, n, count_ones ? KM_SCAN_IS_ONE : KM_SCAN_PLAIN, WS_SORT_TMP))) return rc;
     KM_HIP(c, hipMemcpyAsync(out, d + n, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     KM_HIP(c, hipStreamSynchronize(c->stream));
@@ -1787,7 +1796,7 @@ int km_select_keys(km_ctx *c, const unsigned long long *keys, size_t n, int H, i
     KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
     *out_n = 0;
     if (n == 0) return KM_OK;
-    KM_HIP(c, hipMemcpyAsync(d_keys, keys, n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d_keys, keys, n * sizeof(unsigned long long)); if (rch) return rch; }
     unsigned long long *sorted = nullptr;
     if ((rc = ks_sort_keys_desc(c, d_keys, n, &sorted))) return rc;
     if ((rc = ks_select(c, sorted, n, H, W, max_corners, min_distance, d_xy, cap, sc, nullptr, true))) return rc;
@@ -1856,7 +1865,7 @@ int km_band_track_dev(km_ctx *c, const uint8_t *d_lap_ref, const uint8_t *d_lap_
     float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
     km_scalars *sc = scalars(c);
     if (!d_p0 || !d_p1 || !d_p0r || !sc) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpyAsync(d_p0, p0, pb, hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, d_p0, p0, pb); if (rch) return rch; }
     int *d_flag = &sc->n_batches;
     KM_HIP(c, hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
     {
