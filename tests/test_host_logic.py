@@ -377,3 +377,32 @@ def test_frame_stream_orders_results_bounds_depth_and_restores_the_switch_interv
     with FrameStream(None, depth=0, gil_switch_interval=None) as s0:
         d = s0.submit(_FakePair(), conf)
         assert len(d) == 1 and list(d[0].frame.columns) == ["x0", "y0", "dx", "dy", "score"]
+
+
+# ---------------------------------------------------------------------------- inline-assembly hazards of the built kernels
+def test_inline_assembly_hazard_scan_of_the_device_code(tmp_path):
+    """The kernels write DOT / DPP / packed instructions as inline assembly, which LLVM's hazard recogniser cannot see into: the
+    required wait states are padded by hand.  `tools/hazard_scan.py` re-derives them from the gfx950 assembly of every source that
+    contains inline assembly (cross-compiled here, no GPU needed) - a violated hazard would be a silent, data-dependent wrong value."""
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "karios_amd", "csrc")
+    srcs = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and ("asm" in open(os.path.join(csrc, f)).read() or f in ("k_eig2.hip", "k_eig3.hip"))]
+    assert {"k_eig3.hip", "k_lk.hip", "k_dense.hip", "k_fft.hip"} <= set(srcs), srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+             "-fno-gpu-flush-denormals-to-zero", "-I/opt/rocm/include", "--cuda-device-only", "-S"]      # (the Makefile's flags)
+
+    def build(f):
+        out = str(tmp_path / (f[:-4] + ".s"))
+        subprocess.run([hipcc, *flags, "-o", out, os.path.join(csrc, f)], check=True, capture_output=True, timeout=900)
+        return out
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        asm = list(ex.map(build, srcs))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hazard_scan.py"), *asm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("0 potential DOT hazards") == len(asm) and r.stdout.count("0 potential DPP hazards") == len(asm), r.stdout[-2000:]

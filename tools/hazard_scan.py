@@ -127,6 +127,8 @@ def scan_dpp(path):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) < 2:
+        sys.exit("usage: hazard_scan.py <device assembly .s> ...   (hipcc --offload-arch=gfx950 ... --cuda-device-only -S -o k.s k.hip)")
     bad = 0
     for p in sys.argv[1:]:
         dz = scan_dpp(p)
