@@ -136,13 +136,19 @@ int km_d2h(km_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int km_host_alloc(km_ctx *ctx, size_t bytes, void **hptr);
 int km_host_free(km_ctx *ctx /* may be NULL: the block outlived its context */, void *hptr);
 /* Asynchronous strided upload on the context's COPY stream: `rows` rows of `width_bytes` bytes, pitches in bytes.  Returns
- * at once when `src_host` is page-locked (a pageable source is copied completely before the call returns); every later call on
+ * at once when `src_host` is page-locked; a pageable source is packed into the context's page-locked ring chunk by chunk
+ * (csrc/staging.hip) and has been read completely when the call returns - no runtime copy ever touches pageable memory; every later call on
  * the context that launches kernels waits (on the device, not
  * on the host) for the uploads queued so far, so pair / tile i+1 can travel while pair / tile i computes.  The caller keeps
  * `src_host` alive and unmodified, and `dst_dev` unused by earlier work, until km_upload_wait or that later call returns. */
 int km_upload_async(km_ctx *ctx, void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch,
                     size_t width_bytes, size_t rows);
 int km_upload_wait(km_ctx *ctx);   /* host-side wait for the uploads queued so far */
+/* Diagnosis of klt.py:252-253 ("a tile is matched as read"): with KARIOS_HIP_UPLOAD_CHECKSUM=1 in the environment a row-checksum
+ * kernel runs on the library stream right behind every host-buffer upload of the blocking entry points and is compared with the
+ * host's checksum of the source rows when the call completes (mismatches are reported on stderr, see csrc/staging.hip).
+ * *armed = uploads checked so far on this context, *missed = uploads whose first consumer saw rows that differ from the source. */
+int km_upload_check_stats(km_ctx *ctx, int64_t *armed, int64_t *missed);
 /* Finer ordering for pipelines: km_upload_mark returns a ticket for "the uploads queued so far" and takes them out of the
  * automatic wait above; km_upload_join makes the compute stream wait (on the device) for that ticket only.  Upload pair i+1,
  * mark, launch the kernels of pair i, join, launch the kernels of pair i+1: the copy hides under pair i's compute. */
@@ -171,6 +177,9 @@ int km_to_uint8(km_ctx *ctx, const void *img, int dtype, int H, int W, ptrdiff_t
 int km_auto_mask(km_ctx *ctx, const void *mon, const void *ref, int dtype, int H, int W,
                  ptrdiff_t stride_mon, ptrdiff_t stride_ref, const double *nodata_mon,
                  const double *nodata_ref, uint8_t *mask, int64_t *valid);
+/* Test hook: the oscillation stop of the LK kernels' iteration (cv2.calcOpticalFlowPyrLK, klt.py:134-140; OpenCV compares the
+ * float32 |delta + prevDelta| with the DOUBLE literal 0.01) evaluated on the device for n host quadruples (ddx, pdx, ddy, pdy). */
+int km_lk_oscillation_probe(km_ctx *ctx, const float *quads, int n, uint8_t *out);
 /* cv2.Laplacian(u8, CV_8U, ksize) (klt.py:359-360, 427-434, 480-483) */
 int km_laplacian_u8(km_ctx *ctx, const uint8_t *src, int H, int W, int ksize, uint8_t *dst);
 /* cornerMinEigenVal inside cv2.goodFeaturesToTrack (klt.py:120) */

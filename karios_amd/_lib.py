@@ -65,6 +65,7 @@ SIGNATURES = {
     "km_host_free": (_i, [_vp, _vp]),
     "km_upload_async": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t]),
     "km_upload_wait": (_i, [_vp]),
+    "km_upload_check_stats": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "km_upload_mark": (_i, [_vp, _pi]),
     "km_upload_join": (_i, [_vp, _i]),
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "km_band_track_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _pi]),
     "km_to_uint8": (_i, [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _pd]),
     "km_auto_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _vp, C.POINTER(C.c_int64)]),
+    "km_lk_oscillation_probe": (_i, [_vp, _vp, _i, _vp]),
     "km_laplacian_u8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "km_min_eigen": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "km_good_features": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _d, _i, _vp, _i, _pi]),
@@ -208,6 +210,12 @@ class Context:
             raise KariosHipError(f"km_ctx_create(device={device}) failed ({rc}): {msg.decode() if msg else ''}")
         self.handle = h
         self.device = device
+        # The context is not thread-safe and finalizers (`__del__` of buffers / pairs) run on whichever thread drops the last
+        # reference or triggers the cyclic GC - e.g. FrameStream's worker.  Library calls of finalizers are therefore queued here
+        # and run by the owning thread at its next call (`drain`) instead of racing with it.
+        self._owner = threading.get_ident()
+        self._abandoned = []
+        self._abandoned_lock = threading.Lock()
         self._alive = [True]      # shared with the finalizers of this context's page-locked arrays (`pinned_empty`)
         # development / A-B measurements: KARIOS_HIP_OPTIONS="lk2=0,eig3=0" applies `set_option` to every new context
         for item in filter(None, os.environ.get("KARIOS_HIP_OPTIONS", "").split(",")):
@@ -220,6 +228,7 @@ class Context:
 
     def dev_alloc(self, nbytes: int) -> tuple[int, int]:
         """-> (device pointer, capacity).  Capacities are multiples of 2 MiB so that boxes of similar size share buffers."""
+        self.drain()
         cap = max(1, (int(nbytes) + (2 << 20) - 1) >> 21) << 21
         pool = self.__dict__.setdefault("_pool", {})
         free = pool.get(cap)
@@ -253,6 +262,32 @@ class Context:
                 self.lib.km_dev_free(self.handle, C.c_void_p(p))
         self._pool, self._pool_bytes = {}, 0
 
+    def run_or_defer(self, fn):
+        """Run `fn()` (library calls on this context) now when called on the owning thread, otherwise leave it for that thread."""
+        if threading.get_ident() == self.__dict__.get("_owner"):
+            self.drain()
+            fn()
+        else:
+            with self._abandoned_lock:
+                self._abandoned.append(fn)
+
+    def drain(self):
+        """Owning thread: run what finalizers on other threads left behind (released buffers, unused upload tickets)."""
+        if not self.__dict__.get("_abandoned"):
+            return
+        with self._abandoned_lock:
+            todo, self._abandoned = self._abandoned, []
+        for fn in todo:
+            try:
+                fn()
+            except Exception:  # noqa: BLE001 - a finalizer's failure must not break the caller's call
+                pass
+
+    def adopt(self):
+        """Declare the calling thread the context's owner (a context handed from the thread that created it to another one)."""
+        self._owner = threading.get_ident()
+        self.drain()
+
     def check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.km_last_error(self.handle)
@@ -260,6 +295,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            self._owner = threading.get_ident()      # (whoever closes it has it to itself)
+            self.drain()
             # page-locked arrays that outlive the context are released without it (km_host_free(NULL, p)); the staging area the
             # context itself owns goes first, while its streams still exist
             self.__dict__.pop("_kp_staging", None)
@@ -284,6 +321,12 @@ class Context:
 
     def set_profiling(self, on: bool):
         self.check(self.lib.km_set_profiling(self.handle, int(bool(on))), "km_set_profiling")
+
+    def upload_check_stats(self):
+        """-> (uploads checked, uploads whose first consumer saw stale rows) with KARIOS_HIP_UPLOAD_CHECKSUM=1 (csrc/staging.hip)."""
+        a, m = C.c_int64(), C.c_int64()
+        self.check(self.lib.km_upload_check_stats(self.handle, C.byref(a), C.byref(m)), "km_upload_check_stats")
+        return int(a.value), int(m.value)
 
     def set_option(self, name: str, value: int):
         """Knob of include/karios_hip.h km_set_option, e.g. set_option("fused_eig", 0) or the test knobs "key_cap",

@@ -14,6 +14,18 @@
 
 static thread_local std::string g_last_error;
 
+// results for the caller: DMA into the context's page-locked landing arena, then (KM_FLUSH) complete the stream and copy out
+#define KM_D2H(c, dst, src, bytes)                                           \
+    do {                                                                     \
+        const int rq_ = km_d2h_queue((c), (dst), (src), (bytes));            \
+        if (rq_) return rq_;                                                 \
+    } while (0)
+#define KM_FLUSH(c)                                                          \
+    do {                                                                     \
+        const int rq_ = km_d2h_flush(c);                                     \
+        if (rq_) return rq_;                                                 \
+    } while (0)
+
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -141,6 +153,7 @@ int km_ctx_destroy(km_ctx *c)
     kp_destroy(c);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->pinned_rb) (void)hipHostFree(c->pinned_rb);
+    km_ring_destroy(c);
     for (km_frame_slot &f : c->fslot) {
         if (f.host) (void)hipHostFree(f.host);
         if (f.done) (void)hipEventDestroy(f.done);
@@ -298,16 +311,16 @@ int km_h2d(km_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
-    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rcs = km_h2d_staged(c, c->stream, dst, bytes, src, bytes, bytes, 1); if (rcs) return rcs; }
+    KM_FLUSH(c);
     return KM_OK;
 }
 int km_d2h(km_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
-    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, dst, src, bytes);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -338,17 +351,10 @@ int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, siz
         KM_HIP(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     }
     if (rows == 0 || width_bytes == 0) return KM_OK;
-    // page-locked source (km_host_alloc / hipHostMalloc / hipHostRegister): truly asynchronous.  Pageable source: the copy is
-    // completed before the call returns (see upload_image: a pageable copy that later work merely queues behind was the one
-    // suspect of the stale-input mismatches of the blocking tile call)
-    hipPointerAttribute_t at;
-    const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
-    (void)hipGetLastError();
-    if (dst_pitch == width_bytes && src_pitch == width_bytes)
-        KM_HIP(c, hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyHostToDevice, c->copy_stream));
-    else
-        KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
-    if (!pinned) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
+    // page-locked source (km_host_alloc / hipHostMalloc / hipHostRegister): DMA'd in place, truly asynchronous.  Pageable source:
+    // packed into the context's page-locked ring chunk by chunk (staging.hip) - the call returns when the source has been read,
+    // the DMAs stay ordered on the copy stream; no runtime copy ever reads pageable memory
+    { const int rcs = km_h2d_staged(c, c->copy_stream, dst, dst_pitch, src, src_pitch, width_bytes, rows); if (rcs) return rcs; }
     c->copy_pending = true;
     return KM_OK;
 }
@@ -389,6 +395,13 @@ int km_upload_wait(km_ctx *c)
     if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
     return KM_OK;
 }
+int km_upload_check_stats(km_ctx *c, int64_t *armed, int64_t *missed)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    if (armed) *armed = (int64_t)c->chk_armed_total;
+    if (missed) *missed = (int64_t)c->chk_miss_total;
+    return KM_OK;
+}
 int km_set_image_window(km_ctx *c, int ox, int oy, int H_image, int W_image)
 {
     if (!c) return km_fail(c, KM_E_ARG, "null context");
@@ -421,6 +434,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
+    km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->spec_used = false; c->spec_flags = 0;
     // early min / max (klt_tile_dev_impl): only a tile call that DIRECTLY follows a tile call may start its K1 beside the previous
     // unit's LK - any call in between may have produced the rasters on the main stream (km_shift_image_dev ...)
@@ -444,14 +458,11 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE)
     return KM_OK;
 }
 
-// strided host image -> dense device buffer in workspace slot
-// Host -> device copy of caller (pageable) memory on the library stream, COMPLETE on return: see upload_image for why nothing is
-// queued behind such a copy any more.  (Copies from the library's own page-locked buffers stay asynchronous.)
+// Host -> device copy of caller memory on the library stream through the page-locked ring: `src` has been read completely on
+// return, the DMA is ordered on the stream like any kernel (staging.hip).
 static int h2d_now(km_ctx *c, void *dst, const void *src, size_t bytes)
 {
-    KM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
-    return KM_OK;
+    return km_h2d_staged(c, c->stream, dst, bytes, src, bytes, bytes, 1);
 }
 
 // diagnosis (KARIOS_HIP_VERIFY_UPLOAD): read a device image back on the library stream and compare it with its host source
@@ -461,8 +472,9 @@ static int verify_upload(km_ctx *c, const char *when, int slot, const void *host
     if (!verify) return KM_OK;
     const size_t row = (size_t)W * elem;
     std::vector<char> back((size_t)H * row);
-    KM_HIP(c, hipMemcpyAsync(back.data(), d, back.size(), hipMemcpyDeviceToHost, c->stream));
+    KM_D2H(c, back.data(), d, back.size());
     KM_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rq = km_d2h_flush(c); if (rq) return rq; }
     int bad = 0, first = -1, last = -1;
     for (int y = 0; y < H; y++)
         if (memcmp(back.data() + (size_t)y * row, (const char *)host + (size_t)y * stride * elem, row) != 0) { bad++; if (first < 0) first = y; last = y; }
@@ -475,16 +487,20 @@ static int upload_image(km_ctx *c, int slot, const void *host, size_t elem, int 
 {
     void *d = km_ws(c, slot, (size_t)H * W * elem);
     if (!d) return KM_E_NOMEM;
-    KM_HIP(c, hipMemcpy2DAsync(d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H, hipMemcpyHostToDevice,
-                               c->stream));
-    // The copy is COMPLETE before anything else is enqueued.  The source is pageable caller memory; twice in ~37 000 cases of a
-    // six-process soak (images up to 1500 px, every CPU core busy with the oracles) the kernels of the blocking km_klt_tile call
-    // behind such a copy saw partly stale destination rows (min / max of the monitored raster -32768 / 30720 where numpy says
-    // -4021 / 7987; seven of 1549 corners off; never the resident-pair path, never reproduced in isolation in 29 000 calls).  With the
-    // wait - and in a third soak that also read every upload back and compared it - the mismatch did not recur.  The host-buffer
-    // entry points are blocking anyway; resident pairs upload from page-locked memory on the copy stream and join by event.
-    static const bool async_upload = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;   // (restores the old behaviour for the soak)
-    if (!async_upload) KM_HIP(c, hipStreamSynchronize(c->stream));
+    // Caller memory is pageable.  Twice in ~37 000 cases of a six-process soak (images up to 1500 px, every CPU core busy with the
+    // oracles) the kernels of the blocking km_klt_tile call behind `hipMemcpy2DAsync(pageable rows)` saw partly stale destination rows
+    // (min / max of the monitored raster -32768 / 30720 where numpy says -4021 / 7987; seven of 1549 corners off; never the resident-
+    // pair path).  Round 3 completed such copies before anything else was enqueued; since round 4 the rows travel through the
+    // library's own page-locked ring (staging.hip) and the runtime never sees pageable memory.  KARIOS_HIP_ASYNC_HOST_UPLOAD=1
+    // restores the ORIGINAL behaviour for the control soak (with KARIOS_HIP_UPLOAD_CHECKSUM=1: what did the next kernel see?).
+    static const bool async_upload = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;
+    if (async_upload)
+        KM_HIP(c, hipMemcpy2DAsync(d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H, hipMemcpyHostToDevice, c->stream));
+    else {
+        const int rcs = km_h2d_staged(c, c->stream, d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H);
+        if (rcs) return rcs;
+    }
+    { const int rca = km_upload_check_arm(c, slot == WS_RAW_A ? "ref / image A" : slot == WS_RAW_B ? "mon / image B" : slot == WS_MASK_IN ? "mask" : "u8 image", host, elem, H, W, stride, d); if (rca) return rca; }
     *dptr = d;
     return verify_upload(c, "after upload", slot, host, elem, H, W, stride, d);
 }
@@ -637,8 +653,8 @@ static int gftt_dev(km_ctx *c, const uint8_t *d_img, const uint8_t *d_mask, int 
 static int read_stats(km_ctx *c, km_scalars *sc)
 {
     km_scalars h;
-    KM_HIP(c, hipMemcpyAsync(&h, sc, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, &h, sc, sizeof h);
+    KM_FLUSH(c);
     c->stats.n_init = h.n_corners;
     c->stats.n_select_batches = h.n_batches;
     c->stats.max_eig = h.max_eig;
@@ -662,8 +678,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         if (n_p0 > cap) return km_fail(c, KM_E_ARG, "p0 count %d exceeds capacity %d", n_p0, cap);
         if (n_p0 > 0 && d_p0_in != d_p0)
             KM_HIP(c, hipMemcpyAsync(d_p0, d_p0_in, (size_t)n_p0 * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        KM_HIP(c, hipMemcpyAsync(&sc->n_corners, &n_p0, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));  // n_p0 is a stack variable
+        { const int rch = h2d_now(c, &sc->n_corners, &n_p0, sizeof(int)); if (rch) return rch; }   // (n_p0 is a stack variable: staged)
     }
     km_pyr A, B;
     // Speculative corner path (k_select2.hip): no host synchronisation, fixed capacities, flags instead of retries.  The
@@ -868,10 +883,10 @@ int km_to_uint8(km_ctx *c, const void *img, int dtype, int H, int W, ptrdiff_t s
     if (dtype != KM_U8) { if ((rc = kd_minmax(c, d_img, dtype, H, W, W, sc->mm))) return rc; }
     else KM_HIP(c, hipMemsetAsync(sc->mm, 0, sizeof sc->mm, c->stream));
     if ((rc = kd_to_uint8(c, d_img, dtype, H, W, W, sc->mm, invert, d_out))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    KM_D2H(c, out, d_out, (size_t)H * W);
     double mm[2];
-    KM_HIP(c, hipMemcpyAsync(mm, sc->mm, sizeof mm, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, mm, sc->mm, sizeof mm);
+    KM_FLUSH(c);
     if (out_minmax) { out_minmax[0] = mm[0]; out_minmax[1] = mm[1]; }
     return KM_OK;
 }
@@ -891,9 +906,9 @@ int km_auto_mask(km_ctx *c, const void *mon, const void *ref, int dtype, int H, 
     if (!sc || !d_mask) return KM_E_NOMEM;
     if ((rc = kd_auto_mask(c, d_mon, d_ref, dtype, H, W, W, W, nodata_mon, nodata_ref, d_mask, &sc->valid))) return rc;
     unsigned long long v = 0;
-    KM_HIP(c, hipMemcpyAsync(mask, d_mask, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipMemcpyAsync(&v, &sc->valid, sizeof v, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, mask, d_mask, (size_t)H * W);
+    KM_D2H(c, &v, &sc->valid, sizeof v);
+    KM_FLUSH(c);
     if (valid) *valid = (int64_t)v;
     return KM_OK;
 }
@@ -908,8 +923,8 @@ int km_laplacian_u8(km_ctx *c, const uint8_t *src, int H, int W, int ksize, uint
     uint8_t *d_dst = (uint8_t *)km_ws(c, WS_U8_A, (size_t)H * W);
     if (!d_dst) return KM_E_NOMEM;
     if ((rc = kd_laplacian_u8(c, (const uint8_t *)d_src, H, W, ksize, d_dst))) return rc;
-    KM_HIP(c, hipMemcpyAsync(dst, d_dst, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, dst, d_dst, (size_t)H * W);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -924,8 +939,8 @@ int km_min_eigen(km_ctx *c, const uint8_t *src, int H, int W, int block, float *
     float *d_eig = (float *)km_ws(c, WS_EIG, (size_t)H * W * sizeof(float));
     if (!sc || !d_eig) return KM_E_NOMEM;
     if ((rc = kd_min_eigen(c, (const uint8_t *)d_src, nullptr, H, W, block, d_eig, &sc->max_eig_key))) return rc;
-    KM_HIP(c, hipMemcpyAsync(eig, d_eig, (size_t)H * W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, eig, d_eig, (size_t)H * W * sizeof(float));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -952,8 +967,8 @@ int km_good_features(km_ctx *c, const uint8_t *img, const uint8_t *mask, int H, 
     int n = c->stats.n_init;
     if (n > cap) return km_fail(c, KM_E_ARG, "good_features: %d corners exceed capacity %d", n, cap);
     if (n > 0) {
-        KM_HIP(c, hipMemcpyAsync(out_xy, d_xy, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        KM_D2H(c, out_xy, d_xy, (size_t)n * 2 * sizeof(float));
+        KM_FLUSH(c);
     }
     *out_n = n;
     return KM_OK;
@@ -970,8 +985,8 @@ int km_pyrdown_u8(km_ctx *c, const uint8_t *src, int H, int W, uint8_t *dst)
     uint8_t *d_dst = (uint8_t *)km_ws(c, WS_U8_A, on);
     if (!d_dst) return KM_E_NOMEM;
     if ((rc = kd_pyrdown_u8(c, (const uint8_t *)d_src, H, W, d_dst))) return rc;
-    KM_HIP(c, hipMemcpyAsync(dst, d_dst, on, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, dst, d_dst, on);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -992,8 +1007,25 @@ int km_pyrlk(km_ctx *c, const uint8_t *prev, const uint8_t *next, int H, int W, 
     km_pyr A, B;
     if ((rc = build_pyramid_pair(c, (const uint8_t *)d_prev, (const uint8_t *)d_next, H, W, win, max_level, &A, &B))) return rc;
     if ((rc = kl_track(c, A, B, d_in, nullptr, n, win, max_count, epsilon, false, d_out, nullptr))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out_pts, d_out, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out_pts, d_out, (size_t)n * 2 * sizeof(float));
+    KM_FLUSH(c);
+    return KM_OK;
+}
+
+// test hook: the oscillation predicate of the LK kernels (k_lk.hip: lk_oscillates) on n host quadruples (ddx, pdx, ddy, pdy)
+int km_lk_oscillation_probe(km_ctx *c, const float *quads, int n, uint8_t *out)
+{
+    int rc;
+    if ((rc = begin_call(c))) return rc;
+    if (n < 0 || (n > 0 && (!quads || !out))) return km_fail(c, KM_E_ARG, "lk_oscillation_probe: bad arguments");
+    if (n == 0) return KM_OK;
+    float *d_q = (float *)km_ws(c, WS_MISC0, (size_t)n * 4 * sizeof(float));
+    uint8_t *d_o = (uint8_t *)km_ws(c, WS_MISC2, (size_t)n);
+    if (!d_q || !d_o) return KM_E_NOMEM;
+    { const int rch = h2d_now(c, d_q, quads, (size_t)n * 4 * sizeof(float)); if (rch) return rch; }
+    if ((rc = kl_oscillation_probe(c, d_q, n, d_o))) return rc;
+    KM_D2H(c, out, d_o, (size_t)n);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1006,10 +1038,10 @@ static int fetch_tracks(km_ctx *c, km_scalars *sc, const float *d_p0, const floa
     if (n > cap) return km_fail(c, KM_E_ARG, "%d corners exceed capacity %d", n, cap);
     if (n > 0) {
         const size_t b = (size_t)n * 2 * sizeof(float);
-        KM_HIP(c, hipMemcpyAsync(p0, d_p0, b, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipMemcpyAsync(p1, d_p1, b, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipMemcpyAsync(p0r, d_p0r, b, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        KM_D2H(c, p0, d_p0, b);
+        KM_D2H(c, p1, d_p1, b);
+        KM_D2H(c, p0r, d_p0r, b);
+        KM_FLUSH(c);
     }
     *out_n = n;
     return KM_OK;
@@ -1110,13 +1142,13 @@ int km_tile_prefilter(km_ctx *c, const void *ref, const void *mon, int dtype, in
                                         lap_ref, lap_mon, d_mask, &sc->valid)))
         return rc;
     unsigned long long valid = 0;
-    KM_HIP(c, hipMemcpyAsync(out_lap_ref, lap_ref, n, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipMemcpyAsync(out_lap_mon, lap_mon, n, hipMemcpyDeviceToHost, c->stream));
+    KM_D2H(c, out_lap_ref, lap_ref, n);
+    KM_D2H(c, out_lap_mon, lap_mon, n);
     if (out_mask) {
-        KM_HIP(c, hipMemcpyAsync(out_mask, d_mask, n, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
+        KM_D2H(c, out_mask, d_mask, n);
+        KM_D2H(c, &valid, &sc->valid, sizeof valid);
     }
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_FLUSH(c);
     if (out_valid) *out_valid = out_mask ? (int64_t)valid : -1;
     return KM_OK;
 }
@@ -1233,8 +1265,8 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     }
     km_scalars *land = c->spec_used ? (km_scalars *)km_pinned_rb(c, sizeof(km_scalars)) : nullptr;
     if (land) KM_HIP(c, hipMemcpyAsync(land, sc, sizeof *land, hipMemcpyDeviceToHost, c->stream));   // diagnostics of the sync-free corner path
-    KM_HIP(c, hipMemcpyAsync(host_out, d_out, ob, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, host_out, d_out, ob);
+    KM_FLUSH(c);
     c->stats.n_init = ((const int *)host_out)[1];
     if (land) {
         c->stats.valid_pixels = (int64_t)land->valid;
@@ -1329,9 +1361,9 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
         if ((rc = gftt_dev(c, lap_ref + (size_t)k * na, mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, p0, cap, sc)))
             return rc;
         KM_HIP(c, hipMemcpyAsync(&d_counts[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-        KM_HIP(c, hipMemcpyAsync(&n_p0[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        KM_D2H(c, &n_p0[k], &sc->n_corners, sizeof(int));
     }
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_FLUSH(c);
     // ---- nk*nk tracker runs (mon kernel outer, ref kernel inner), all queued before one synchronisation
     const int n_lim = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
     {
@@ -1348,10 +1380,10 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
             }
     }
     int kept[64];
-    KM_HIP(c, hipMemcpyAsync(kept, d_counts + nk, (size_t)nk * nk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KM_D2H(c, kept, d_counts + nk, (size_t)nk * nk * sizeof(int));
     unsigned long long valid = 0;
-    KM_HIP(c, hipMemcpyAsync(&valid, &sc->valid, sizeof valid, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, &valid, &sc->valid, sizeof valid);
+    KM_FLUSH(c);
     c->stats.valid_pixels = (int64_t)valid;
     double best_ratio = -1.0;
     int best = -1;
@@ -1380,8 +1412,8 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
                            (const float *)(trk_store + (size_t)(2 * best + 1) * pts), &d_counts[br], n_lim, cap, 0.1f, x_off, y_off, d_out)))
             return rc;
     }
-    KM_HIP(c, hipMemcpyAsync(host_out, d_out, fb, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, host_out, d_out, fb);
+    KM_FLUSH(c);
     c->stats.n_init = ((const int *)host_out)[1];
     return KM_OK;
 }
@@ -1495,8 +1527,8 @@ int km_zncc_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Hr
         if ((rc = kz_zncc(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, d_out)))
             return rc;
     }
-    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out, d_out, (size_t)n * sizeof(double));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1519,9 +1551,9 @@ int km_zncc_windows(km_ctx *c, const void *img1, const void *img2, int dtype1, i
     if (!d_uv || !d_out || !d_fl) return KM_E_NOMEM;
     { const int rch = h2d_now(c, d_uv, uv, (size_t)count * 4 * sizeof(int)); if (rch) return rch; }
     if ((rc = kz_zncc_windows(c, d1, d2, dtype1, dtype2, H1, W1, H2, W2, W1, W2, d_uv, half_size, count, d_out, d_fl))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (out_outside) KM_HIP(c, hipMemcpyAsync(out_outside, d_fl, (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out, d_out, (size_t)count * sizeof(double));
+    if (out_outside) KM_D2H(c, out_outside, d_fl, (size_t)count);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1559,9 +1591,9 @@ int km_mi_batch(km_ctx *c, const void *ref, const void *mon, int dtype, int Href
     if ((rc = kmi_batch(c, d_ref, d_mon, dtype, Href, Wref, Hmon, Wmon, Wref, Wmon, kp, kp + n, kp + 2 * (size_t)n, kp + 3 * (size_t)n, n, nullptr,
                         nullptr, 0.f, out_st ? d_out : nullptr, out_nmi ? d_out + n : nullptr)))
         return rc;
-    if (out_st) KM_HIP(c, hipMemcpyAsync(out_st, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (out_nmi) KM_HIP(c, hipMemcpyAsync(out_nmi, d_out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (out_st) KM_D2H(c, out_st, d_out, (size_t)n * sizeof(double));
+    if (out_nmi) KM_D2H(c, out_nmi, d_out + n, (size_t)n * sizeof(double));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1605,8 +1637,8 @@ int km_dn_keep_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, i
     { const int rch = h2d_now(c, d_xy + n, y0, (size_t)n * sizeof(float)); if (rch) return rch; }
     if (n_no > 0) { const int rch = h2d_now(c, d_nv, no_values, (size_t)n_no * sizeof(double)); if (rch) return rch; }
     if ((rc = kf_dn_keep(c, d_ref, d_mon, dtype, H, W, sref, smon, d_xy, d_xy + n, n, d_nv, n_no, nodata_ref, nodata_mon, d_keep))) return rc;
-    KM_HIP(c, hipMemcpyAsync(keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, keep, d_keep, (size_t)n);
+    KM_FLUSH(c);
     for (int i = 0; i < n; i++)
         if (keep[i] > 1) return km_fail(c, KM_E_ARG, "dn_keep: key point %d (%g, %g) lies outside the %dx%d image", i, (double)x0[i], (double)y0[i], W, H);
     return KM_OK;
@@ -1630,8 +1662,8 @@ int km_shift_image(km_ctx *c, const void *img, int elem_size, int H, int W, ptrd
     void *d_out = km_ws(c, WS_RAW_B, (size_t)H * W * elem_size);
     if (!d_out) return KM_E_NOMEM;
     if ((rc = kd_shift_image(c, d_img, elem_size, H, W, W, y_off, x_off, d_out))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out, d_out, (size_t)H * W * elem_size, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out, d_out, (size_t)H * W * elem_size);
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1656,8 +1688,8 @@ int km_minmax_dev(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff
     if (!sc) return KM_E_NOMEM;
     if (dtype == KM_U8) { out_minmax[0] = out_minmax[1] = 0.0; return KM_OK; }   // (_to_uint8 passes uint8 through, klt.py:44-45)
     if ((rc = kd_minmax(c, d_img, dtype, H, W, stride, sc->mm))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out_minmax, sc->mm, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out_minmax, sc->mm, 2 * sizeof(double));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1686,8 +1718,8 @@ int km_band_prefilter_dev(km_ctx *c, const void *d_ref, const void *d_mon, int d
     KM_HIP(c, hipMemsetAsync(&sc->valid, 0, sizeof sc->valid, c->stream));
     if ((rc = kd_count_nonzero(c, d_mask, (size_t)H * W, &sc->valid))) return rc;
     unsigned long long v = 0;
-    KM_HIP(c, hipMemcpyAsync(&v, &sc->valid, sizeof v, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, &v, &sc->valid, sizeof v);
+    KM_FLUSH(c);
     *valid_owned = (int64_t)v;
     return KM_OK;
 }
@@ -1712,8 +1744,8 @@ int km_band_eigen_dev(km_ctx *c, const uint8_t *d_lap_ref, const uint8_t *d_mask
         if (!eig) return KM_E_NOMEM;
         if ((rc = kd_min_eigen(c, d_lap_ref, d_mask, H, W, block, eig, &sc->max_eig_key))) return rc;
     } else if (rc) return rc;
-    KM_HIP(c, hipMemcpyAsync(local_max_key, &sc->max_eig_key, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, local_max_key, &sc->max_eig_key, sizeof(unsigned));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1728,7 +1760,7 @@ int km_band_keys_dev(km_ctx *c, const uint8_t *d_mask, int H, int W, double qual
     km_scalars *sc = scalars(c);
     unsigned long long *keys = (unsigned long long *)c->ws[WS_KEYS0].p;
     if (!sc || !keys || !c->band_capk) return km_fail(c, KM_E_ARG, "band_keys: km_band_eigen_dev has not run on this context");
-    KM_HIP(c, hipMemcpyAsync(&sc->max_eig_key, &global_max_key, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    { const int rch = h2d_now(c, &sc->max_eig_key, &global_max_key, sizeof(unsigned)); if (rch) return rch; }
     if (!c->band_fused) {
         const float *eig = (const float *)c->ws[WS_EIG].p;
         if ((rc = kd_candidates(c, eig, d_mask, H, W, quality, sc, keys, c->band_capk, false))) return rc;
@@ -1740,8 +1772,8 @@ int km_band_keys_dev(km_ctx *c, const uint8_t *d_mask, int H, int W, double qual
     if (c->band_fused && hs.pad0 != 0u) return km_fail(c, KM_E_UNSUPPORTED, "band_keys: plateau image overflowed the fused kernel's stage");
     if ((size_t)hs.n_cand > c->band_capk) return km_fail(c, KM_E_UNSUPPORTED, "band_keys: candidate buffer overflow (%u keys)", hs.n_cand);
     if (nkept > cap) return km_fail(c, KM_E_ARG, "band_keys: %zu keys exceed the capacity %zu", nkept, cap);
-    if (nkept) KM_HIP(c, hipMemcpyAsync(out_keys, kept, nkept * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (nkept) KM_D2H(c, out_keys, kept, nkept * sizeof(unsigned long long));
+    KM_FLUSH(c);
     *n_out = nkept; *n_total = ntotal;
     return KM_OK;
 }
@@ -1759,9 +1791,9 @@ int km_sort_pairs_u64(km_ctx *c, unsigned long long *keys, unsigned *vals, size_
     { const int rch = h2d_now(c, dk, keys, n * sizeof(unsigned long long)); if (rch) return rch; }
     if (vals) { const int rch = h2d_now(c, dv, vals, n * sizeof(unsigned)); if (rch) return rch; }
     if ((rc = km_sort_u64(c, dk, dk + n, dv, dv ? dv + n : nullptr, n, descending != 0))) return rc;
-    KM_HIP(c, hipMemcpyAsync(keys, dk, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    if (vals) KM_HIP(c, hipMemcpyAsync(vals, dv, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, keys, dk, n * sizeof(unsigned long long));
+    if (vals) KM_D2H(c, vals, dv, n * sizeof(unsigned));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1775,8 +1807,8 @@ int km_exclusive_scan_u32(km_ctx *c, const unsigned *in, unsigned *out, size_t n
     if (!d) return KM_E_NOMEM;
     { const int rch = h2d_now(c, d, in, n * sizeof(unsigned)); if (rch) return rch; }
     if ((rc = km_exclusive_scan(c, d, d + n, n, count_ones ? KM_SCAN_IS_ONE : KM_SCAN_PLAIN, WS_SORT_TMP))) return rc;
-    KM_HIP(c, hipMemcpyAsync(out, d + n, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, out, d + n, n * sizeof(unsigned));
+    KM_FLUSH(c);
     return KM_OK;
 }
 
@@ -1804,8 +1836,8 @@ int km_select_keys(km_ctx *c, const unsigned long long *keys, size_t n, int H, i
     const int m = c->stats.n_init;
     if (m > cap) return km_fail(c, KM_E_ARG, "select_keys: %d corners exceed capacity %d", m, cap);
     if (m > 0) {
-        KM_HIP(c, hipMemcpyAsync(out_xy, d_xy, (size_t)m * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        KM_D2H(c, out_xy, d_xy, (size_t)m * 2 * sizeof(float));
+        KM_FLUSH(c);
     }
     *out_n = m;
     return KM_OK;
@@ -1872,10 +1904,10 @@ int km_band_track_dev(km_ctx *c, const uint8_t *d_lap_ref, const uint8_t *d_lap_
         km_stage_timer t(c, ST_LK);
         if ((rc = kl_track(c, A, B, d_p0, nullptr, n, prm->win_size, prm->max_count, prm->epsilon, true, d_p1, d_p0r, d_flag))) return rc;
     }
-    KM_HIP(c, hipMemcpyAsync(p1, d_p1, pb, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipMemcpyAsync(p0r, d_p0r, pb, hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipMemcpyAsync(left_band, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    KM_D2H(c, p1, d_p1, pb);
+    KM_D2H(c, p0r, d_p0r, pb);
+    KM_D2H(c, left_band, d_flag, sizeof(int));
+    KM_FLUSH(c);
     return KM_OK;
 }
 

@@ -134,6 +134,21 @@ struct km_frame_slot {
     std::atomic<int> pending{0};
 };
 
+// staging.hip: page-locked ring between caller memory and the device (no runtime copy ever reads or writes pageable memory)
+#define KM_RING_SLOTS 4
+struct km_ring_slot {
+    void *buf = nullptr;
+    hipEvent_t done = nullptr;      // the DMA that reads the slot
+    bool busy = false;
+};
+struct km_stage_ring {
+    km_ring_slot slot[KM_RING_SLOTS];
+    size_t chunk = 0;
+    int next = 0;
+};
+struct km_land_job { void *dst; const void *pinned; size_t bytes; };
+struct km_chk_job { const char *what; const void *host; size_t elem; int H, W; ptrdiff_t stride; const void *d; size_t off; };
+
 struct km_ctx {
     int device = 0;
     int n_cu = 256;            // compute units of the device (wave slots = n_cu * 4 SIMDs * waves per SIMD)
@@ -156,6 +171,15 @@ struct km_ctx {
     void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
     size_t frame_sink_cap = 0;
     km_buf ws[WS_COUNT];
+    km_stage_ring ring;                  // host -> device staging (staging.hip)
+    void *land = nullptr;                // device -> host landing arena (page-locked), km_d2h_queue / km_d2h_flush
+    size_t land_cap = 0, land_used = 0;
+    hipEvent_t land_ev[2] = {nullptr, nullptr};
+    std::vector<km_land_job> land_jobs;
+    void *chk_dev = nullptr, *chk_host = nullptr;   // KARIOS_HIP_UPLOAD_CHECKSUM: row checksums seen by a kernel right behind each upload
+    size_t chk_used = 0;
+    std::vector<km_chk_job> chk_jobs;
+    long long chk_armed_total = 0, chk_miss_total = 0;
     std::string err;
     // Independent device work queued by the caller to fill the GPU while the host waits for a small read-back (the two
     // synchronisations of the corner selection): km_wait_readback runs ONE deferred job between the copy and the wait.
@@ -214,6 +238,7 @@ struct km_ctx {
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
+    int fft_tw_m[2] = {-1, -1};    //   ... and the 61 M plan they were laid out for (0: Stockham table only)
     size_t fft_work_bytes = 0;
 };
 
@@ -257,6 +282,17 @@ static inline int km_pick_rows(int H, int nstrips, int halo, long wave_slots, in
     return best;
 }
 void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+// staging.hip.  Host -> device: returns when `src` has been read completely; the DMAs (from the ring) are ordered on stream s.
+int km_h2d_staged(km_ctx *c, hipStream_t s, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows);
+static inline int km_h2d_small(km_ctx *c, void *dst, const void *src, size_t bytes) { return km_h2d_staged(c, c->stream, dst, bytes, src, bytes, bytes, 1); }
+// Device -> host on c->stream: queue any number of results, then flush (completes the stream, copies them out of the landing arena)
+int km_d2h_queue(km_ctx *c, void *dst, const void *d_src, size_t bytes);
+int km_d2h_flush(km_ctx *c);
+void km_ring_destroy(km_ctx *c);
+bool km_upload_check_enabled();
+int km_upload_check_arm(km_ctx *c, const char *what, const void *host, size_t elem, int H, int W, ptrdiff_t stride, const void *d);
+int km_upload_check_verify(km_ctx *c);
+void km_upload_check_drop(km_ctx *c);
 // Call right after queuing device-to-host copies the host needs NOW: records an event, queues one deferred job (if any)
 // behind it, then waits for the event only - the GPU keeps working on the job while the host continues.
 int km_wait_readback(km_ctx *ctx);
@@ -380,9 +416,11 @@ struct km_pyr {
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n,
              int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
              float *d_p0r, int *d_left_band = nullptr);
+int kl_oscillation_probe(km_ctx *c, const float *d_q, int n, uint8_t *d_out);   // test hook of the LK kernels' oscillation predicate
 // k_frame.hip
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
              float x_off, float y_off, void *d_out, const km_scalars *d_sc_header = nullptr);   // d_sc_header: header words 2 / 3 = flags, candidate count
+int kf_row_checksum(km_ctx *c, const void *d_img, size_t row_bytes, int rows, unsigned long long *d_out);   // diagnosis of host-buffer uploads (staging.hip)
 // k_zncc.hip
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,
             int Hmon, int Wmon, ptrdiff_t stride_ref, ptrdiff_t stride_mon, const float *d_x0,

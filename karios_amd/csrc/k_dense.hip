@@ -1491,10 +1491,10 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
     const int PW = EIG_TW + L + Rr, PH = EIG_TH + L + Rr, LW = (PW + 2 + 3) & ~3, LH = PH + 2;
     const size_t sm = (((size_t)LH * LW + 15) & ~(size_t)15) + (size_t)PH * PW * 4 + (size_t)3 * PH * EIG_TW * 4;
     if (sm > 160 * 1024 - 256) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d needs %zu B LDS", block, sm);
-    static size_t attr_bytes = 0;  // dynamic-LDS opt-in, raised on demand (kernel also holds a few static words)
-    if (sm > 48 * 1024 && sm > attr_bytes) {
-        KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        attr_bytes = sm;
+    static unsigned long long opted = 0;  // dynamic-LDS opt-in, per DEVICE (hipFuncSetAttribute applies to the current one); the kernel also holds a few static words
+    if (sm > 48 * 1024 && !(opted & (1ull << (c->device & 63)))) {
+        KM_HIP(c, hipFuncSetAttribute((const void *)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        opted |= 1ull << (c->device & 63);
     }
     dim3 grid((W + EIG_TW - 1) / EIG_TW, (H + EIG_TH - 1) / EIG_TH);
     unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)grid.x * grid.y * sizeof(unsigned));

@@ -703,8 +703,9 @@ struct fft_tables {
 
 int upload_twiddles(km_ctx *c, int which, int N, const f61_plan *p61, fft_tables *out)
 {
-    static bool t61_ready = false;            // (cos, sin)(2 pi j k / 61), j, k = 1 .. 30, for the first form's radix-61 butterfly
-    if (!t61_ready) {
+    static unsigned long long t61_ready = 0;  // per DEVICE (a constant-memory symbol lives in each device's code object): bit = device ordinal
+    const unsigned long long dev_bit = 1ull << (c->device & 63);
+    if (!(t61_ready & dev_bit)) {             // (cos, sin)(2 pi j k / 61), j, k = 1 .. 30, for the first form's radix-61 butterfly
         std::vector<float2> h(900);
         for (int k = 1; k <= 30; k++)
             for (int j = 1; j <= 30; j++) {
@@ -712,14 +713,14 @@ int upload_twiddles(km_ctx *c, int which, int N, const f61_plan *p61, fft_tables
                 h[(size_t)(k - 1) * 30 + (j - 1)] = make_float2((float)cos(ang), (float)sin(ang));
             }
         KM_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_t61), h.data(), 900 * sizeof(float2)));
-        t61_ready = true;
+        t61_ready |= dev_bit;
     }
     const int M = p61 ? p61->M : 0;
     const size_t total = (size_t)N + (size_t)M + (p61 ? (size_t)N : 0);
     float2 *d = (float2 *)km_ws(c, which ? WS_FFT_TW1 : WS_FFT_TW0, (size_t)(2 * FFT_NMAX + F61_MMAX) * sizeof(float2));
     if (!d) return KM_E_NOMEM;
     out->tw = d; out->twM = p61 ? d + N : nullptr; out->big = p61 ? d + N + M : nullptr;
-    if (c->fft_tw_n[which] == N) return KM_OK;
+    if (c->fft_tw_n[which] == N && c->fft_tw_m[which] == M) return KM_OK;   // (the table's layout depends on the plan: N alone is not a key)
     std::vector<float2> h(total);
     for (int n = 0; n < N; n++) {
         const double a = -2.0 * M_PI * (double)n / (double)N;
@@ -736,9 +737,8 @@ int upload_twiddles(km_ctx *c, int which, int N, const f61_plan *p61, fft_tables
                 h[(size_t)N + M + (size_t)t * M + j] = make_float2((float)cos(a), (float)sin(a));
             }
     }
-    KM_HIP(c, hipMemcpyAsync(d, h.data(), total * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));          // `h` goes out of scope
-    c->fft_tw_n[which] = N;
+    { const int rcs = km_h2d_staged(c, c->stream, d, total * sizeof(float2), h.data(), total * sizeof(float2), total * sizeof(float2), 1); if (rcs) return rcs; }   // (`h` has been read on return)
+    c->fft_tw_n[which] = N; c->fft_tw_m[which] = M;
     return KM_OK;
 }
 
@@ -747,10 +747,10 @@ int launch_rows(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, f
                 const float2 *tw, int mode)
 {
     const size_t lds = (size_t)N * sizeof(float2);
-    static size_t opted = 0;
-    if (lds > 48 * 1024 && lds > opted) {
+    static unsigned long long opted = 0;   // per instantiation (static local of the template) and per DEVICE (hipFuncSetAttribute applies to the current one)
+    if (lds > 48 * 1024 && !(opted & (1ull << (c->device & 63)))) {
         KM_HIP(c, hipFuncSetAttribute((const void *)fft_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FFT_NMAX * sizeof(float2))));
-        opted = lds;   // per instantiation (static local of the template)
+        opted |= 1ull << (c->device & 63);
     }
     const int grid = nrows < c->n_cu * 8 ? nrows : c->n_cu * 8;
     fft_rows_kernel<T><<<grid, FFT_T, lds, c->stream>>>(a, b, sa, sb, data, mag, N, nrows, plan, tw, mode);
@@ -763,11 +763,11 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
                      const fft_tables &tb, float2 *out_plane)
 {
     const size_t lds = ((size_t)N + (size_t)plan.M) * sizeof(float2);
-    static bool opted = false;
-    if (!opted) {
+    static unsigned long long opted = 0;   // per instantiation and per DEVICE: hipFuncSetAttribute applies to the current device only
+    if (!(opted & (1ull << (c->device & 63)))) {
         KM_HIP(c, hipFuncSetAttribute((const void *)fft61_rows_kernel<T, MC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)((FFT_NMAX + F61_MMAX) * sizeof(float2))));
-        opted = true;   // per instantiation (static local of the template)
+        opted |= 1ull << (c->device & 63);
     }
     const int grid = nrows < c->n_cu ? nrows : c->n_cu;      // one 88-KB workgroup per CU: each walks its rows with the next one in flight
     fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg, out_plane);
@@ -879,8 +879,7 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
         f61_top2_reduce_kernel<<<1, 1024, 0, c->stream>>>(top2, H, d_res);
         KM_LAUNCH_CHECK(c);
         unsigned long long res[2] = {0, 0};
-        KM_HIP(c, hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        { int rq = km_d2h_queue(c, res, d_res, sizeof res); if (!rq) rq = km_d2h_flush(c); if (rq) return rq; }
         h1 = res[0];
         flat = h1 ? 0xffffffffull - (h1 & 0xffffffffull) : 0ull;
         b1 = (unsigned)(h1 >> 32); b2 = (unsigned)res[1];
@@ -889,13 +888,11 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
         KM_HIP(c, hipMemsetAsync(k2, 0, sizeof *k2, c->stream));
         argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, ~0ull, k1);
         KM_LAUNCH_CHECK(c);
-        KM_HIP(c, hipMemcpyAsync(&h1, k1, sizeof h1, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        { int rq = km_d2h_queue(c, &h1, k1, sizeof h1); if (!rq) rq = km_d2h_flush(c); if (rq) return rq; }
         flat = h1 ? 0xffffffffull - (h1 & 0xffffffffull) : 0ull;
         argmax_f32_kernel<<<c->n_cu * 8, 256, 0, c->stream>>>(cc, n, flat, k2);
         KM_LAUNCH_CHECK(c);
-        KM_HIP(c, hipMemcpyAsync(&h2, k2, sizeof h2, hipMemcpyDeviceToHost, c->stream));
-        KM_HIP(c, hipStreamSynchronize(c->stream));
+        { int rq = km_d2h_queue(c, &h2, k2, sizeof h2); if (!rq) rq = km_d2h_flush(c); if (rq) return rq; }
         b1 = (unsigned)(h1 >> 32); b2 = (unsigned)(h2 >> 32);
     }
     float v1, v2;

@@ -187,10 +187,10 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
         const int rpt = (int)((n_sort + FBP_T - 1) / FBP_T);
         auto launch = [&](auto rpt_tag) -> int {
             constexpr int RPT = decltype(rpt_tag)::value;
-            static size_t opted = 0;
-            if (smem > 48 * 1024 && smem > opted) {
+            static unsigned long long opted = 0;   // per instantiation and per DEVICE
+            if (smem > 48 * 1024 && !(opted & (1ull << (c->device & 63)))) {
                 KM_HIP(c, hipFuncSetAttribute((const void *)fb_place_kernel<RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-                opted = 144 * 1024;
+                opted |= 1ull << (c->device & 63);
             }
             fb_place_kernel<RPT><<<32, FBP_T, smem, c->stream>>>(keys, tmp, cap, hdr, out, shift, nbins);
             return KM_OK;
@@ -270,6 +270,31 @@ int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d
 {
     if (n_max <= 0) return KM_OK;
     fb_count_kernel<<<32, 256, 0, c->stream>>>(d_p0, d_p0r, d_n, n_max, back_thr, d_count);   // *d_count zeroed by the caller
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// ------------------------------------------------------------------ KARIOS_HIP_UPLOAD_CHECKSUM (staging.hip): what does a kernel right behind an upload see?
+// out[y] = sum over the bytes b_i of row y of (b_i + 1) * (2 i + 1)  (mod 2^64; the host evaluates the same sum on the source rows)
+__global__ __launch_bounds__(256) void row_checksum_kernel(const uint8_t *__restrict__ img, size_t row_bytes, int rows, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long part[4];
+    const int y = blockIdx.x;
+    if (y >= rows) return;
+    const uint8_t *p = img + (size_t)y * row_bytes;
+    unsigned long long s = 0;
+    for (size_t i = threadIdx.x; i < row_bytes; i += 256) s += (unsigned long long)(p[i] + 1u) * (unsigned long long)(2 * i + 1);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[y] = part[0] + part[1] + part[2] + part[3];
+}
+
+
+int kf_row_checksum(km_ctx *c, const void *d_img, size_t row_bytes, int rows, unsigned long long *d_out)
+{
+    if (rows <= 0) return KM_OK;
+    row_checksum_kernel<<<rows, 256, 0, c->stream>>>((const uint8_t *)d_img, row_bytes, rows, d_out);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

@@ -170,6 +170,14 @@ __device__ __forceinline__ uint32_t lk_pack16(int lo, int hi) { return __builtin
 
 // Track one point from image pyramid I to J (all lanes hold identical scalars).
 // run_desc[t] = y | x0 << 8 | n << 16 (n = 0: the lane has no t-th run).
+// OpenCV's oscillation stop (lkpyramid.cpp, LKTrackerInvoker): `std::abs(delta.x + prevDelta.x) < 0.01 && std::abs(delta.y +
+// prevDelta.y) < 0.01` - the float32 sum, its float32 magnitude, promoted to double against the DOUBLE literal 0.01.  0.01f is
+// 0.00999999977...: a sum of exactly 0.01f passes OpenCV's test and would fail `< 0.01f` (tests/test_gpu_parity.py::test_lk_oscillation_literal).
+__device__ __host__ __forceinline__ bool lk_oscillates(float ddx, float pdx, float ddy, float pdy)
+{
+    return (double)fabsf(ddx + pdx) < 0.01 && (double)fabsf(ddy + pdy) < 0.01;
+}
+
 template <int NR>
 __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float py, int win, int max_count, double epsilon,
                                const int (&run_desc)[NR], uint8_t *raw, short *derx, uint8_t *jp, float &outx, float &outy, bool &left_band)
@@ -356,7 +364,7 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             nx += ddx; ny += ddy;
             resx = nx + half; resy = ny + half;
             if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= epsilon) break;
-            if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+            if (j > 0 && lk_oscillates(ddx, pdx, ddy, pdy)) {
                 resx -= ddx * 0.5f; resy -= ddy * 0.5f;
                 break;
             }
@@ -623,7 +631,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
             nx += ddx; ny += ddy;
             resx = nx + half; resy = ny + half;
             if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= epsilon) break;
-            if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+            if (j > 0 && lk_oscillates(ddx, pdx, ddy, pdy)) {
                 resx -= ddx * 0.5f; resy -= ddy * 0.5f;
                 break;
             }
@@ -820,6 +828,20 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     case 4: lk_kernel<4><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
     default: lk_kernel<5><<<nblk, 64 * LK_WPB, sm_all, c->stream>>>(g, (int)smw); break;
     }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// test hook of the predicate above (km_lk_oscillation_probe): one thread per quadruple
+__global__ void lk_oscillation_probe_kernel(const float *__restrict__ q, int n, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lk_oscillates(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]) ? 1 : 0;
+}
+int kl_oscillation_probe(km_ctx *c, const float *d_q, int n, uint8_t *d_out)
+{
+    if (n <= 0) return KM_OK;
+    lk_oscillation_probe_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_q, n, d_out);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

@@ -188,8 +188,7 @@ int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H
     first_index_kernel<<<2048, 256, 0, c->stream>>>(ra, n, keys, idx);
     KM_LAUNCH_CHECK(c);
     unsigned long long flat = 0;
-    KM_HIP(c, hipMemcpyAsync(&flat, idx, sizeof(flat), hipMemcpyDeviceToHost, c->stream));
-    KM_HIP(c, hipStreamSynchronize(c->stream));
+    { int rq = km_d2h_queue(c, &flat, idx, sizeof(flat)); if (!rq) rq = km_d2h_flush(c); if (rq) return rq; }
     if (flat == ~0ull) flat = 0;  // all-NaN surface: np.argmax would return the first NaN; 0 by convention
     double r = (double)(flat / (unsigned long long)W), col = (double)(flat % (unsigned long long)W);
     // np.fix(N/2) thresholds; axes of length 1 -> 0

@@ -116,6 +116,16 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, winSize=(25, 25), max
     return out.reshape(-1, 1, 2)
 
 
+def lk_oscillation_probe(quads, ctx: Context | None = None):
+    """Test hook: the LK kernels' oscillation stop (OpenCV: float32 |delta + prevDelta| against the double literal 0.01,
+    klt.py:134-140) evaluated on the device for (n, 4) float32 rows (ddx, pdx, ddy, pdy) -> bool array."""
+    c = _ctx(ctx)
+    q = np.ascontiguousarray(quads, np.float32).reshape(-1, 4)
+    out = np.zeros(q.shape[0], np.uint8)
+    c.check(c.lib.km_lk_oscillation_probe(c.handle, ptr(q), q.shape[0], ptr(out)), "km_lk_oscillation_probe")
+    return out.astype(bool)
+
+
 def make_params(conf, mon_ksize=1, ref_ksize=1, invert_mon=False) -> KltParams:
     """KLTConfiguration duck type (core/configuration.py:36-50) -> km_klt_params with the fixed
     LK criteria of klt.py:128-132."""

@@ -30,8 +30,10 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            self.ctx.dev_release(self.ptr, self._cap, self.upload_in_flight)
-            self.ptr = None
+            ptr_, self.ptr = self.ptr, None
+            ctx, cap, flying = self.ctx, self._cap, self.upload_in_flight
+            # (a finalizer may run on another thread than the context's: the release is then left for the owning thread)
+            ctx.run_or_defer(lambda: ctx.dev_release(ptr_, cap, flying))
 
     def __del__(self):
         try:
@@ -156,10 +158,12 @@ class ResidentPair:
 
     def __del__(self):
         # a pair that was uploaded (e.g. prefetched) but never used still holds an upload ticket: give its slot and event back
+        # (never from the finalizer's thread unless it is the context's own: km_upload_join mutates the context)
         try:
             t = self.__dict__.pop("_upload_ticket", -1)
-            if t >= 0 and getattr(self.ctx, "handle", None):
-                self.ctx.lib.km_upload_join(self.ctx.handle, t)
+            ctx = self.ctx
+            if t >= 0 and getattr(ctx, "handle", None):
+                ctx.run_or_defer(lambda: ctx.handle and ctx.lib.km_upload_join(ctx.handle, t))
         except Exception:  # pragma: no cover - interpreter shutdown
             pass
 
@@ -246,6 +250,7 @@ class ResidentPair:
 
     def _ready(self):
         """Before the first kernel on this pair: its uploads (and only its uploads) must have landed."""
+        self.ctx.drain()
         t = self.__dict__.pop("_upload_ticket", -1)
         if t >= 0:
             self.ctx.check(self.ctx.lib.km_upload_join(self.ctx.handle, t), "km_upload_join")

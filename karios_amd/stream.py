@@ -12,6 +12,7 @@ callers and `ResidentPair.match_pipelined` share one implementation.
 from __future__ import annotations
 
 import sys
+import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
@@ -19,6 +20,32 @@ from dataclasses import dataclass, field
 from pandas import DataFrame
 
 from .resident import PendingFrame, RawFrame, ResidentPair
+
+
+# The interpreter's switch interval is process-global: open streams are counted, the original value is saved by the FIRST one
+# and restored by the LAST one to close (two overlapping streams closing out of order would otherwise leave it lowered for good).
+_gil_lock = threading.Lock()
+_gil_open = 0
+_gil_saved = None
+
+
+def _gil_interval_acquire(interval: float) -> None:
+    global _gil_open, _gil_saved
+    with _gil_lock:
+        if _gil_open == 0:
+            _gil_saved = sys.getswitchinterval()
+        _gil_open += 1
+        if sys.getswitchinterval() > interval:
+            sys.setswitchinterval(interval)
+
+
+def _gil_interval_release() -> None:
+    global _gil_open, _gil_saved
+    with _gil_lock:
+        _gil_open -= 1
+        if _gil_open == 0 and _gil_saved is not None:
+            sys.setswitchinterval(_gil_saved)
+            _gil_saved = None
 
 
 @dataclass
@@ -45,7 +72,8 @@ class FrameStream:
                         beside `submit`: a context is not thread-safe)
     gil_switch_interval the submitting thread spends ~0.1 ms per unit inside the library and the rest in Python next to the worker;
                         with CPython's default 5 ms switch interval a thread that needs the GIL can wait that long for the other to
-                        yield it.  The stream lowers the interval while it is open and restores it on close; None leaves it alone.
+                        yield it.  The stream lowers the (process-global!) interval while it is open; the value found by the first
+                        open stream comes back when the last one closes (reference-counted).  None leaves it alone.
     """
 
     def __init__(self, confidence_threshold: float | None = None, depth: int = 1, host_stage=None, want_spans: bool = False,
@@ -54,10 +82,10 @@ class FrameStream:
         self.score_columns = (confidence_threshold is not None) if score_columns is None else bool(score_columns)
         self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="karios-frame")
         self._pending: deque = deque()
-        self._old_interval = None
+        self._holds_interval = False
         if gil_switch_interval is not None:
-            self._old_interval = sys.getswitchinterval()
-            sys.setswitchinterval(gil_switch_interval)
+            _gil_interval_acquire(gil_switch_interval)
+            self._holds_interval = True
         self.units_redone = 0
 
     # ------------------------------------------------------------------ context manager
@@ -72,9 +100,15 @@ class FrameStream:
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
-        if self._old_interval is not None:
-            sys.setswitchinterval(self._old_interval)
-            self._old_interval = None
+        if self._holds_interval:
+            self._holds_interval = False
+            _gil_interval_release()
+
+    def __del__(self):
+        try:
+            self.close()           # an abandoned stream (a generator that was never exhausted) must not keep the interval lowered
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------ the two halves
     def _host_half(self, pair: ResidentPair, pend):

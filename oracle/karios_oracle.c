@@ -495,6 +495,14 @@ static inline void lk_weights(float a, float b, int *w00, int *w01, int *w10, in
     *w11 = 16384 - *w00 - *w01 - *w10;
 }
 
+/* Oscillation stop of LKTrackerInvoker (OpenCV 4.8 lkpyramid.cpp): `std::abs(delta.x + prevDelta.x) < 0.01 && std::abs(delta.y +
+ * prevDelta.y) < 0.01` - a float32 sum and magnitude promoted to double against the DOUBLE literal (0.01f = 0.00999999977... passes).
+ * Exported for the known-answer test. */
+int ko_lk_oscillates(float ddx, float pdx, float ddy, float pdy)
+{
+    return (double)fabsf(ddx + pdx) < 0.01 && (double)fabsf(ddy + pdy) < 0.01;
+}
+
 /* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(w,w), maxLevel,
  * criteria=(EPS|COUNT, max_count, eps)) with flags=0, minEigThreshold=1e-4
  * (klt.py:128-140).  status/err are not produced: KARIOS
@@ -612,7 +620,8 @@ int ko_pyrlk(const uint8_t *prev, const uint8_t *next, int H, int W,
                     if (level == 0 && iters) iters[p] = j + 1;
                     /* Point2f::ddot: double accumulation of the f32 deltas */
                     if ((double)ddx * ddx + (double)ddy * ddy <= epsilon) break;
-                    if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+                    /* OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 - float32 magnitude against the DOUBLE literal */
+                    if (j > 0 && ko_lk_oscillates(ddx, pdx, ddy, pdy)) {
                         out_pts[2 * p] -= ddx * 0.5f;
                         out_pts[2 * p + 1] -= ddy * 0.5f;
                         break;

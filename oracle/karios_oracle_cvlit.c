@@ -123,6 +123,14 @@ static inline void weights(float a, float b, int *w00, int *w01, int *w10, int *
 
 int ko_pyrdown_u8(const uint8_t *src, int H, int W, uint8_t *dst);   /* karios_oracle.c: integer, identical in both paths */
 
+/* Oscillation stop of LKTrackerInvoker (OpenCV 4.8 lkpyramid.cpp): `std::abs(delta.x + prevDelta.x) < 0.01 && std::abs(delta.y +
+ * prevDelta.y) < 0.01` - a float32 sum and magnitude promoted to double against the DOUBLE literal (0.01f = 0.00999999977... passes).
+ * Exported for the known-answer test. */
+int kl_lk_oscillates(float ddx, float pdx, float ddy, float pdy)
+{
+    return (double)fabsf(ddx + pdx) < 0.01 && (double)fabsf(ddy + pdy) < 0.01;
+}
+
 /* calcOpticalFlowPyrLK with OpenCV's float32 lane accumulation (see the file header); same interface as ko_pyrlk. */
 int kl_pyrlk_cv(const uint8_t *prev, const uint8_t *next, int H, int W, const float *pts, int n, int win, int max_level, int max_count,
                 double eps, float *out_pts)
@@ -224,7 +232,8 @@ int kl_pyrlk_cv(const uint8_t *prev, const uint8_t *next, int H, int W, const fl
                     nx += ddx; ny += ddy;
                     out_pts[2 * p] = nx + half; out_pts[2 * p + 1] = ny + half;
                     if ((double)ddx * ddx + (double)ddy * ddy <= epsilon) break;
-                    if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+                    /* OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 - float32 magnitude against the DOUBLE literal */
+                    if (j > 0 && kl_lk_oscillates(ddx, pdx, ddy, pdy)) {
                         out_pts[2 * p] -= ddx * 0.5f; out_pts[2 * p + 1] -= ddy * 0.5f;
                         break;
                     }

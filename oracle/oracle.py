@@ -20,7 +20,8 @@ from types import SimpleNamespace
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libkarios_oracle.so")
+# KARIOS_ORACLE_SO: another build of the same sources, e.g. libkarios_oracle_asan.so (`make -C oracle asan`, tests/test_host_asan.py)
+_SO = os.environ.get("KARIOS_ORACLE_SO") or os.path.join(_HERE, "libkarios_oracle.so")
 
 _DT = {np.dtype("uint8"): 0, np.dtype("uint16"): 1, np.dtype("int16"): 2,
        np.dtype("float32"): 3, np.dtype("float64"): 4}
@@ -28,6 +29,8 @@ _DT = {np.dtype("uint8"): 0, np.dtype("uint16"): 1, np.dtype("int16"): 2,
 
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc).  Building the checker is not using it."""
+    if os.environ.get("KARIOS_ORACLE_SO"):
+        return _SO                      # (built by whoever chose it)
     newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("karios_oracle.c", "karios_oracle_cvlit.c", "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
@@ -292,6 +295,14 @@ def pyr_lk(prev, nxt, pts, win=25, max_level=1, max_count=30, eps=0.03, return_i
         raise RuntimeError(f"ko_pyrlk rc={rc}")
     out = out.reshape(n, 1, 2)
     return (out, it[:n]) if return_iters else out
+
+
+def lk_oscillates(ddx, pdx, ddy, pdy, literal_oracle: bool = False) -> bool:
+    """The oscillation stop of calcOpticalFlowPyrLK's iteration: float32 sums and magnitudes against OpenCV's
+    DOUBLE literal 0.01.  `literal_oracle`: the second (OpenCV-literal) oracle's copy of the predicate."""
+    f = lib().kl_lk_oscillates if literal_oracle else lib().ko_lk_oscillates
+    f.argtypes = [C.c_float] * 4
+    return bool(f(float(ddx), float(pdx), float(ddy), float(pdy)))
 
 
 def filter_outliers(x0, y0, x1, y1, score):

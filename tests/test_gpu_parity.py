@@ -601,3 +601,66 @@ def test_user_mask_valid_pixel_count(ops, shape, seed):
             assert status == "no_valid_pixels"
         else:
             assert st.valid_pixels == int(np.count_nonzero(mask)), (kind, shape)
+
+
+def test_lk_oscillation_literal(ops, O):
+    """The LK kernels' oscillation stop == the oracle's == OpenCV's declared types: float32 |delta + prevDelta| against the DOUBLE
+    literal 0.01, driven to exactly float32(0.01) and one ulp either side."""
+    from test_oracle_golden import _oscillation_quads
+    q, want = _oscillation_quads()
+    np.testing.assert_array_equal(ops.lk_oscillation_probe(q), want)
+    rng = np.random.default_rng(9)
+    r = rng.uniform(-0.02, 0.02, (4000, 4)).astype(np.float32)
+    np.testing.assert_array_equal(ops.lk_oscillation_probe(r), np.array([O.lk_oscillates(*row) for row in r]))
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.float32, np.uint8])
+def test_klt_tile_from_pageable_strided_box_through_the_ring(ops, O, dtype, monkeypatch):
+    """klt.py:252-253: a tile is matched as read.  Host rasters are pageable numpy views (row stride > width, odd offsets); they
+    travel through the library's page-locked staging ring (csrc/staging.hip) in several chunks - the ring is shrunk to 64-KB
+    slots so that a 700 x 900 box wraps it many times - and the result equals the oracle's on the packed box."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent(f"""
+        import numpy as np, sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        from karios_amd import ops, synth
+        from oracle import oracle as O
+        mon, ref = synth.make_pair(900, 1100, 0.4, -0.3, seed=77)
+        dt = np.dtype({np.dtype(dtype).name!r})
+        if dt == np.uint8:
+            mon, ref = (mon >> 5).astype(np.uint8), (ref >> 5).astype(np.uint8)
+        elif dt == np.int16:
+            mon, ref = (mon.astype(np.int32) - 4000).astype(np.int16), (ref.astype(np.int32) - 4000).astype(np.int16)
+        elif dt == np.float32:
+            mon, ref = mon.astype(np.float32) * np.float32(0.37), ref.astype(np.float32) * np.float32(0.37)
+        mb, rb = mon[101:801, 57:957], ref[101:801, 57:957]
+        conf = O.default_conf(maxCorners=2000)
+        for rep in range(3):
+            st, tr = ops.klt_tile(rb, mb, conf, mon_ksize=7, ref_ksize=7)
+            assert st == "ok"
+            exp = O.klt_tile(np.ascontiguousarray(mb), np.ascontiguousarray(rb), conf)
+            p0 = O.good_features(exp["lap_ref"], exp["mask"], conf.maxCorners, conf.qualityLevel, conf.minDistance, conf.blocksize)
+            p1 = O.pyr_lk(exp["lap_ref"], exp["lap_mon"], p0, 25)
+            p0r = O.pyr_lk(exp["lap_mon"], exp["lap_ref"], p1, 25)
+            assert np.array_equal(tr[0], p0) and np.array_equal(tr[1], p1) and np.array_equal(tr[2], p0r)
+        from karios_amd._lib import default_context
+        armed, missed = default_context().upload_check_stats()
+        assert armed >= 6 and missed == 0, (armed, missed)
+        print("ring ok", armed)
+    """)
+    env = dict(os.environ, KARIOS_HIP_RING_CHUNK_KB="64", KARIOS_HIP_UPLOAD_CHECKSUM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ring ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "MISS" not in out.stderr
+
+
+def test_large_results_leave_through_the_landing_arena(ops, O):
+    """Results larger than the page-locked landing arena (8 MB) are copied out piecewise: a 3000 x 3100 min-eigenvalue map (37 MB)
+    and its uint8 stretch equal the oracle's."""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (3000, 3100), dtype=np.uint8)
+    np.testing.assert_array_equal(ops.laplacian_u8(a, 5), O.laplacian_u8(a, 5))
+    b = rng.integers(0, 9000, (2100, 2300)).astype(np.uint16)
+    np.testing.assert_array_equal(ops.to_uint8(b), O.to_uint8(b))
+    e = ops.min_eigen(a[:1500, :1700], 5)
+    np.testing.assert_array_equal(e, O.min_eigen(np.ascontiguousarray(a[:1500, :1700]), 5))

@@ -379,6 +379,42 @@ def test_frame_stream_orders_results_bounds_depth_and_restores_the_switch_interv
         assert len(d) == 1 and list(d[0].frame.columns) == ["x0", "y0", "dx", "dy", "score"]
 
 
+def test_switch_interval_survives_overlapping_streams_closed_out_of_order():
+    """the interval is process-global; stream A (opened first) closing before stream B must not leave it lowered."""
+    from karios_amd.stream import FrameStream
+    before = sys.getswitchinterval()
+    a = FrameStream(None)
+    b = FrameStream(None)
+    assert sys.getswitchinterval() == pytest.approx(1e-4, abs=5e-6)
+    a.close()
+    assert sys.getswitchinterval() == pytest.approx(1e-4, abs=5e-6)   # B is still open
+    b.close()
+    b.close()                                                     # idempotent
+    assert sys.getswitchinterval() == pytest.approx(before)
+    c = FrameStream(None)
+    del c                                                         # an abandoned stream gives the interval back too
+    import gc
+    gc.collect()
+    assert sys.getswitchinterval() == pytest.approx(before)
+
+
+def test_finalizers_on_a_foreign_thread_leave_their_library_calls_to_the_owning_thread():
+    """`ResidentPair.__del__` / `DeviceBuffer.__del__` may run on FrameStream's worker (cyclic GC); the context is not
+    thread-safe, so their calls are queued and run by the owner's next call."""
+    import threading
+    from karios_amd._lib import Context
+    ctx = object.__new__(Context)                                # no device needed: only the bookkeeping is exercised
+    ctx._owner, ctx._abandoned, ctx._abandoned_lock, ctx.handle = threading.get_ident(), [], threading.Lock(), None
+    ran = []
+    ctx.run_or_defer(lambda: ran.append(("own", threading.get_ident())))
+    assert ran == [("own", threading.get_ident())]
+    t = threading.Thread(target=lambda: ctx.run_or_defer(lambda: ran.append(("deferred", threading.get_ident()))))
+    t.start(); t.join()
+    assert len(ran) == 1 and len(ctx._abandoned) == 1             # not run on the foreign thread
+    ctx.drain()
+    assert ran[1] == ("deferred", threading.get_ident()) and not ctx._abandoned
+
+
 # ---------------------------------------------------------------------------- inline-assembly hazards of the built kernels
 def test_inline_assembly_hazard_scan_of_the_device_code(tmp_path):
     """The kernels write DOT / DPP / packed instructions as inline assembly, which LLVM's hazard recogniser cannot see into: the

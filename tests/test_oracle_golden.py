@@ -413,3 +413,34 @@ def test_real_opencv_result_columns_and_zncc_bounds_rule():
     differ = np.flatnonzero(expect_nan != csv_nan)
     assert len(differ) == 2 and (g["y0"][differ] == S - 28).all() and not csv_nan[differ].any()
     assert not (csv_nan & ~expect_nan).any()                                     # no NaN the rule does not explain (e.g. flat windows)
+
+
+def _oscillation_quads():
+    """(ddx, pdx, ddy, pdy) rows whose float32 sums sit exactly on, one ulp below and one ulp above float32(0.01), and OpenCV's verdict:
+    `std::abs(delta.x + prevDelta.x) < 0.01` compares a float32 with the DOUBLE literal - float32(0.01) = 0.00999999977... passes."""
+    f = np.float32
+    edge = f(0.01)
+    below, above = np.nextafter(edge, f(0)), np.nextafter(edge, f(1))
+    rows, want = [], []
+    rng = np.random.default_rng(5)
+    for target, verdict in ((edge, True), (below, True), (above, False), (-edge, True), (-above, False)):
+        found = 0
+        while found < 8:
+            p = f(rng.uniform(-0.02, 0.02))
+            d = f(target - p)
+            if f(d + p) != target:
+                continue
+            rows.append((d, p, f(0.001), f(-0.0005))); want.append(verdict)       # x decides
+            rows.append((f(0.001), f(-0.0005), d, p)); want.append(verdict)       # y decides
+            found += 1
+    return np.array(rows, np.float32), np.array(want)
+
+
+def test_lk_oscillation_literal_is_double(O):
+    """OpenCV's oscillation stop uses the double literal 0.01; a float32 sum of exactly float32(0.01) stops the
+    iteration (it would not with `< 0.01f`).  Both oracles' predicates (the one the tracker loops call) are checked."""
+    q, want = _oscillation_quads()
+    assert float(np.float32(0.01)) < 0.01 and float(np.nextafter(np.float32(0.01), np.float32(1))) > 0.01
+    for lit in (False, True):
+        got = np.array([O.lk_oscillates(*row, literal_oracle=lit) for row in q])
+        np.testing.assert_array_equal(got, want)
