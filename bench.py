@@ -11,7 +11,10 @@ score -> per-key-point ZNCC of the rows with score >= 0.4 (BASELINE config 2: "S
 only, 1 MI355X"; default processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000), driven through the product's
 `karios_amd.stream.FrameStream` (one pair in flight behind the one being submitted).  With N > 1 every rank matches its own
 band pair (weak scaling: the reference's tiles / bands are independent) and the per-band key-point blocks are all-gathered over
-RCCL inside the timed region.
+RCCL inside the timed region WITHOUT the host in the loop: the block goes from the library's stream straight into a send ring
+in HBM, a side stream waits for it on the device and issues the all-gather asynchronously, counts are accumulated on the device
+and read once, behind the last step (`karios_amd.parallel.RankBlockExchange`).  `KARIOS_BENCH_EXCHANGE=1` runs the same exchange
+with a ONE-rank RCCL group at N = 1 (the code path of the driver's 8-GPU run, executed on one GPU: tests/test_gpu_bench.py).
 
 Objects on the same line
   roofline      the largest kernel of the step: bytes it must move / its hipEvent span on the library's stream (see `roofline_of`);
@@ -19,6 +22,9 @@ Objects on the same line
                 N = 1); its `parity` object is SURVEY 8(d)'s gate on the measured pair (GPU frame of the timed loop vs the oracle);
   end_to_end    the drop-in path: page-locked host rasters -> `karios_amd.matcher.KLT.match` -> DataFrame + ZNCC
                 (PCIe-inclusive; never `value`);
+  full_scoring  the WHOLE of `_handle_klt_results`' scoring (core.py:894-907) in the device call of the tile: KLT + ZNCC +
+                `mutual_info_score` + `mi_score` (FrameStream(mutual_info=True)), with the MI kernel's roofline and - in the
+                cpu_baseline leg - an in-run gate against the oracle on all rows of the measured pair;
   in_flight     the same workload with THREE independent pairs in flight on the one GPU (one library context each);
   config3       BASELINE config 3 (large-shift pre-alignment: phase correlation + shift_image + KLT) at 10980^2 with its own
                 roofline, the path the transform took and a gate (offset == generator truth == oracle on a 1098^2 crop);
@@ -55,6 +61,7 @@ FUSED_EIG_BYTES_PER_PX = 2.0         # fused K3+K4: read lap_ref 1 + mask 1; the
 LK_BYTES_PER_POINT = 6272.0          # 2 directions x 2 levels x (28x28 I-patch + 28x28 J-patch), u8
 ZNCC_BYTES_PER_POINT = 7396.0        # 2 x 43x43 x 2 B
 SELECT_BYTES_PER_CANDIDATE = 16.0    # candidate ranking
+MI_BYTES_PER_POINT = 12996.0         # 2 x 57x57 x 2 B chips per scored key point
 PHASE_BYTES_PER_PX_F64 = 116.0       # SURVEY 8(d) large-shift model executed in fp64 (reference precision)
 PHASE_BYTES_PER_PX_F32 = 60.0        # SURVEY 8(d) large-shift model in float32 (28 forward + 12 cross power + 16 inverse + 4 arg-max)
 SHIFT_BYTES_PER_PX = 4.0
@@ -76,6 +83,7 @@ def parse(argv=None):
     ap.add_argument("--no-in-flight", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-full-scoring", action="store_true")
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
@@ -157,7 +165,34 @@ def parity_gate(frame, res, zncc_oracle):
     return out
 
 
-def cpu_baseline(mon, ref, conf_kw, runs, gpu_frame=None):
+def full_scoring_gate(O, mon, ref, frame):
+    """core.py:894-907 on the measured pair: the device's `mutual_info_score` / `mi_score` / `zncc_score` columns of EVERY row against
+    the oracle evaluated on the frame's own key points (their identity with the oracle's is the headline gate): NaN exactly where
+    score < 0.4 or the chip leaves the image, <= 1e-9 elsewhere."""
+    if frame is None or "mutual_info_score" not in frame.columns:
+        return {"checked": False}
+    x0, y0, dx, dy, sc = (frame[c].to_numpy() for c in ("x0", "y0", "dx", "dy", "score"))
+    keep = sc >= np.float32(0.4)
+    out = {"checked": True, "rows": int(len(frame)), "rows_scored": int(keep.sum())}
+    want = {"zncc_score": np.full(len(frame), np.nan), "mutual_info_score": np.full(len(frame), np.nan), "mi_score": np.full(len(frame), np.nan)}
+    if keep.any():
+        want["zncc_score"][keep] = O.zncc_batch(ref, mon, x0[keep], y0[keep], dx[keep], dy[keep])
+        st, nmi = O.mi_batch(ref, mon, x0[keep], y0[keep], dx[keep], dy[keep])
+        want["mutual_info_score"][keep], want["mi_score"][keep] = st, nmi
+    ok = True
+    for col, w in want.items():
+        g = frame[col].to_numpy()
+        same_nan = bool(np.array_equal(np.isnan(g), np.isnan(w)))
+        both = ~np.isnan(g) & ~np.isnan(w)
+        err = float(np.abs(g[both] - w[both]).max()) if both.any() else 0.0
+        out[col] = {"nan_pattern_identical": same_nan, "max_abs_diff": err, "finite_rows": int(both.sum())}
+        ok = ok and same_nan and err <= 1e-9
+    out["tolerance"] = 1e-9
+    out["passed"] = bool(ok)
+    return out
+
+
+def cpu_baseline(mon, ref, conf_kw, runs, gpu_frame=None, scored_frame=None):
     """Oracle (kind 'port') on the SAME full pair, all usable cores: median of `runs` timed passes after one warm-up;
     plus a 1-thread figure on the top tenth of the image (maxCorners scaled to the same corner density)."""
     from oracle import oracle as O
@@ -194,6 +229,10 @@ def cpu_baseline(mon, ref, conf_kw, runs, gpu_frame=None):
            "single_thread": {"value": rows1 * S / 1e6 / t1, "unit": "Mpx/s", "cores": 1,
                              "sample": f"top {rows1} rows, maxCorners {conf1.maxCorners}, median of 3 passes, {t1:.2f} s"}}
     out["parity"] = parity_gate(gpu_frame, res, None if res is None else res.get("_zncc_kept"))
+    if scored_frame is not None:
+        O.set_threads(cores)
+        out["full_scoring_parity"] = full_scoring_gate(O, mon, ref, scored_frame)
+        O.set_threads(min(O.max_threads(), O.team_size()))
     live = cv2_live(mon, ref, dict(maxCorners=conf.maxCorners), res)
     if live is not None:
         out["opencv_live"] = live
@@ -286,6 +325,70 @@ def end_to_end(mon, ref, ctx, steps):
                     "upload of pair i+1 (482 MB) on the copy stream under the compute of pair i",
             "upload_bytes_per_pair": int(mon.nbytes + ref.nbytes), "pcie_GBps": (mon.nbytes + ref.nbytes) / dt / 1e9,
             "pageable_numpy_ms_per_pair": dt_plain * 1e3}
+
+
+# ---------------------------------------------------------------------------------------------------- full scoring
+def full_scoring(ctx, pair, conf, S, steps):
+    """The reference's per-tile loop scores every confident candidate three times (core.py:894-907: ZNCC, `mutual_info_score`,
+    `mi_score`; the two mutual-information scores are ~90 % of its scoring time).  Here all three ride in the
+    device call of the tile: one pair in flight through FrameStream(mutual_info=True), same pair as the headline."""
+    from karios_amd.stream import FrameStream
+    with FrameStream(0.4, depth=1, want_spans=True, mutual_info=True) as stream:
+        last = [None]
+        rows = [0]
+
+        def take(res):
+            for d in res:
+                last[0] = d
+                rows[0] += d.raw.n_rows
+
+        for _ in range(6):
+            take(stream.submit(pair, conf))
+        take(stream.drain())
+        ctx.sync()
+        rows[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            take(stream.submit(pair, conf))
+        take(stream.drain())
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        n_rows = rows[0] // steps
+        # stage spans (untimed pass, every stage bracketed)
+        ctx.set_profiling(True)
+        ctx.set_option("profile_stage", -1)
+        ctx.set_option("profile_every", 1)
+        spans, n = {}, 0
+        for _ in range(6):
+            for d in stream.submit(pair, conf):
+                if any(v > 0 for v in d.spans.values()):
+                    n += 1
+                    for k, v in d.spans.items():
+                        spans[k] = spans.get(k, 0.0) + v
+        for d in stream.drain():
+            if any(v > 0 for v in d.spans.values()):
+                n += 1
+                for k, v in d.spans.items():
+                    spans[k] = spans.get(k, 0.0) + v
+        ctx.set_profiling(False)
+    frame = last[0].frame
+    n_scored = 0 if frame is None else int((frame["score"].to_numpy() >= np.float32(0.4)).sum())
+    stage = {k: round(v / max(1, n), 4) for k, v in spans.items() if v > 0}
+    mi_ms = stage.get("mutual_info", 0.0)
+    roof = {"kernel": "mi_kernel (k_mi.hip): 32x32 joint histogram of two 57x57 chips per scored key point, both scores", "bound": "hbm",
+            "bytes_model": f"{MI_BYTES_PER_POINT:.0f} B x {n_scored} scored key points (DESIGN section 4, K12)",
+            "achieved": (MI_BYTES_PER_POINT * n_scored / (mi_ms * 1e-3) / 1e9) if mi_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "span_ms": mi_ms or None}
+    roof["frac"] = None if roof["achieved"] is None else roof["achieved"] / HBM_PEAK_GBS
+    pmc = pmc_traffic("mi_kernel", S)
+    roof["traffic"] = pmc.get("traffic")
+    if pmc:
+        roof.update({k: v for k, v in pmc.items() if k != "traffic"})
+    return {"workload": f"BASELINE config 2 pair ({S}x{S}), KLT + ZNCC + mutual_info_score + mi_score = the whole scoring of _handle_klt_results "
+                        "(api/core.py:894-907) in the tile's device call; one pair in flight (FrameStream(0.4, mutual_info=True))",
+            "steps": steps, "ms_per_pair": dt * 1e3, "Mpx_per_s": S * S / 1e6 / dt, "matched_keypoints_per_sec": n_rows / dt,
+            "matched_keypoints_per_pair": n_rows, "scored_rows_per_pair": n_scored, "columns": (None if frame is None else list(frame.columns)),
+            "stage_ms": stage, "roofline": roof}, frame
 
 
 # ---------------------------------------------------------------------------------------------------- in flight
@@ -668,7 +771,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     ranks_seen, devices = 1, [{"rank": 0, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)}]
-    if world > 1:
+    # KARIOS_BENCH_EXCHANGE=1: the N > 1 code path - process group, RCCL all-gather of the frame blocks, device-side counting - with a
+    # group of ONE rank (what an 8-GPU job runs, executed on the one GPU a builder has; tests/test_gpu_bench.py)
+    force_exchange = world == 1 and os.environ.get("KARIOS_BENCH_EXCHANGE") == "1"
+    if force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+    if world > 1 or force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl" on ROCm) in production; gloo lets the multi-rank logic be exercised with several ranks sharing one GPU
         # (development box) - the collectives then run on CPU tensors
@@ -689,7 +798,7 @@ def main():
     from karios_amd import synth
     from karios_amd._lib import Context
     from karios_amd.core import KLTConfiguration
-    from karios_amd.parallel import gather_rank_blocks
+    from karios_amd.parallel import RankBlockExchange
     from karios_amd.resident import ResidentPair
     from karios_amd.stream import FrameStream
 
@@ -720,15 +829,31 @@ def main():
     # block -> pandas DataFrame + radial error / angle columns, numpy as in the reference) while the device already works on the
     # next pair.  Every frame is complete before the closing fence, so K timed steps are K finished pairs.
     stage_sum = {}
-    totals = {"rows": 0, "frames": 0, "n_init": 0, "redone": 0, "last": None}
+    totals = {"rows": 0, "frames": 0, "n_init": 0, "redone": 0, "redone_rows": 0, "last": None}
+    # the path's only exchange step: one all-gather of every rank's key-point block per step.  RCCL: issued on a side stream
+    # behind a DEVICE-side wait for the block, counted on the device, read once behind the last step - the submitting thread never
+    # waits for a collective (round 3 staged the block through the host and read a count back in every step)
+    ex = RankBlockExchange(ctx, conf.maxCorners, True, device=coll_dev) if (world > 1 or force_exchange) else None
+    step_no = [0, 0]                    # units submitted / (gloo) units handed to the exchange
+
+    def submit_step():
+        if ex is not None and ex.on_gpu:
+            k = step_no[0]
+            step_no[0] += 1
+            ex.arm(k)
+            return stream.submit(pair, conf, on_submitted=lambda pend, k=k: ex.issue(k, pend))
+        return stream.submit(pair, conf)
 
     def take(results):
-        """Finished steps: their frames, and - the path's only exchange step - the all-gather of every rank's key-point block
-        (device pipeline layout) over RCCL; the gathered blocks stay in HBM."""
+        """Finished steps: their frames (the exchange of their blocks was issued when they were submitted; development runs on gloo
+        hand the finished host block over here)."""
         for d in results:
             n_rows = d.raw.n_rows
-            if world > 1:
-                _, n_rows = gather_rank_blocks(d.raw.block, conf.maxCorners, True, device=coll_dev)
+            if ex is not None and not ex.on_gpu:
+                ex.issue(step_no[1], host_block=d.raw.block)
+                step_no[1] += 1
+            if d.redone:
+                totals["redone_rows"] += n_rows
             totals["rows"] += n_rows
             totals["frames"] += 1
             totals["n_init"] = int(d.raw.block[:4].view(np.int32)[1])
@@ -743,13 +868,13 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_exchange:
             dist.barrier()
             torch.cuda.synchronize()
 
     stream = FrameStream(0.4, depth=max(0, min(2, a.depth)), want_spans=True)
     for _ in range(a.warmup):
-        take(stream.submit(pair, conf))
+        take(submit_step())
     take(stream.drain())
     # settle (untimed, on top of the W warm-up steps): a fresh box ramps its clocks over the first few hundred milliseconds of
     # load - windows of 20 steps are repeated until two consecutive ones agree within 2 % (at least 1 s, at most 3 s of work: the first
@@ -760,7 +885,7 @@ def main():
         fence()
         t_w = time.perf_counter()
         for _ in range(20):
-            take(stream.submit(pair, conf))
+            take(submit_step())
         take(stream.drain())
         fence()
         cur = time.perf_counter() - t_w
@@ -793,7 +918,7 @@ def main():
     ctx.set_profiling(True)
     stage_sum.clear()
     for _ in range(8):
-        take(stream.submit(pair, conf))
+        take(submit_step())
     take(stream.drain())
     fence()
     probe = {k: v for k, v in stage_sum.items() if k in ("stretch_laplacian_mask", "min_eigen", "lk_fwd_bwd") and v > 0}
@@ -805,14 +930,28 @@ def main():
     if a.timed_stage == "none":
         ctx.set_profiling(False)
     stage_sum.clear()
-    totals.update(rows=0, frames=0, redone=0, span_samples=0)
+    totals.update(rows=0, frames=0, redone=0, redone_rows=0, span_samples=0)
+    if ex is not None:
+        ex.finish()                    # (everything issued so far is accounted for ...)
+        ex.rows.zero_(); ex.flagged.zero_()      # ... and the counters restart with the timed region
     fence()
     t0 = time.perf_counter()
     marks = [t0]
     for _ in range(a.steps):
-        take(stream.submit(pair, conf))
+        take(submit_step())
         marks.append(time.perf_counter())
     take(stream.drain())              # the last pair's frame: part of the timed region
+    exchange = None
+    if ex is not None:
+        # every rank's matched key points of the K steps, counted on the device from the GATHERED blocks; units the synchronisation-
+        # free corner path flagged were repeated exactly by their owner: their rows travel in one closing all-reduce
+        rows_gathered, flagged_blocks = ex.finish()
+        extra = torch.tensor([totals["redone_rows"]], device=coll_dev, dtype=torch.int64)
+        dist.all_reduce(extra)
+        exchange = {"backend": backend if world > 1 else "nccl (one-rank group, KARIOS_BENCH_EXCHANGE=1)", "blocks_in": "HBM (km_set_frame_sink -> send ring)" if ex.on_gpu else "host (gloo development run)",
+                    "collectives_per_step": 1, "host_waits_per_step": 0 if ex.on_gpu else "lagged (gloo)", "send_ring_slots": ex.slots,
+                    "rows_from_gathered_blocks": rows_gathered, "flagged_blocks_gathered": flagged_blocks, "rows_of_exactly_repeated_units": int(extra.item()),
+                    "steps_exchanged": a.steps}
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -825,7 +964,7 @@ def main():
                    "in_order_ms": gaps_in_order,
                    "note": "host-side intervals between consecutive submit() returns inside the timed region (one pair in flight)"}
     assert totals["frames"] == a.steps
-    n_kp_total = totals["rows"]
+    n_kp_total = totals["rows"] if exchange is None else exchange["rows_from_gathered_blocks"] + exchange["rows_of_exactly_repeated_units"]
     frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
     timed_samples = totals.get("span_samples", 0)
     timed_ms = stage_sum.get(timed_stage, 0.0) / max(1, timed_samples)
@@ -838,7 +977,7 @@ def main():
     stage_sum.clear()
     keep = dict(totals)
     for _ in range(stage_steps):
-        take(stream.submit(pair, conf))
+        take(submit_step())
     take(stream.drain())
     fence()
     totals.update(keep)
@@ -874,7 +1013,7 @@ def main():
                                    "(karios_amd.stream.FrameStream, depth 1)", "pairs_per_step": world,
                        "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
             "world": world, "launcher": os.environ.get("KARIOS_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "single process"),
-            "backend": (backend if world > 1 else None), "rccl_ranks_seen": ranks_seen, "devices": devices,
+            "backend": (backend if (world > 1 or force_exchange) else None), "rccl_ranks_seen": ranks_seen, "devices": devices, "exchange": exchange,
             "matched_keypoints_per_sec": n_kp_total / dt,
             "matched_keypoints_per_pair": (0 if frame is None else len(frame)),
             "n_init": int(stats.n_init), "n_candidates": n_cand,
@@ -899,6 +1038,9 @@ def main():
     host_pair = None
     if solo and not (a.no_cpu_baseline and a.no_end_to_end):
         host_pair = (mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16))
+    scored_frame = None
+    if solo and not a.no_full_scoring:
+        out["full_scoring"], scored_frame = full_scoring(ctx, pair, conf, S, max(6, min(20, a.steps)))
     del pair
     if solo and not a.no_in_flight:
         out["in_flight"] = in_flight(dev, conf, S, (mon_t, ref_t))
@@ -914,15 +1056,23 @@ def main():
         torch.cuda.empty_cache()
     if not a.no_config4 and S == 10980:
         c4 = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)))
+        if solo:
+            # A/B of the one tuning choice of this workload: the rank's units on ONE library context against up to three
+            c4_one = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)), n_ctx_max=1)
+            c4["contexts_in_flight_ab"] = {"1": {"ms_per_step": c4_one["ms_per_step"], "units_repeated_exactly": c4_one["units_repeated_exactly_on_this_rank"]},
+                                           str(c4["contexts_in_flight_per_rank"]): {"ms_per_step": c4["ms_per_step"], "units_repeated_exactly": c4["units_repeated_exactly_on_this_rank"]},
+                                           "note": "same 16 units, same box, back to back; the object's value is the multi-context run"}
         if rank == 0:
             out["config4"] = c4
     if solo and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only
-        cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs, gpu_frame=last_frame)
+        cb = cpu_baseline(host_pair[0], host_pair[1], dict(maxCorners=conf.maxCorners), a.cpu_runs, gpu_frame=last_frame, scored_frame=scored_frame)
+        if "full_scoring" in out:
+            out["full_scoring"]["parity"] = cb.pop("full_scoring_parity", {"checked": False})
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_port"] = mpx_per_s / cb["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

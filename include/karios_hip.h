@@ -113,6 +113,11 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "mm_early"     1 (default): a unit submitted with km_klt_tile_frame_submit directly behind another one starts its min / max
  *                  on the second stream as soon as the previous unit's LK launch starts, and streams its two rasters beside
  *                  that instruction-bound kernel (KM_PATH_MM_EARLY); 0: on the library's stream, behind the previous unit's tail
+ *   "frame_mi"     1: frame blocks that carry the ZNCC column (km_klt_tile_frame_zncc_dev, km_klt_tile_frame_submit with full images)
+ *                  also carry `mutual_info_score` (MutualInfoService, mutual_info_service.py:73-130) and `mi_score`
+ *                  (ZNCCService.compute_mi, zncc_service.py:240-287) of the same rows - the whole scoring of
+ *                  KariosAPI._handle_klt_results (api/core.py:894-907) in the tile call: two more float64 columns of `cap`
+ *                  entries behind the zncc column (NaN where score < threshold or the chip leaves the image); 0 (default): ZNCC only
  *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
@@ -168,6 +173,10 @@ int km_phase_info(km_ctx *ctx, int *path, double *margin);
 /* Optional device-side copy of every frame block the km_klt_tile_frame_* entry points produce (same layout), e.g. a slice of
  * the send buffer of an RCCL all-gather: the block then never bounces through host memory.  NULL switches it off. */
 int km_set_frame_sink(km_ctx *ctx, void *d_dst, size_t capacity_bytes);
+/* Hand-over of a SUBMITTED frame (km_klt_tile_frame_submit with a frame sink set) to a stream of the caller without the host:
+ * `hip_stream` (a hipStream_t - e.g. the stream the RCCL all-gather of the per-tile blocks, klt.py:220-253 / SURVEY 8e, is issued
+ * on) waits on the device until the block of frame `ticket` has reached the sink. */
+int km_stream_wait_frame(km_ctx *ctx, int ticket, void *hip_stream);
 
 /* ---- fine-grained mirrors (host buffers) -------------------------------- */
 /* _to_uint8 (matcher/klt.py:42-49) [+ 255-x, klt.py:419]; out_minmax[2] nullable */

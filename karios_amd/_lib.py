@@ -69,6 +69,7 @@ SIGNATURES = {
     "km_upload_mark": (_i, [_vp, _pi]),
     "km_upload_join": (_i, [_vp, _i]),
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
+    "km_stream_wait_frame": (_i, [_vp, _i, _vp]),
     "km_phase_info": (_i, [_vp, _pi, _pd]),
     "km_set_image_window": (_i, [_vp, _i, _i, _i, _i]),
     "km_minmax_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _pd]),

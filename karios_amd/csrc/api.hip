@@ -157,6 +157,7 @@ int km_ctx_destroy(km_ctx *c)
     for (km_frame_slot &f : c->fslot) {
         if (f.host) (void)hipHostFree(f.host);
         if (f.done) (void)hipEventDestroy(f.done);
+        if (f.sunk) (void)hipEventDestroy(f.sunk);
     }
     for (int i = 0; i < WS_COUNT; i++)
         if (c->ws[i].p) (void)hipFree(c->ws[i].p);
@@ -212,6 +213,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
+    if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
     if (strcmp(name, "profile_every") == 0) { c->opt_profile_every = value < 1 ? 1 : value; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
     if (strcmp(name, "stash_cap") == 0) { c->opt_stash_cap = value < 0 ? 0 : value; return KM_OK; }
@@ -1202,13 +1204,17 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                       (rc = check_image(c, d_mon_full, Hf, Wf, smon_f, "klt_tile_frame_zncc_dev"))))
         return rc;
     if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: bad dtype %d", dtype);
+    // the frame's (x0, y0) ordering buckets the rows by tile column (k_frame.hip: x0 - x_off < 65536); wider tiles are refused, not mis-ordered
+    if (W > 65535) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: tile of %d columns (the device-side frame ordering holds at most 65535)", W);
     if ((!host_out && !slot) || cap <= 0) return km_fail(c, KM_E_ARG, "klt_tile_frame_dev: null output");
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
-    c->evs_used[c->ev_cur][ST_ZNCC] = false;
+    c->evs_used[c->ev_cur][ST_ZNCC] = false; c->evs_used[c->ev_cur][ST_MI] = false;
     km_scalars *sc = scalars(c);
     const size_t pb = (size_t)cap * 2 * sizeof(float);
-    const size_t fb = 16 + (size_t)cap * 6 * sizeof(float), ob = fb + (with_zncc ? (size_t)cap * sizeof(double) : 0);
+    // block: header | x0 | y0 | dx | dy | score | index bits (float32) | zncc [| mutual_info_score | mi_score] (float64)
+    const bool with_mi = with_zncc && c->opt_frame_mi;
+    const size_t fb = 16 + (size_t)cap * 6 * sizeof(float), ob = fb + (with_zncc ? (size_t)cap * sizeof(double) : 0) + (with_mi ? (size_t)cap * 2 * sizeof(double) : 0);
     float *d_p0 = (float *)km_ws(c, WS_PTS0, pb), *d_p1 = (float *)km_ws(c, WS_PTS1, pb), *d_p0r = (float *)km_ws(c, WS_PTS2, pb);
     char *d_out = (char *)km_ws(c, WS_FRAME, ob);
     if (!sc || !d_p0 || !d_p1 || !d_p0r || !d_out) return KM_E_NOMEM;
@@ -1237,10 +1243,25 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                                    (double *)(d_out + fb))))
             return rc;
     }
+    if (with_mi) {
+        // the other two scores of _handle_klt_results (core.py:894-907) for the same rows, behind ZNCC in the same call: the chips of
+        // a key point (57 x 57, around the 43 x 43 ZNCC window) are still in the XCD's L2
+        km_stage_timer t(c, ST_MI);
+        const float *f = (const float *)(d_out + 16);
+        double *st = (double *)(d_out + fb) + cap;
+        if ((rc = kmi_batch(c, d_ref_full, d_mon_full, dtype, Hf, Wf, Hf, Wf, sref_f, smon_f, f, f + cap, f + 2 * (size_t)cap, f + 3 * (size_t)cap, n_max,
+                            (const int *)d_out, f + 4 * (size_t)cap, (float)zncc_threshold, st, st + cap)))
+            return rc;
+    }
     if (c->frame_sink) {
         if (c->frame_sink_cap < ob) return km_fail(c, KM_E_ARG, "frame sink of %zu bytes is smaller than the %zu-byte frame block", c->frame_sink_cap, ob);
         KM_HIP(c, hipMemcpyAsync(c->frame_sink, d_out, ob, hipMemcpyDeviceToDevice, c->stream));
-    }
+        if (slot) {   // km_stream_wait_frame: a stream of the caller (the one an RCCL collective is issued on) can wait for exactly this copy
+            if (!slot->sunk) KM_HIP(c, hipEventCreateWithFlags(&slot->sunk, hipEventDisableTiming));
+            KM_HIP(c, hipEventRecord(slot->sunk, c->stream));
+            slot->sunk_valid = true;
+        }
+    } else if (slot) slot->sunk_valid = false;
     if (slot) {
         if (slot->cap < ob) {
             if (slot->host) KM_HIP(c, hipHostFree(slot->host));
@@ -1295,6 +1316,7 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
         (rc = check_image(c, d_mon, H, W, smon, "klt_auto_ksize")))
         return rc;
     if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_auto_ksize: bad dtype %d", dtype);
+    if (W > 65535) return km_fail(c, KM_E_ARG, "klt_auto_ksize: tile of %d columns (the device-side frame ordering holds at most 65535)", W);
     if (!ksizes || nk < 1 || nk > 8 || !host_out || !out_ratios || !out_best || cap <= 0) return km_fail(c, KM_E_ARG, "klt_auto_ksize: bad arguments");
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
@@ -1474,6 +1496,18 @@ int km_frame_wait(km_ctx *c, int ticket, const void **block, size_t *bytes)
     slot->pending.store(0, std::memory_order_release);
     *block = slot->host;
     if (bytes) *bytes = slot->bytes;
+    return KM_OK;
+}
+
+// Device-side hand-over of a submitted frame's block to a stream of the CALLER: `hip_stream` (a hipStream_t, e.g. the stream an RCCL
+// all-gather of the frame sink is issued on) waits - on the device, the host does not block - until the block of frame `ticket` has
+// been written to the frame sink that was set when the frame was submitted.
+int km_stream_wait_frame(km_ctx *c, int ticket, void *hip_stream)
+{
+    if (!c || ticket < 0 || ticket >= KM_FRAME_SLOTS) return km_fail(c, KM_E_ARG, "km_stream_wait_frame: bad ticket %d", ticket);
+    km_frame_slot *slot = &c->fslot[ticket];
+    if (!slot->sunk || !slot->sunk_valid) return km_fail(c, KM_E_ARG, "km_stream_wait_frame: frame %d was submitted without a frame sink", ticket);
+    KM_HIP(c, hipStreamWaitEvent((hipStream_t)hip_stream, slot->sunk, 0));
     return KM_OK;
 }
 

@@ -131,6 +131,8 @@ struct km_frame_slot {
     void *host = nullptr;
     size_t cap = 0, bytes = 0;
     hipEvent_t done = nullptr;
+    hipEvent_t sunk = nullptr;      // the frame's block is in the frame sink (km_set_frame_sink): recorded on the compute stream behind the copy
+    bool sunk_valid = false;
     std::atomic<int> pending{0};
 };
 
@@ -219,6 +221,7 @@ struct km_ctx {
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
     bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
     bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
+    bool opt_frame_mi = false;     // "frame_mi" 1: frames scored by the tile entry points (ZNCC of the rows with score >= threshold) also carry the two mutual-information scores of those rows (core.py:894-907): two more float64 columns behind zncc
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
     // km_klt_tile_frame_submit (a frame's spans are read after ITS completion, while the next one is already recording)

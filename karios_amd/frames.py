@@ -65,9 +65,19 @@ def assemble(cols: dict[str, np.ndarray], x_off=0, y_off=0, clip_outliers: bool 
     return DataFrame(data, index=order, copy=False)
 
 
-def block_to_frame(block: np.ndarray, cap: int, with_zncc: bool = False, radial: bool = False, own: bool = False) -> DataFrame | None:
-    """Frame block of the device pipeline (km_klt_tile_frame[_zncc]_dev: 4 int32 {rows, Ninit, 0, 0}, then `cap` float32 per
-    column x0 | y0 | dx | dy | score | index bits, then `cap` float64 zncc) -> DataFrame; None when no corner was found.
+SCORE_COLUMNS = ("zncc_score", "mutual_info_score", "mi_score")     # float64 columns of a scored frame, in block order (core.py:894-907)
+
+
+def block_words(cap: int, with_zncc=False) -> int:
+    """float32 words of one frame block.  `with_zncc` counts the float64 score columns behind the six float32 ones: False / 0 none,
+    True / 1 `zncc_score`, 3 `zncc_score | mutual_info_score | mi_score` (the whole of `_handle_klt_results`' scoring)."""
+    return 4 + (6 + 2 * int(with_zncc)) * cap
+
+
+def block_to_frame(block: np.ndarray, cap: int, with_zncc=False, radial: bool = False, own: bool = False) -> DataFrame | None:
+    """Frame block of the device pipeline (km_klt_tile_frame[_zncc]_dev: 4 int32 {rows, Ninit, flags, candidates}, then `cap` float32
+    per column x0 | y0 | dx | dy | score | index bits, then `cap` float64 per score column - `with_zncc` = their number, see
+    `block_words`) -> DataFrame; None when no corner was found.
     `radial`: with the `radial error` / `angle` columns of `radial_angle_columns` already in place (one DataFrame construction
     instead of two column insertions, which cost more than every array operation of the host stage together).  `own`: the block
     belongs to the frame from now on (the columns become views of it instead of copies)."""
@@ -77,8 +87,8 @@ def block_to_frame(block: np.ndarray, cap: int, with_zncc: bool = False, radial:
     body = block[4:]
     take = (lambda a: a) if own else (lambda a: a.copy())
     data = {name: take(body[i * cap:i * cap + rows]) for i, name in enumerate(COLUMNS)}
-    if with_zncc:
-        data["zncc_score"] = take(body[6 * cap:8 * cap].view(np.float64)[:rows])
+    for k in range(int(with_zncc)):
+        data[SCORE_COLUMNS[k]] = take(body[(6 + 2 * k) * cap:(8 + 2 * k) * cap].view(np.float64)[:rows])
     if radial:
         data["radial error"], data["angle"] = _radial_angle(data["dx"], data["dy"])
     labels = body[5 * cap:5 * cap + rows].view(np.int32).astype(np.int64)

@@ -55,9 +55,10 @@ def frame_capacity(conf, units) -> int:
     return max((max(1, (u.x_size * u.y_size) // 4) for u in units), default=1)
 
 
-def block_len(cap: int, with_zncc: bool) -> int:
-    """float32 words of one frame block (layout of km_klt_tile_frame[_zncc]_dev, see include/karios_hip.h)."""
-    return 4 + (8 if with_zncc else 6) * cap
+def block_len(cap: int, with_zncc=False) -> int:
+    """float32 words of one frame block (layout of km_klt_tile_frame[_zncc]_dev, see include/karios_hip.h; `with_zncc` = number
+    of float64 score columns: False / True / 3, `frames.block_words`)."""
+    return frames.block_words(cap, with_zncc)
 
 
 # ---------------------------------------------------------------------------- one unit on the device
@@ -116,6 +117,24 @@ def _world():
     return 1, 0
 
 
+def _group_up() -> bool:
+    """A process group exists: the collectives are ISSUED even when it has a single rank (the RCCL / gloo code path of a one-rank
+    job is the one an eight-rank job takes; without a group the exchange steps reduce to identities)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def _collective_device(ctx=None, device=None):
+    """Where the collectives' tensors live: HBM for RCCL ("nccl"), host memory for gloo / no group."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if _group_up() and dist.get_backend() == "nccl":
+        return torch.device("cuda", ctx.device if ctx is not None else torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_block_tensor(send, n_units: int):
     """All-gather of every rank's `send` tensor, rows = (unit id | frame block), unit id < 0 for padding rows.  `send` lives
     where the collective runs (RCCL: HBM, gloo: host memory) and the result stays there.
@@ -123,7 +142,7 @@ def gather_block_tensor(send, n_units: int):
     import torch
     import torch.distributed as dist
     ws, _ = _world()
-    if ws == 1:
+    if not _group_up():
         recv = send
     else:
         recv = torch.empty((ws * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
@@ -151,8 +170,7 @@ def gather_blocks(local: dict[int, np.ndarray | None], n_units: int, cap: int, w
         send[slot, 0] = idx
         if blk is not None:
             send[slot, 1:] = blk[:L]
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if ws > 1 and dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _collective_device(device=device)
     return gather_block_tensor(torch.from_numpy(send).to(device), n_units).cpu().numpy()
 
 
@@ -163,17 +181,119 @@ def gather_rank_blocks(block: np.ndarray | None, cap: int, with_zncc: bool = Fal
     import torch.distributed as dist
     L = block_len(cap, with_zncc)
     ws, _ = _world()
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if ws > 1 and dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _collective_device(device=device)
     mine = torch.zeros(L, dtype=torch.float32) if block is None else torch.from_numpy(np.ascontiguousarray(block[:L]))
     t_send = mine.to(device)
-    if ws == 1:
+    if not _group_up():
         t_recv = t_send.reshape(1, L)
     else:
         t_recv = torch.empty((ws, L), dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(t_recv.reshape(-1), t_send)
     total = int(t_recv[:, 0].contiguous().view(torch.int32).sum().item())      # header word 0 = n_rows (int32 bit pattern)
     return t_recv, total
+
+
+class RankBlockExchange:
+    """The exchange step of a band-parallel STREAM of units (one unit per rank and step, `klt.py:220-253`: tiles / bands are
+    independent; SURVEY 8e: one flat all-gather of the fixed-size key-point blocks) without the host in the loop.
+
+    RCCL: the library writes step s's frame block straight into slot `s % slots` of a send ring in HBM (`km_set_frame_sink`), a side
+    stream waits ON THE DEVICE for exactly that copy (`km_stream_wait_frame`), the all-gather is issued there with `async_op=True`,
+    and the matched-row / flagged-block counts are accumulated by two tiny kernels behind it - nothing is read back before
+    `finish()`.  gloo (development: ranks sharing a GPU): the host block is gathered asynchronously and waited for `slots - 1`
+    steps later.
+
+        ex = RankBlockExchange(ctx, cap, n_scores)
+        for s in range(steps):
+            ex.arm(s)                                            # frame sink -> send slot
+            stream.submit(pair, conf, on_submitted=lambda p, s=s: ex.issue(s, p))
+        rows, flagged = ex.finish()
+    """
+
+    def __init__(self, ctx, cap: int, with_zncc=True, device=None, slots: int = 4):
+        import torch
+        from collections import deque
+        self.ctx, self.cap, self.L, self.slots = ctx, cap, block_len(cap, with_zncc), max(2, int(slots))
+        self.ws, self.rank = _world()
+        self.grouped = _group_up()
+        self.device = _collective_device(ctx, device)
+        self.on_gpu = self.device.type == "cuda"
+        self.send = torch.zeros((self.slots, self.L), dtype=torch.float32, device=self.device)
+        self.recv = torch.zeros((self.slots, self.ws, self.L), dtype=torch.float32, device=self.device)
+        self.rows = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.flagged = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.side = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.done = [None] * self.slots            # torch events: the slot's collective and its bookkeeping have finished
+        self.pending = deque()                     # gloo: (work, slot) issued and not waited for yet
+        self.issued = 0
+
+    def arm(self, step: int) -> None:
+        """Before submitting step `step`: its block goes to the step's send slot (RCCL); the slot's previous collective - `slots`
+        steps old - has long finished, the check is free."""
+        if not self.on_gpu:
+            return
+        slot = step % self.slots
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()
+        c = self.ctx
+        c.check(c.lib.km_set_frame_sink(c.handle, self.send[slot].data_ptr(), self.L * 4), "km_set_frame_sink")
+
+    def _account(self, slot: int) -> None:
+        import torch
+        hdr = self.recv[slot][:, :4].contiguous().view(torch.int32)
+        good = hdr[:, 2] == 0
+        self.rows += torch.where(good, hdr[:, 0], torch.zeros_like(hdr[:, 0])).sum()
+        self.flagged += (~good).sum()
+
+    def issue(self, step: int, pending=None, host_block=None) -> None:
+        """Right behind the submission of step `step` (`pending`: its PendingFrame; gloo: `host_block` once the frame is finished)."""
+        import torch
+        import torch.distributed as dist
+        slot = step % self.slots
+        if self.on_gpu:
+            c = self.ctx
+            c.check(c.lib.km_set_frame_sink(c.handle, None, 0), "km_set_frame_sink")
+            c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
+            with torch.cuda.stream(self.side):
+                if self.grouped:
+                    work = dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True)
+                    work.wait()                    # (orders the side stream behind the collective: no host wait)
+                else:
+                    self.recv[slot][0].copy_(self.send[slot])
+                self._account(slot)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.done[slot] = ev
+        else:
+            blk = np.zeros(self.L, np.float32) if host_block is None else np.ascontiguousarray(host_block[:self.L])
+            self.send[slot].copy_(torch.from_numpy(blk))
+            if self.grouped:
+                self.pending.append((dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True), slot))
+            else:
+                self.recv[slot][0].copy_(self.send[slot])
+                self.pending.append((None, slot))
+            while len(self.pending) > self.slots - 1:
+                self._retire()
+        self.issued += 1
+
+    def _retire(self) -> None:
+        work, slot = self.pending.popleft()
+        if work is not None:
+            work.wait()
+        self._account(slot)
+
+    def finish(self) -> tuple[int, int]:
+        """-> (matched key points of every rank and step, gathered blocks that were flagged by the synchronisation-free corner path
+        - their rows are NOT counted: the owner repeated those units exactly and knows their rows)."""
+        while self.pending:
+            self._retire()
+        if self.on_gpu:
+            self.side.synchronize()
+        return int(self.rows.item()), int(self.flagged.item())
+
+    def last_blocks(self, step: int):
+        """The gathered blocks of step `step` (tensor (world, block_len), rank order) while its slot has not been reused."""
+        return self.recv[step % self.slots]
 
 
 def blocks_to_frames(blocks: np.ndarray, cap: int, with_zncc: bool = False) -> list[DataFrame | None]:
@@ -204,7 +324,7 @@ def pack_frame(frame: DataFrame | None, cap: int, with_zncc: bool = False) -> np
 
 def unpack_frame(blk: np.ndarray, cap: int | None = None, with_zncc: bool = False) -> DataFrame | None:
     if cap is None:
-        cap = (len(blk) - 4) // (8 if with_zncc else 6)
+        cap = (len(blk) - 4) // (6 + 2 * int(with_zncc))
     return frames.block_to_frame(blk, cap, with_zncc)
 
 
@@ -298,11 +418,12 @@ def match_tile_banded(mon_img, ref_img, mask_img, conf, zncc_threshold=None, hal
         raise ValueError("match_tile_banded: fixed kernel sizes / polarity, no outlier filtering")
     if halo % 2 or halo < 32:
         raise ValueError("halo must be an even number of rows >= 32")
-    coll = torch.device(device) if device is not None else (torch.device("cuda", ctx.device) if ws > 1 and dist.get_backend() == "nccl" else torch.device("cpu"))
+    coll = _collective_device(ctx, device)
+    grouped = _group_up()
 
     def reduce_(values, op, dtype=torch.float64):
         t = torch.as_tensor(np.asarray(values), dtype=dtype).to(coll)
-        if ws > 1:
+        if grouped:
             dist.all_reduce(t, op=op)
         return t.cpu().numpy()
 
@@ -368,7 +489,7 @@ def match_tile_banded(mon_img, ref_img, mask_img, conf, zncc_threshold=None, hal
         width = max(1, int(counts.max()))
         send = torch.zeros(width, dtype=torch.int64)
         send[:len(mine)] = torch.from_numpy(mine.view(np.int64).copy())
-        if ws > 1:
+        if grouped:
             flat = torch.empty(ws * width, dtype=torch.int64, device=coll)
             dist.all_gather_into_tensor(flat, send.to(coll))
             recv = flat.view(ws, width)

@@ -69,7 +69,8 @@ class DeviceBuffer:
 
 class RawFrame:
     """One tile's frame block as the device pipeline delivers it (layout of km_klt_tile_frame[_zncc]_dev): 4 int32
-    {n_rows, n_init, 0, 0} + 6*cap float32 (x0 | y0 | dx | dy | score | index bits) (+ cap float64 zncc)."""
+    {n_rows, n_init, flags, candidates} + 6*cap float32 (x0 | y0 | dx | dy | score | index bits) + `with_zncc` x cap float64
+    (0 / False: none; 1 / True: zncc; 3: zncc | mutual_info_score | mi_score, `frames.block_words`)."""
     __slots__ = ("block", "cap", "with_zncc")
 
     def __init__(self, block: np.ndarray, cap: int, with_zncc: bool):
@@ -123,7 +124,7 @@ class PendingFrame:
             rc = c.lib.km_frame_wait(c.handle, self.ticket, C.byref(blk), C.byref(nbytes))
             if rc != 0:
                 raise KariosHipError(f"km_frame_wait(ticket {self.ticket}) failed with status {rc}")
-            n32 = 4 + (8 if self.with_zncc else 6) * self.cap
+            n32 = frames.block_words(self.cap, self.with_zncc)
             pinned = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_float)), shape=(n32,))
             self._raw = RawFrame(pinned.copy(), self.cap, self.with_zncc)   # the pinned slot is reused 3 submissions later
         return self._raw
@@ -312,7 +313,7 @@ class ResidentPair:
             c.check(c.lib.km_d2h(c.handle, pts[i].ctypes.data_as(C.c_void_p), C.c_void_p(d), n * 8), "km_d2h")
         return "ok", tuple(p.reshape(-1, 1, 2) for p in pts)
 
-    def match_tile(self, conf, box=None, zncc_threshold=None, ksizes=None, invert_mon=None, origin=None) -> DataFrame | None:
+    def match_tile(self, conf, box=None, zncc_threshold=None, ksizes=None, invert_mon=None, origin=None, mutual_info: bool = False) -> DataFrame | None:
         """One tile of `KLT.match` (reference klt.py:236-349) on resident data with fixed Laplacian kernel sizes and
         polarity: `ksizes` (mon, ref) / `invert_mon` default to the configuration's (its 'auto' values are the caller's
         business: `karios_amd.matcher.KLT`).  `origin` (x, y) is added to the key points (default: the box offset).
@@ -338,17 +339,35 @@ class ResidentPair:
                     z[keep] = self.zncc(*(points[c].to_numpy()[keep] for c in ("x0", "y0", "dx", "dy")))
                 points["zncc_score"] = z
             return points
-        return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, ksizes=ksizes, invert_mon=invert_mon)
+        return self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, ksizes=ksizes, invert_mon=invert_mon, mutual_info=mutual_info)
+
+    def _frame_mi(self, on: bool):
+        """Context manager: frames scored inside also carry `mutual_info_score` / `mi_score` (km_set_option "frame_mi")."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def scope():
+            if not on:
+                yield
+                return
+            self.ctx.set_option("frame_mi", 1)
+            try:
+                yield
+            finally:
+                self.ctx.set_option("frame_mi", 0)
+        return scope()
 
     def _match_tile_device_frame(self, conf, box, x_off, y_off, zncc_threshold=None, build_frame=True, ksizes=None,
-                                 invert_mon=None) -> DataFrame | None:
-        """Tile pipeline + FB test + score + (x0, y0) ordering on the device, one D2H copy of the finished frame."""
+                                 invert_mon=None, mutual_info: bool = False) -> DataFrame | None:
+        """Tile pipeline + FB test + score + (x0, y0) ordering (+ ZNCC [+ MI / NMI] of the confident rows) on the device, one D2H
+        copy of the finished frame."""
         c = self.ctx
+        n_scores = 0 if zncc_threshold is None else (3 if mutual_info else 1)
         _, _, bx, by, off = self._box(box)
         prm = self._params(conf, ksizes, invert_mon)
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
-        if self._host_frame is None or self._host_frame.size < 4 + 8 * cap:
-            self._host_frame = np.empty(4 + 8 * cap, np.float32)
+        if self._host_frame is None or self._host_frame.size < frames.block_words(cap, 3):
+            self._host_frame = np.empty(frames.block_words(cap, 3), np.float32)
         buf = self._host_frame
         ref, mon, mask, nr, nm = self._image_args(off)
         if zncc_threshold is None:
@@ -356,14 +375,14 @@ class ResidentPair:
                                                 C.byref(prm), float(x_off), float(y_off), buf.ctypes.data_as(C.c_void_p), cap),
                     "km_klt_tile_frame_dev")
         else:
-            with self._windowed():
+            with self._windowed(), self._frame_mi(n_scores == 3):
                 c.check(c.lib.km_klt_tile_frame_zncc_dev(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
                                                          C.byref(prm), float(x_off), float(y_off), C.c_void_p(self.ref_ptr),
                                                          C.c_void_p(self.mon_ptr), self.y_size, self.x_size, self.x_size, self.x_size,
                                                          float(zncc_threshold), buf.ctypes.data_as(C.c_void_p), cap), "km_klt_tile_frame_zncc_dev")
         if not build_frame:
             return None
-        frame = frames.block_to_frame(buf, cap, zncc_threshold is not None)
+        frame = frames.block_to_frame(buf, cap, n_scores)
         if frame is not None:
             frame.attrs["Ninit"] = int(buf[:2].view(np.int32)[1])
         return frame
@@ -397,26 +416,26 @@ class ResidentPair:
         n_init = int(buf[:2].view(np.int32)[1])
         return frames.block_to_frame(buf, cap), scores, (int(best[0]), int(best[1])), n_init
 
-    def match_tile_raw(self, conf, box=None, zncc_threshold=None, origin=None) -> "RawFrame":
+    def match_tile_raw(self, conf, box=None, zncc_threshold=None, origin=None, mutual_info: bool = False) -> "RawFrame":
         """GPU half of `match_tile`: runs the device pipeline and returns the raw frame block (a private copy), leaving
         the pandas half to `RawFrame.to_frame()` - which may run in another thread while this thread already drives the
         next tile (ctypes releases the GIL inside the library).  Fixed kernel size / polarity, no outlier filtering."""
         if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False):
             raise KariosHipError("ResidentPair.match_tile_raw: 'auto' modes and outlier filtering need ResidentPair.match_tile / matcher.KLT")
         x_off, y_off = origin if origin is not None else ((box[0], box[1]) if box is not None else (0, 0))
-        with_zncc = zncc_threshold is not None
+        with_zncc = 0 if zncc_threshold is None else (3 if mutual_info else 1)
         # host blocks rotate through a ring of three: the previous block may still be read by the host half of the pipeline
         ring = self.__dict__.setdefault("_raw_ring", [None, None, None])
         slot = self.__dict__.get("_raw_slot", 0)
         self._raw_slot = (slot + 1) % len(ring)
         self._host_frame = ring[slot]
-        self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, build_frame=False)
+        self._match_tile_device_frame(conf, box, x_off, y_off, zncc_threshold, build_frame=False, mutual_info=mutual_info)
         bx, by = (box[2], box[3]) if box is not None else (self.x_size, self.y_size)
         cap = conf.maxCorners if conf.maxCorners > 0 else max(1, (bx * by) // 4)
         block, ring[slot], self._host_frame = self._host_frame, self._host_frame, None
-        return RawFrame(block[:4 + (8 if with_zncc else 6) * cap], cap, with_zncc)
+        return RawFrame(block[:frames.block_words(cap, with_zncc)], cap, with_zncc)
 
-    def submit_tile(self, conf, box=None, zncc_threshold=None, origin=None) -> PendingFrame:
+    def submit_tile(self, conf, box=None, zncc_threshold=None, origin=None, mutual_info: bool = False) -> PendingFrame:
         """Asynchronous `match_tile_raw` (km_klt_tile_frame_submit): returns when the tile's last kernel and the copy of
         its frame block are enqueued, so the next `submit_tile` queues its dense stages right behind them - no GPU idle
         time between tiles.  Up to three tiles may be pending; `PendingFrame.wait()` may run in another thread."""
@@ -428,9 +447,10 @@ class ResidentPair:
         cap = prm.max_corners if prm.max_corners > 0 else max(1, (bx * by) // 4)
         ref, mon, mask, nr, nm = self._image_args(off)
         with_zncc = zncc_threshold is not None
+        n_scores = 0 if not with_zncc else (3 if mutual_info else 1)
         ticket = C.c_int(-1)
         x_off, y_off = origin if origin is not None else (bx_off, by_off)
-        with self._windowed():
+        with self._windowed(), self._frame_mi(n_scores == 3):
             c.check(c.lib.km_klt_tile_frame_submit(c.handle, ref, mon, self.code, by, bx, self.x_size, self.x_size, mask, self.x_size, nr, nm,
                                                    C.byref(prm), float(x_off), float(y_off),
                                                    C.c_void_p(self.ref_ptr) if with_zncc else None, C.c_void_p(self.mon_ptr) if with_zncc else None,
@@ -440,10 +460,10 @@ class ResidentPair:
             before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "1") or 0))
             c.set_option("speculative", 0)
             try:
-                return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off))
+                return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off), mutual_info=mutual_info)
             finally:
                 c.set_option("speculative", before)
-        return PendingFrame(c, ticket.value, cap, with_zncc, redo=exact)
+        return PendingFrame(c, ticket.value, cap, n_scores, redo=exact)
 
     def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
         """`match` as a pipeline (`karios_amd.stream.FrameStream`): tile i+1 is submitted to the device (`submit_tile`) while a
@@ -469,7 +489,7 @@ class ResidentPair:
     def last_block(self, cap: int, with_zncc: bool) -> np.ndarray:
         """The raw frame block of the last `match_tile` call: 4 int32 header + 6*cap float32 (+ cap float64), the unit of
         the multi-GPU gather (no pandas round trip)."""
-        return self._host_frame[:4 + (8 if with_zncc else 6) * cap]
+        return self._host_frame[:frames.block_words(cap, with_zncc)]
 
     def match(self, conf):
         """All tiles in the reference order (x outer, y inner; klt.py:220-232)."""
@@ -550,7 +570,7 @@ class ResidentPair:
             if keep.any():
                 z[keep] = self.zncc(frame["x0"].to_numpy()[keep], frame["y0"].to_numpy()[keep], dx[keep], dy[keep])
             frame["zncc_score"] = z
-        if mutual_info:
+        if mutual_info and "mutual_info_score" not in frame.columns:     # else: scored by the device call that produced the frame
             st = np.full(len(frame), np.nan, np.float64)
             nmi = np.full(len(frame), np.nan, np.float64)
             if keep.any():

@@ -65,6 +65,8 @@ class FrameStream:
                         beside the device half of unit i+1; 0: synchronous; 2 x contexts when the pairs sit on several contexts
                         of one GPU - a context holds at most three frames in flight)
     confidence_threshold  rows with score >= threshold get their ZNCC in the SAME device call (`zncc_score` column); None: bare frames
+    mutual_info         with a threshold: the SAME device call also scores `mutual_info_score` and `mi_score` of those rows - the
+                        whole of `_handle_klt_results`' scoring (core.py:894-907) behind the tile, no second pass over the key points
     score_columns       the frame also carries the `radial error` / `angle` columns of `_handle_klt_results` (core.py:872-893);
                         default: whenever a threshold is given
     host_stage          optional callable(frame, pair) -> frame run on the CALLING thread when a frame is collected (a stage that
@@ -77,8 +79,9 @@ class FrameStream:
     """
 
     def __init__(self, confidence_threshold: float | None = None, depth: int = 1, host_stage=None, want_spans: bool = False,
-                 gil_switch_interval: float | None = 1e-4, score_columns: bool | None = None):
+                 gil_switch_interval: float | None = 1e-4, score_columns: bool | None = None, mutual_info: bool = False):
         self.threshold, self.depth, self.host_stage, self.want_spans = confidence_threshold, max(0, int(depth)), host_stage, want_spans
+        self.mutual_info = bool(mutual_info) and confidence_threshold is not None
         self.score_columns = (confidence_threshold is not None) if score_columns is None else bool(score_columns)
         self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="karios-frame")
         self._pending: deque = deque()
@@ -119,7 +122,7 @@ class FrameStream:
         if not raw.flags:
             frame = raw.to_frame(radial=self.score_columns)
             if frame is not None and self.score_columns and raw.with_zncc:
-                frame = pair.score_frame(frame, self.threshold)     # every column is in place: pure numpy, no library call
+                frame = pair.score_frame(frame, self.threshold, mutual_info=self.mutual_info)     # every column is in place: pure numpy, no library call
         return raw, spans, frame
 
     def _collect(self, item) -> StreamResult:
@@ -130,7 +133,7 @@ class FrameStream:
             raw = pend.redo()
             frame = raw.to_frame(radial=self.score_columns)
             if frame is not None and self.score_columns and self.threshold is not None:
-                frame = pair.score_frame(frame, self.threshold)
+                frame = pair.score_frame(frame, self.threshold, mutual_info=self.mutual_info)
             redone = True
             self.units_redone += 1
         if frame is not None and self.host_stage is not None:
@@ -138,16 +141,19 @@ class FrameStream:
         return StreamResult(frame, raw, tag, redone, spans)
 
     # ------------------------------------------------------------------ API
-    def submit(self, pair: ResidentPair, conf, box=None, origin=None, tag=None) -> list[StreamResult]:
+    def submit(self, pair: ResidentPair, conf, box=None, origin=None, tag=None, on_submitted=None) -> list[StreamResult]:
         """Queue one unit on `pair`'s context; returns the units collected to keep at most `depth` pending (oldest first -
-        possibly none)."""
+        possibly none).  `on_submitted(pending_frame)` runs on the calling thread right behind the submission (e.g. the hand-over
+        of the unit's block to a collective: `karios_amd.parallel.RankBlockExchange.issue`)."""
         if self._pool is None:
             raise RuntimeError("FrameStream is closed")
         # maxCorners == 0 (unbounded) sizes the frame block for a quarter of the tile's pixels: no pinned 3-slot ring for that
         if conf.maxCorners > 0:
-            pend = pair.submit_tile(conf, box, self.threshold, origin)
+            pend = pair.submit_tile(conf, box, self.threshold, origin, mutual_info=self.mutual_info)
         else:
-            pend = pair.match_tile_raw(conf, box, self.threshold, origin)    # (blocking; repeats a flagged tile itself)
+            pend = pair.match_tile_raw(conf, box, self.threshold, origin, mutual_info=self.mutual_info)    # (blocking; repeats a flagged tile itself)
+        if on_submitted is not None:
+            on_submitted(pend)
         self._pending.append((pair, pend, tag, self._pool.submit(self._host_half, pair, pend)))
         out = []
         while len(self._pending) > self.depth:

@@ -199,6 +199,8 @@ ok(lib.km_klt_tile_frame_zncc_dev(ctx, dr, dm, 1, H, W, W, W, None, 0, None, Non
 hdr = block[:4].view(np.int32)
 assert 0 < hdr[0] <= hdr[1] <= cap
 err(lib.km_klt_tile_frame_zncc_dev(ctx, dr, dm, 1, H, W, W, W, None, 0, None, None, C.byref(prm), 0.0, 0.0, dr, dm, H, W, W, W, 0.4, None, cap), "frame null out", KM_E_ARG)
+err(lib.km_klt_tile_frame_zncc_dev(ctx, dr, dm, 1, 1, 65536, 65536, 65536, None, 0, None, None, C.byref(prm), 0.0, 0.0, dr, dm, H, W, W, W, 0.4, P(block), cap),
+    "frame of a 65536-column tile", KM_E_ARG)
 ok(lib.km_dev_alloc(ctx, blk_bytes, C.byref(sink)), "dev_alloc sink")
 ok(lib.km_set_frame_sink(ctx, sink, blk_bytes), "frame_sink")
 tickets = []

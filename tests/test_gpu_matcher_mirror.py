@@ -211,3 +211,75 @@ def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape, fft_
         np.testing.assert_array_equal(got, O.phase_cross_correlation(b, a))
         if min(H, W) >= 200:                      # (a small image shifted by a good part of its size has no reliable peak)
             np.testing.assert_array_equal(got, [sy, sx])
+
+
+def test_phase_correlation_survives_toggling_the_row_form_on_one_context(ops, O):
+    """the twiddle cache of k_fft.hip was keyed on the row length only, but the table's layout depends on the
+    plan (the 61 * M form appends two sub-tables) - the SAME shape with fft61 = 0 and then fft61 = 1 on one context returned early
+    with never-uploaded tables.  Same shape, both orders, several sides that both forms accept."""
+    from karios_amd._lib import Context
+    for (H, W) in ((366, 366), (1098, 1220), (427, 915)):
+        base, _ = synth.make_pair(H + 80, W + 80, 0.0, 0.0, seed=H + W + 1, noise_sigma=0.0)
+        a = base[40:40 + H, 40:40 + W]
+        b = base[40 - 9:40 - 9 + H, 40 + 13:40 + 13 + W]
+        want = O.phase_cross_correlation(b, a)
+        for order in ((0, 1, 0, 1), (1, 0, 1)):
+            ctx = Context()
+            try:
+                for form in order:
+                    ctx.set_option("fft61", form)
+                    got = ops.phase_cross_correlation(b, a, ctx=ctx)
+                    assert ctx.phase_info()[0] == 1            # the float32 path answered (no double-precision rescue)
+                    np.testing.assert_array_equal(got, want)
+            finally:
+                ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.int16, np.uint8, np.float32])
+def test_frames_scored_with_both_mutual_information_columns_in_the_tile_call(ops, O, dtype):
+    """`KariosAPI._handle_klt_results` (api/core.py:894-907) scores every confident candidate with ZNCC, `mutual_info_score`
+    (mutual_info_service.py:73-130) and `mi_score` (zncc_service.py:240-287); with `mutual_info=True` all three ride in the tile's
+    device call.  Blocking call, submitted call and FrameStream give the same block; the columns equal the oracle's on the frame's
+    key points (<= 1e-9, NaN exactly where score < threshold or the chip leaves the image); the ZNCC-only frame is unchanged."""
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    from karios_amd.stream import FrameStream
+    from karios_amd import results
+    mon, ref = synth.make_pair(640, 760, 0.4, -0.3, seed=31, nodata_wedge=True)
+    if dtype == np.uint8:
+        mon, ref = (mon >> 5).astype(np.uint8), (ref >> 5).astype(np.uint8)
+    elif dtype == np.int16:
+        mon, ref = (mon.astype(np.int32) - 4000).astype(np.int16), (ref.astype(np.int32) - 4000).astype(np.int16)
+    elif dtype == np.float32:
+        mon, ref = mon.astype(np.float32) * np.float32(0.37), ref.astype(np.float32) * np.float32(0.37)
+    pair = ResidentPair.upload(mon, ref)
+    conf = KLTConfiguration(maxCorners=1500)
+    f1 = pair.match_tile(conf, zncc_threshold=0.4)
+    f3 = pair.match_tile(conf, zncc_threshold=0.4, mutual_info=True)
+    assert list(f3.columns) == ["x0", "y0", "dx", "dy", "score", "zncc_score", "mutual_info_score", "mi_score"]
+    pd.testing.assert_frame_equal(f3[list(f1.columns)], f1, check_exact=True)
+    x0, y0, dx, dy, sc = (f3[c].to_numpy() for c in ("x0", "y0", "dx", "dy", "score"))
+    keep = sc >= np.float32(0.4)
+    assert keep.sum() > 200 and (~keep).sum() > 0
+    st, nmi = O.mi_batch(ref, mon, x0[keep], y0[keep], dx[keep], dy[keep])
+    for col, want in (("mutual_info_score", st), ("mi_score", nmi)):
+        got = f3[col].to_numpy()
+        assert np.all(np.isnan(got[~keep]))
+        assert np.array_equal(np.isnan(got[keep]), np.isnan(want))
+        assert np.nanmax(np.abs(got[keep] - want)) <= 1e-9
+    assert np.isnan(st).any() or True                      # (key points near the wedge / border: NaN by the bounds rule)
+    # submitted form == blocking form, bit for bit
+    raw = pair.submit_tile(conf, zncc_threshold=0.4, mutual_info=True).result()
+    assert raw.with_zncc == 3
+    pd.testing.assert_frame_equal(raw.to_frame(), f3, check_exact=True)
+    # FrameStream: the whole of _handle_klt_results' scoring columns, no second pass
+    with FrameStream(0.4, depth=1, mutual_info=True) as s:
+        got = s.submit(pair, conf) + s.drain()
+    fs = got[0].frame
+    assert {"radial error", "angle", "zncc_score", "mutual_info_score", "mi_score"} <= set(fs.columns)
+    for col in ("zncc_score", "mutual_info_score", "mi_score"):
+        np.testing.assert_array_equal(fs[col].to_numpy().view(np.int64), f3[col].to_numpy().view(np.int64))
+    # ... and the host-side scorer leaves device-scored columns alone (results.handle_klt_results reorders, never recomputes)
+    again = pair.score_frame(f3.copy(), 0.4, mutual_info=True)
+    np.testing.assert_array_equal(again["mi_score"].to_numpy().view(np.int64), f3["mi_score"].to_numpy().view(np.int64))
+    assert list(again[results.CSV_COLUMNS].columns) == results.CSV_COLUMNS

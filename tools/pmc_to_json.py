@@ -25,8 +25,10 @@ STAGES = {   # stage key -> kernel-name fragments
     "zncc": ("zncc_kernel",),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
+    "mi_kernel": ("mi_kernel",),
+    "dn_keep": ("dn_keep_kernel",),
 }
-ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce"}
+ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_kernel", "dn": "dn_keep_kernel"}
 
 
 def load(path):
@@ -51,6 +53,11 @@ def durations(trace):
 def main():
     root, size = sys.argv[1], sys.argv[2]
     mode = "config3" if "--config3" in sys.argv else "config2"
+    for arg in sys.argv[3:]:
+        if arg.startswith("--mode="):
+            mode = arg.split("=", 1)[1]          # which kernel counts the units profiled (ONCE_PER_PAIR)
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv[3:] if a.startswith("--only=")]
+    only = only[0] if only else None
     commit = open(os.path.join(root, "commit.txt")).read().strip()
     merged = collections.defaultdict(lambda: collections.defaultdict(float))
     launch_count = collections.Counter()
@@ -67,6 +74,8 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     db = json.load(open(dst)) if os.path.exists(dst) else {}
     for stage, frags in STAGES.items():
+        if only is not None and stage not in only:
+            continue
         names = [n for n in merged if any(f in n for f in frags)]
         if not names:
             continue
