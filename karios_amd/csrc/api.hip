@@ -211,6 +211,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
+    if (strcmp(name, "lk_pair") == 0) { c->opt_lk_pair = value < 0 ? 0 : value > 2 ? 2 : value; return KM_OK; }
     if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
     if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
@@ -356,7 +357,14 @@ int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, siz
     // page-locked source (km_host_alloc / hipHostMalloc / hipHostRegister): DMA'd in place, truly asynchronous.  Pageable source:
     // packed into the context's page-locked ring chunk by chunk (staging.hip) - the call returns when the source has been read,
     // the DMAs stay ordered on the copy stream; no runtime copy ever reads pageable memory
-    { const int rcs = km_h2d_staged(c, c->copy_stream, dst, dst_pitch, src, src_pitch, width_bytes, rows); if (rcs) return rcs; }
+    static const bool old_async = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;   // control soak: the ORIGINAL behaviour (rounds 1 - 3a): the runtime copies pageable rows
+    if (old_async) {
+        if (dst_pitch == width_bytes && src_pitch == width_bytes) KM_HIP(c, hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyHostToDevice, c->copy_stream));
+        else KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        const int rcs = km_h2d_staged(c, c->copy_stream, dst, dst_pitch, src, src_pitch, width_bytes, rows);
+        if (rcs) return rcs;
+    }
     c->copy_pending = true;
     return KM_OK;
 }

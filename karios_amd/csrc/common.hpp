@@ -84,6 +84,7 @@ enum km_slot {
     WS_FFT_TW0,     // twiddle tables of the float32 FFT (row length of the first / second dimension), kept between calls
     WS_FFT_TW1,
     WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
+    WS_MI_TABLE,    // c ln c, c = 0 .. 57^2 (k_mi.hip)
     WS_COUNT
 };
 
@@ -219,6 +220,7 @@ struct km_ctx {
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
+    int opt_lk_pair = 1;           // "lk_pair" 1 (default): winSize 25 through the pair form of the second LK form (two key points per wavefront, one per 32-lane half); 0: one key point per wavefront
     bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
     bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
     bool opt_frame_mi = false;     // "frame_mi" 1: frames scored by the tile entry points (ZNCC of the rows with score >= threshold) also carry the two mutual-information scores of those rows (core.py:894-907): two more float64 columns behind zncc
@@ -241,6 +243,7 @@ struct km_ctx {
     void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
     int fft_h = 0, fft_w = 0;
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
+    bool mi_table_ready = false;   // WS_MI_TABLE holds its table
     int fft_tw_m[2] = {-1, -1};    //   ... and the 61 M plan they were laid out for (0: Stockham table only)
     size_t fft_work_bytes = 0;
 };

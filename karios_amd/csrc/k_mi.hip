@@ -9,6 +9,12 @@
 // Key-point rounding / bounds rules are those of the ZNCC kernel (`_compute_mutual_info` = `_compute_zncc`).
 #include "common.hpp"
 
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#define LK_LIKE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define MI_CHIP 57
 #define MI_MARGIN 28
 #define MI_NPX (MI_CHIP * MI_CHIP)
@@ -145,11 +151,162 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Integer pixel types (uint8 / uint16 / int16 - everything the reference reads from a raster except float32).  Round 4: the same
+// scores from the same histogram, with the arithmetic the data allows:
+//   * bins.  numpy's edges are linspace(lo, hi, 33) = lo + i * (R / 32), R = hi - lo.  For integer samples R / 32 is a dyadic
+//     rational, exact in float64, and so is every edge; "edge_i <= x" is the integer statement i * R <= 32 (x - lo): the bin is
+//     floor(32 (x - lo) / R), the maximum folded into bin 31 (numpy's on_edge rule).  No float64 division, no edge table.
+//   * entropies.  A cell holds c of N = 3249 samples: -sum p ln p = ln N - (1 / N) sum c ln c, and c ln c comes from a 3250-entry
+//     float64 table (host libm, uploaded once per context) - the first form spent most of its instructions in 18 float64 log()
+//     calls per lane.  The two "undefined" cases of the reference (H(X,Y) == 0; H(X) + H(Y) == 0) both mean ONE occupied cell
+//     and are detected on the counts, never on a rounded entropy.
+//   * chips stay in registers as packed 16-bit pairs (51 VGPRs instead of 204 for float64 copies), key points are dealt to the
+//     XCDs in contiguous eighths of the (x0, y0)-ordered rows like the ZNCC kernel's (neighbouring chips overlap in one L2).
+// Results agree with the first form (and the oracle's numpy) to ~1e-15; the gate is 1e-9.
+template <typename T>
+__global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                                     ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                                     const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                                     const float *__restrict__ score, float score_thr, double *__restrict__ out_studholme,
+                                                     double *__restrict__ out_nmi, km_window win, const double *__restrict__ clogc)
+{
+    __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
+    const int n_rows = d_n ? min(*d_n, n) : n;
+    const unsigned per = ((unsigned)(n_rows + 3) / 4 + KM_XCDS - 1) / KM_XCDS, blk = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = (int)blk * 4 + wv;
+    if (blockIdx.x / KM_XCDS >= per || k >= n_rows) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    auto give = [&](double v) { if (lane == 0) { if (out_studholme) out_studholme[k] = v; if (out_nmi) out_nmi[k] = v; } };
+    if (score && !(score[k] >= score_thr)) { give(nan); return; }
+    const float fx0 = x0[k], fy0 = y0[k];
+    int X0 = (int)fx0, Y0 = (int)fy0;
+    const float sx = __fadd_rn(fx0, dx[k]), sy = __fadd_rn(fy0, dy[k]);
+    bool ok = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+    int X1 = 0, Y1 = 0;
+    if (ok) {
+        X1 = __float2int_rn(sx); Y1 = __float2int_rn(sy);
+        const int Wr = win.H ? win.W : Wref, Hr = win.H ? win.H : Href, Wm = win.H ? win.W : Wmon, Hm = win.H ? win.H : Hmon;   // see k_zncc.hip
+        ok = !(X0 - MI_MARGIN < 0 || Y0 - MI_MARGIN < 0 || X1 - MI_MARGIN < 0 || Y1 - MI_MARGIN < 0) &&
+             !(X0 >= Wr - MI_MARGIN || Y0 >= Hr - MI_MARGIN || X1 >= Wm - MI_MARGIN || Y1 >= Hm - MI_MARGIN);
+    }
+    if (!ok) { give(nan); return; }
+    if (win.H) {
+        X0 -= win.ox; X1 -= win.ox; Y0 -= win.oy; Y1 -= win.oy;
+        if (X0 - MI_MARGIN < 0 || Y0 - MI_MARGIN < 0 || X1 - MI_MARGIN < 0 || Y1 - MI_MARGIN < 0 || X0 + MI_MARGIN >= Wref || Y0 + MI_MARGIN >= Href ||
+            X1 + MI_MARGIN >= Wmon || Y1 + MI_MARGIN >= Hmon) {
+            give(__longlong_as_double((long long)KM_NAN_OUTSIDE_WINDOW));
+            return;
+        }
+    }
+    unsigned *hist = s_hist[wv];
+#pragma unroll
+    for (int i = 0; i < MI_BINS * MI_BINS / 64; i++) hist[i * 64 + lane] = 0;
+    // chips -> registers (biased to unsigned 16 bit: the bias cancels in x - lo), per-chip minimum / maximum
+    constexpr int BIAS = std::is_signed<T>::value ? 32768 : 0;
+    const T *pr = ref + (ptrdiff_t)(Y0 - MI_MARGIN) * sref + (X0 - MI_MARGIN);
+    const T *pm = mon + (ptrdiff_t)(Y1 - MI_MARGIN) * smon + (X1 - MI_MARGIN);
+    unsigned pk[MI_PER_LANE];
+    int mn1 = 1 << 30, mx1 = -1, mn2 = 1 << 30, mx2 = -1;
+#pragma unroll
+    for (int i = 0; i < MI_PER_LANE; i++) {
+        const int idx = i * 64 + lane;
+        pk[i] = 0;
+        if (idx < MI_NPX) {
+            const int r = (idx * 1150) >> 16, cx = idx - r * MI_CHIP;          // idx / 57 for idx < 3264
+            const int a = (int)pr[(ptrdiff_t)r * sref + cx] + BIAS, b = (int)pm[(ptrdiff_t)r * smon + cx] + BIAS;
+            pk[i] = (unsigned)a | ((unsigned)b << 16);
+            mn1 = min(mn1, a); mx1 = max(mx1, a); mn2 = min(mn2, b); mx2 = max(mx2, b);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn1 = min(mn1, __shfl_xor(mn1, o)); mx1 = max(mx1, __shfl_xor(mx1, o));
+        mn2 = min(mn2, __shfl_xor(mn2, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
+    }
+    const int R1 = mx1 - mn1, R2 = mx2 - mn2;
+    const float rc1 = R1 ? 1.f / (float)R1 : 0.f, rc2 = R2 ? 1.f / (float)R2 : 0.f;
+    LK_LIKE_SYNC();
+#pragma unroll
+    for (int i = 0; i < MI_PER_LANE; i++) {
+        if (i * 64 + lane < MI_NPX) {
+            // floor(32 d / R): a float32 estimate (32 d < 2^21 is exact, the reciprocal is within one ulp) corrected by one step either way
+            const int n1 = 32 * ((int)(pk[i] & 0xffffu) - mn1), n2 = 32 * ((int)(pk[i] >> 16) - mn2);
+            int q1 = (int)((float)n1 * rc1), q2 = (int)((float)n2 * rc2);
+            q1 += ((q1 + 1) * R1 <= n1) ? 1 : 0; q1 -= (q1 * R1 > n1) ? 1 : 0;
+            q2 += ((q2 + 1) * R2 <= n2) ? 1 : 0; q2 -= (q2 * R2 > n2) ? 1 : 0;
+            // a constant chip: numpy widens the range to [v - 0.5, v + 0.5], the samples sit in the middle bin 16
+            const int b1 = R1 ? min(q1, MI_BINS - 1) : MI_BINS / 2, b2 = R2 ? min(q2, MI_BINS - 1) : MI_BINS / 2;
+            atomicAdd(&hist[b1 * MI_BINS + b2], 1u);
+        }
+    }
+    LK_LIKE_SYNC();
+    // sum c ln c over the joint cells (16 per lane) and over the two marginals (lane b < 32: row b / column b)
+    double sxy = 0;
+    int occupied = 0;
+#pragma unroll
+    for (int i = 0; i < MI_BINS * MI_BINS / 64; i++) {
+        const unsigned c = hist[i * 64 + lane];
+        occupied += c != 0;
+        sxy += clogc[c];
+    }
+    double sxm = 0, sym = 0;
+    if (lane < MI_BINS) {
+        unsigned rx = 0, ry = 0;
+#pragma unroll 8
+        for (int j = 0; j < MI_BINS; j++) { rx += hist[lane * MI_BINS + ((j + lane) & (MI_BINS - 1))]; ry += hist[j * MI_BINS + lane]; }
+        sxm = clogc[rx]; sym = clogc[ry];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) occupied += __shfl_xor(occupied, o);
+    sxy = mi_wave_sum(sxy); sxm = mi_wave_sum(sxm); sym = mi_wave_sum(sym);
+    if (lane == 0) {
+        const double lnN = clogc[MI_NPX] / (double)MI_NPX, invN = 1.0 / (double)MI_NPX;
+        const double hxy = lnN - sxy * invN, hx = lnN - sxm * invN, hy = lnN - sym * invN;
+        // one occupied cell: H(X,Y) = H(X) = H(Y) = 0 exactly in the reference -> both scores undefined (NaN)
+        if (out_studholme) out_studholme[k] = occupied == 1 ? nan : (hx + hy) / hxy;
+        if (out_nmi) out_nmi[k] = occupied == 1 ? nan : 2.0 * (hx + hy - hxy) / (hx + hy);
+    }
+}
+
+// c ln c for c = 0 .. 57^2 (float64, host libm), in a workspace slot of the context
+static const double *mi_table(km_ctx *c)
+{
+    double *d = (double *)km_ws(c, WS_MI_TABLE, (size_t)(MI_NPX + 1) * sizeof(double));
+    if (!d) return nullptr;
+    if (!c->mi_table_ready) {
+        std::vector<double> h((size_t)MI_NPX + 1);
+        h[0] = 0.0;
+        for (int i = 1; i <= MI_NPX; i++) h[(size_t)i] = (double)i * log((double)i);
+        if (km_h2d_staged(c, c->stream, d, h.size() * 8, h.data(), h.size() * 8, h.size() * 8, 1) != KM_OK) return nullptr;
+        c->mi_table_ready = true;
+    }
+    return d;
+}
+
 int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
               ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, const int *d_n,
               const float *d_score, float score_thr, double *d_studholme, double *d_nmi)
 {
     if (n <= 0) return KM_OK;
+    static const bool first_form = getenv("KARIOS_HIP_MI_FIRST_FORM") != nullptr;     // A/B: the round-3 kernel for every pixel type
+    if (dtype != KM_F32 && !first_form) {
+        const double *tab = mi_table(c);
+        if (!tab) return KM_E_NOMEM;
+        const int nbx = (int)km_xcd_grid((unsigned)((n + 3) / 4));
+#define KM_MII(T) mi_int_kernel<T><<<nbx, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_studholme, d_nmi, c->window, tab)
+        switch (dtype) {
+        case KM_U8: KM_MII(uint8_t); break;
+        case KM_U16: KM_MII(uint16_t); break;
+        case KM_I16: KM_MII(int16_t); break;
+        default: return km_fail(c, KM_E_ARG, "mi: bad dtype %d", dtype);
+        }
+#undef KM_MII
+        KM_LAUNCH_CHECK(c);
+        return KM_OK;
+    }
     const int nb = (n + 3) / 4;
 #define KM_MI(T) mi_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_studholme, d_nmi, c->window)
     switch (dtype) {
