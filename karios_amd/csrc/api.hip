@@ -204,6 +204,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "roctx") == 0) { c->opt_roctx = value != 0; return KM_OK; }
     if (strcmp(name, "fft_cross") == 0) { c->opt_fft_cross_fused = value != 0; return KM_OK; }
     if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
+    if (strcmp(name, "fft_ts") == 0) { c->opt_fft_ts = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
@@ -211,7 +212,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
     if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
     if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
-    if (strcmp(name, "lk_pair") == 0) { c->opt_lk_pair = value < 0 ? 0 : value > 2 ? 2 : value; return KM_OK; }
+    if (strcmp(name, "lk_pair") == 0) { c->opt_lk_pair = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
     if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
     if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
@@ -1261,15 +1262,9 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
                             (const int *)d_out, f + 4 * (size_t)cap, (float)zncc_threshold, st, st + cap)))
             return rc;
     }
-    if (c->frame_sink) {
-        if (c->frame_sink_cap < ob) return km_fail(c, KM_E_ARG, "frame sink of %zu bytes is smaller than the %zu-byte frame block", c->frame_sink_cap, ob);
-        KM_HIP(c, hipMemcpyAsync(c->frame_sink, d_out, ob, hipMemcpyDeviceToDevice, c->stream));
-        if (slot) {   // km_stream_wait_frame: a stream of the caller (the one an RCCL collective is issued on) can wait for exactly this copy
-            if (!slot->sunk) KM_HIP(c, hipEventCreateWithFlags(&slot->sunk, hipEventDisableTiming));
-            KM_HIP(c, hipEventRecord(slot->sunk, c->stream));
-            slot->sunk_valid = true;
-        }
-    } else if (slot) slot->sunk_valid = false;
+    if (c->frame_sink && c->frame_sink_cap < ob)
+        return km_fail(c, KM_E_ARG, "frame sink of %zu bytes is smaller than the %zu-byte frame block", c->frame_sink_cap, ob);
+    if (c->frame_sink && !slot) KM_HIP(c, hipMemcpyAsync(c->frame_sink, d_out, ob, hipMemcpyDeviceToDevice, c->stream));
     if (slot) {
         if (slot->cap < ob) {
             if (slot->host) KM_HIP(c, hipHostFree(slot->host));
@@ -1286,6 +1281,15 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
         }
         KM_HIP(c, hipEventRecord(c->ev_tail, c->stream));
         KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_tail, 0));
+        slot->sunk_valid = false;
+        if (c->frame_sink) {
+            // the device-side copy of the block (km_set_frame_sink) leaves there too: on the compute stream it cost the next unit 11 us.
+            // km_stream_wait_frame: a stream of the caller (the one an RCCL collective is issued on) can wait for exactly this copy
+            KM_HIP(c, hipMemcpyAsync(c->frame_sink, d_out, ob, hipMemcpyDeviceToDevice, c->d2h_stream));
+            if (!slot->sunk) KM_HIP(c, hipEventCreateWithFlags(&slot->sunk, hipEventDisableTiming));
+            KM_HIP(c, hipEventRecord(slot->sunk, c->d2h_stream));
+            slot->sunk_valid = true;
+        }
         KM_HIP(c, hipMemcpyAsync(slot->host, d_out, ob, hipMemcpyDeviceToHost, c->d2h_stream));
         KM_HIP(c, hipEventRecord(slot->done, c->d2h_stream));
         c->frame_copy = slot->done;

@@ -217,10 +217,11 @@ struct km_ctx {
     int opt_fft_dbg = 0;           // development: bits that skip phases of the 61 M row kernel (timing experiments; results are then wrong)
     bool opt_roctx = false;        // "roctx": roctx ranges around the stages
     bool opt_fft_cross_fused = true;   // "fft_cross": the cross-power step fused into the first inverse pass's row load (61 M rows)
+    bool opt_fft_ts = false;       // "fft_ts" 1: rows of length 61 M on both sides - the two transposes are folded into the stores of the row passes in front of them (8-byte stores at a stride of one row, XCD-contiguous rows so that the lines fill up in L2): correct, the plane crosses HBM four times instead of six - and SLOWER (4.86 against 4.66 ms at 10980^2: the row kernels' store phase grows by more than the two 0.42-ms transposes cost).  0 (default): transpose kernels
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
-    int opt_lk_pair = 1;           // "lk_pair" 1 (default): winSize 25 through the pair form of the second LK form (two key points per wavefront, one per 32-lane half); 0: one key point per wavefront
+    int opt_lk_pair = 0;           // "lk_pair" 1: winSize 25 through the PAIR form of the second LK form (two key points per wavefront, one per 32-lane half): bit-identical, fewer per-point instructions in the template pass, and SLOWER (0.31 against 0.26 ms at 20 000 corners beside the next unit's min / max): 155 VGPRs = 3 waves per SIMD instead of 6, and the per-half address arithmetic the compiler rematerialises in the iteration loop eats what the shared per-point chain saves.  0 (default): one key point per wavefront
     bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
     bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
     bool opt_frame_mi = false;     // "frame_mi" 1: frames scored by the tile entry points (ZNCC of the rows with score >= threshold) also carry the two mutual-information scores of those rows (core.py:894-907): two more float64 columns behind zncc

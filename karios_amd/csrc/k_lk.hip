@@ -1067,13 +1067,9 @@ __device__ __forceinline__ void lk4_body(const lk_args &g, const int *__restrict
 }
 
 // the reference's window (matching_winsize 25): 125 runs of 5 px = four per lane of a half.  155 VGPRs unconstrained = 3 waves per
-// SIMD = 24 key points per CU in flight (the second form: 6 waves x 1 point); the 4-wave build (128 VGPRs, 20 dwords spilled) is
-// kept for the A/B (km_set_option("lk_pair", 2)).
+// SIMD = 24 key points per CU in flight (the second form: 6 waves x 1 point).  A 4-wave build (128 VGPRs) spills 20 dwords, and the
+// spill code reads inline-assembly DOT results inside their hazard window (tools/hazard_scan.py found it): not built.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void lk4_kernel_win25(lk_args g, const int *__restrict__ order)
-{
-    lk4_body<4, 25, 9>(g, order);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lk4_kernel_win25_w4(lk_args g, const int *__restrict__ order)
 {
     lk4_body<4, 25, 9>(g, order);
 }
@@ -1161,8 +1157,7 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
         if (win == 25 && c->opt_lk_pair) {
             // pair form: two key points per wavefront (8 patches of LDS)
             const unsigned nblk4 = km_xcd_grid(((unsigned)n_max + 1u) / 2u);
-            if (c->opt_lk_pair == 2) lk4_kernel_win25_w4<<<nblk4, 64, 2 * sm2, c->stream>>>(g, order);
-            else lk4_kernel_win25<<<nblk4, 64, 2 * sm2, c->stream>>>(g, order);
+            lk4_kernel_win25<<<nblk4, 64, 2 * sm2, c->stream>>>(g, order);
         }
         else if (win == 25) lk2_kernel_win25<<<nblk2, 64, sm2, c->stream>>>(g, order);
         else switch (nr) {

@@ -210,7 +210,9 @@ class RankBlockExchange:
         rows, flagged = ex.finish()
     """
 
-    def __init__(self, ctx, cap: int, with_zncc=True, device=None, slots: int = 4):
+    HISTORY = 4096                    # steps whose gathered headers are kept on the device before they are folded into the counters
+
+    def __init__(self, ctx, cap: int, with_zncc=True, device=None, slots: int = 4, parts: str = "sink,wait,gather,account"):
         import torch
         from collections import deque
         self.ctx, self.cap, self.L, self.slots = ctx, cap, block_len(cap, with_zncc), max(2, int(slots))
@@ -218,32 +220,50 @@ class RankBlockExchange:
         self.grouped = _group_up()
         self.device = _collective_device(ctx, device)
         self.on_gpu = self.device.type == "cuda"
+        self.parts = set(parts.split(","))          # (tools/exchange_probe.py switches stages off to price them; everything on otherwise)
         self.send = torch.zeros((self.slots, self.L), dtype=torch.float32, device=self.device)
         self.recv = torch.zeros((self.slots, self.ws, self.L), dtype=torch.float32, device=self.device)
+        # the 16-byte headers of every gathered block of the last HISTORY steps: ONE small device copy per step; rows / flags are
+        # summed from them when the history is full and in finish() - the submitting thread launches nothing else
+        self.hist = torch.zeros((self.HISTORY, self.ws, 4), dtype=torch.int32, device=self.device)
+        self.hist_n = 0
         self.rows = torch.zeros((), dtype=torch.int64, device=self.device)
         self.flagged = torch.zeros((), dtype=torch.int64, device=self.device)
         self.side = torch.cuda.Stream(self.device) if self.on_gpu else None
-        self.done = [None] * self.slots            # torch events: the slot's collective and its bookkeeping have finished
+        self.done = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]   # the slot's collective + header copy have finished
+        self.used = [False] * self.slots
         self.pending = deque()                     # gloo: (work, slot) issued and not waited for yet
         self.issued = 0
+        self._sink_set = False
 
     def arm(self, step: int) -> None:
         """Before submitting step `step`: its block goes to the step's send slot (RCCL); the slot's previous collective - `slots`
         steps old - has long finished, the check is free."""
-        if not self.on_gpu:
+        if not self.on_gpu or "sink" not in self.parts:
             return
         slot = step % self.slots
-        if self.done[slot] is not None:
+        if self.used[slot]:
             self.done[slot].synchronize()
         c = self.ctx
         c.check(c.lib.km_set_frame_sink(c.handle, self.send[slot].data_ptr(), self.L * 4), "km_set_frame_sink")
+        self._sink_set = True
 
-    def _account(self, slot: int) -> None:
+    def _fold(self) -> None:
+        """History of headers -> counters (a handful of small device ops, once per HISTORY steps and at the end)."""
         import torch
-        hdr = self.recv[slot][:, :4].contiguous().view(torch.int32)
-        good = hdr[:, 2] == 0
-        self.rows += torch.where(good, hdr[:, 0], torch.zeros_like(hdr[:, 0])).sum()
+        if self.hist_n == 0:
+            return
+        h = self.hist[:self.hist_n].reshape(-1, 4)
+        good = h[:, 2] == 0
+        self.rows += torch.where(good, h[:, 0], torch.zeros_like(h[:, 0])).sum()
         self.flagged += (~good).sum()
+        self.hist_n = 0
+
+    def _keep_headers(self, slot: int) -> None:
+        if self.hist_n == self.HISTORY:
+            self._fold()
+        self.hist[self.hist_n].copy_(self.recv[slot][:, :4].view(self.hist.dtype), non_blocking=True)
+        self.hist_n += 1
 
     def issue(self, step: int, pending=None, host_block=None) -> None:
         """Right behind the submission of step `step` (`pending`: its PendingFrame; gloo: `host_block` once the frame is finished)."""
@@ -252,18 +272,23 @@ class RankBlockExchange:
         slot = step % self.slots
         if self.on_gpu:
             c = self.ctx
-            c.check(c.lib.km_set_frame_sink(c.handle, None, 0), "km_set_frame_sink")
-            c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
-            with torch.cuda.stream(self.side):
-                if self.grouped:
-                    work = dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True)
-                    work.wait()                    # (orders the side stream behind the collective: no host wait)
-                else:
-                    self.recv[slot][0].copy_(self.send[slot])
-                self._account(slot)
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                self.done[slot] = ev
+            if "wait" in self.parts and "sink" in self.parts:
+                c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
+                prev = torch.cuda.current_stream(self.device)
+                torch.cuda.set_stream(self.side)
+                try:
+                    if "gather" in self.parts:
+                        if self.grouped:
+                            work = dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True)
+                            work.wait()                    # (orders the side stream behind the collective: no host wait)
+                        else:
+                            self.recv[slot][0].copy_(self.send[slot], non_blocking=True)
+                    if "account" in self.parts:
+                        self._keep_headers(slot)
+                    self.done[slot].record(self.side)
+                    self.used[slot] = True
+                finally:
+                    torch.cuda.set_stream(prev)
         else:
             blk = np.zeros(self.L, np.float32) if host_block is None else np.ascontiguousarray(host_block[:self.L])
             self.send[slot].copy_(torch.from_numpy(blk))
@@ -280,16 +305,29 @@ class RankBlockExchange:
         work, slot = self.pending.popleft()
         if work is not None:
             work.wait()
-        self._account(slot)
+        self._keep_headers(slot)
 
     def finish(self) -> tuple[int, int]:
         """-> (matched key points of every rank and step, gathered blocks that were flagged by the synchronisation-free corner path
-        - their rows are NOT counted: the owner repeated those units exactly and knows their rows)."""
+        - their rows are NOT counted: the owner repeated those units exactly and knows their rows).  Resets nothing but the sink."""
+        import torch
         while self.pending:
             self._retire()
         if self.on_gpu:
+            if self._sink_set:
+                c = self.ctx
+                c.check(c.lib.km_set_frame_sink(c.handle, None, 0), "km_set_frame_sink")
+                self._sink_set = False
+            with torch.cuda.stream(self.side):
+                self._fold()
             self.side.synchronize()
+        else:
+            self._fold()
         return int(self.rows.item()), int(self.flagged.item())
+
+    def reset_counts(self) -> None:
+        """Counters back to zero (call with everything issued so far finished: after `finish()`)."""
+        self.rows.zero_(); self.flagged.zero_(); self.hist_n = 0
 
     def last_blocks(self, step: int):
         """The gathered blocks of step `step` (tensor (world, block_len), rank order) while its slot has not been reused."""

@@ -421,7 +421,10 @@ def mi_batch(ref, mon, x0, y0, dx, dy):
     for k, c1, c2 in _kp_chips(np.asarray(ref), np.asarray(mon), x0, y0, dx, dy):
         if c1 is None:
             continue
-        h, _, _ = np.histogram2d(c1.ravel(), c2.ravel(), bins=32)
+        # float64 samples -> float64 bin edges, whatever numpy runs here: the reference's environment (pandas 2.1 / opencv 4.8 =>
+        # numpy 1.x) evaluates `np.linspace(float32 min, float32 max, 33)` in float64 for float32 chips as well, and
+        # `_mutual_information` casts explicitly (zncc_service.py:134-135); numpy >= 2 would give float32 edges for float32 chips
+        h, _, _ = np.histogram2d(c1.ravel().astype(np.float64), c2.ravel().astype(np.float64), bins=32)
         pxy = h / h.sum()
         px, py = pxy.sum(axis=1), pxy.sum(axis=0)
         ent = lambda p, lg: -np.sum(p[p > 0] * lg(p[p > 0]))

@@ -122,18 +122,24 @@ def _bench(args, env_extra, timeout=900):
     return json.loads(lines[0])
 
 
-def test_bench_headline_with_the_rccl_exchange_in_the_loop_keeps_the_submit_cadence():
-    """bench.py's N > 1 headline loop (RCCL all-gather of every step's block inside the timed region) on a one-rank group: the
-    exchange must not put the host back into the step - submit intervals within 3 % of the plain N = 1 run -
-    and the device-side count of the gathered blocks equals the frames' rows."""
+def test_bench_headline_with_the_rccl_exchange_in_the_loop():
+    """bench.py's N > 1 headline loop (RCCL all-gather of every step's block inside the timed region) on a one-rank group: the device-
+    side count of the gathered blocks equals the frames' rows, nothing is flagged, no host wait per step is reported."""
     common = ["--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-end-to-end", "--no-config3", "--no-config4", "--no-config5",
               "--no-in-flight", "--no-full-scoring"]
-    plain = _bench(common, {})
     exch = _bench(common, {"KARIOS_BENCH_EXCHANGE": "1"})
     e = exch["exchange"]
     assert exch["backend"] == "nccl" and e["host_waits_per_step"] == 0 and e["flagged_blocks_gathered"] == 0
     assert e["rows_from_gathered_blocks"] == 40 * exch["matched_keypoints_per_pair"]
-    assert plain["exchange"] is None
-    ratio = exch["step_spread"]["median_ms"] / plain["step_spread"]["median_ms"]
-    assert ratio <= 1.03, (exch["step_spread"]["median_ms"], plain["step_spread"]["median_ms"])
-    assert exch["ms_per_step"] <= 1.05 * plain["ms_per_step"], (exch["ms_per_step"], plain["ms_per_step"])
+    assert exch["matched_keypoints_per_pair"] > 10000
+
+
+def test_the_exchange_does_not_put_the_host_back_into_the_step():
+    """with the all-gather in the loop the step must stay within 3 % of the plain loop.  Measured inside ONE process
+    (tools/exchange_probe.py --json: plain and exchanging loops alternate on the same box; two processes differ by 1 - 2 % on this pool)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_probe.py"), "150", "--json"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert all(rows == [150 * 20000, 0] for rows in out["rows_per_run"]), out["rows_per_run"]
+    assert out["ratio_ms_per_step"] <= 1.03 and out["ratio_median"] <= 1.03, (out["plain_ms_per_step"], out["exchange_ms_per_step"], out["plain_median_ms"], out["exchange_median_ms"])
