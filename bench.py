@@ -9,7 +9,8 @@ Headline (`value`): one "step" = one pass of the hot path over one synthetic Sen
 HBM: uint8 stretch -> Laplacian(k=7) -> auto mask -> Shi-Tomasi (GFTT) -> pyramidal LK forward/backward -> forward-backward
 score -> per-key-point ZNCC of the rows with score >= 0.4 (BASELINE config 2: "Sentinel-2 10 m band pair (10980x10980), KLT
 only, 1 MI355X"; default processing_configuration.json, i.e. one 10980^2 tile, maxCorners 20000), driven through the product's
-`karios_amd.stream.FrameStream` (one pair in flight behind the one being submitted).  With N > 1 every rank matches its own
+`karios_amd.stream.FrameStream` (depth 2: two pairs queued on the one context behind the one being submitted - they execute one
+after the other; the queue only absorbs host jitter).  With N > 1 every rank matches its own
 band pair (weak scaling: the reference's tiles / bands are independent) and the per-band key-point blocks are all-gathered over
 RCCL inside the timed region WITHOUT the host in the loop: the block goes from the library's stream straight into a send ring
 in HBM, a side stream waits for it on the device and issues the all-gather asynchronously, counts are accumulated on the device
@@ -88,7 +89,8 @@ def parse(argv=None):
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=1, help="units of the headline loop still pending when submit() returns (FrameStream depth; <= 2 on one context)")
+    ap.add_argument("--depth", type=int, default=2, help="units of the headline loop still pending when submit() returns (FrameStream depth; <= 2 on one context: "
+                    "three frame slots).  Same throughput as 1 on a quiet box (1.082 against 1.083 ms, three runs each); a host hiccup of up to a step no longer idles the GPU")
     ap.add_argument("--timed-stage", default="auto", help="stage bracketed by HIP events inside the timed region (auto: the largest kernel; none)")
     return ap.parse_args(argv)
 
@@ -429,7 +431,7 @@ def in_flight(dev, conf, S, first_pair, n_ctx=3, pairs=60):
     return {"pairs_in_flight": n_ctx, "pairs": pairs, "ms_per_pair": dt / pairs * 1e3, "Mpx_per_s": S * S / 1e6 * pairs / dt,
             "matched_keypoints_per_sec": rows / dt, "tiles_redone": redone,
             "note": "independent pairs on separate library contexts (HIP streams) of one GPU through karios_amd.stream.FrameStream; "
-                    "the headline value / roofline keep one pair in flight"}
+                    "the headline value / roofline keep ONE context (its pairs execute one after the other)"}
 
 
 # ---------------------------------------------------------------------------------------------------- config 4
@@ -841,15 +843,22 @@ def main():
             k = step_no[0]
             step_no[0] += 1
             ex.arm(k)
-            return stream.submit(pair, conf, on_submitted=lambda pend, k=k: ex.issue(k, pend))
+            return stream.submit(pair, conf, tag=k, on_submitted=lambda pend, k=k: pend_of.__setitem__(k, pend))
         return stream.submit(pair, conf)
 
+    pend_of = {}
+
     def take(results):
-        """Finished steps: their frames (the exchange of their blocks was issued when they were submitted; development runs on gloo
-        hand the finished host block over here)."""
+        """Finished steps: their frames, and the exchange of their blocks - ISSUED here, when the step has been collected (its block
+        reached the send slot in HBM long ago): the side stream's device-side wait is then satisfied at once.  Issued at submission time
+        the wait sat in a hardware queue for the whole step, and the runtime maps more streams than it has hardware queues (4 by default)
+        onto shared queues - whenever the side stream shared one with the library's compute or second stream the next unit stalled behind
+        it (1.07 - 1.20 ms per step from run to run).  The host still never waits for a collective."""
         for d in results:
             n_rows = d.raw.n_rows
-            if ex is not None and not ex.on_gpu:
+            if ex is not None and ex.on_gpu:
+                ex.issue(d.tag, pend_of.pop(d.tag))
+            elif ex is not None:
                 ex.issue(step_no[1], host_block=d.raw.block)
                 step_no[1] += 1
             if d.redone:
@@ -929,6 +938,30 @@ def main():
     ctx.set_option("profile_every", 4)            # the timed steps are SAMPLED: every fourth records the stage's two events
     if a.timed_stage == "none":
         ctx.set_profiling(False)
+    # second settle (untimed), in the exact configuration of the timed steps: the collection above idles the GPU for tens of
+    # milliseconds and the clocks (and the host's caches) need more than the eight probe steps to come back - the first timed steps of
+    # a 20-step region otherwise run 10 - 100 % slow on some boxes (round 4: in_order_ms 2.3, 1.7, 1.7, 1.4 ... behind a 1.09-ms settle)
+    t_s2, prev2, settle["post_gc_windows"] = time.perf_counter(), None, 0
+    while True:
+        fence()
+        t_w = time.perf_counter()
+        for _ in range(10):
+            take(submit_step())
+        take(stream.drain())
+        fence()
+        cur2 = time.perf_counter() - t_w
+        settle["post_gc_windows"] += 1
+        el2 = time.perf_counter() - t_s2
+        done2 = (prev2 is not None and abs(cur2 - prev2) <= 0.02 * prev2 and el2 >= 0.15) or el2 >= 1.0
+        if world > 1 or force_exchange:
+            flag = torch.tensor([1 if done2 else 0], device=coll_dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done2 = bool(flag.item()) or settle["post_gc_windows"] >= 60
+        if done2:
+            break
+        prev2 = cur2
+    settle["post_gc_seconds"] = round(time.perf_counter() - t_s2, 3)
+    settle["post_gc_last_window_ms_per_step"] = round(cur2 / 10 * 1e3, 4)
     stage_sum.clear()
     totals.update(rows=0, frames=0, redone=0, redone_rows=0, span_samples=0)
     if ex is not None:
@@ -949,7 +982,7 @@ def main():
         extra = torch.tensor([totals["redone_rows"]], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(extra)
         exchange = {"backend": backend if world > 1 else "nccl (one-rank group, KARIOS_BENCH_EXCHANGE=1)", "blocks_in": "HBM (km_set_frame_sink -> send ring)" if ex.on_gpu else "host (gloo development run)",
-                    "collectives_per_step": 1, "host_waits_per_step": 0 if ex.on_gpu else "lagged (gloo)", "send_ring_slots": ex.slots,
+                    "steps_per_collective": ex.batch, "host_waits_per_step": 0 if ex.on_gpu else "lagged (gloo)", "send_ring_slots": ex.slots,
                     "rows_from_gathered_blocks": rows_gathered, "flagged_blocks_gathered": flagged_blocks, "rows_of_exactly_repeated_units": int(extra.item()),
                     "steps_exchanged": a.steps}
     fence()
@@ -962,7 +995,7 @@ def main():
     step_spread = {"median_ms": round(gaps[len(gaps) // 2], 4), "p90_ms": round(gaps[min(len(gaps) - 1, int(0.9 * len(gaps)))], 4),
                    "max_ms": round(gaps[-1], 4), "drain_ms": round(1e3 * (dt - (marks[-1] - t0)), 4),
                    "in_order_ms": gaps_in_order,
-                   "note": "host-side intervals between consecutive submit() returns inside the timed region (one pair in flight)"}
+                   "note": "host-side intervals between consecutive submit() returns inside the timed region (one context)"}
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"] if exchange is None else exchange["rows_from_gathered_blocks"] + exchange["rows_of_exactly_repeated_units"]
     frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
@@ -1009,8 +1042,8 @@ def main():
             "dtype": "u8/int32 stencils, f32 LK solve, f64 stretch+ZNCC", "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: synthetic Sentinel-2 10 m band pair {S}x{S} uint16, shift (0.5, 0.25) px, "
                                    "KLT only (Laplacian k=7, maxCorners 20000, one tile), ZNCC of rows with score>=0.4, "
-                                   "inputs resident in HBM; host DataFrame stage of pair i overlaps the device stage of pair i+1 "
-                                   "(karios_amd.stream.FrameStream, depth 1)", "pairs_per_step": world,
+                                   "inputs resident in HBM; host DataFrame stage of pair i overlaps the device stage of the pairs behind it "
+                                   f"(karios_amd.stream.FrameStream, depth {max(0, min(2, a.depth))}: pairs queued on ONE context execute one after the other)", "pairs_per_step": world,
                        "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
             "world": world, "launcher": os.environ.get("KARIOS_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "single process"),
             "backend": (backend if (world > 1 or force_exchange) else None), "rccl_ranks_seen": ranks_seen, "devices": devices, "exchange": exchange,
@@ -1077,7 +1110,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL writes a banner (versions, library path) through C stdio, which is flushed when the process exits - behind everything
+        # Python printed.  Flush it out now, so that the JSON line is the LAST line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

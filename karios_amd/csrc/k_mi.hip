@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, 
     int mn1 = 1 << 30, mx1 = -1, mn2 = 1 << 30, mx2 = -1;
 #pragma unroll
     for (int i = 0; i < MI_PER_LANE; i++) {
+        // (lane L taking 51 CONSECUTIVE pixels instead - so that the 64 pixels of one histogram step fall into different cells and their LDS
+        // atomics do not serialise - was measured: 0.66 against 0.12 ms; the uncoalesced chip loads cost far more than the conflicts)
         const int idx = i * 64 + lane;
         pk[i] = 0;
         if (idx < MI_NPX) {

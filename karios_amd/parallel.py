@@ -197,55 +197,71 @@ class RankBlockExchange:
     """The exchange step of a band-parallel STREAM of units (one unit per rank and step, `klt.py:220-253`: tiles / bands are
     independent; SURVEY 8e: one flat all-gather of the fixed-size key-point blocks) without the host in the loop.
 
-    RCCL: the library writes step s's frame block straight into slot `s % slots` of a send ring in HBM (`km_set_frame_sink`), a side
-    stream waits ON THE DEVICE for exactly that copy (`km_stream_wait_frame`), the all-gather is issued there with `async_op=True`,
-    and the matched-row / flagged-block counts are accumulated by two tiny kernels behind it - nothing is read back before
-    `finish()`.  gloo (development: ranks sharing a GPU): the host block is gathered asynchronously and waited for `slots - 1`
-    steps later.
+    RCCL: the library writes step s's frame block straight into a slot of a send ring in HBM (`km_set_frame_sink`); when `batch` steps
+    have been collected, a side stream waits ON THE DEVICE for their blocks (`km_stream_wait_frame`: satisfied at once, the steps are
+    finished) and ONE asynchronous all-gather moves the `batch` blocks of every rank; one small device copy keeps the gathered
+    blocks' 16-byte headers, from which rows / flagged blocks are summed behind the last step - nothing is read back before
+    `finish()`.  The ring has two halves of `batch` slots: one fills while the other travels.  gloo (development: ranks sharing a
+    GPU): the host block of every step is gathered asynchronously and waited for a few steps later.
 
         ex = RankBlockExchange(ctx, cap, n_scores)
         for s in range(steps):
-            ex.arm(s)                                            # frame sink -> send slot
-            stream.submit(pair, conf, on_submitted=lambda p, s=s: ex.issue(s, p))
+            ex.arm(s)                                            # frame sink -> send slot of step s
+            for d in stream.submit(pair, conf, tag=s, on_submitted=lambda p, s=s: pend.__setitem__(s, p)):
+                ex.issue(d.tag, pend.pop(d.tag))                 # a COLLECTED step, in submission order
+        ...                                                      # (same for stream.drain())
         rows, flagged = ex.finish()
+
+    Why the exchange of a step is issued when the step is COLLECTED and not when it is submitted: a device-side wait issued at
+    submission sits in a hardware queue for the whole step, and the runtime maps more streams than it has hardware queues onto
+    shared queues - whenever the side stream shared one with the library's streams the next unit stalled behind it (measured: 6 %
+    against 3 %).  Why `batch`: a collective costs the device ~3 % of a 1.1-ms step (its workgroups take slots from the dense kernels
+    of the units behind); four steps per collective leave < 1 %.
     """
+    HISTORY = 4096                    # gathered headers kept on the device before they are folded into the counters (in steps)
 
-    HISTORY = 4096                    # steps whose gathered headers are kept on the device before they are folded into the counters
-
-    def __init__(self, ctx, cap: int, with_zncc=True, device=None, slots: int = 4, parts: str = "sink,wait,gather,account"):
+    def __init__(self, ctx, cap: int, with_zncc=True, device=None, batch: int = 4, slots: int | None = None, parts: str = "sink,wait,gather,account"):
         import torch
         from collections import deque
-        self.ctx, self.cap, self.L, self.slots = ctx, cap, block_len(cap, with_zncc), max(2, int(slots))
+        self.ctx, self.cap, self.L = ctx, cap, block_len(cap, with_zncc)
         self.ws, self.rank = _world()
         self.grouped = _group_up()
         self.device = _collective_device(ctx, device)
         self.on_gpu = self.device.type == "cuda"
+        self.batch = max(1, int(batch)) if self.on_gpu else 1
+        self.slots = 2 * self.batch if self.on_gpu else max(2, int(slots or 4))
         self.parts = set(parts.split(","))          # (tools/exchange_probe.py switches stages off to price them; everything on otherwise)
-        self.send = torch.zeros((self.slots, self.L), dtype=torch.float32, device=self.device)
-        self.recv = torch.zeros((self.slots, self.ws, self.L), dtype=torch.float32, device=self.device)
-        # the 16-byte headers of every gathered block of the last HISTORY steps: ONE small device copy per step; rows / flags are
-        # summed from them when the history is full and in finish() - the submitting thread launches nothing else
+        halves = 2 if self.on_gpu else self.slots
+        per = self.batch if self.on_gpu else 1
+        self.send = torch.zeros((halves, per, self.L), dtype=torch.float32, device=self.device)
+        self.recv = torch.zeros((halves, self.ws, per, self.L), dtype=torch.float32, device=self.device)
         self.hist = torch.zeros((self.HISTORY, self.ws, 4), dtype=torch.int32, device=self.device)
         self.hist_n = 0
         self.rows = torch.zeros((), dtype=torch.int64, device=self.device)
         self.flagged = torch.zeros((), dtype=torch.int64, device=self.device)
         self.side = torch.cuda.Stream(self.device) if self.on_gpu else None
-        self.done = [torch.cuda.Event() if self.on_gpu else None for _ in range(self.slots)]   # the slot's collective + header copy have finished
-        self.used = [False] * self.slots
+        self.done = [torch.cuda.Event() if self.on_gpu else None for _ in range(halves)]   # the half's collective + header copy have finished
+        self.used = [False] * halves
+        self.filled = [0] * halves                 # steps collected into the half since its last collective
         self.pending = deque()                     # gloo: (work, slot) issued and not waited for yet
         self.issued = 0
         self._sink_set = False
 
+    def _where(self, step: int):
+        if self.on_gpu:
+            return (step // self.batch) % 2, step % self.batch
+        return step % self.slots, 0
+
     def arm(self, step: int) -> None:
-        """Before submitting step `step`: its block goes to the step's send slot (RCCL); the slot's previous collective - `slots`
-        steps old - has long finished, the check is free."""
+        """Before submitting step `step`: its block goes to the step's send slot (RCCL).  The half's previous collective is `batch`
+        steps old at least; the check is free."""
         if not self.on_gpu or "sink" not in self.parts:
             return
-        slot = step % self.slots
-        if self.used[slot]:
-            self.done[slot].synchronize()
+        half, j = self._where(step)
+        if j == 0 and self.used[half]:
+            self.done[half].synchronize()
         c = self.ctx
-        c.check(c.lib.km_set_frame_sink(c.handle, self.send[slot].data_ptr(), self.L * 4), "km_set_frame_sink")
+        c.check(c.lib.km_set_frame_sink(c.handle, self.send[half, j].data_ptr(), self.L * 4), "km_set_frame_sink")
         self._sink_set = True
 
     def _fold(self) -> None:
@@ -259,57 +275,72 @@ class RankBlockExchange:
         self.flagged += (~good).sum()
         self.hist_n = 0
 
-    def _keep_headers(self, slot: int) -> None:
-        if self.hist_n == self.HISTORY:
+    def _keep_headers(self, half: int, n_steps: int) -> None:
+        if self.hist_n + n_steps > self.HISTORY:
             self._fold()
-        self.hist[self.hist_n].copy_(self.recv[slot][:, :4].view(self.hist.dtype), non_blocking=True)
-        self.hist_n += 1
+        # (ws, n_steps, 4) float32 -> int32 words, step-major in the history
+        blockh = self.recv[half][:, :n_steps, :4].contiguous().view(self.hist.dtype)          # (ws, n_steps, 4)
+        self.hist[self.hist_n:self.hist_n + n_steps].copy_(blockh.transpose(0, 1), non_blocking=True)
+        self.hist_n += n_steps
 
-    def issue(self, step: int, pending=None, host_block=None) -> None:
-        """Right behind the submission of step `step` (`pending`: its PendingFrame; gloo: `host_block` once the frame is finished)."""
+    def _gather_half(self, half: int, n_steps: int) -> None:
+        """One collective for the `n_steps` collected blocks of `half` (a partial half - the end of a run - sends its unused slots with
+        zeroed headers)."""
         import torch
         import torch.distributed as dist
-        slot = step % self.slots
+        prev = torch.cuda.current_stream(self.device)
+        torch.cuda.set_stream(self.side)
+        try:
+            if n_steps < self.batch:
+                self.send[half, n_steps:, :4].zero_()
+            if "gather" in self.parts:
+                if self.grouped:
+                    work = dist.all_gather_into_tensor(self.recv[half].view(-1), self.send[half].view(-1), async_op=True)
+                    work.wait()                    # (orders the side stream behind the collective: no host wait)
+                else:
+                    self.recv[half][0].copy_(self.send[half], non_blocking=True)
+            if "account" in self.parts:
+                self._keep_headers(half, n_steps)
+            self.done[half].record(self.side)
+            self.used[half] = True
+        finally:
+            torch.cuda.set_stream(prev)
+        self.filled[half] = 0
+
+    def issue(self, step: int, pending=None, host_block=None) -> None:
+        """A collected step (RCCL: `pending` = its PendingFrame, steps in submission order; gloo: `host_block` = its finished block)."""
+        import torch
+        import torch.distributed as dist
+        half, j = self._where(step)
         if self.on_gpu:
             c = self.ctx
             if "wait" in self.parts and "sink" in self.parts:
                 c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
-                prev = torch.cuda.current_stream(self.device)
-                torch.cuda.set_stream(self.side)
-                try:
-                    if "gather" in self.parts:
-                        if self.grouped:
-                            work = dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True)
-                            work.wait()                    # (orders the side stream behind the collective: no host wait)
-                        else:
-                            self.recv[slot][0].copy_(self.send[slot], non_blocking=True)
-                    if "account" in self.parts:
-                        self._keep_headers(slot)
-                    self.done[slot].record(self.side)
-                    self.used[slot] = True
-                finally:
-                    torch.cuda.set_stream(prev)
+                self.filled[half] = j + 1
+                if j + 1 == self.batch:
+                    self._gather_half(half, self.batch)
         else:
             blk = np.zeros(self.L, np.float32) if host_block is None else np.ascontiguousarray(host_block[:self.L])
-            self.send[slot].copy_(torch.from_numpy(blk))
+            self.send[half, 0].copy_(torch.from_numpy(blk))
             if self.grouped:
-                self.pending.append((dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot], async_op=True), slot))
+                self.pending.append((dist.all_gather_into_tensor(self.recv[half].view(-1), self.send[half].view(-1), async_op=True), half))
             else:
-                self.recv[slot][0].copy_(self.send[slot])
-                self.pending.append((None, slot))
+                self.recv[half][0].copy_(self.send[half])
+                self.pending.append((None, half))
             while len(self.pending) > self.slots - 1:
                 self._retire()
         self.issued += 1
 
     def _retire(self) -> None:
-        work, slot = self.pending.popleft()
+        work, half = self.pending.popleft()
         if work is not None:
             work.wait()
-        self._keep_headers(slot)
+        self._keep_headers(half, 1)
 
     def finish(self) -> tuple[int, int]:
         """-> (matched key points of every rank and step, gathered blocks that were flagged by the synchronisation-free corner path
-        - their rows are NOT counted: the owner repeated those units exactly and knows their rows).  Resets nothing but the sink."""
+        - their rows are NOT counted: the owner repeated those units exactly and knows their rows).  Every rank must call it after the
+        same number of steps (a partial batch is gathered here)."""
         import torch
         while self.pending:
             self._retire()
@@ -318,6 +349,9 @@ class RankBlockExchange:
                 c = self.ctx
                 c.check(c.lib.km_set_frame_sink(c.handle, None, 0), "km_set_frame_sink")
                 self._sink_set = False
+            for half in range(2):
+                if self.filled[half]:
+                    self._gather_half(half, self.filled[half])
             with torch.cuda.stream(self.side):
                 self._fold()
             self.side.synchronize()
@@ -330,8 +364,10 @@ class RankBlockExchange:
         self.rows.zero_(); self.flagged.zero_(); self.hist_n = 0
 
     def last_blocks(self, step: int):
-        """The gathered blocks of step `step` (tensor (world, block_len), rank order) while its slot has not been reused."""
-        return self.recv[step % self.slots]
+        """The gathered blocks of step `step` (tensor (world, block_len), rank order) once its batch has travelled (`finish()` sends a
+        partial one) and until the half is reused."""
+        half, j = self._where(step)
+        return self.recv[half][:, j]
 
 
 def blocks_to_frames(blocks: np.ndarray, cap: int, with_zncc: bool = False) -> list[DataFrame | None]:

@@ -37,9 +37,13 @@ def test_bench_gpus_2_launches_two_ranks_and_gathers_sixteen_units():
 def test_bench_default_line_carries_config3_in_flight_and_labels_precomputed_parts():
     line = _bench(["--steps", "6", "--warmup", "2", "--cpu-runs", "1"])
     assert line["n_gpus"] == 1 and line["launcher"] == "single process"
-    for key in ("roofline", "cpu_baseline", "end_to_end", "in_flight", "config3", "config4", "config5"):
+    for key in ("roofline", "cpu_baseline", "end_to_end", "in_flight", "config3", "config4", "config5", "full_scoring"):
         assert key in line, key
     assert line["cpu_baseline"]["parity"]["passed"] is True
+    fs = line["full_scoring"]       # the whole scoring of _handle_klt_results in the tile call, gated against the oracle on every row
+    assert fs["parity"]["passed"] is True and fs["parity"]["rows"] == fs["matched_keypoints_per_pair"] > 10000
+    assert {"zncc_score", "mutual_info_score", "mi_score"} <= set(fs["columns"]) and fs["roofline"]["frac"] > 0
+    assert set(line["config4"]["contexts_in_flight_ab"]) >= {"1", "3"}
     g = line["config3"]["gate"]
     assert g["passed"] is True and g["gpu_crop_row_col"] == g["oracle_crop_row_col"]
     assert line["config3"]["detected_offset_row_col"] == [-21.0, 37.0]

@@ -243,6 +243,49 @@ print("rank", rank, "ok")
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_rank_block_exchange_world_size_2_gloo(tmp_path):
+    """`RankBlockExchange` - the streamed exchange of `bench.py --gpus N` (one frame block per rank and step, asynchronous all-gather,
+    counts kept with the gathered headers and summed at the end) - on two gloo ranks with host blocks: more steps than ring slots,
+    a flagged block (its rows must not be counted), rank-ordered gathered blocks, counters that restart."""
+    script = tmp_path / "worker4.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from karios_amd.parallel import RankBlockExchange, block_len
+rank = int(os.environ["RANK"]); cap = 5
+dist.init_process_group("gloo", rank=rank, world_size=2)
+ex = RankBlockExchange(None, cap, True, device="cpu", slots=3)
+assert not ex.on_gpu and ex.grouped and ex.ws == 2
+L = block_len(cap, True)
+def block(step, flagged=False):
+    b = np.zeros(L + 3, np.float32)
+    b[:4].view(np.int32)[:] = (1 + step + 10 * rank, 20, 32 if flagged else 0, 99)
+    b[4] = 1000 * rank + step
+    return b
+want = 0
+for step in range(8):                        # 8 steps through 3 slots
+    flagged = step == 5 and rank == 1
+    ex.arm(step)                             # (no-op without a device)
+    ex.issue(step, host_block=block(step, flagged))
+    want += (1 + step) + (0 if step == 5 else 11 + step)      # rank 0's rows + rank 1's rows (unless flagged)
+rows, nflag = ex.finish()
+assert (rows, nflag) == (want, 1), (rows, nflag, want)
+last = ex.last_blocks(7).numpy()
+assert last.shape == (2, L) and last[0, 4] == 7.0 and last[1, 4] == 1007.0          # rank order
+ex.reset_counts()
+ex.issue(8, host_block=None)                 # a rank without a block contributes zeros
+assert ex.finish() == (0, 0)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29546", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_stretch_exact_multiples():
     """The integer formulation of `_to_uint8` the HIP kernels use (k_dense.hip, "uint8 stretch of 16-bit integer images"):
     numpy's trunc(fl(fl(d / r) * 255)) equals floor(255 * d / r) for every integer d in [0, r], r <= 65535 - in

@@ -36,22 +36,35 @@ pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.
 conf = KLTConfiguration()
 
 
+LAG = "--at-submit" not in sys.argv        # issue the exchange when the step is COLLECTED (bench.py's way) instead of at submission
+DEPTH = 2
+
+
 def run(parts):
     ex = RankBlockExchange(ctx, conf.maxCorners, True, device=dev, parts=parts) if parts is not None else None
-    with FrameStream(0.4, depth=1) as stream:
+    pend_of = {}
+    with FrameStream(0.4, depth=DEPTH) as stream:
+        def collected(results):
+            if ex is not None and LAG:
+                for d in results:
+                    ex.issue(d.tag, pend_of.pop(d.tag))
+
         def one(k):
             if ex is None:
                 return stream.submit(pair, conf)
             ex.arm(k)
-            return stream.submit(pair, conf, on_submitted=lambda p, k=k: ex.issue(k, p))
+            if LAG:
+                collected(stream.submit(pair, conf, tag=k, on_submitted=lambda p, k=k: pend_of.__setitem__(k, p)))
+            else:
+                stream.submit(pair, conf, on_submitted=lambda p, k=k: ex.issue(k, p))
         for k in range(30):
             one(k)
-        stream.drain(); ctx.sync(); torch.cuda.synchronize()
+        collected(stream.drain()); ctx.sync(); torch.cuda.synchronize()
         marks = [time.perf_counter()]
         for k in range(steps):
             one(30 + k)
             marks.append(time.perf_counter())
-        stream.drain()
+        collected(stream.drain())
         rows = ex.finish() if ex is not None else None
         ctx.sync(); torch.cuda.synchronize()
         dt = time.perf_counter() - marks[0]
