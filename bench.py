@@ -979,11 +979,14 @@ def main():
         # every rank's matched key points of the K steps, counted on the device from the GATHERED blocks; units the synchronisation-
         # free corner path flagged were repeated exactly by their owner: their rows travel in one closing all-reduce
         rows_gathered, flagged_blocks = ex.finish()
-        extra = torch.tensor([totals["redone_rows"]], device=coll_dev, dtype=torch.int64)
-        dist.all_reduce(extra)
+        redone_rows = 0
+        if flagged_blocks:               # (every rank read the same gathered headers: all of them enter the collective, or none)
+            extra = torch.tensor([totals["redone_rows"]], device=coll_dev, dtype=torch.int64)
+            dist.all_reduce(extra)
+            redone_rows = int(extra.item())
         exchange = {"backend": backend if world > 1 else "nccl (one-rank group, KARIOS_BENCH_EXCHANGE=1)", "blocks_in": "HBM (km_set_frame_sink -> send ring)" if ex.on_gpu else "host (gloo development run)",
                     "steps_per_collective": ex.batch, "host_waits_per_step": 0 if ex.on_gpu else "lagged (gloo)", "send_ring_slots": ex.slots,
-                    "rows_from_gathered_blocks": rows_gathered, "flagged_blocks_gathered": flagged_blocks, "rows_of_exactly_repeated_units": int(extra.item()),
+                    "rows_from_gathered_blocks": rows_gathered, "flagged_blocks_gathered": flagged_blocks, "rows_of_exactly_repeated_units": redone_rows,
                     "steps_exchanged": a.steps}
     fence()
     dt = time.perf_counter() - t0

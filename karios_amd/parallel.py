@@ -242,7 +242,8 @@ class RankBlockExchange:
         self.side = torch.cuda.Stream(self.device) if self.on_gpu else None
         self.done = [torch.cuda.Event() if self.on_gpu else None for _ in range(halves)]   # the half's collective + header copy have finished
         self.used = [False] * halves
-        self.filled = [0] * halves                 # steps collected into the half since its last collective
+        self.filled = [0] * halves                 # slot index behind the last step collected into the half since its last collective
+        self.first = [0] * halves                  # slot index of the first one (a run may start or restart in the middle of a half)
         self.pending = deque()                     # gloo: (work, slot) issued and not waited for yet
         self.issued = 0
         self._sink_set = False
@@ -279,20 +280,23 @@ class RankBlockExchange:
         if self.hist_n + n_steps > self.HISTORY:
             self._fold()
         # (ws, n_steps, 4) float32 -> int32 words, step-major in the history
-        blockh = self.recv[half][:, :n_steps, :4].contiguous().view(self.hist.dtype)          # (ws, n_steps, 4)
+        blockh = self.recv[half][:, :n_steps, :4].contiguous().view(self.hist.dtype)
         self.hist[self.hist_n:self.hist_n + n_steps].copy_(blockh.transpose(0, 1), non_blocking=True)
         self.hist_n += n_steps
 
-    def _gather_half(self, half: int, n_steps: int) -> None:
-        """One collective for the `n_steps` collected blocks of `half` (a partial half - the end of a run - sends its unused slots with
-        zeroed headers)."""
+    def _gather_half(self, half: int) -> None:
+        """One collective for the blocks collected into `half`: slots [first, filled).  The other slots of the half (a run that starts,
+        restarts or ends in the middle of a half) hold older blocks: they travel with zeroed headers and count nothing."""
         import torch
         import torch.distributed as dist
+        lo, hi = self.first[half], self.filled[half]
         prev = torch.cuda.current_stream(self.device)
         torch.cuda.set_stream(self.side)
         try:
-            if n_steps < self.batch:
-                self.send[half, n_steps:, :4].zero_()
+            if lo > 0:
+                self.send[half, :lo, :4].zero_()
+            if hi < self.batch:
+                self.send[half, hi:, :4].zero_()
             if "gather" in self.parts:
                 if self.grouped:
                     work = dist.all_gather_into_tensor(self.recv[half].view(-1), self.send[half].view(-1), async_op=True)
@@ -300,7 +304,7 @@ class RankBlockExchange:
                 else:
                     self.recv[half][0].copy_(self.send[half], non_blocking=True)
             if "account" in self.parts:
-                self._keep_headers(half, n_steps)
+                self._keep_headers(half, self.batch)
             self.done[half].record(self.side)
             self.used[half] = True
         finally:
@@ -316,9 +320,11 @@ class RankBlockExchange:
             c = self.ctx
             if "wait" in self.parts and "sink" in self.parts:
                 c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
+                if self.filled[half] == 0:
+                    self.first[half] = j
                 self.filled[half] = j + 1
                 if j + 1 == self.batch:
-                    self._gather_half(half, self.batch)
+                    self._gather_half(half)
         else:
             blk = np.zeros(self.L, np.float32) if host_block is None else np.ascontiguousarray(host_block[:self.L])
             self.send[half, 0].copy_(torch.from_numpy(blk))
@@ -351,13 +357,16 @@ class RankBlockExchange:
                 self._sink_set = False
             for half in range(2):
                 if self.filled[half]:
-                    self._gather_half(half, self.filled[half])
+                    self._gather_half(half)
             with torch.cuda.stream(self.side):
                 self._fold()
+                both = torch.stack([self.rows, self.flagged])
             self.side.synchronize()
         else:
             self._fold()
-        return int(self.rows.item()), int(self.flagged.item())
+            both = torch.stack([self.rows, self.flagged])
+        rows, flagged = both.tolist()                 # ONE read-back
+        return int(rows), int(flagged)
 
     def reset_counts(self) -> None:
         """Counters back to zero (call with everything issued so far finished: after `finish()`)."""

@@ -25,10 +25,10 @@ STAGES = {   # stage key -> kernel-name fragments
     "zncc": ("zncc_kernel",),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
-    "mi_kernel": ("mi_kernel",),
+    "mi_kernel": ("mi_kernel", "mi_int_kernel"),
     "dn_keep": ("dn_keep_kernel",),
 }
-ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_kernel", "dn": "dn_keep_kernel"}
+ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel"}
 
 
 def load(path):
