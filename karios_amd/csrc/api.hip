@@ -44,9 +44,11 @@ void *km_ws(km_ctx *c, int slot, size_t bytes)
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return b.p;
     if (b.p) {
-        // the library's streams (compute, second stream of the sync-free tile path) may still use the old buffer
-        (void)hipDeviceSynchronize();
-        (void)hipFree(b.p);
+        // The library's streams may still use the old buffer: it is RETIRED, not freed - work already queued keeps a valid buffer,
+        // new work gets the new one, and nothing synchronises (round 3 did hipDeviceSynchronize + hipFree here: a device-wide stall
+        // under the feet of every other context on the GPU).  Retired buffers are released when the context is next synchronised
+        // by its owner (km_ctx_sync) or destroyed.  Slots only grow, and by 6 % head-room at least: a handful of regrows per context.
+        c->retired.push_back(b.p);
         b.p = nullptr; b.cap = 0;
     }
     size_t want = bytes + bytes / 16 + 256;
@@ -161,6 +163,11 @@ int km_ctx_destroy(km_ctx *c)
     }
     for (int i = 0; i < WS_COUNT; i++)
         if (c->ws[i].p) (void)hipFree(c->ws[i].p);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
+    for (void *p : c->retired) (void)hipFree(p);
+    c->retired.clear();
     if (c->ev_ready)
         for (int k = 0; k <= KM_FRAME_SLOTS; k++)
             for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(c->evs[k][i][0]); (void)hipEventDestroy(c->evs[k][i][1]); }
@@ -186,6 +193,13 @@ int km_ctx_sync(km_ctx *c)
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipStreamSynchronize(c->stream));
     if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks of submitted tiles
+    if (!c->retired.empty()) {
+        // workspace buffers replaced by larger ones: nothing of this context uses them any more once its streams are idle
+        if (c->aux_stream) KM_HIP(c, hipStreamSynchronize(c->aux_stream));
+        if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
+        for (void *p : c->retired) (void)hipFree(p);
+        c->retired.clear();
+    }
     return KM_OK;
 }
 

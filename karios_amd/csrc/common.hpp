@@ -174,6 +174,7 @@ struct km_ctx {
     void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
     size_t frame_sink_cap = 0;
     km_buf ws[WS_COUNT];
+    std::vector<void *> retired;         // workspace buffers replaced by larger ones (km_ws): freed at the next km_ctx_sync / destroy
     km_stage_ring ring;                  // host -> device staging (staging.hip)
     void *land = nullptr;                // device -> host landing arena (page-locked), km_d2h_queue / km_d2h_flush
     size_t land_cap = 0, land_used = 0;

@@ -157,14 +157,17 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
 // scores from the same histogram, with the arithmetic the data allows:
 //   * bins.  numpy's edges are linspace(lo, hi, 33) = lo + i * (R / 32), R = hi - lo.  For integer samples R / 32 is a dyadic
 //     rational, exact in float64, and so is every edge; "edge_i <= x" is the integer statement i * R <= 32 (x - lo): the bin is
-//     floor(32 (x - lo) / R), the maximum folded into bin 31 (numpy's on_edge rule).  No float64 division, no edge table.
+//     floor(32 (x - lo) / R), the maximum folded into bin 31 (numpy's on_edge rule) - one multiplication by a per-chip constant
+//     (see the kernel).  No float64 division per pixel, no edge table.
 //   * entropies.  A cell holds c of N = 3249 samples: -sum p ln p = ln N - (1 / N) sum c ln c, and c ln c comes from a 3250-entry
 //     float64 table (host libm, uploaded once per context) - the first form spent most of its instructions in 18 float64 log()
 //     calls per lane.  The two "undefined" cases of the reference (H(X,Y) == 0; H(X) + H(Y) == 0) both mean ONE occupied cell
 //     and are detected on the counts, never on a rounded entropy.
-//   * chips stay in registers as packed 16-bit pairs (51 VGPRs instead of 204 for float64 copies), key points are dealt to the
-//     XCDs in contiguous eighths of the (x0, y0)-ordered rows like the ZNCC kernel's (neighbouring chips overlap in one L2).
+//   * chips stay in registers as packed 16-bit pairs (57 VGPRs instead of 204 for float64 copies; lane = chip column, one chip row per
+//     step), key points are dealt to the XCDs in contiguous eighths of the (x0, y0)-ordered rows like the ZNCC kernel's (neighbouring
+//     chips overlap in one L2).
 // Results agree with the first form (and the oracle's numpy) to ~1e-15; the gate is 1e-9.
+// (144 - 168 VGPRs = 3 waves per SIMD; 128 for a fourth wave spills ~70 bytes - measured as built: 0.097 ms at 20 000 points)
 template <typename T>
 __global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
                                                      ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
@@ -204,42 +207,57 @@ __global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, 
     unsigned *hist = s_hist[wv];
 #pragma unroll
     for (int i = 0; i < MI_BINS * MI_BINS / 64; i++) hist[i * 64 + lane] = 0;
-    // chips -> registers (biased to unsigned 16 bit: the bias cancels in x - lo), per-chip minimum / maximum
-    constexpr int BIAS = std::is_signed<T>::value ? 32768 : 0;
-    const T *pr = ref + (ptrdiff_t)(Y0 - MI_MARGIN) * sref + (X0 - MI_MARGIN);
-    const T *pm = mon + (ptrdiff_t)(Y1 - MI_MARGIN) * smon + (X1 - MI_MARGIN);
-    unsigned pk[MI_PER_LANE];
-    int mn1 = 1 << 30, mx1 = -1, mn2 = 1 << 30, mx2 = -1;
+    // chips -> registers.  Lane = chip column (57 of 64 lanes work), one chip row per step: no index arithmetic, the row base is a
+    // scalar; a pixel pair (ref, mon) is one register of two 16-bit halves (biased to unsigned: the bias cancels in x - lo), and the
+    // per-chip minimum / maximum run in packed 16-bit arithmetic (the PMC pass of the first integer form: 3 058 VALU instructions per
+    // key point at 82 % pipe occupancy - the kernel is bound by instruction issue, not by its LDS atomics)
+    constexpr unsigned BIAS2 = std::is_signed<T>::value ? 0x80008000u : 0u;
+    const int bx0 = __builtin_amdgcn_readfirstlane(X0 - MI_MARGIN), by0 = __builtin_amdgcn_readfirstlane(Y0 - MI_MARGIN);
+    const int bx1 = __builtin_amdgcn_readfirstlane(X1 - MI_MARGIN), by1 = __builtin_amdgcn_readfirstlane(Y1 - MI_MARGIN);
+    const T *pr = ref + (ptrdiff_t)by0 * sref + bx0;
+    const T *pm = mon + (ptrdiff_t)by1 * smon + bx1;
+    const bool col_on = lane < MI_CHIP;
+    const int cl = col_on ? lane : 0;
+    typedef unsigned short mi_us2 __attribute__((ext_vector_type(2)));
+    unsigned pk[MI_CHIP];
+    mi_us2 vmin = {0xffff, 0xffff}, vmax = {0, 0};
 #pragma unroll
-    for (int i = 0; i < MI_PER_LANE; i++) {
-        // (lane L taking 51 CONSECUTIVE pixels instead - so that the 64 pixels of one histogram step fall into different cells and their LDS
-        // atomics do not serialise - was measured: 0.66 against 0.12 ms; the uncoalesced chip loads cost far more than the conflicts)
-        const int idx = i * 64 + lane;
-        pk[i] = 0;
-        if (idx < MI_NPX) {
-            const int r = (idx * 1150) >> 16, cx = idx - r * MI_CHIP;          // idx / 57 for idx < 3264
-            const int a = (int)pr[(ptrdiff_t)r * sref + cx] + BIAS, b = (int)pm[(ptrdiff_t)r * smon + cx] + BIAS;
-            pk[i] = (unsigned)a | ((unsigned)b << 16);
-            mn1 = min(mn1, a); mx1 = max(mx1, a); mn2 = min(mn2, b); mx2 = max(mx2, b);
-        }
+    for (int i = 0; i < MI_CHIP; i++) {
+        const unsigned a = (unsigned)(unsigned short)pr[(ptrdiff_t)i * sref + cl], b = (unsigned)(unsigned short)pm[(ptrdiff_t)i * smon + cl];
+        pk[i] = (a | (b << 16)) ^ BIAS2;             // (int16: two's complement + 0x8000 = the value + 32768, for both halves at once)
+        const mi_us2 v = __builtin_bit_cast(mi_us2, pk[i]);
+        vmin = __builtin_elementwise_min(vmin, v);
+        vmax = __builtin_elementwise_max(vmax, v);
     }
+    if (!col_on) { vmin = mi_us2{0xffff, 0xffff}; vmax = mi_us2{0, 0}; }
+    int mn1 = vmin.x, mx1 = vmax.x, mn2 = vmin.y, mx2 = vmax.y;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mn1 = min(mn1, __shfl_xor(mn1, o)); mx1 = max(mx1, __shfl_xor(mx1, o));
         mn2 = min(mn2, __shfl_xor(mn2, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
     }
     const int R1 = mx1 - mn1, R2 = mx2 - mn2;
-    const float rc1 = R1 ? 1.f / (float)R1 : 0.f, rc2 = R2 ? 1.f / (float)R2 : 0.f;
+    // floor(32 d / R) for 0 <= d <= R < 2^16 by ONE multiplication: with L = ceil(log2 R), s = 21 + L and M = ceil(2^s / R),
+    // M R = 2^s + e with 0 <= e < R <= 2^L, hence 32 d M / 2^s = 32 d / R + 32 d e / (R 2^s) and the excess is below
+    // 2^21 2^L / (R 2^s) = 1 / R: it cannot carry a quotient with fractional part <= (R - 1) / R over the next integer.  M <= 2^22, the
+    // product d M < 2^38: a 64-bit multiply-add and a 64-bit shift by s - 5.  (M from a float64 division: 2^s / R is an integer only
+    // for R a power of two, where the division is exact; otherwise it lies >= 1 / R from the integers, far beyond its 2^-31 error.)
+    auto magic = [](int R, unsigned &M, int &sh) {
+        const int L = R > 1 ? 32 - __clz(R - 1) : 0;
+        M = R ? (unsigned)ceil(ldexp(1.0, 21 + L) / (double)R) : 0u;
+        sh = 21 + L - 5;
+    };
+    unsigned M1, M2;
+    int sh1, sh2;
+    magic(R1, M1, sh1); magic(R2, M2, sh2);
     LK_LIKE_SYNC();
+    if (col_on) {
 #pragma unroll
-    for (int i = 0; i < MI_PER_LANE; i++) {
-        if (i * 64 + lane < MI_NPX) {
-            // floor(32 d / R): a float32 estimate (32 d < 2^21 is exact, the reciprocal is within one ulp) corrected by one step either way
-            const int n1 = 32 * ((int)(pk[i] & 0xffffu) - mn1), n2 = 32 * ((int)(pk[i] >> 16) - mn2);
-            int q1 = (int)((float)n1 * rc1), q2 = (int)((float)n2 * rc2);
-            q1 += ((q1 + 1) * R1 <= n1) ? 1 : 0; q1 -= (q1 * R1 > n1) ? 1 : 0;
-            q2 += ((q2 + 1) * R2 <= n2) ? 1 : 0; q2 -= (q2 * R2 > n2) ? 1 : 0;
-            // a constant chip: numpy widens the range to [v - 0.5, v + 0.5], the samples sit in the middle bin 16
+        for (int i = 0; i < MI_CHIP; i++) {
+            const unsigned d1 = (pk[i] & 0xffffu) - (unsigned)mn1, d2 = (pk[i] >> 16) - (unsigned)mn2;
+            const int q1 = (int)(unsigned)(((unsigned long long)d1 * M1) >> sh1), q2 = (int)(unsigned)(((unsigned long long)d2 * M2) >> sh2);
+            // the maximum folds into the last bin (numpy's on_edge rule); a constant chip: numpy widens the range to [v - 0.5, v + 0.5],
+            // the samples sit in the middle bin 16
             const int b1 = R1 ? min(q1, MI_BINS - 1) : MI_BINS / 2, b2 = R2 ? min(q2, MI_BINS - 1) : MI_BINS / 2;
             atomicAdd(&hist[b1 * MI_BINS + b2], 1u);
         }

@@ -59,18 +59,26 @@ def main():
     only = [a.split("=", 1)[1].split(",") for a in sys.argv[3:] if a.startswith("--only=")]
     only = only[0] if only else None
     commit = open(os.path.join(root, "commit.txt")).read().strip()
-    merged = collections.defaultdict(lambda: collections.defaultdict(float))
-    launch_count = collections.Counter()
+    # Every pass is a run of its own and the workload's settle phases are time-bound: the passes differ in the number of launches.
+    # Counters are therefore averaged PER LAUNCH inside their own pass and scaled by the kernel's launches per unit of the trace pass.
+    merged = collections.defaultdict(lambda: collections.defaultdict(float))     # kernel -> counter -> mean per launch
+    launch_count = collections.Counter()                                          # kernel -> launches in the trace pass (v)
     for p in ("f", "w", "v"):
         per, launches = load(os.path.join(root, p, "p_counter_collection.csv"))
         for name, cs in per.items():
             for c, v in cs.items():
-                merged[name][c] += v
-        for (name, c), k in launches.items():
-            launch_count[name] = max(launch_count[name], k)
+                merged[name][c] = v / max(1, launches[(name, c)])
+        if p == "v":
+            for (name, c), k in launches.items():
+                launch_count[name] = max(launch_count[name], k)
     dur, dn = durations(os.path.join(root, "v", "p_kernel_trace.csv"))
     marker = next((n for n in launch_count if ONCE_PER_PAIR[mode] in n), None)
     pairs = launch_count[marker] if marker else 1
+    for name in list(merged):                       # mean per launch -> per unit (pair / call)
+        scale = launch_count.get(name, 0) / pairs
+        for c in merged[name]:
+            merged[name][c] *= scale
+    pairs_for_sums = 1                              # (the sums below are per unit already)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     db = json.load(open(dst)) if os.path.exists(dst) else {}
     for stage, frags in STAGES.items():
@@ -83,15 +91,15 @@ def main():
         for n in names:
             for c, v in merged[n].items():
                 tot[c] += v
-        fetch, write = tot.get("FETCH_SIZE", 0.0) / pairs, tot.get("WRITE_SIZE", 0.0) / pairs
+        fetch, write = tot.get("FETCH_SIZE", 0.0), tot.get("WRITE_SIZE", 0.0)
         us = sum(dur[n] for n in names) / pairs
-        cycles = tot.get("GRBM_GUI_ACTIVE", 0.0) / pairs / 8.0          # the counter sums the 8 XCDs
-        valu = tot.get("SQ_INSTS_VALU", 0.0) / pairs
+        cycles = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # the counter sums the 8 XCDs
+        valu = tot.get("SQ_INSTS_VALU", 0.0)
         entry = {str(size): int(round((2 * fetch + write) * 1024)), "measured_at": commit,
                  "_detail": {"kernels": sorted({n.split("(")[0][:60] for n in names}), "launches_per_pair": round(sum(launch_count[n] for n in names) / pairs, 2),
                              "pairs_profiled": pairs, "FETCH_SIZE_KB": round(fetch), "WRITE_SIZE_KB": round(write),
-                             "SQ_INSTS_VALU": round(valu), "SQ_INSTS_LDS": round(tot.get("SQ_INSTS_LDS", 0.0) / pairs),
-                             "SQ_WAVES": round(tot.get("SQ_WAVES", 0.0) / pairs), "kernel_cycles": round(cycles),
+                             "SQ_INSTS_VALU": round(valu), "SQ_INSTS_LDS": round(tot.get("SQ_INSTS_LDS", 0.0)),
+                             "SQ_WAVES": round(tot.get("SQ_WAVES", 0.0)), "kernel_cycles": round(cycles),
                              "kernel_us_under_counters": round(us, 1),
                              "valu_pipe_busy": round(4 * valu / (1024 * cycles), 3) if cycles else None,
                              "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per pair (gfx950: FETCH_SIZE counts 64 B per 128-B request); separate rocprofv3 "
