@@ -264,6 +264,14 @@ void *km_pinned_rb(km_ctx *c, size_t bytes);   // >= bytes of pinned host memory
 #define KM_XCDS 8u
 static inline unsigned km_xcd_grid(unsigned ntiles) { return ((ntiles + KM_XCDS - 1) / KM_XCDS) * KM_XCDS; }
 #ifdef __HIPCC__
+// One pixel of a chip through a buffer descriptor: `rs` = the chip's origin (wave-uniform), voff = the lane's byte offset inside a row,
+// soff = the row's byte offset (scalar): `buffer_load_ushort v, v_off, s[rs], s_row offen` - no vector instruction goes into addresses.
+template <typename T>
+__device__ __forceinline__ unsigned km_chip_px(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    if constexpr (sizeof(T) == 1) return (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0);
+    else return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
+}
 __device__ __forceinline__ bool km_xcd_tile(unsigned ntiles, unsigned &tile)
 {
     const unsigned per = (ntiles + KM_XCDS - 1) / KM_XCDS, w = blockIdx.x;

@@ -216,14 +216,18 @@ __global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, 
     const int bx1 = __builtin_amdgcn_readfirstlane(X1 - MI_MARGIN), by1 = __builtin_amdgcn_readfirstlane(Y1 - MI_MARGIN);
     const T *pr = ref + (ptrdiff_t)by0 * sref + bx0;
     const T *pm = mon + (ptrdiff_t)by1 * smon + bx1;
+    const __amdgpu_buffer_rsrc_t bra = __builtin_amdgcn_make_buffer_rsrc((void *)pr, 0, (int)(((MI_CHIP - 1) * sref + MI_CHIP) * (ptrdiff_t)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brb = __builtin_amdgcn_make_buffer_rsrc((void *)pm, 0, (int)(((MI_CHIP - 1) * smon + MI_CHIP) * (ptrdiff_t)sizeof(T)), 0x00020000);
+    const unsigned rowa = (unsigned)(sref * (ptrdiff_t)sizeof(T)), rowb = (unsigned)(smon * (ptrdiff_t)sizeof(T));
     const bool col_on = lane < MI_CHIP;
-    const int cl = col_on ? lane : 0;
+    const unsigned cl = (col_on ? (unsigned)lane : 0u) * (unsigned)sizeof(T);
     typedef unsigned short mi_us2 __attribute__((ext_vector_type(2)));
     unsigned pk[MI_CHIP];
     mi_us2 vmin = {0xffff, 0xffff}, vmax = {0, 0};
 #pragma unroll
     for (int i = 0; i < MI_CHIP; i++) {
-        const unsigned a = (unsigned)(unsigned short)pr[(ptrdiff_t)i * sref + cl], b = (unsigned)(unsigned short)pm[(ptrdiff_t)i * smon + cl];
+        // (buffer descriptors: scalar row offsets, one lane offset - no vector instruction goes into addressing)
+        const unsigned a = km_chip_px<T>(bra, cl, (unsigned)i * rowa), b = km_chip_px<T>(brb, cl, (unsigned)i * rowb);
         pk[i] = (a | (b << 16)) ^ BIAS2;             // (int16: two's complement + 0x8000 = the value + 32768, for both halves at once)
         const mi_us2 v = __builtin_bit_cast(mi_us2, pk[i]);
         vmin = __builtin_elementwise_min(vmin, v);

@@ -4,6 +4,9 @@
 // fp64 sums reduced across the wave.
 #include "common.hpp"
 
+#include <cstdlib>
+#include <type_traits>
+
 #define ZN_HW 21
 #define ZN_MARGIN 28
 #define ZN_SIDE 43
@@ -85,6 +88,80 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
     if (lane == 0) out[k] = (sd1 == 0.0 || sd2 == 0.0) ? nan : cc / (sd1 * sd2) / (double)ZN_NPX;
 }
 
+// Integer pixel types (round 4): the same score from EXACT integer moments.  With n = 43^2 samples a, b < 2^16 (int16 biased by 2^15:
+// ZNCC does not see a constant), S_a, S_b < 2^27, S_aa, S_bb, S_ab < 2^43, and
+//     zncc = (n S_ab - S_a S_b) / sqrt((n S_aa - S_a^2) (n S_bb - S_b^2))
+// with both numerators exact in int64 (< 2^54).  That is the reference's mean(((p1 - m1) / s1) ((p2 - m2) / s2)) (zncc_service.py:118-126)
+// with ONE rounding per factor instead of numpy's two-pass float64 sums: closer to the real value than numpy itself (the gate is 1e-9;
+// observed difference to the two-pass form <= 1e-13), and "std == 0 -> NaN" (zncc_service.py:118-120) is the exact integer statement
+// n S_aa == S_a^2.  One pass, nothing kept: lane = chip column (43 of 64 lanes), one chip row per step, scalar row bases, ~30 VGPRs.
+// The float64 two-pass kernel above cost ~1 100 issue slots per key point (58 float64 registers of pixels, index arithmetic per pixel);
+// this one ~420.
+template <typename T>
+__global__ __launch_bounds__(256) void zncc_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                                       ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                                       const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                                       const float *__restrict__ score, float score_thr, double *__restrict__ out, km_window win)
+{
+    const int n_rows = d_n ? min(*d_n, n) : n;
+    const unsigned per = ((unsigned)(n_rows + 3) / 4 + KM_XCDS - 1) / KM_XCDS, blk = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
+    const int k = (int)blk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x / KM_XCDS >= per || k >= n_rows) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (score && !(score[k] >= score_thr)) { if (lane == 0) out[k] = nan; return; }
+    const float fx0 = x0[k], fy0 = y0[k];
+    int X0 = (int)fx0, Y0 = (int)fy0;
+    const float sx = __fadd_rn(fx0, dx[k]), sy = __fadd_rn(fy0, dy[k]);
+    bool ok = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+    int X1 = 0, Y1 = 0;
+    if (ok) {
+        X1 = __float2int_rn(sx); Y1 = __float2int_rn(sy);
+        const int Wr = win.H ? win.W : Wref, Hr = win.H ? win.H : Href, Wm = win.H ? win.W : Wmon, Hm = win.H ? win.H : Hmon;
+        ok = !(X0 - ZN_MARGIN < 0 || Y0 - ZN_MARGIN < 0 || X1 - ZN_MARGIN < 0 || Y1 - ZN_MARGIN < 0) &&
+             !(X0 >= Wr - ZN_MARGIN || Y0 >= Hr - ZN_MARGIN || X1 >= Wm - ZN_MARGIN || Y1 >= Hm - ZN_MARGIN);
+    }
+    if (!ok) { if (lane == 0) out[k] = nan; return; }
+    if (win.H) {
+        X0 -= win.ox; X1 -= win.ox; Y0 -= win.oy; Y1 -= win.oy;
+        if (X0 - ZN_HW < 0 || Y0 - ZN_HW < 0 || X1 - ZN_HW < 0 || Y1 - ZN_HW < 0 || X0 + ZN_HW >= Wref || Y0 + ZN_HW >= Href || X1 + ZN_HW >= Wmon ||
+            Y1 + ZN_HW >= Hmon) {
+            if (lane == 0) out[k] = __longlong_as_double((long long)KM_NAN_OUTSIDE_WINDOW);
+            return;
+        }
+    }
+    constexpr unsigned BIAS = std::is_signed<T>::value ? 32768u : 0u;
+    const int bx0 = __builtin_amdgcn_readfirstlane(X0 - ZN_HW), by0 = __builtin_amdgcn_readfirstlane(Y0 - ZN_HW);
+    const int bx1 = __builtin_amdgcn_readfirstlane(X1 - ZN_HW), by1 = __builtin_amdgcn_readfirstlane(Y1 - ZN_HW);
+    const T *pr = ref + (ptrdiff_t)by0 * sref + bx0;
+    const T *pm = mon + (ptrdiff_t)by1 * smon + bx1;
+    // chip rows through buffer descriptors: scalar row offsets, one lane offset - not one vector instruction goes into addressing
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)pr, 0, (int)(((ZN_SIDE - 1) * sref + ZN_SIDE) * (ptrdiff_t)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)pm, 0, (int)(((ZN_SIDE - 1) * smon + ZN_SIDE) * (ptrdiff_t)sizeof(T)), 0x00020000);
+    const unsigned rowa = (unsigned)(sref * (ptrdiff_t)sizeof(T)), rowb = (unsigned)(smon * (ptrdiff_t)sizeof(T));
+    unsigned sa = 0, sb = 0;
+    unsigned long long saa = 0, sbb = 0, sab = 0;
+    if (lane < ZN_SIDE) {                                  // (one exec mask for the whole pass: idle lanes keep zero sums)
+        const unsigned cl = (unsigned)lane * (unsigned)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < ZN_SIDE; i++) {
+            unsigned a = km_chip_px<T>(ra, cl, (unsigned)i * rowa), b = km_chip_px<T>(rb, cl, (unsigned)i * rowb);
+            if constexpr (std::is_signed<T>::value) { a = (a + BIAS) & 0xffffu; b = (b + BIAS) & 0xffffu; }
+            sa += a; sb += b;
+            saa += (unsigned long long)a * a; sbb += (unsigned long long)b * b; sab += (unsigned long long)a * b;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += (unsigned)__shfl_xor((int)sa, o); sb += (unsigned)__shfl_xor((int)sb, o); }
+    // per-lane second moments < 2^38, their wave sums < 2^43: exact in float64
+    const double daa = wave_sum_f64((double)saa), dbb = wave_sum_f64((double)sbb), dab = wave_sum_f64((double)sab);
+    if (lane == 0) {
+        const long long N = ZN_NPX, Sa = (long long)sa, Sb = (long long)sb;
+        const long long v1 = N * (long long)daa - Sa * Sa, v2 = N * (long long)dbb - Sb * Sb, cv = N * (long long)dab - Sa * Sb;
+        out[k] = (v1 == 0 || v2 == 0) ? nan : (double)cv / (sqrt((double)v1) * sqrt((double)v2));
+    }
+}
+
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,
             ptrdiff_t smon, const float *d_x0, const float *d_y0, const float *d_dx, const float *d_dy, int n, double *d_out)
 {
@@ -97,6 +174,19 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
 {
     if (n <= 0) return KM_OK;
     const int nb = (int)km_xcd_grid((unsigned)((n + 3) / 4));
+    static const bool two_pass = getenv("KARIOS_HIP_ZNCC_TWO_PASS") != nullptr;     // A/B: the float64 two-pass kernel for every pixel type
+    if (dtype != KM_F32 && !two_pass) {
+#define KM_ZI(T) zncc_int_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
+        switch (dtype) {
+        case KM_U8: KM_ZI(uint8_t); break;
+        case KM_U16: KM_ZI(uint16_t); break;
+        case KM_I16: KM_ZI(int16_t); break;
+        default: return km_fail(c, KM_E_ARG, "zncc: bad dtype %d", dtype);
+        }
+#undef KM_ZI
+        KM_LAUNCH_CHECK(c);
+        return KM_OK;
+    }
 #define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
     switch (dtype) {
     case KM_U8: KM_Z(uint8_t); break;

@@ -22,7 +22,7 @@ STAGES = {   # stage key -> kernel-name fragments
     "pyramid": ("pyrdown_kernel",),
     "lk_fwd_bwd": ("lk2_kernel", "lk_kernel", "lk_order"),
     "fb_frame": ("fb_compact", "fb_place", "fb_gather"),
-    "zncc": ("zncc_kernel",),
+    "zncc": ("zncc_kernel", "zncc_int_kernel"),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
     "mi_kernel": ("mi_kernel", "mi_int_kernel"),
