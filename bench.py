@@ -784,6 +784,9 @@ def main():
         # RCCL ("nccl" on ROCm) in production; gloo lets the multi-rank logic be exercised with several ranks sharing one GPU
         # (development box) - the collectives then run on CPU tensors
         if backend == "nccl":
+            # RCCL's version banner goes to STDOUT unless NCCL_DEBUG is NONE (tools/rccl_banner_probe.py, run 17: NONE is the only
+            # setting of the ones tried that removes it; RCCL_LOG_LEVEL does not) - stdout is the JSON line's.  An explicit NCCL_DEBUG wins.
+            os.environ.setdefault("NCCL_DEBUG", "NONE")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
