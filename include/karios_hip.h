@@ -168,8 +168,14 @@ int km_upload_join(km_ctx *ctx, int ticket);
 #define KM_NAN_OUTSIDE_WINDOW 0x7ff80000dead0000ull
 int km_set_image_window(km_ctx *ctx, int ox, int oy, int H_image, int W_image);
 /* Which evaluation the last km_phase_shift* call used: *path = 1 float32 hand-written FFT (k_fft.hip), 2 double precision
- * (rocFFT); *margin = (largest - second largest) / largest sample of |cross-correlation| seen by the float32 path. */
+ * (hand-written too, k_fft64.hip); *margin = (largest - second largest) / largest sample of |cross-correlation| seen by the
+ * float32 path. */
 int km_phase_info(km_ctx *ctx, int *path, double *margin);
+/* Test hook, host only (no device, no context): how the double-precision transform behind km_phase_shift* (large_offset.py:39)
+ * decomposes a side of n pixels - levels[2 i] = length of level i, levels[2 i + 1] = 0 (radices 2/3/5/7 in LDS) or 1 (one prime,
+ * 11 .. 127); *bluestein = length of the chirp-z convolution when n has a larger prime factor (then no levels), else 0;
+ * negpos[pos] (n ints, may be NULL) = position at which the forward levels leave the negated frequency of position pos. */
+int km_phase_plan(int n, int along_columns, int *levels, int cap_levels, int *n_levels, int *bluestein, int *negpos);
 /* Optional device-side copy of every frame block the km_klt_tile_frame_* entry points produce (same layout), e.g. a slice of
  * the send buffer of an RCCL all-gather: the block then never bounces through host memory.  NULL switches it off. */
 int km_set_frame_sink(km_ctx *ctx, void *d_dst, size_t capacity_bytes);

@@ -71,6 +71,7 @@ SIGNATURES = {
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
     "km_stream_wait_frame": (_i, [_vp, _i, _vp]),
     "km_phase_info": (_i, [_vp, _pi, _pd]),
+    "km_phase_plan": (_i, [_i, _i, _vp, _i, _pi, _pi, _vp]),
     "km_set_image_window": (_i, [_vp, _i, _i, _i, _i]),
     "km_minmax_dev": (_i, [_vp, _vp, _i, _i, _i, _sz, _pd]),
     "km_band_prefilter_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _pd, _pd, _pd, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)]),

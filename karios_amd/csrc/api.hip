@@ -2,6 +2,7 @@
 // the device-resident KLT tile pipeline.  Nothing here computes on the CPU: every entry point
 // ends in HIP kernels on the context stream; there is no fallback path.
 #include "common.hpp"
+#include "fft64_plan.hpp"
 #include <vector>
 
 #include <dlfcn.h>
@@ -439,6 +440,22 @@ int km_phase_info(km_ctx *c, int *path, double *margin)
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     if (path) *path = c->phase_path;
     if (margin) *margin = c->phase_margin;
+    return KM_OK;
+}
+int km_phase_plan(int n, int along_columns, int *levels, int cap_levels, int *n_levels, int *bluestein, int *negpos)
+{
+    if (n < 1 || cap_levels < 0 || (cap_levels > 0 && !levels)) return KM_E_ARG;
+    f64plan::dimplan P;
+    if (!f64plan::plan_dim(n, along_columns ? 256 : F64_SMOOTH_MAX, &P)) return KM_E_UNSUPPORTED;
+    if ((int)P.lv.size() > cap_levels) return KM_E_ARG;
+    for (size_t i = 0; i < P.lv.size(); i++) { levels[2 * i] = P.lv[i].n; levels[2 * i + 1] = P.lv[i].kind; }
+    if (n_levels) *n_levels = (int)P.lv.size();
+    if (bluestein) *bluestein = P.blue ? P.L : 0;
+    if (negpos) {
+        std::vector<int> ng;
+        f64plan::host_negpos(P, ng);
+        for (int i = 0; i < n; i++) negpos[i] = ng[(size_t)i];
+    }
     return KM_OK;
 }
 int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)

@@ -85,6 +85,12 @@ enum km_slot {
     WS_FFT_TW1,
     WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
     WS_MI_TABLE,    // c ln c, c = 0 .. 57^2 (k_mi.hip)
+    WS_F64_TWX,     // k_fft64.hip: exp(-2 pi i j / W), exp(-2 pi i j / H) ...
+    WS_F64_TWY,
+    WS_F64_NEGX,    //   ... position of the negated frequency along x / y ...
+    WS_F64_NEGY,
+    WS_F64_BLUEX,   //   ... and the tables of a Bluestein dimension
+    WS_F64_BLUEY,
     WS_COUNT
 };
 
@@ -242,12 +248,10 @@ struct km_ctx {
     km_klt_stats stats;
     int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (rocFFT)
     double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
-    void *fft_plan_fwd = nullptr, *fft_plan_inv = nullptr;
-    int fft_h = 0, fft_w = 0;
+    int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
     bool mi_table_ready = false;   // WS_MI_TABLE holds its table
     int fft_tw_m[2] = {-1, -1};    //   ... and the 61 M plan they were laid out for (0: Stockham table only)
-    size_t fft_work_bytes = 0;
 };
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
@@ -454,6 +458,9 @@ int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Hr
 int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W,
                    ptrdiff_t stride_a, ptrdiff_t stride_b, double out_rc[2]);
 void kp_destroy(km_ctx *c);
+// k_fft64.hip: the double-precision evaluation (any side length)
+int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t stride_a, ptrdiff_t stride_b,
+                       double out_rc[2]);
 // k_fft.hip: hand-written float32 phase correlation (sides with prime factors in {2,3,5,7,61}, <= 12288)
 bool kp_fast_supported(int H, int W);
 int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H, int W, ptrdiff_t stride_a, ptrdiff_t stride_b,

@@ -485,3 +485,60 @@ def test_inline_assembly_hazard_scan_of_the_device_code(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hazard_scan.py"), *asm], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("0 potential DOT hazards") == len(asm) and r.stdout.count("0 potential DPP hazards") == len(asm), r.stdout[-2000:]
+
+
+def _levels_forward(x, levels):
+    """numpy model of the forward levels of k_fft64.hip: level l replaces, in every block of n_l R_l consecutive elements and for
+    every r < R_l, the n_l elements at stride R_l by their DFT times W_{n_l R_l}^(r k) - in place."""
+    x = x.copy()
+    N = len(x)
+    tw = np.exp(-2j * np.pi * np.arange(N) / N)
+    R = N
+    for n in levels:
+        Nl, R = R, R // n
+        for blk in range(N // Nl):
+            for r in range(R):
+                idx = blk * Nl + r + R * np.arange(n)
+                x[idx] = np.fft.fft(x[idx]) * tw[(r * np.arange(n)) * (N // Nl)]
+    return x
+
+
+def test_phase_plan_levels_multiply_to_the_side_and_pair_every_frequency_with_its_negative():
+    """km_phase_plan (host only): the level plan of the double-precision phase correlation (large_offset.py:39 is complex128) for
+    Sentinel-2 sides, smooth sides, sides with other small primes and sides that need Bluestein; the positions of the negated
+    frequencies are checked against a numpy model of the level arithmetic and numpy's own FFT."""
+    import ctypes as C
+    from karios_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    for n, cols in [(10980, 0), (10980, 1), (5490, 0), (1830, 1), (3721, 0), (1, 0), (2, 1), (7, 0), (61, 0), (122, 1), (1000, 0), (1000, 1),
+                    (4096, 0), (4096, 1), (65536, 1), (2 * 3 * 5 * 7 * 11 * 13, 0), (127 * 4, 1), (131, 0), (10007, 1), (2 * 257, 0), (6000, 1)]:
+        levels = (C.c_int * 32)()
+        nl, blue = C.c_int(-1), C.c_int(-1)
+        neg = np.full(n, -1, np.int32)
+        assert lib.km_phase_plan(n, cols, levels, 16, C.byref(nl), C.byref(blue), neg.ctypes.data_as(C.c_void_p)) == 0
+        lv = [(levels[2 * i], levels[2 * i + 1]) for i in range(nl.value)]
+        big_prime = max([p for p in range(2, n + 1) if n % p == 0 and all(p % q for q in range(2, int(p ** 0.5) + 1))], default=1) if n < 70000 else 0
+        if big_prime > 127:
+            assert blue.value >= 2 * n - 1 and blue.value & (blue.value - 1) == 0 and not lv
+            np.testing.assert_array_equal(neg, (n - np.arange(n)) % n)
+            continue
+        assert blue.value == 0 and int(np.prod([a for a, _ in lv] or [1])) == n
+        for i, (a, kind) in enumerate(lv):
+            if kind == 1:
+                assert 11 <= a <= 127 and all(a % q for q in range(2, a))
+            else:
+                assert all(p in (2, 3, 5, 7) for p in range(2, a + 1) if a % p == 0 and all(p % q for q in range(2, p)))
+                assert a <= (2048 if (not cols and i == len(lv) - 1) else 256)
+        np.testing.assert_array_equal(neg[neg], np.arange(n))                       # an involution
+        if n <= 11000 and lv:
+            x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            X, ref = _levels_forward(x, [a for a, _ in lv]), np.fft.fft(x)
+            scale = np.abs(ref).max()
+            pos_of = np.empty(n, np.int64)                                           # frequency at each position, from the spectrum itself
+            for pos in rng.integers(0, n, 40):
+                f = int(np.argmin(np.abs(ref - X[pos])))
+                assert abs(ref[f] - X[pos]) < 1e-9 * scale
+                assert abs(X[neg[pos]] - ref[(-f) % n]) < 1e-9 * scale
+    assert lib.km_phase_plan(0, 0, levels, 16, None, None, None) < 0
+    assert lib.km_phase_plan(10980, 0, levels, 1, None, None, None) < 0                 # two levels do not fit one slot
