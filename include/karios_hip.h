@@ -119,9 +119,12 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *                  KariosAPI._handle_klt_results (api/core.py:894-907) in the tile call: two more float64 columns of `cap`
  *                  entries behind the zncc column (NaN where score < threshold or the chip leaves the image); 0 (default): ZNCC only
  *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
- *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (rocFFT), the reference's precision; 0 (default):
+ *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (k_fft64.hip), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
  *                  float32 correlation peak is not at least 1 % above every other sample
+ *   "f64_plain"    1: the double-precision transform packs the images in a pass of its own and finds the arg-max in two
+ *                  passes behind the last level (default 0: both ends ride in the level kernels); development knobs of the
+ *                  same transform: "f64_prime_t", "f64_smooth_t" (transforms per workgroup tile, 0 = default)
  *   "profile_stage" with km_set_profiling(1): time only stage i of km_stage_name (every timed span records two events on the
  *                  library stream and the kernels either side no longer overlap: ~6 us per span); -1 (default): every stage
  * Returns KM_E_ARG for an unknown name. */

@@ -341,7 +341,7 @@ class Context:
         return self.__dict__.get("_options", {}).get(name, default)
 
     def phase_info(self) -> tuple[int, float]:
-        """(path, margin) of the last phase correlation: path 1 = float32 hand-written FFT, 2 = double precision (rocFFT)."""
+        """(path, margin) of the last phase correlation: path 1 = float32 hand-written FFT, 2 = double precision (hand-written too, k_fft64.hip)."""
         path, margin = C.c_int(), C.c_double()
         self.check(self.lib.km_phase_info(self.handle, C.byref(path), C.byref(margin)), "km_phase_info")
         return path.value, margin.value

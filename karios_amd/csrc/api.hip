@@ -221,6 +221,9 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
     if (strcmp(name, "fft_ts") == 0) { c->opt_fft_ts = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
+    if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "f64_plain") == 0) { c->opt_f64_plain = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
     if (strcmp(name, "aux_early") == 0) { c->opt_aux_early = value != 0; return KM_OK; }

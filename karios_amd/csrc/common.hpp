@@ -226,7 +226,7 @@ struct km_ctx {
     bool opt_fft_cross_fused = true;   // "fft_cross": the cross-power step fused into the first inverse pass's row load (61 M rows)
     bool opt_fft_ts = false;       // "fft_ts" 1: rows of length 61 M on both sides - the two transposes are folded into the stores of the row passes in front of them (8-byte stores at a stride of one row, XCD-contiguous rows so that the lines fill up in L2): correct, the plane crosses HBM four times instead of six - and SLOWER (4.86 against 4.66 ms at 10980^2: the row kernels' store phase grows by more than the two 0.42-ms transposes cost).  0 (default): transpose kernels
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
-    bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision through rocFFT (the reference's precision)
+    bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision, k_fft64.hip (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
     int opt_lk_pair = 0;           // "lk_pair" 1: winSize 25 through the PAIR form of the second LK form (two key points per wavefront, one per 32-lane half): bit-identical, fewer per-point instructions in the template pass, and SLOWER (0.31 against 0.26 ms at 20 000 corners beside the next unit's min / max): 155 VGPRs = 3 waves per SIMD instead of 6, and the per-half address arithmetic the compiler rematerialises in the iteration loop eats what the shared per-point chain saves.  0 (default): one key point per wavefront
     bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
@@ -246,9 +246,12 @@ struct km_ctx {
     void *pinned_rb = nullptr;
     size_t pinned_rb_cap = 0;
     km_klt_stats stats;
-    int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (rocFFT)
+    int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (k_fft64.hip)
     double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
+    int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
+    int opt_f64_smooth_t = 0;      // "f64_smooth_t": the same for the smooth level kernel (default 8)
+    bool opt_f64_plain = false;    // "f64_plain" 1: pack pass in front, two arg-max passes behind (instead of fusing both ends into the level kernels)
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
     bool mi_table_ready = false;   // WS_MI_TABLE holds its table
     int fft_tw_m[2] = {-1, -1};    //   ... and the 61 M plan they were laid out for (0: Stockham table only)

@@ -42,18 +42,27 @@ __device__ __forceinline__ cd c_mul(cd a, cd b) { return make_double2(fma(a.x, b
 struct lvl_args {
     cd *data;
     const cd *tw;                    // exp(-2 pi i j / N), j < N  (N = length of the dimension)
+    const cd *ltw;                   // inter-level twiddles of this level, laid out like a block of the data: ltw[k R + r] = W_{n R}^(r k)
+    const cd *ptab;                  // prime level: (cos, -sin)(2 pi j k / p) at [(j - 1) (h + 7) + k - 1], j = 1 .. h + 2, k = 1 .. h + 7 (h = (p - 1) / 2)
     long long se, sb, s_blk, s_r;    // strides in elements: between the elements of a transform, between the transforms of a tile, of `a`
     int n;                           // transform length
-    int T, logT;                     // transforms per workgroup (a power of two unless `contiguous`)
+    int T, logT;                     // transforms per workgroup (a power of two in the smooth kernel unless `contiguous`)
     int AR;                          // a -> (a / AR) * s_blk + (a % AR) * s_r
     int B, tiles_b;                  // transforms along b, tiles of T
     int tw_mode;                     // inter-level twiddle W_{n R}^(q k):  0 none, 1 q = b, 2 q = a % AR
-    int tw_scale;                    // N / (n R)
+    int ltw_R;                       // R of this level
     int N;
     int inverse;
-    int contiguous;                  // smooth kernel: every transform is contiguous in memory (se == 1): the lanes walk i, not t
+    int contiguous;                  // the transforms of a tile are contiguous in memory one after the other (se == 1, sb == n)
     int nst;
     int radix[F64_MAX_STAGES];
+    // first forward level along the rows: the plane z = a + i b is read from the two images instead (pixel (y, x); no pack pass)
+    const void *img_a, *img_b;
+    long long img_sa, img_sb;
+    // last inverse level: the outputs are the correlation surface - every workgroup reports the largest |cc| it wrote (bit pattern)
+    // and the first flat index that attains it: best[2 wg], best[2 wg + 1]  (two passes over the plane are gone)
+    unsigned long long *best;
+    int dbg;                         // development ("fft_dbg"): 1 skip the arithmetic, 2 skip the loads, 4 skip the stores - timing experiments, results are wrong
 };
 
 // ---------------------------------------------------------------------------------------------------------------- small DFTs
@@ -132,10 +141,60 @@ __device__ __forceinline__ long long tile_base(const lvl_args &A, int a, int b0)
     return (long long)(a / A.AR) * A.s_blk + (long long)(a % A.AR) * A.s_r + (long long)b0 * A.sb;
 }
 
+// IMG: pixel type of the images the first forward level reads (KM_U8 / KM_U16 / KM_I16 / KM_F32), or -1: the plane (a kernel per
+// type: a run-time switch per pixel put every load of the unrolled batch into a basic block of its own)
+template <int IMG> __device__ __forceinline__ double px_f64(const void *p, size_t off)
+{
+    if constexpr (IMG == KM_U8) return (double)((const uint8_t *)p)[off];
+    else if constexpr (IMG == KM_U16) return (double)((const uint16_t *)p)[off];
+    else if constexpr (IMG == KM_I16) return (double)((const int16_t *)p)[off];
+    else return (double)((const float *)p)[off];
+}
+template <int IMG> __device__ __forceinline__ cd px_pair(const lvl_args &A, int y, int x)
+{
+    return make_double2(px_f64<IMG>(A.img_a, (size_t)y * (size_t)A.img_sa + (size_t)x), px_f64<IMG>(A.img_b, (size_t)y * (size_t)A.img_sb + (size_t)x));
+}
+
+// (largest |cc| as bits, first flat index): a thread's running best, the wavefront's, the workgroup's
+struct best_t {
+    unsigned long long bits = 0, idx = ~0ull;
+    __device__ __forceinline__ void see(cd v, unsigned long long flat)
+    {
+        const double m = hypot(v.x, v.y);
+        if (m == m) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+            if (b > bits || (b == bits && flat < idx)) { bits = b; idx = flat; }
+        }
+    }
+    __device__ __forceinline__ void merge(unsigned long long ob, unsigned long long oi)
+    {
+        if (ob > bits || (ob == bits && oi < idx)) { bits = ob; idx = oi; }
+    }
+};
+__device__ __forceinline__ void best_publish(best_t bt, unsigned long long *out, unsigned long long *s_b /* 8 words of LDS */)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(bt.bits, o), oi = __shfl_xor(bt.idx, o);
+        bt.merge(ob, oi);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_b[2 * wave] = bt.bits; s_b[2 * wave + 1] = bt.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best_t r;
+        for (int w = 0; w < 4; w++) r.merge(s_b[2 * w], s_b[2 * w + 1]);
+        out[2 * (size_t)blockIdx.x] = r.bits; out[2 * (size_t)blockIdx.x + 1] = r.idx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- smooth level
-__global__ __launch_bounds__(256) void f64_smooth_kernel(const lvl_args A)
+// n T <= 2048 elements per tile: at most 8 per thread - all of a thread's loads are in flight before the first one is consumed
+#define F64_SM_PER_THREAD 8
+template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(const lvl_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    __shared__ unsigned long long s_b[8];
     const int n = A.n, T = A.T, logT = A.logT;
     cd *buf0 = (cd *)smem64, *buf1 = buf0 + n * T, *twl = buf1 + n * T;       // twl[j] = exp(-2 pi i j / n)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,32 +203,51 @@ __global__ __launch_bounds__(256) void f64_smooth_kernel(const lvl_args A)
     const int qa = a % A.AR;
     cd *__restrict__ data = A.data;
     const cd *__restrict__ tw = A.tw;
-    for (int j = tid; j < n; j += 256) twl[j] = tw[(size_t)j * (size_t)(A.N / n)];
+    const cd *__restrict__ ltw = A.ltw;
     const bool contig = A.contiguous != 0;
-    const int lsi = contig ? 1 : T, lst = contig ? n : 1;
-
-    auto ld = [&](int i, int t) {
-        cd v = data[base + (long long)i * A.se + (long long)t * A.sb];
-        if (A.inverse) {
-            v.y = -v.y;                                                        // inverse DFT = conj . DFT . conj
-            if (A.tw_mode) v = c_mul(v, tw[(size_t)(A.tw_mode == 1 ? b0 + t : qa) * (size_t)i * (size_t)A.tw_scale]);   // conj(x conj w) = conj(x) w
-        }
-        buf0[i * lsi + t * lst] = v;
+    const int lsi = contig ? 1 : T;
+    const unsigned magic_n = (unsigned)((0x100000000ull + (unsigned)n - 1) / (unsigned)n);     // e / n for e < 2048 (n >= 2)
+    // element e of the tile (= its LDS slot): strided tiles are [i][t] (t = e % T), contiguous tiles [t][i] (the memory order)
+    auto split = [&](int e, int &i, int &t) {
+        if (contig) { t = (int)__umulhi((unsigned)e, magic_n); i = e - t * n; }
+        else { t = e & (T - 1); i = e >> logT; }
     };
-    if (contig) {
-        for (int t = wave; t < nt; t += 4)
-            for (int i = lane; i < n; i += 64) ld(i, t);
-    } else {
-        for (int idx = tid; idx < n * T; idx += 256) {
-            const int t = idx & (T - 1), i = idx >> logT;
-            if (t < nt) ld(i, t); else buf0[idx] = make_double2(0.0, 0.0);
+    auto addr = [&](int e, int i, int t) { return contig ? base + e : base + (long long)i * A.se + t; };
+    {
+        cd v[F64_SM_PER_THREAD], w[F64_SM_PER_THREAD];
+        const bool pre = A.inverse && A.tw_mode;
+#pragma unroll
+        for (int u = 0; u < F64_SM_PER_THREAD; u++) {
+            const int e = tid + 256 * u;
+            int i, t;
+            split(e, i, t);
+            v[u] = make_double2(0.0, 0.0);
+            w[u] = make_double2(1.0, 0.0);
+            if (e < n * T && t < nt && !(A.dbg & 2)) {
+                if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + t, i) : px_pair<IMG>(A, a, b0 + t + i * (int)A.se);
+                else v[u] = data[addr(e, i, t)];
+                if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)(A.tw_mode == 1 ? b0 + t : qa)];
+            }
+        }
+        for (int j = tid; j < n; j += 256) twl[j] = tw[(size_t)j * (size_t)(A.N / n)];
+#pragma unroll
+        for (int u = 0; u < F64_SM_PER_THREAD; u++) {
+            const int e = tid + 256 * u;
+            if (e < n * T) {
+                cd x = v[u];
+                if (A.inverse) {
+                    x.y = -x.y;                                                // inverse DFT = conj . DFT . conj
+                    if (pre) x = c_mul(x, w[u]);                               // conj(x conj w) = conj(x) w
+                }
+                buf0[e] = x;
+            }
         }
     }
     __syncthreads();
 
     cd *src = buf0, *dst = buf1;
     int Ns = 1;
-    for (int s = 0; s < A.nst; s++) {
+    for (int s = 0; s < ((A.dbg & 1) ? 0 : A.nst); s++) {
         const int R = A.radix[s], nb = n / R, twstep = n / (Ns * R);
         const unsigned magic = Ns > 1 ? (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns) : 0u;
         auto run = [&](auto rc) {
@@ -178,7 +256,7 @@ __global__ __launch_bounds__(256) void f64_smooth_kernel(const lvl_args A)
                 for (int t = wave; t < nt; t += 4)
                     for (int b = lane; b < nb; b += 64) bfly<RR>(src, dst, b, nb, Ns, magic, 1, t * n, twl, twstep);
             } else {
-                for (int idx = tid; idx < nb * T; idx += 256) bfly<RR>(src, dst, idx >> logT, nb, Ns, magic, T, idx & (T - 1), twl, twstep);
+                for (int idx = tid; idx < nb * T; idx += 256) bfly<RR>(src, dst, idx >> logT, nb, Ns, magic, lsi, idx & (T - 1), twl, twstep);
             }
         };
         switch (R) {
@@ -193,104 +271,188 @@ __global__ __launch_bounds__(256) void f64_smooth_kernel(const lvl_args A)
         Ns *= R;
     }
 
-    auto st = [&](int i, int t) {
-        cd v = src[i * lsi + t * lst];
-        if (A.inverse) v.y = -v.y;
-        else if (A.tw_mode) v = c_mul(v, tw[(size_t)(A.tw_mode == 1 ? b0 + t : qa) * (size_t)i * (size_t)A.tw_scale]);
-        data[base + (long long)i * A.se + (long long)t * A.sb] = v;
-    };
-    if (contig) {
-        for (int t = wave; t < nt; t += 4)
-            for (int i = lane; i < n; i += 64) st(i, t);
-    } else {
-        for (int idx = tid; idx < n * T; idx += 256) {
-            const int t = idx & (T - 1), i = idx >> logT;
-            if (t < nt) st(i, t);
+    best_t bt;
+    {
+        const bool post = !A.inverse && A.tw_mode;
+        cd w[F64_SM_PER_THREAD];
+        if (post) {
+#pragma unroll
+            for (int u = 0; u < F64_SM_PER_THREAD; u++) {
+                const int e = tid + 256 * u;
+                int i, t;
+                split(e, i, t);
+                w[u] = make_double2(1.0, 0.0);
+                if (e < n * T && t < nt) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)(A.tw_mode == 1 ? b0 + t : qa)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < F64_SM_PER_THREAD; u++) {
+            const int e = tid + 256 * u;
+            int i, t;
+            split(e, i, t);
+            if (e < n * T && t < nt) {
+                cd x = src[e];
+                if (A.inverse) x.y = -x.y;
+                else if (post) x = c_mul(x, w[u]);
+                const long long o = addr(e, i, t);
+                if (!(A.dbg & 4)) data[o] = x;
+                if (A.best) bt.see(x, (unsigned long long)o);
+            }
         }
     }
+    if (A.best) best_publish(bt, A.best, s_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- prime level
-__global__ __launch_bounds__(256) void f64_prime_kernel(const lvl_args A)
+#define F64_PR_BATCH 8     // rows of the tile a wavefront has in flight at once while it fills the LDS
+template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const lvl_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    __shared__ unsigned long long s_b[8];
     cd *sm = (cd *)smem64;                                                     // [i][t], t < T <= 64
     const int p = A.n, T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
     const long long base = tile_base(A, a, b0);
     cd *__restrict__ data = A.data;
-    const cd *__restrict__ tw = A.tw;
-    const int q = A.tw_mode == 1 ? b0 + lane : a % A.AR;
+    const cd *__restrict__ ltw = A.ltw;
+    const int q = A.tw_mode == 1 ? b0 + lane : a % A.AR;                       // (tw_mode 2: the same for the whole workgroup)
     const long long loff = (long long)lane * A.sb;
-    for (int i = wave; i < p; i += 4) {
-        cd v = make_double2(0.0, 0.0);
-        if (lane < nt) {
-            v = data[base + (long long)i * A.se + loff];
-            if (A.inverse) {
-                v.y = -v.y;
-                if (A.tw_mode) v = c_mul(v, tw[(size_t)q * (size_t)i * (size_t)A.tw_scale]);
+    const bool pre = A.inverse && A.tw_mode, contig = A.contiguous != 0;
+    for (int u0 = 0; wave + 4 * u0 < p; u0 += F64_PR_BATCH) {
+        cd v[F64_PR_BATCH], w[F64_PR_BATCH];
+#pragma unroll
+        for (int u = 0; u < F64_PR_BATCH; u++) {
+            const int i = wave + 4 * (u0 + u);
+            v[u] = make_double2(0.0, 0.0);
+            w[u] = make_double2(1.0, 0.0);
+            if (i < p && lane < nt && !(A.dbg & 2)) {
+                if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + lane, i) : px_pair<IMG>(A, a, b0 + lane + i * (int)A.se);
+                else v[u] = data[base + (long long)i * A.se + loff];
+                if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)q];
             }
         }
-        if (lane < T) sm[i * T + lane] = v;
+#pragma unroll
+        for (int u = 0; u < F64_PR_BATCH; u++) {
+            const int i = wave + 4 * (u0 + u);
+            if (i < p && lane < T) {
+                cd x = v[u];
+                if (A.inverse) {
+                    x.y = -x.y;
+                    if (pre) x = c_mul(x, w[u]);
+                }
+                sm[i * T + lane] = x;
+            }
+        }
     }
     __syncthreads();
     const int h = (p - 1) / 2;
-    const size_t tws = (size_t)(A.N / p);
     const int l = min(lane, T - 1);
-    auto put = [&](int k, cd v) {
-        if (lane >= nt) return;                                                // (q of an idle lane would index past the table)
+    best_t bt;
+    const bool post = !A.inverse && A.tw_mode;
+    auto put = [&](int k, cd v, cd w) {
+        if (lane >= nt) return;
         if (A.inverse) v.y = -v.y;
-        else if (A.tw_mode) v = c_mul(v, tw[(size_t)q * (size_t)k * (size_t)A.tw_scale]);
-        data[base + (long long)k * A.se + loff] = v;
+        else if (post) v = c_mul(v, w);
+        const long long o = base + (long long)k * A.se + loff;
+        if (!(A.dbg & 4)) data[o] = v;
+        if (A.best) bt.see(v, (unsigned long long)o);
     };
-    // the coefficient addresses are the same for every lane: through the constant address space they become scalar loads
+    auto ltw_of = [&](int k) {                                                 // W_{n R}^(q k): one coalesced row of the table per k
+        return post && lane < nt ? ltw[(size_t)k * (size_t)A.ltw_R + (size_t)q] : make_double2(1.0, 0.0);
+    };
+    // the coefficient addresses are the same for every lane: through the constant address space they become scalar loads; the
+    // table holds one row per j with k running along it, so that the eight coefficient pairs of a step are 128 consecutive bytes
+    // (two wide scalar loads and one pointer step; an index (j k) mod p stepped and wrapped per coefficient cost 7 scalar
+    // instructions each - more issue slots than the FMAs they feed)
     typedef const __attribute__((address_space(4))) double *scalar_f64_ptr;
-    const scalar_f64_ptr twc = (scalar_f64_ptr)(unsigned long long)tw;
-    auto coef = [&](int i) { const size_t o = 2 * (size_t)i * tws; return make_double2(twc[o], twc[o + 1]); };
+    const scalar_f64_ptr ptab = (scalar_f64_ptr)(unsigned long long)A.ptab;
+    const size_t prow = 2 * (size_t)(h + 7);                                   // doubles per table row
     for (int g0 = wave * F64_KB; g0 < h; g0 += 4 * F64_KB) {                   // (uniform per wavefront)
         cd C[F64_KB], S[F64_KB], w[F64_KB];
-        int idx[F64_KB];
+        const scalar_f64_ptr col = ptab + 2 * (size_t)g0;                      // k = g0 + 1 .. g0 + 8
 #pragma unroll
         for (int kk = 0; kk < F64_KB; kk++) {
             C[kk] = S[kk] = make_double2(0.0, 0.0);
-            idx[kk] = g0 + kk + 1;                                             // (j k) mod p for j = 1, k = g0 + kk + 1 < p
-            w[kk] = coef(idx[kk]);                                             // (cos, -sin)(2 pi j k / p)
+            w[kk] = make_double2(col[2 * kk], col[2 * kk + 1]);                // j = 1
         }
         const cd x0 = sm[l];
         cd sum = x0;
         cd xa = sm[T + l], xb = sm[(p - 1) * T + l];
-        for (int j = 1; j <= h; j++) {
-            // inputs and coefficients of j + 1 travel while j is accumulated (j = h fetches a pair nobody uses)
-            const cd nxa = sm[(j + 1) * T + l], nxb = sm[(p - j - 1) * T + l];
-            cd nw[F64_KB];
+        // two steps of j per trip, the inputs and coefficients of the next step travelling while the current one is accumulated
+        // (registers alternate: no copies; a wavefront issues one instruction per four cycles whatever its kind, so every
+        // instruction that is not one of the 32 FMAs of a step counts)
+        auto fetch = [&](int j, cd &na, cd &nb, cd *nw) {                      // step j (its table column is j - 1)
+            na = sm[j * T + l]; nb = sm[(p - j) * T + l];
 #pragma unroll
-            for (int kk = 0; kk < F64_KB; kk++) {
-                idx[kk] += g0 + kk + 1;
-                if (idx[kk] >= p) idx[kk] -= p;
-                nw[kk] = coef(idx[kk]);
-            }
-            const cd fa = c_add(xa, xb), fb = c_sub(xa, xb);
+            for (int kk = 0; kk < F64_KB; kk++) nw[kk] = make_double2(col[(size_t)(j - 1) * prow + 2 * kk], col[(size_t)(j - 1) * prow + 2 * kk + 1]);
+        };
+        auto accumulate = [&](const cd &pa, const cd &pb, const cd *cw) {
+            const cd fa = c_add(pa, pb), fb = c_sub(pa, pb);
             sum = c_add(sum, fa);
 #pragma unroll
             for (int kk = 0; kk < F64_KB; kk++) {
-                C[kk].x = fma(fa.x, w[kk].x, C[kk].x); C[kk].y = fma(fa.y, w[kk].x, C[kk].y);
-                S[kk].x = fma(fb.x, w[kk].y, S[kk].x); S[kk].y = fma(fb.y, w[kk].y, S[kk].y);      // S = - sum (x_j - x_{p-j}) sin
-                w[kk] = nw[kk];
+                C[kk].x = fma(fa.x, cw[kk].x, C[kk].x); C[kk].y = fma(fa.y, cw[kk].x, C[kk].y);
+                S[kk].x = fma(fb.x, cw[kk].y, S[kk].x); S[kk].y = fma(fb.y, cw[kk].y, S[kk].y);    // S = - sum (x_j - x_{p-j}) sin
             }
-            xa = nxa; xb = nxb;
+        };
+        const int hh = (A.dbg & 1) ? 0 : h;
+        for (int j = 1; j <= hh; j += 2) {
+            cd ya, yb, w1[F64_KB];
+            fetch(j + 1, ya, yb, w1);                                          // (j + 1 = h + 1: fetched, never used)
+            __builtin_amdgcn_sched_barrier(0);                                 // the loads stay up here: their latency is the 32 FMAs below
+            accumulate(xa, xb, w);
+            __builtin_amdgcn_sched_barrier(0);                                 // ... and nothing that waits for them moves in front of the FMAs
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0) HERE: LDS and scalar loads share the counter and return
+            __builtin_amdgcn_sched_barrier(0);                                 // out of order between them - a wait for the LDS data placed behind the next scalar loads would wait for those too
+            if (j + 1 > hh) break;
+            fetch(j + 2, xa, xb, w);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(ya, yb, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int nk = min(F64_KB, h - g0);
+        // the inter-level twiddles of this group's outputs: all loads first
+        cd wk[F64_KB], wm[F64_KB];
+#pragma unroll
+        for (int kk = 0; kk < F64_KB; kk++) {
+            const int k = min(g0 + kk + 1, h);
+            wk[kk] = ltw_of(k);
+            wm[kk] = ltw_of(p - k);
+        }
 #pragma unroll
         for (int kk = 0; kk < F64_KB; kk++) {
             if (kk < nk) {
                 const int k = g0 + kk + 1;
                 const double cr = x0.x + C[kk].x, ci = x0.y + C[kk].y;
-                put(k, make_double2(cr - S[kk].y, ci + S[kk].x));              // x0 + C + i S
-                put(p - k, make_double2(cr + S[kk].y, ci - S[kk].x));          // x0 + C - i S
+                put(k, make_double2(cr - S[kk].y, ci + S[kk].x), wk[kk]);      // x0 + C + i S
+                put(p - k, make_double2(cr + S[kk].y, ci - S[kk].x), wm[kk]);  // x0 + C - i S
             }
         }
-        if (g0 == 0) put(0, sum);
+        if (g0 == 0) put(0, sum, make_double2(1.0, 0.0));                      // (k = 0: W^0)
+    }
+    if (A.best) best_publish(bt, A.best, s_b);
+}
+
+// every workgroup's (bits, first index) -> the plane's: out[0] = first flat index of the largest |cc| (~0: none, e.g. all NaN)
+__global__ __launch_bounds__(1024) void f64_best_reduce_kernel(const unsigned long long *__restrict__ best, size_t count, unsigned long long *out)
+{
+    __shared__ unsigned long long s_r[32];
+    best_t bt;
+    for (size_t i = threadIdx.x; i < count; i += 1024) bt.merge(best[2 * i], best[2 * i + 1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(bt.bits, o), oi = __shfl_xor(bt.idx, o);
+        bt.merge(ob, oi);
+    }
+    if ((threadIdx.x & 63) == 0) { s_r[2 * (threadIdx.x >> 6)] = bt.bits; s_r[2 * (threadIdx.x >> 6) + 1] = bt.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best_t r;
+        for (int w = 0; w < 16; w++) r.merge(s_r[2 * w], s_r[2 * w + 1]);
+        out[0] = r.idx;
     }
 }
 
@@ -431,21 +593,90 @@ int opt_in_lds(km_ctx *c)
     static unsigned long long opted = 0;     // per DEVICE
     const unsigned long long bit = 1ull << (c->device & 63);
     if (!(opted & bit)) {
-        KM_HIP(c, hipFuncSetAttribute((const void *)f64_smooth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KM_HIP(c, hipFuncSetAttribute((const void *)f64_prime_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *kernels[] = {(const void *)f64_smooth_kernel<-1>, (const void *)f64_smooth_kernel<KM_U8>, (const void *)f64_smooth_kernel<KM_U16>,
+                                 (const void *)f64_smooth_kernel<KM_I16>, (const void *)f64_smooth_kernel<KM_F32>,
+                                 (const void *)f64_prime_kernel<-1>, (const void *)f64_prime_kernel<KM_U8>, (const void *)f64_prime_kernel<KM_U16>,
+                                 (const void *)f64_prime_kernel<KM_I16>, (const void *)f64_prime_kernel<KM_F32>};
+        for (const void *k : kernels) KM_HIP(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         opted |= bit;
     }
     return KM_OK;
 }
 
+// device tables of one dimension: [exp(-2 pi i j / N), j < N] [inter-level twiddles of every level with R > 1, each laid out
+// like a block of the data: k R + r -> W_{n R}^(r k)]
+struct dim_tabs {
+    const cd *tw = nullptr;
+    const cd *ltw[16] = {nullptr};
+    const cd *ptab[16] = {nullptr};      // prime levels: the coefficient rows of f64_prime_kernel
+};
+inline size_t ptab_len(int p) { const size_t h = (size_t)(p - 1) / 2; return (h + 7) * (h + 2); }
+size_t host_dim_tables(const dimplan &P, std::vector<cd> &h, size_t ltw_off[16], size_t ptab_off[16])
+{
+    const int N = std::max(P.N, 1);
+    host_twiddles(N, h);
+    for (size_t l = 0; l < P.lv.size() && l < 16; l++) {
+        const lvl &L = P.lv[l];
+        ltw_off[l] = ptab_off[l] = 0;
+        if (L.kind == 1) {
+            const int p = L.n, hh = (p - 1) / 2;
+            ptab_off[l] = h.size();
+            h.resize(h.size() + ptab_len(p));
+            cd *t = &h[ptab_off[l]];
+            for (int k = 1; k <= hh + 7; k++)
+                for (int j = 1; j <= hh + 2; j++) t[(size_t)(j - 1) * (hh + 7) + (k - 1)] = h[(size_t)(((long long)j * k) % p) * (size_t)(N / p)];
+        }
+        if (L.R <= 1) continue;
+        ltw_off[l] = h.size();
+        const size_t Nl = (size_t)L.n * L.R, scale = (size_t)N / Nl;
+        h.resize(h.size() + Nl);
+        cd *t = &h[ltw_off[l]];
+        for (int k = 0; k < L.n; k++)
+            for (int r = 0; r < L.R; r++) t[(size_t)k * L.R + r] = h[(size_t)r * k * scale];
+    }
+    return h.size();
+}
+void bind_dim_tables(const dimplan &P, const cd *d, const size_t ltw_off[16], const size_t ptab_off[16], dim_tabs *T)
+{
+    T->tw = d;
+    for (size_t l = 0; l < P.lv.size() && l < 16; l++) {
+        T->ltw[l] = ltw_off[l] ? d + ltw_off[l] : nullptr;
+        T->ptab[l] = ptab_off[l] ? d + ptab_off[l] : nullptr;
+    }
+}
+// the offsets alone (tables already on the device)
+void dim_table_offsets(const dimplan &P, size_t ltw_off[16], size_t ptab_off[16], size_t *total)
+{
+    size_t n = (size_t)std::max(P.N, 1);
+    for (size_t l = 0; l < P.lv.size() && l < 16; l++) {
+        ltw_off[l] = ptab_off[l] = 0;
+        if (P.lv[l].kind == 1) { ptab_off[l] = n; n += ptab_len(P.lv[l].n); }
+        if (P.lv[l].R <= 1) continue;
+        ltw_off[l] = n;
+        n += (size_t)P.lv[l].n * P.lv[l].R;
+    }
+    *total = n;
+}
+
+struct lvl_extra {
+    const void *img_a = nullptr, *img_b = nullptr;     // first forward level along the rows: read the images
+    long long img_sa = 0, img_sb = 0;
+    int img_dtype = 0;
+    bool want_best = false;                             // last inverse level: report (largest |cc|, first index) per workgroup
+    unsigned long long *best = nullptr;                 //   -> WS_FFT_TOP2, `best_count` entries of two words
+    size_t best_count = 0;
+};
+
 // one level over a plane of `rows` rows of `width` elements (contiguous): along the rows (`cols` false, dimension length = width) or
 // along the columns (dimension length = rows)
-int run_level(km_ctx *c, cd *data, const cd *tw, int N, const lvl &L, bool inverse, bool cols, int rows, int width)
+int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, int level_index, bool inverse, bool cols, int rows, int width,
+              lvl_extra *extra = nullptr)
 {
     lvl_args A;
-    A.data = data; A.tw = tw; A.n = L.n; A.N = N; A.inverse = inverse ? 1 : 0;
+    A.data = data; A.tw = tabs.tw; A.ltw = tabs.ltw[level_index]; A.ptab = tabs.ptab[level_index]; A.ltw_R = L.R; A.n = L.n; A.N = N; A.inverse = inverse ? 1 : 0;
+    A.img_a = A.img_b = nullptr; A.img_sa = A.img_sb = 0; A.best = nullptr; A.dbg = c->opt_fft_dbg;
+    int img = -1;
     const long long Nl = (long long)L.n * L.R;
-    A.tw_scale = (int)(N / Nl);
     long long nA;
     if (!cols) {
         if (L.R > 1) {
@@ -461,24 +692,27 @@ int run_level(km_ctx *c, cd *data, const cd *tw, int N, const lvl &L, bool inver
         A.AR = L.R; nA = (long long)(rows / Nl) * L.R; A.s_blk = Nl * width; A.s_r = width;
         A.B = width; A.sb = 1; A.se = (long long)L.R * width; A.tw_mode = L.R > 1 ? 2 : 0; A.contiguous = 0;
     }
+    if (A.tw_mode && !A.ltw) return km_fail(c, KM_E_ARG, "phase correlation: level twiddles missing");
     A.nst = L.nst;
     for (int i = 0; i < F64_MAX_STAGES; i++) A.radix[i] = L.radix[i];
     size_t lds;
     if (L.kind == 1) {
-        const int tmax = std::min(64, std::max(1, 4096 / L.n));
+        int tmax = std::min(64, std::max(1, 4096 / L.n));
+        if (c->opt_f64_prime_t > 0) tmax = std::min(tmax, c->opt_f64_prime_t);
         const int tiles = (A.B + tmax - 1) / tmax;
         A.T = (A.B + tiles - 1) / tiles; A.logT = 0;
         A.tiles_b = (A.B + A.T - 1) / A.T;
         lds = (size_t)L.n * A.T * sizeof(cd);
     } else if (A.contiguous) {
         int T = std::max(1, std::min(8, F64_SMOOTH_MAX / L.n));
+        if (c->opt_f64_smooth_t > 0) T = std::min(T, c->opt_f64_smooth_t);
         T = std::min(T, A.B);
         A.T = T; A.logT = 0;
         A.tiles_b = (A.B + T - 1) / T;
         lds = ((size_t)2 * L.n * T + L.n) * sizeof(cd);
     } else {
         int T = 8, lg = 3;
-        while (T > 1 && L.n * T > F64_SMOOTH_MAX) { T >>= 1; lg--; }
+        while (T > 1 && (L.n * T > F64_SMOOTH_MAX || (c->opt_f64_smooth_t > 0 && T > c->opt_f64_smooth_t))) { T >>= 1; lg--; }
         while (T > 1 && (T >> 1) >= A.B) { T >>= 1; lg--; }
         A.T = T; A.logT = lg;
         A.tiles_b = (A.B + T - 1) / T;
@@ -486,67 +720,82 @@ int run_level(km_ctx *c, cd *data, const cd *tw, int N, const lvl &L, bool inver
     }
     const long long grid = nA * A.tiles_b;
     if (grid <= 0 || grid > 0x7fffffffll) return km_fail(c, KM_E_ARG, "phase correlation: plane too large");
-    if (L.kind == 1) f64_prime_kernel<<<(unsigned)grid, 256, lds, c->stream>>>(A);
-    else f64_smooth_kernel<<<(unsigned)grid, 256, lds, c->stream>>>(A);
+    if (extra) {
+        A.img_a = extra->img_a; A.img_b = extra->img_b; A.img_sa = extra->img_sa; A.img_sb = extra->img_sb;
+        if (extra->img_a) img = extra->img_dtype;
+        if (extra->want_best) {
+            extra->best = (unsigned long long *)km_ws(c, WS_FFT_TOP2, (size_t)grid * 2 * sizeof(unsigned long long));
+            if (!extra->best) return KM_E_NOMEM;
+            extra->best_count = (size_t)grid;
+            A.best = extra->best;
+        }
+    }
+    auto launch = [&](auto ic) {
+        constexpr int IMG = decltype(ic)::value;
+        if (L.kind == 1) f64_prime_kernel<IMG><<<(unsigned)grid, 256, lds, c->stream>>>(A);
+        else f64_smooth_kernel<IMG><<<(unsigned)grid, 256, lds, c->stream>>>(A);
+    };
+    switch (img) {
+    case KM_U8: launch(std::integral_constant<int, KM_U8>{}); break;
+    case KM_U16: launch(std::integral_constant<int, KM_U16>{}); break;
+    case KM_I16: launch(std::integral_constant<int, KM_I16>{}); break;
+    case KM_F32: launch(std::integral_constant<int, KM_F32>{}); break;
+    default: launch(std::integral_constant<int, -1>{}); break;
+    }
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
 struct blue_tabs {
     dimplan inner;                 // plan of the power-of-two length L (rows of the scratch)
-    const cd *tw = nullptr;        // exp(-2 pi i j / L)
+    dim_tabs tabs;                 // its tables
     const cd *chirp = nullptr;     // exp(-i pi m^2 / N), m < N
     cd *bhat = nullptr;            // transform of the chirp filter, in the permuted order the forward levels leave
 };
 
-int fft_rows_levels(km_ctx *c, cd *data, const cd *tw, const dimplan &P, bool inverse, int rows, int width)
+// all levels of one dimension; `first` / `last`: extras of the first forward level / the last inverse level (level 0 either way)
+int fft_levels(km_ctx *c, cd *data, const dim_tabs &tabs, const dimplan &P, bool inverse, bool cols, int rows, int width, lvl_extra *level0 = nullptr)
 {
     const int nl = (int)P.lv.size();
     for (int i = 0; i < nl; i++) {
-        const int rc = run_level(c, data, tw, P.N, P.lv[(size_t)(inverse ? nl - 1 - i : i)], inverse, false, rows, width);
-        if (rc) return rc;
-    }
-    return KM_OK;
-}
-int fft_cols_levels(km_ctx *c, cd *data, const cd *tw, const dimplan &P, bool inverse, int rows, int width)
-{
-    const int nl = (int)P.lv.size();
-    for (int i = 0; i < nl; i++) {
-        const int rc = run_level(c, data, tw, P.N, P.lv[(size_t)(inverse ? nl - 1 - i : i)], inverse, true, rows, width);
+        const int l = inverse ? nl - 1 - i : i;
+        const int rc = run_level(c, data, tabs, P.N, P.lv[(size_t)l], l, inverse, cols, rows, width, l == 0 ? level0 : nullptr);
         if (rc) return rc;
     }
     return KM_OK;
 }
 
-// tables of a Bluestein dimension in workspace slot `slot`: [tw_L (L)] [chirp (N)] [bhat (L)]
+// tables of a Bluestein dimension in workspace slot `slot`: [tables of the inner length L] [chirp (N)] [bhat (L)]
 int blue_prepare(km_ctx *c, int slot, const dimplan &P, blue_tabs *B)
 {
     const int N = P.N, L = P.L;
-    if (!plan_dim(L, F64_SMOOTH_MAX, &B->inner) || B->inner.blue) return km_fail(c, KM_E_UNSUPPORTED, "phase correlation: side %d too long", N);
-    cd *d = (cd *)km_ws(c, slot, ((size_t)2 * L + N) * sizeof(cd));
-    if (!d) return KM_E_NOMEM;
-    std::vector<cd> h((size_t)2 * L + N);
-    std::vector<cd> twL;
-    host_twiddles(L, twL);
-    std::copy(twL.begin(), twL.end(), h.begin());
+    if (!plan_dim(L, F64_SMOOTH_MAX, &B->inner) || B->inner.blue || B->inner.lv.size() > 16)
+        return km_fail(c, KM_E_UNSUPPORTED, "phase correlation: side %d too long", N);
+    std::vector<cd> h;
+    size_t off[16], poff[16];
+    const size_t nt = host_dim_tables(B->inner, h, off, poff);
+    h.resize(nt + (size_t)N + (size_t)L);
     const long double pi = 3.141592653589793238462643383279502884L;
     for (int m = 0; m < N; m++) {
         const long long e = ((long long)m * m) % (2ll * N);                    // exp(-i pi m^2 / N) = exp(-2 pi i e / 2N)
         const long double ang = pi * (long double)e / (long double)N;
-        h[(size_t)L + m] = make_double2((double)cosl(ang), -(double)sinl(ang));
+        h[nt + (size_t)m] = make_double2((double)cosl(ang), -(double)sinl(ang));
     }
-    cd *filt = &h[(size_t)L + N];
+    cd *filt = &h[nt + (size_t)N];
     for (int m = 0; m < L; m++) filt[m] = make_double2(0.0, 0.0);
     for (int m = 0; m < N; m++) {
-        const cd ch = h[(size_t)L + m];
+        const cd ch = h[nt + (size_t)m];
         const cd cj = make_double2(ch.x, -ch.y);
         filt[m] = cj;
         if (m) filt[L - m] = cj;
     }
+    cd *d = (cd *)km_ws(c, slot, h.size() * sizeof(cd));
+    if (!d) return KM_E_NOMEM;
     int rc = km_h2d_small(c, d, h.data(), h.size() * sizeof(cd));
     if (rc) return rc;
-    B->tw = d; B->chirp = d + L; B->bhat = d + L + N;
-    return fft_rows_levels(c, B->bhat, B->tw, B->inner, false, 1, L);
+    bind_dim_tables(B->inner, d, off, poff, &B->tabs);
+    B->chirp = d + nt; B->bhat = d + nt + N;
+    return fft_levels(c, B->bhat, B->tabs, B->inner, false, false, 1, L);
 }
 
 // DFT (or unnormalised inverse x N) of every row of a contiguous [rows][N] array, natural order in and out
@@ -562,11 +811,11 @@ int blue_rows(km_ctx *c, cd *x, int rows, const dimplan &P, const blue_tabs &B, 
         const dim3 g((unsigned)std::min((L + 255) / 256, 64), (unsigned)std::min(nr, 4096));
         blue_in_kernel<<<g, 256, 0, c->stream>>>(xr, s, B.chirp, nr, N, L, inverse ? 1 : 0);
         KM_LAUNCH_CHECK(c);
-        int rc = fft_rows_levels(c, s, B.tw, B.inner, false, nr, L);
+        int rc = fft_levels(c, s, B.tabs, B.inner, false, false, nr, L);
         if (rc) return rc;
         blue_mul_kernel<<<g, 256, 0, c->stream>>>(s, B.bhat, nr, L);
         KM_LAUNCH_CHECK(c);
-        rc = fft_rows_levels(c, s, B.tw, B.inner, true, nr, L);
+        rc = fft_levels(c, s, B.tabs, B.inner, true, false, nr, L);
         if (rc) return rc;
         blue_out_kernel<<<g, 256, 0, c->stream>>>(xr, s, B.chirp, nr, N, L, inverse ? 1 : 0);
         KM_LAUNCH_CHECK(c);
@@ -607,13 +856,17 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
     km_scalars *sc = (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars));
     if (!z || !sc) return KM_E_NOMEM;
 
-    // tables: twiddles and negated-frequency positions of both dimensions (kept between calls for the same shape)
-    cd *twx = nullptr, *twy = nullptr;
+    if (PX.lv.size() > 16 || PY.lv.size() > 16) return km_fail(c, KM_E_UNSUPPORTED, "phase correlation: no plan for %d x %d", H, W);
+    // tables: twiddles (+ the inter-level twiddles) and negated-frequency positions of both dimensions, kept between calls for the same shape
+    dim_tabs TX, TY;
     int *negx = nullptr, *negy = nullptr;
     {
         const bool same = c->f64_h == H && c->f64_w == W;
-        twx = (cd *)km_ws(c, WS_F64_TWX, (size_t)std::max(W, 1) * sizeof(cd));
-        twy = (cd *)km_ws(c, WS_F64_TWY, (size_t)std::max(H, 1) * sizeof(cd));
+        size_t offx[16], offy[16], poffx[16], poffy[16], nx = 0, ny = 0;
+        dim_table_offsets(PX, offx, poffx, &nx);
+        dim_table_offsets(PY, offy, poffy, &ny);
+        cd *twx = (cd *)km_ws(c, WS_F64_TWX, nx * sizeof(cd));
+        cd *twy = (cd *)km_ws(c, WS_F64_TWY, ny * sizeof(cd));
         negx = (int *)km_ws(c, WS_F64_NEGX, (size_t)std::max(W, 1) * sizeof(int));
         negy = (int *)km_ws(c, WS_F64_NEGY, (size_t)std::max(H, 1) * sizeof(int));
         if (!twx || !twy || !negx || !negy) return KM_E_NOMEM;
@@ -621,9 +874,10 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
             c->f64_h = c->f64_w = 0;
             std::vector<cd> t;
             std::vector<int> ng;
-            host_twiddles(std::max(W, 1), t);
+            size_t off[16], poff[16];
+            if (host_dim_tables(PX, t, off, poff) != nx) return km_fail(c, KM_E_ARG, "phase correlation: table size");
             if ((rc = km_h2d_small(c, twx, t.data(), t.size() * sizeof(cd)))) return rc;
-            host_twiddles(std::max(H, 1), t);
+            if (host_dim_tables(PY, t, off, poff) != ny) return km_fail(c, KM_E_ARG, "phase correlation: table size");
             if ((rc = km_h2d_small(c, twy, t.data(), t.size() * sizeof(cd)))) return rc;
             host_negpos(PX, ng);
             if ((rc = km_h2d_small(c, negx, ng.data(), ng.size() * sizeof(int)))) return rc;
@@ -631,6 +885,8 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
             if ((rc = km_h2d_small(c, negy, ng.data(), ng.size() * sizeof(int)))) return rc;
             c->f64_h = H; c->f64_w = W;
         }
+        bind_dim_tables(PX, twx, offx, poffx, &TX);
+        bind_dim_tables(PY, twy, offy, poffy, &TY);
     }
     blue_tabs BX, BY;
     if (PX.blue && (rc = blue_prepare(c, WS_F64_BLUEX, PX, &BX))) return rc;
@@ -641,23 +897,33 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
         if (!zt) return KM_E_NOMEM;
     }
 
-    switch (dtype) {
-    case KM_U8: rc = launch_pack<uint8_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
-    case KM_U16: rc = launch_pack<uint16_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
-    case KM_I16: rc = launch_pack<int16_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
-    case KM_F32: rc = launch_pack<float>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
-    default: return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d", dtype);
+    // with level kernels along the rows, the first of them reads the images itself and the last inverse one reports the arg-max;
+    // otherwise (one-pixel-wide image, Bluestein along the rows) a pack pass in front and two reduction passes behind
+    const bool fused_ends = W > 1 && !PX.blue && !PX.lv.empty() && !c->opt_f64_plain;
+    lvl_extra first, last;
+    if (fused_ends) {
+        first.img_a = d_a; first.img_b = d_b; first.img_sa = stride_a; first.img_sb = stride_b; first.img_dtype = dtype;
+        last.want_best = true;
+        if (dtype != KM_U8 && dtype != KM_U16 && dtype != KM_I16 && dtype != KM_F32) return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d", dtype);
+    } else {
+        switch (dtype) {
+        case KM_U8: rc = launch_pack<uint8_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
+        case KM_U16: rc = launch_pack<uint16_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
+        case KM_I16: rc = launch_pack<int16_t>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
+        case KM_F32: rc = launch_pack<float>(c, d_a, d_b, stride_a, stride_b, H, W, z); break;
+        default: return km_fail(c, KM_E_ARG, "phase_shift: bad dtype %d", dtype);
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
 
     auto along_rows = [&](bool inverse) -> int {
         if (W <= 1) return KM_OK;
         if (PX.blue) return blue_rows(c, z, H, PX, BX, inverse);
-        return fft_rows_levels(c, z, twx, PX, inverse, H, W);
+        return fft_levels(c, z, TX, PX, inverse, false, H, W, fused_ends ? (inverse ? &last : &first) : nullptr);
     };
     auto along_cols = [&](bool inverse) -> int {
         if (H <= 1) return KM_OK;
-        if (!PY.blue) return fft_cols_levels(c, z, twy, PY, inverse, H, W);
+        if (!PY.blue) return fft_levels(c, z, TY, PY, inverse, true, H, W);
         int r = transpose(c, z, zt, H, W);
         if (!r) r = blue_rows(c, zt, W, PY, BY, inverse);
         if (!r) r = transpose(c, zt, z, W, H);
@@ -675,12 +941,17 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
 
     unsigned long long *keys = &sc->argmax_key;                  // max bits
     unsigned long long *idx = (unsigned long long *)&sc->valid;  // reused as the first-index slot
-    KM_HIP(c, hipMemsetAsync(keys, 0, sizeof(unsigned long long), c->stream));
-    KM_HIP(c, hipMemsetAsync(idx, 0xff, sizeof(unsigned long long), c->stream));
-    f64_absmax_kernel<<<2048, 256, 0, c->stream>>>(z, n, keys);
-    KM_LAUNCH_CHECK(c);
-    f64_first_index_kernel<<<2048, 256, 0, c->stream>>>(z, n, keys, idx);
-    KM_LAUNCH_CHECK(c);
+    if (fused_ends) {
+        f64_best_reduce_kernel<<<1, 1024, 0, c->stream>>>(last.best, last.best_count, idx);
+        KM_LAUNCH_CHECK(c);
+    } else {
+        KM_HIP(c, hipMemsetAsync(keys, 0, sizeof(unsigned long long), c->stream));
+        KM_HIP(c, hipMemsetAsync(idx, 0xff, sizeof(unsigned long long), c->stream));
+        f64_absmax_kernel<<<2048, 256, 0, c->stream>>>(z, n, keys);
+        KM_LAUNCH_CHECK(c);
+        f64_first_index_kernel<<<2048, 256, 0, c->stream>>>(z, n, keys, idx);
+        KM_LAUNCH_CHECK(c);
+    }
     unsigned long long flat = 0;
     { int rq = km_d2h_queue(c, &flat, idx, sizeof(flat)); if (!rq) rq = km_d2h_flush(c); if (rq) return rq; }
     if (flat == ~0ull) flat = 0;  // all-NaN surface: np.argmax would return the first NaN; 0 by convention

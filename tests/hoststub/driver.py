@@ -248,6 +248,14 @@ ok(lib.km_zncc_windows(ctx, P(ref), P(mon.astype(np.float64)), 1, 4, H, W, H, W,
 q = rng.uniform(-0.02, 0.02, (64, 4)).astype(np.float32)
 o = np.zeros(64, np.uint8)
 ok(lib.km_lk_oscillation_probe(ctx, P(q), 64, P(o)), "oscillation probe")
+# the host-side planning of the double-precision phase correlation (no device, no context): levels, Bluestein, position tables
+for n_side, cols in ((10980, 0), (10980, 1), (1, 0), (7, 1), (3721, 0), (10007, 1), (65536, 1), (2 * 3 * 5 * 7 * 11 * 13, 0)):
+    lv = (C.c_int * 32)()
+    nl, bl = C.c_int(-1), C.c_int(-1)
+    ng = np.full(n_side, -1, np.int32)
+    assert lib.km_phase_plan(n_side, cols, lv, 16, C.byref(nl), C.byref(bl), P(ng)) == 0
+    assert (bl.value > 0) == (n_side == 10007) and ng.min() >= 0 and ng.max() < n_side
+assert lib.km_phase_plan(0, 0, lv, 16, None, None, None) < 0 and lib.km_phase_plan(10980, 0, lv, 1, None, None, None) < 0
 rc_ = (C.c_double * 2)()
 ok(lib.km_phase_shift(ctx, P(ref), P(mon), 1, H, W, W, W, rc_), "phase_shift")
 

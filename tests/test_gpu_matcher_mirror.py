@@ -185,7 +185,7 @@ def fft_form(request, ops):
                                    (427, 915), (2135, 128), (64, 5490), (10980, 61), (3660, 854)])
 def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape, fft_form):
     """k_fft.hip (float32, radices 2/3/4/5/7/61; rows of length 61 * M as 61-point transforms + M-point transforms per wavefront)
-    against the double-precision rocFFT path and the oracle: same integer shifts on shifted copies (clear peak -> fast path is
+    against the double-precision path (k_fft64.hip, hand-written as well) and the oracle: same integer shifts on shifted copies (clear peak -> fast path is
     trusted), and the double path takes over when the peak is split evenly."""
     from karios_amd._lib import default_context
     H, W = shape
@@ -211,6 +211,44 @@ def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape, fft_
         np.testing.assert_array_equal(got, O.phase_cross_correlation(b, a))
         if min(H, W) >= 200:                      # (a small image shifted by a good part of its size has no reliable peak)
             np.testing.assert_array_equal(got, [sy, sx])
+
+
+@pytest.mark.parametrize("shape", [(61, 45), (96, 130), (1, 300), (300, 1), (2, 2), (3, 5), (11, 13), (127, 254), (131, 200), (200, 131), (257, 263),
+                                   (1000, 1009), (4096, 64), (64, 4096), (4099, 37), (37, 4099), (512, 6000), (2135, 128), (122, 3721), (1830, 1098)])
+def test_double_precision_phase_correlation_for_every_kind_of_side(ops, O, shape):
+    """k_fft64.hip (complex128 like the reference, large_offset.py:39; hand-written - no FFT library is linked): sides with only small
+    prime factors (levels in LDS), with a prime of 11 .. 127 such as Sentinel-2's 61 (a level kernel of its own), with larger primes
+    (Bluestein's chirp-z along that dimension), one-pixel-wide images, and sides that need three levels - same integer shifts as the
+    oracle, on every pixel type, with the image loads / the arg-max fused into the first / last level and as passes of their own."""
+    from karios_amd._lib import default_context
+    H, W = shape
+    ctx = default_context()
+    base, _ = synth.make_pair(H + 80, W + 80, 0.0, 0.0, seed=H * 3 + W, noise_sigma=0.0)
+    rng = np.random.default_rng(H * 7 + W)
+    ctx.set_option("phase_fp64", 1)
+    try:
+        for trial, dtype in enumerate((np.uint16, np.uint8, np.int16, np.float32)):
+            sy = int(rng.integers(-min(30, H // 8), min(30, H // 8) + 1))
+            sx = int(rng.integers(-min(30, W // 8), min(30, W // 8) + 1))
+            a = base[40:40 + H, 40:40 + W]
+            b = base[40 - sy:40 - sy + H, 40 - sx:40 - sx + W]
+            if dtype == np.uint8:
+                a, b = (a >> 6).astype(np.uint8), (b >> 6).astype(np.uint8)
+            elif dtype == np.int16:
+                a, b = (a.astype(np.int32) - 9000).astype(np.int16), (b.astype(np.int32) - 9000).astype(np.int16)
+            elif dtype == np.float32:
+                a, b = a.astype(np.float32) * np.float32(0.25), b.astype(np.float32) * np.float32(0.25)
+            want = O.phase_cross_correlation(b, a)
+            for plain in (0, 1):
+                ctx.set_option("f64_plain", plain)
+                got = ops.phase_cross_correlation(b, a)
+                assert ctx.phase_info()[0] == 2
+                np.testing.assert_array_equal(got, want, err_msg=f"{shape} {dtype.__name__} plain={plain}")
+            if min(H, W) >= 200:
+                np.testing.assert_array_equal(got, [sy, sx])
+    finally:
+        ctx.set_option("phase_fp64", 0)
+        ctx.set_option("f64_plain", 0)
 
 
 def test_phase_correlation_survives_toggling_the_row_form_on_one_context(ops, O):

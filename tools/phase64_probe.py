@@ -7,7 +7,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from karios_amd import synth                                             # noqa: E402
 import karios_amd.ops as ops                                             # noqa: E402
 from karios_amd._lib import default_context                             # noqa: E402
@@ -17,7 +18,7 @@ def main():
     from oracle import oracle as O
     ctx = default_context()
     ctx.set_option("phase_fp64", 1)
-    shapes = [(64, 64), (96, 130), (61, 45), (128, 128), (244, 183), (366, 366), (122, 3721), (2135, 128), (1, 300), (300, 1), (2, 2), (3, 5),
+    shapes = [] if len(sys.argv) > 1 and sys.argv[1] == 'time' else [(64, 64), (96, 130), (61, 45), (128, 128), (244, 183), (366, 366), (122, 3721), (2135, 128), (1, 300), (300, 1), (2, 2), (3, 5),
               (11, 13), (127, 254), (131, 200), (200, 131), (257, 263), (1000, 1009), (1098, 1220), (4096, 64), (64, 4096), (2048, 2048),
               (4099, 37), (37, 4099), (512, 6000), (6000, 512), (3001, 3001)]
     bad = 0
@@ -42,8 +43,15 @@ def main():
     mon = np.roll(ref, (-21, 37), (0, 1))
     pair = ResidentPair.upload(mon, ref)
     res = {}
-    for mode in (1, 0):
+    for mode, opts in ((1, {}), (1, {"f64_smooth_t": 4}), (1, {"f64_smooth_t": 2}), (1, {"fft_dbg": 1}), (1, {"fft_dbg": 2}), (1, {"fft_dbg": 4}),
+                       (1, {"fft_dbg": 6}), (1, {"fft_dbg": 7}), (0, {})):
         ctx.set_option("phase_fp64", mode)
+        ctx.set_option("f64_plain", 0)
+        ctx.set_option("f64_prime_t", 0)
+        ctx.set_option("f64_smooth_t", 0)
+        ctx.set_option("fft_dbg", 0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
         times = []
         for i in range(4):
             ctx.sync()
@@ -51,8 +59,8 @@ def main():
             got = pair.phase_offset()
             ctx.sync()
             times.append(1e3 * (time.perf_counter() - t0))
-        res["fp64" if mode else "f32"] = {"ms": times, "shift": None if got is None else [float(v) for v in got], "path": ctx.phase_info()[0]}
-        print(mode, times, got, ctx.phase_info(), flush=True)
+        res[("fp64" if mode else "f32") + "".join(f" {k}={v}" for k, v in opts.items())] = {"ms": times, "shift": None if got is None else [float(v) for v in got], "path": ctx.phase_info()[0]}
+        print(mode, opts, [round(t, 2) for t in times], got, ctx.phase_info(), flush=True)
     print(json.dumps({"mismatches": bad, "full_size": res}))
     return 1 if bad else 0
 
