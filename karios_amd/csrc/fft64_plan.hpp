@@ -29,17 +29,25 @@ inline void factor_primes(int N, std::vector<int> &out)
     if (N > 1) out.push_back(N);
 }
 
+// radices of a smooth level, in stage order: 7s and 5s, then 6s (a 2 and a 3 in ONE pass over the LDS: 180 = 5 x 6 x 6 is three
+// stages instead of the four of 5 x 4 x 3 x 3), 4s, and what is left of the 3s and 2s
 inline bool smooth_radices(int n, lvl *L)
 {
-    static const int radices[] = {7, 5, 4, 3, 2};
     L->nst = 0;
-    for (int r : radices)
-        while (n % r == 0) {
-            if (L->nst == F64_MAX_STAGES) return false;
-            L->radix[L->nst++] = r;
-            n /= r;
-        }
-    return n == 1;
+    auto push = [&](int r) { if (L->nst == F64_MAX_STAGES) return false; L->radix[L->nst++] = r; return true; };
+    int c[8] = {0};
+    for (int p : {2, 3, 5, 7})
+        while (n % p == 0) { c[p]++; n /= p; }
+    if (n != 1) return false;
+    for (int i = 0; i < c[7]; i++) if (!push(7)) return false;
+    for (int i = 0; i < c[5]; i++) if (!push(5)) return false;
+    int sixes = std::min(c[2], c[3]);
+    for (int i = 0; i < sixes; i++) if (!push(6)) return false;
+    int twos = c[2] - sixes, threes = c[3] - sixes;
+    for (; twos >= 2; twos -= 2) if (!push(4)) return false;
+    for (; threes > 0; threes--) if (!push(3)) return false;
+    if (twos && !push(2)) return false;
+    return L->nst > 0;
 }
 
 // levels of one dimension.  `last_cap`: longest smooth level allowed at the end (rows: its transforms are contiguous, 2048; columns:

@@ -88,6 +88,17 @@ template <int R> __device__ __forceinline__ void dft_r(cd *v)
     if constexpr (R == 2) {
         const cd a = v[0], b = v[1];
         v[0] = c_add(a, b); v[1] = c_sub(a, b);
+    } else if constexpr (R == 6) {
+        // 2 x 3: X[2 k] = DFT3(v_j + v_{j+3})[k],  X[2 k + 1] = DFT3((v_j - v_{j+3}) W_6^j)[k]
+        cd e[3], o[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { e[j] = c_add(v[j], v[j + 3]); o[j] = c_sub(v[j], v[j + 3]); }
+        o[1] = c_mul(o[1], make_double2(0.5, -0.86602540378443864676));
+        o[2] = c_mul(o[2], make_double2(-0.5, -0.86602540378443864676));
+        dft_r<3>(e);
+        dft_r<3>(o);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[2 * k] = e[k]; v[2 * k + 1] = o[k]; }
     } else if constexpr (R == 4) {
         const cd a = c_add(v[0], v[2]), b = c_sub(v[0], v[2]), c = c_add(v[1], v[3]), d = c_sub(v[1], v[3]);
         v[0] = c_add(a, c); v[2] = c_sub(a, c);
@@ -197,7 +208,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
     __shared__ unsigned long long s_b[8];
     const int n = A.n, T = A.T, logT = A.logT;
     cd *buf0 = (cd *)smem64, *buf1 = buf0 + n * T, *twl = buf1 + n * T;       // twl[j] = exp(-2 pi i j / n)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
     const long long base = tile_base(A, a, b0);
     const int qa = a % A.AR;
@@ -253,14 +264,19 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
         auto run = [&](auto rc) {
             constexpr int RR = decltype(rc)::value;
             if (contig) {
-                for (int t = wave; t < nt; t += 4)
-                    for (int b = lane; b < nb; b += 64) bfly<RR>(src, dst, b, nb, Ns, magic, 1, t * n, twl, twstep);
+                // (flat over the tile like the strided form: one wavefront per transform left 64 - n / R lanes idle)
+                const unsigned magic_nb = (unsigned)((0x100000000ull + (unsigned)nb - 1) / (unsigned)nb);
+                for (int idx = tid; idx < nb * nt; idx += 256) {
+                    const int t = nb > 1 ? (int)__umulhi((unsigned)idx, magic_nb) : idx;
+                    bfly<RR>(src, dst, idx - t * nb, nb, Ns, magic, 1, t * n, twl, twstep);
+                }
             } else {
                 for (int idx = tid; idx < nb * T; idx += 256) bfly<RR>(src, dst, idx >> logT, nb, Ns, magic, lsi, idx & (T - 1), twl, twstep);
             }
         };
         switch (R) {
         case 7: run(std::integral_constant<int, 7>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
         case 5: run(std::integral_constant<int, 5>{}); break;
         case 4: run(std::integral_constant<int, 4>{}); break;
         case 3: run(std::integral_constant<int, 3>{}); break;

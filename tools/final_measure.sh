@@ -10,14 +10,18 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_c2 -o c2 -- python3 $R/bench.py --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --steps 20 --warmup 5 > $R/gpurun_out/prof_${TAG}_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_c3 -o c3 -- python3 $R/bench.py --config 3 --steps 5 --warmup 1 > $R/gpurun_out/prof_${TAG}_c3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_ep -o ep -- python3 $R/tools/entry_points_workload.py 10980 scoring,dn,auto,banded > $R/gpurun_out/prof_${TAG}_ep.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_f64 -o f64 -- python3 $R/tools/phase64_workload.py 10980 5 > $R/gpurun_out/prof_${TAG}_f64.log 2>&1
 cd $R
+python3 tools/summarize_rocprof.py $(find gpurun_out/prof_${TAG}_f64 -name 'f64_kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats_phase_fp64.md 5
 python3 tools/summarize_rocprof.py $(find gpurun_out/prof_${TAG}_c2 -name 'c2_kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats_config2.md
 python3 tools/summarize_rocprof.py $(find gpurun_out/prof_${TAG}_c3 -name 'c3_kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats_config3.md 6
 python3 tools/summarize_rocprof.py $(find gpurun_out/prof_${TAG}_ep -name 'ep_kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats_entry_points.md
 PMC_COMMIT=$COMMIT bash tools/pmc_collect.sh ${TAG}_c2 bench.py --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-full-scoring --steps 12 --warmup 3
 PMC_COMMIT=$COMMIT bash tools/pmc_collect.sh ${TAG}_ep tools/entry_points_workload.py 10980 scoring,dn
 PMC_COMMIT=$COMMIT bash tools/pmc_collect.sh ${TAG}_c3 bench.py --config 3 --steps 4 --warmup 1
+PMC_COMMIT=$COMMIT bash tools/pmc_collect.sh ${TAG}_f64 tools/phase64_workload.py 10980 3
 tail -1 gpurun_out/bench_${TAG}.json | cut -c1-300
 head -30 gpurun_out/${TAG}_kernel_stats_config2.md
 head -14 gpurun_out/${TAG}_kernel_stats_config3.md
 head -30 gpurun_out/${TAG}_kernel_stats_entry_points.md
+head -16 gpurun_out/${TAG}_kernel_stats_phase_fp64.md

@@ -27,8 +27,12 @@ STAGES = {   # stage key -> kernel-name fragments
     "shift_image": ("shift_kernel",),
     "mi_kernel": ("mi_kernel", "mi_int_kernel"),
     "dn_keep": ("dn_keep_kernel",),
+    "phase_correlation_f64": ("f64_prime_kernel", "f64_smooth_kernel", "f64_cross_kernel", "f64_best_reduce", "f64_pack", "f64_absmax", "f64_first_index"),
+    "phase_f64_prime_level": ("f64_prime_kernel",),
+    "phase_f64_smooth_level": ("f64_smooth_kernel",),
+    "phase_f64_cross_power": ("f64_cross_kernel",),
 }
-ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel"}
+ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel", "f64": "f64_best_reduce"}
 
 
 def load(path):
