@@ -142,6 +142,8 @@ int km_ctx_create(int device, km_ctx **out)
     if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_AUX_PYRAMID")) c->opt_aux_pyramid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
+    if (const char *e = getenv("KARIOS_HIP_MM_EARLY_AT")) c->opt_mm_early_at = atoi(e);
+    if (const char *e = getenv("KARIOS_HIP_TAIL_OVERLAP")) c->opt_tail_overlap = atoi(e) != 0;  // A/B switch: the scoring tail of a submitted unit beside the next unit's first kernels
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -177,6 +179,8 @@ int km_ctx_destroy(km_ctx *c)
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
+    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
     if (c->ev_lk_start) (void)hipEventDestroy(c->ev_lk_start);
     if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -193,7 +197,8 @@ int km_ctx_sync(km_ctx *c)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks of submitted tiles
+    if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks (and overlapped tails) of submitted tiles
+    c->tail_pending = false; c->tail_defer = false;
     if (!c->retired.empty()) {
         // workspace buffers replaced by larger ones: nothing of this context uses them any more once its streams are idle
         if (c->aux_stream) KM_HIP(c, hipStreamSynchronize(c->aux_stream));
@@ -223,6 +228,8 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "mm_early_at") == 0) { c->opt_mm_early_at = value; return KM_OK; }
+    if (strcmp(name, "tail_overlap") == 0) { c->opt_tail_overlap = value != 0; return KM_OK; }
     if (strcmp(name, "f64_plain") == 0) { c->opt_f64_plain = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
@@ -474,10 +481,26 @@ int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)
 // ------------------------------------------------------------------ helpers
 // stage timers are cleared per pipeline: the KLT entry points own [ST_MINMAX, ST_LK], ZNCC owns ST_ZNCC
 enum { RESET_NONE = 0, RESET_KLT = 1, RESET_ZNCC = 2 };
-static int begin_call(km_ctx *c, int reset = RESET_NONE)
+// the main stream waits for the scoring kernels of the last overlapped unit (no-op when it already has)
+static int tail_wait_now(km_ctx *c)
+{
+    if (c->tail_pending) {
+        KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail_done, 0));
+        c->tail_pending = false;
+    }
+    c->tail_defer = false;
+    return KM_OK;
+}
+
+static int begin_call(km_ctx *c, int reset = RESET_NONE, bool defer_tail = false)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
+    // a previous submit left its frame / ZNCC / MI kernels on the copy stream: everything waits for them here, except a directly
+    // following submit, whose first kernels (min / max, Laplacians, eigenvalues) touch nothing the tail reads - it waits in front
+    // of its corner selection (klt_track_dev)
+    if (c->tail_pending && defer_tail && !getenv("KARIOS_HIP_POISON_WS")) c->tail_defer = true;
+    else { const int rct = tail_wait_now(c); if (rct) return rct; }
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->spec_used = false; c->spec_flags = 0;
@@ -558,7 +581,13 @@ static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride,
     return KM_OK;
 }
 
-static km_scalars *scalars(km_ctx *c) { return (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars)); }
+// two scalar blocks: the tail of an overlapped unit reads its corner count / flags while the next unit zeroes and fills its own
+#define KM_SC_STRIDE ((sizeof(km_scalars) + 255) / 256 * 256)
+static km_scalars *scalars(km_ctx *c, int which = 0)
+{
+    char *p = (char *)km_ws(c, WS_SCALARS, 2 * KM_SC_STRIDE);
+    return p ? (km_scalars *)(p + (size_t)which * KM_SC_STRIDE) : nullptr;
+}
 
 // pyramid of one image into caller-provided storage (levels >= 1 packed from `store`); returns the bytes used
 static int build_pyramid_single(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, uint8_t *store, km_pyr *P, size_t *used)
@@ -730,6 +759,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     // caller reads sc->flags with the tile's result and repeats a flagged tile with c->spec_allowed = false.
     bool spec = !d_p0_in && c->spec_allowed && c->opt_speculative && c->fused_eig && prm->max_corners > 0 && prm->min_distance >= 1 &&
                 !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor && !c->opt_select_first;
+    if (!spec && (rc = tail_wait_now(c))) return rc;     // (only the sync-free form defers the wait for the previous unit's tail)
     if (spec) {
         const size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
@@ -739,6 +769,14 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         // memory system idle, and the ranking / selection chain behind it (small latency-bound kernels) then has the GPU to itself;
         // forked behind it (round 2) the pyramids stretched the chain's one-workgroup kernels from 8 to 36 us.
         bool forked = false;
+        // where the NEXT unit's early min / max may start ("mm_early_at": 0 in front of LK, 1 in front of the selection sweeps, 2 in
+        // front of the ranking): it must end before this unit's LK does, or the next Laplacian waits for it
+        auto mark_mm_start = [&]() -> int {
+            if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
+            KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
+            c->lk_start_valid = true;
+            return KM_OK;
+        };
         auto fork_pyramids = [&]() -> int {
             if (!c->aux_stream) {
                 // lowest priority: when a kernel of the main stream and a pyramid kernel become ready together (both wait for the
@@ -778,10 +816,15 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         } else if (rc) return rc;
         else {
             if (c->opt_aux_pyramid && !forked && (rc = fork_pyramids())) return rc;
+            // the selection rewrites the scratch and the point lists the previous unit's frame / ZNCC / MI kernels read: they have
+            // had the Laplacian and eigenvalue passes of this unit (0.55 ms) to finish
+            if ((rc = tail_wait_now(c))) return rc;
+            if (c->opt_mm_early_at == 2 && (rc = mark_mm_start())) return rc;
             {
                 km_stage_timer t(c, ST_SORT);
                 rc = kf_rank(c, keys, capk, H, W, prm->max_corners, prm->quality_level, prm->min_distance, sc);
             }
+            if (rc == KM_OK && c->opt_mm_early_at == 1 && (rc = mark_mm_start())) return rc;
             if (rc == KM_OK) {
                 km_stage_timer t(c, ST_SELECT);
                 rc = kf_select(c, H, W, prm->max_corners, prm->min_distance, d_p0, cap, sc);
@@ -800,6 +843,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             }
         }
     }
+    if ((rc = tail_wait_now(c))) return rc;              // (every fall-back of the block above)
     if (spec) {
         // corners, their count and the pyramids are enqueued
     } else if (d_p0_in) {
@@ -828,7 +872,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
         km_stage_timer t(c, ST_LK);
-        if (spec) {
+        if (spec && !c->lk_start_valid) {
             // (the next unit's early min / max starts here)
             if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
             KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
@@ -1240,7 +1284,12 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     // slot != nullptr: km_klt_tile_frame_submit - the block goes to the slot's pinned buffer and the call returns without
     // waiting for the tail of the pipeline (LK, FB test, ZNCC, copy), which then overlaps the caller's next submission
     int rc;
-    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
+    // Tail overlap (submitted units, "tail_overlap"): the frame / ZNCC / MI kernels of a unit - short launches that leave most of the
+    // GPU idle, 0.09 ms of the step - run on the block-copy stream behind the unit's LK, and the main stream goes straight on to
+    // the next unit's Laplacian / eigenvalue passes.  What the two sides share is kept apart: two scalar blocks used in turn, a
+    // count buffer of the frame stage's own (WS_FRAME_CNT), and the next unit waits for this tail in front of its corner selection.
+    const bool overlap = slot != nullptr && c && c->opt_tail_overlap;
+    if ((rc = begin_call(c, RESET_KLT, overlap)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
         (rc = check_image(c, d_mon, H, W, smon, "klt_tile_frame_dev")))
         return rc;
     if (with_zncc && ((rc = check_image(c, d_ref_full, Hf, Wf, sref_f, "klt_tile_frame_zncc_dev")) ||
@@ -1253,7 +1302,8 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
     c->evs_used[c->ev_cur][ST_ZNCC] = false; c->evs_used[c->ev_cur][ST_MI] = false;
-    km_scalars *sc = scalars(c);
+    if (overlap) c->sc_parity ^= 1;
+    km_scalars *sc = scalars(c, overlap ? c->sc_parity : 0);
     const size_t pb = (size_t)cap * 2 * sizeof(float);
     // block: header | x0 | y0 | dx | dy | score | index bits (float32) | zncc [| mutual_info_score | mi_score] (float64)
     const bool with_mi = with_zncc && c->opt_frame_mi;
@@ -1273,7 +1323,27 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     c->spec_allowed = false; c->mm_early_allowed = false;
     if (rc) return rc;
     const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
-    if ((rc = frame_block_free(c))) return rc;
+    if ((rc = tail_wait_now(c))) return rc;                 // (a path that never reached the selection)
+    // from here on the unit's tail: on the copy stream when it overlaps the next unit
+    struct stream_swap {
+        km_ctx *c; hipStream_t saved; bool active;
+        ~stream_swap() { if (active) c->stream = saved; }
+    } swap{c, c->stream, false};
+    if (overlap) {
+        if (!c->d2h_stream) {
+            KM_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+            KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+        }
+        if (!c->ev_front_done) {
+            KM_HIP(c, hipEventCreateWithFlags(&c->ev_front_done, hipEventDisableTiming));
+            KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
+        }
+        KM_HIP(c, hipEventRecord(c->ev_front_done, c->stream));
+        KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_front_done, 0));
+        c->stream = c->d2h_stream;
+        swap.active = true;
+    }
+    if (!overlap && (rc = frame_block_free(c))) return rc;  // (on the copy stream the previous block's copy is simply ahead in the queue)
     {
         km_stage_timer t(c, ST_FRAME);
         if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out, c->spec_used ? sc : nullptr))) return rc;
@@ -1328,6 +1398,12 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
         KM_HIP(c, hipEventRecord(slot->done, c->d2h_stream));
         c->frame_copy = slot->done;
         slot->bytes = ob;
+        if (overlap) {
+            // (recorded behind the copies: the next unit's selection then also finds WS_FRAME and the scalar block free)
+            KM_HIP(c, hipEventRecord(c->ev_tail_done, c->d2h_stream));
+            c->tail_pending = true;
+            c->frame_copy = nullptr;                        // (ev_tail_done covers it)
+        }
         return KM_OK;
     }
     km_scalars *land = c->spec_used ? (km_scalars *)km_pinned_rb(c, sizeof(km_scalars)) : nullptr;

@@ -85,6 +85,7 @@ enum km_slot {
     WS_FFT_TW1,
     WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
     WS_MI_TABLE,    // c ln c, c = 0 .. 57^2 (k_mi.hip)
+    WS_FRAME_CNT,   // k_frame.hip: per-workgroup counts of the compaction (a slot of its own: the frame stage of unit k may run beside the Laplacian / eigenvalue kernels of unit k + 1, which own WS_PARTIAL)
     WS_F64_TWX,     // k_fft64.hip: exp(-2 pi i j / W), exp(-2 pi i j / H) ...
     WS_F64_TWY,
     WS_F64_NEGX,    //   ... position of the negated frequency along x / y ...
@@ -248,6 +249,15 @@ struct km_ctx {
     km_klt_stats stats;
     int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (k_fft64.hip)
     double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
+    // tail overlap (km_klt_tile_frame_submit): frame / ZNCC / MI of unit k run on the block-copy stream beside the first kernels of
+    // unit k + 1; ev_front_done = LK of the unit enqueued, ev_tail_done = its scoring kernels enqueued; tail_pending: the main stream
+    // has not waited for ev_tail_done yet (every entry point does at its start - a directly following submit only in front of its
+    // corner selection, the first stage that rewrites what the tail reads)
+    hipEvent_t ev_front_done = nullptr, ev_tail_done = nullptr;
+    bool tail_pending = false, tail_defer = false;
+    int sc_parity = 0;             // which of the two scalar blocks the last overlapped unit used
+    int opt_mm_early_at = 0;       // "mm_early_at": where the next unit's early min / max may start (0 LK, 1 selection sweeps, 2 ranking)
+    bool opt_tail_overlap = false; // "tail_overlap" (measured: the Laplacian kernel beside it stretches by what the tail saves - off)
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
     int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
     int opt_f64_smooth_t = 0;      // "f64_smooth_t": the same for the smooth level kernel (default 8)

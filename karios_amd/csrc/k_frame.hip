@@ -171,7 +171,7 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
     if (!keys || !ranks || !tmp) return KM_E_NOMEM;
     const int nblk = (n_max + FB_T - 1) / FB_T;
     const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);   // fixed sort length: sentinel keys behind the kept rows
-    unsigned *counts = (unsigned *)km_ws(c, WS_PARTIAL, (size_t)nblk * sizeof(unsigned));
+    unsigned *counts = (unsigned *)km_ws(c, WS_FRAME_CNT, (size_t)nblk * sizeof(unsigned));
     if (!counts) return KM_E_NOMEM;
     fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort, d_sc_header);
     KM_LAUNCH_CHECK(c);

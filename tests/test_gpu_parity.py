@@ -483,6 +483,39 @@ def test_submit_wait_frames_in_flight(ops, O):
         pair.ctx.set_option("speculative", 0)
 
 
+@pytest.mark.parametrize("mutual_info", [False, True])
+def test_submitted_units_with_their_scoring_tail_beside_the_next_unit(ops, O, mutual_info):
+    """`tail_overlap`: frame / ZNCC / MI of unit k on the block-copy stream while unit k + 1's min / max, Laplacians and eigenvalue
+    pass run on the compute stream (two scalar blocks in turn, the wait in front of the corner selection): twelve units of four
+    different tile boxes back to back, two in flight, equal the blocking call's frames - sync-free corner path on (the form that
+    defers the wait), then the exact path and a blocking call in between."""
+    import pandas as pd
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair
+    mon, ref = synth.make_pair(700, 900, 0.35, -0.4, seed=23, nodata_wedge=True)
+    conf = KLTConfiguration(maxCorners=900)
+    pair = ResidentPair.upload(mon, ref)
+    boxes = [(0, 0, 450, 350), (450, 0, 450, 700), (10, 350, 400, 330), None]
+    want = [pair.match_tile(conf, box=b, zncc_threshold=0.4, mutual_info=mutual_info) for b in boxes]
+    pair.ctx.set_option("tail_overlap", 1)
+    try:
+        for spec in (1, 0):
+            pair.ctx.set_option("speculative", spec)
+            pend = []
+            for i in range(12):
+                pend.append((i % 4, pair.submit_tile(conf, box=boxes[i % 4], zncc_threshold=0.4, mutual_info=mutual_info)))
+                if len(pend) == 2:
+                    k, p = pend.pop(0)
+                    pd.testing.assert_frame_equal(want[k], p.result().to_frame())
+                if i == 6:                                   # a blocking call in between waits for the tail in flight
+                    pd.testing.assert_frame_equal(want[2], pair.match_tile(conf, box=boxes[2], zncc_threshold=0.4, mutual_info=mutual_info))
+            for k, p in pend:
+                pd.testing.assert_frame_equal(want[k], p.result().to_frame())
+    finally:
+        pair.ctx.set_option("tail_overlap", 0)
+        pair.ctx.set_option("speculative", 1)
+
+
 def _rest_of_submit_wait_test(pair, conf, boxes, want):
     import pandas as pd
     from karios_amd._lib import KariosHipError
