@@ -122,6 +122,8 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (k_fft64.hip), the reference's precision; 0 (default):
  *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
  *                  float32 correlation peak is not at least 1 % above every other sample
+ *   "fft_herm"     1 (default): the inverse transform of the float32 phase correlation works on the Hermitian half of the cross-power
+ *                  spectrum (sides of the form 61 M); 0: on the full plane
  *   "tail_overlap" 1: the frame / ZNCC / MI kernels of a unit SUBMITTED with km_klt_tile_frame_submit run on the block-copy
  *                  stream, beside the first kernels of the next submitted unit (klt.py:220-253: the per-tile loop); 0 (default): on
  *                  the compute stream (both issue-bound: the overlap is exact and buys nothing)

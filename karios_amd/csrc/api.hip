@@ -228,6 +228,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
     if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "fft_herm") == 0) { c->opt_fft_herm = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early_at") == 0) { c->opt_mm_early_at = value; return KM_OK; }
     if (strcmp(name, "tail_overlap") == 0) { c->opt_tail_overlap = value != 0; return KM_OK; }
     if (strcmp(name, "f64_plain") == 0) { c->opt_f64_plain = value != 0; return KM_OK; }

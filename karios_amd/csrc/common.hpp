@@ -226,6 +226,7 @@ struct km_ctx {
     bool opt_roctx = false;        // "roctx": roctx ranges around the stages
     bool opt_fft_cross_fused = true;   // "fft_cross": the cross-power step fused into the first inverse pass's row load (61 M rows)
     bool opt_fft_ts = false;       // "fft_ts" 1: rows of length 61 M on both sides - the two transposes are folded into the stores of the row passes in front of them (8-byte stores at a stride of one row, XCD-contiguous rows so that the lines fill up in L2): correct, the plane crosses HBM four times instead of six - and SLOWER (4.86 against 4.66 ms at 10980^2: the row kernels' store phase grows by more than the two 0.42-ms transposes cost).  0 (default): transpose kernels
+    bool opt_fft_herm = true;      // "fft_herm" 1 (default): the inverse transform of the float32 phase correlation works on the Hermitian half plane (rows of length 61 M on both sides)
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision, k_fft64.hip (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form

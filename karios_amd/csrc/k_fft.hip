@@ -477,12 +477,16 @@ struct f61_top2 {
 // MODE 0: rows of two real images -> z = a + i b;  1: complex rows in place;  2: complex rows, inverse (conjugate in, conjugate out);
 // 3: like 2 without an output plane: top2[r] = largest / second-largest |cc| of row r;  4: like 2 with the cross-power step fused
 // into the row load: row r of `data` (= Z, transposed spectrum) and its mirror row are read, P(k) is formed on the way into LDS,
-// the inverse transform of the row goes to `out_plane` (a kernel of its own moved 2.9 GB for that)
+// the inverse transform of the row goes to `out_plane` (a kernel of its own moved 2.9 GB for that);  5: the LAST inverse pass on a
+// Hermitian half plane (the cross-power spectrum of two real images: P(-k) = conj P(k), so the first inverse pass only ran the rows
+// kx <= N / 2): a workgroup step takes TWO image rows y1 = 2 r, y2 = 2 r + 1 of the half plane (pitch N / 2 + 1), completes
+// S(kx) = Q_y1(kx) + i Q_y2(kx) by symmetry, and ONE complex transform returns cc_y1 in the real and cc_y2 in the imaginary part -
+// half the rows, half the bytes; both rows report their own (largest, second-largest) |cc| like mode 3
 template <typename T, int MC /* M at compile time (0: run time): the 61 strided reads of a butterfly then carry immediate offsets */, int mode>
 __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__ img_a, const T *__restrict__ img_b, ptrdiff_t sa, ptrdiff_t sb,
                                                            float2 *__restrict__ data, f61_top2 *__restrict__ top2, int N, int nrows, f61_plan plan,
                                                            const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g, int dbg,
-                                                           float2 *__restrict__ out_plane, int ts_ld)
+                                                           float2 *__restrict__ out_plane, int ts_ld, int run_rows /* 0: all `nrows`; mode 4: only rows [0, run_rows); mode 5: row PAIRS */)
 {
     // ts_ld != 0 (modes 0 and 4): the finished row r leaves TRANSPOSED - element i goes to out[i * ts_ld + r] - so that the pass behind
     // it reads contiguous rows again and the 964-MB plane does not cross HBM twice more in a transpose kernel of its own.  Every lane
@@ -491,7 +495,8 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *row = (float2 *)smem;
     float2 *twM = row + N;                                  // exp(-2 pi i n / M), n < M
-    constexpr bool CROSS = mode == 4;
+    constexpr bool CROSS = mode == 4, PAIR = mode == 5;
+    const int nrun = run_rows ? run_rows : nrows;
     __shared__ unsigned long long s_best[F61_T / 64];
     __shared__ unsigned s_second[F61_T / 64];
     const int M = MC ? MC : plan.M;
@@ -501,9 +506,19 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
 
     // the row a thread holds in flight: elements tid + F61_T * u, exactly as loaded (conversions and the conjugation wait for
     // `commit`: an instruction that consumes a load would stall the wavefront until the data has arrived)
-    float2 pf[PF], pg[CROSS ? PF : 1];
+    float2 pf[PF], pg[(CROSS || PAIR) ? PF : 1];
+    constexpr int PFH = PF / 2 + 1;                         // mode 5 loads half rows (N / 2 + 1 elements)
     auto fetch = [&](int r) {
-        if constexpr (CROSS) {
+        if constexpr (PAIR) {
+            const int Wh = N / 2 + 1, y2 = min(2 * r + 1, nrows - 1);
+            const float2 *s1 = data + (size_t)(2 * r) * Wh, *s2 = data + (size_t)y2 * Wh;
+#pragma unroll
+            for (int u = 0; u < PFH; u++) {
+                const int i = min(tid + F61_T * u, Wh - 1);
+                pf[u] = s1[i];
+                pg[u] = s2[i];
+            }
+        } else if constexpr (CROSS) {
             // Z(kx, ky) and Z(-kx, -ky): row r and its mirror row read backwards (element 0 pairs with element 0)
             const int mr = r ? nrows - r : 0;
             const float2 *src = data + (size_t)r * N, *msrc = data + (size_t)mr * N;
@@ -527,7 +542,25 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             for (int u = 0; u < PF; u++) pf[u] = src[min(tid + F61_T * u, N - 1)];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int r) {
+        if constexpr (PAIR) {
+            const int Wh = N / 2 + 1;
+            const bool has2 = 2 * r + 1 < nrows;
+#pragma unroll
+            for (int u = 0; u < PFH; u++) {
+                const int i = tid + F61_T * u;
+                if (i < Wh) {
+                    const float2 q1 = pf[u], q2 = has2 ? pg[u] : make_float2(0.f, 0.f);
+                    // S(i) = q1 + i q2, S(N - i) = conj q1 + i conj q2; stored conjugated (inverse = conj . forward . conj)
+                    if (i == 0 || 2 * i == N) row[i] = make_float2(q1.x, -q2.x);            // self-conjugate frequencies are real
+                    else {
+                        row[i] = make_float2(q1.x - q2.y, -(q1.y + q2.x));
+                        row[N - i] = make_float2(q1.x + q2.y, q1.y - q2.x);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < PF; u++) {
             const int i = tid + F61_T * u;
@@ -546,9 +579,9 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
     };
     int r = blockIdx.x;
     if (ts_ld && (gridDim.x & 7) == 0) r = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD x: rows [32 x, 32 x + 32) of every block of gridDim.x rows
-    if (r < nrows) { fetch(r); commit(); }
+    if (r < nrun) { fetch(r); commit(r); }
     __syncthreads();
-    for (; r < nrows; r += gridDim.x) {
+    for (; r < nrun; r += gridDim.x) {
         // ---- phase A: 61-point transforms of the M butterflies (inputs at stride M, outputs contiguous: Y[j][t] -> row[61 j + t])
         {
             const int part = wave & 3, j = (wave >> 2) * 64 + lane;
@@ -576,7 +609,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
         __syncthreads();
         // ---- the next row starts its way from HBM (consumed after the store below)
         const int rn = r + gridDim.x;
-        if (!CROSS && rn < nrows && !(dbg & 4)) fetch(rn);     // (mode 4 holds two rows: fetched behind the transforms, where the registers are free)
+        if (!CROSS && !PAIR && rn < nrun && !(dbg & 4)) fetch(rn);     // (mode 4 holds two rows: fetched behind the transforms, where the registers are free)
         // ---- phase B: 61 independent length-M transforms, one wavefront each
         for (int tp = wave; tp < ((dbg & 2) ? 0 : 61); tp += F61_T / 64) {
             if constexpr (MC != 0) {
@@ -602,16 +635,20 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             }
         }
         __syncthreads();
-        if (CROSS && rn < nrows && !(dbg & 4)) fetch(rn);
+        if ((CROSS || PAIR) && rn < nrun && !(dbg & 4)) fetch(rn);
         // ---- the finished row leaves (natural order: X[t + 61 m] at row[t + 61 m])
-        if (mode == 3) {
+        if (mode == 3 || PAIR) {
+          for (int half = 0; half < (PAIR ? 2 : 1); half++) {
+            const int ro = PAIR ? 2 * r + half : r;         // the image row these samples belong to
+            if (ro >= nrows) break;                          // (odd number of rows: the last pair has no second one; uniform)
+            if (half) __syncthreads();                       // (s_best / s_second are read by thread 0 below)
             unsigned long long best = 0;
             unsigned second = 0;
             for (int i = tid; i < N; i += F61_T) {
                 const float2 x = row[i];
-                const float a = sqrtf(x.x * x.x + x.y * x.y);
+                const float a = PAIR ? fabsf(half ? x.y : x.x) : sqrtf(x.x * x.x + x.y * x.y);
                 if (a == a) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(a) << 32) | (0xffffffffull - ((unsigned long long)r * (unsigned)N + (unsigned)i));
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(a) << 32) | (0xffffffffull - ((unsigned long long)ro * (unsigned)N + (unsigned)i));
                     if (key > best) { second = max(second, (unsigned)(best >> 32)); best = key; }
                     else second = max(second, __float_as_uint(a));
                 }
@@ -628,8 +665,9 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
                 for (int w = 0; w < F61_T / 64; w++) rb = s_best[w] > rb ? s_best[w] : rb;
                 unsigned rs = 0;
                 for (int w = 0; w < F61_T / 64; w++) rs = max(rs, s_best[w] == rb ? s_second[w] : max(s_second[w], (unsigned)(s_best[w] >> 32)));
-                top2[r].best = rb; top2[r].second = rs; top2[r].pad = 0;
+                top2[ro].best = rb; top2[ro].second = rs; top2[ro].pad = 0;
             }
+          }
         } else {
             if (ts_ld) {
                 float2 *dst = (CROSS ? out_plane : data) + r;
@@ -640,7 +678,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             }
         }
         __syncthreads();
-        if (rn < nrows && !(dbg & 4)) commit();
+        if (rn < nrun && !(dbg & 4)) commit(rn);
         __syncthreads();
     }
 }
@@ -770,7 +808,7 @@ int launch_rows(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, f
 
 template <typename T, int MC, int MODE>
 int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                     const fft_tables &tb, float2 *out_plane, int ts_ld)
+                     const fft_tables &tb, float2 *out_plane, int ts_ld, int run_rows)
 {
     const size_t lds = ((size_t)N + (size_t)plan.M) * sizeof(float2);
     static unsigned long long opted = 0;   // per instantiation and per DEVICE: hipFuncSetAttribute applies to the current device only
@@ -779,8 +817,9 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
                                       (int)((FFT_NMAX + F61_MMAX) * sizeof(float2))));
         opted |= 1ull << (c->device & 63);
     }
-    const int grid = nrows < c->n_cu ? nrows : c->n_cu;      // one 88-KB workgroup per CU: each walks its rows with the next one in flight
-    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg, out_plane, ts_ld);
+    const int nrun = run_rows ? run_rows : nrows;
+    const int grid = nrun < c->n_cu ? nrun : c->n_cu;        // one 88-KB workgroup per CU: each walks its rows with the next one in flight
+    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg, out_plane, ts_ld, run_rows);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -789,26 +828,27 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
 // as a compile-time constant: 10980 = 61 * 180 (10 m), 5490 = 61 * 90 (20 m), 1830 = 61 * 30 (60 m).
 template <typename T, int MODE>
 int launch_rows61_m(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                    const fft_tables &tb, float2 *out_plane, int ts_ld = 0)
+                    const fft_tables &tb, float2 *out_plane, int ts_ld = 0, int run_rows = 0)
 {
     switch (plan.M) {
-    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld);
-    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld);
-    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld);
-    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld);
+    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
+    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
+    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
+    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
     }
 }
 
 template <typename T>
 int launch_rows61(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                  const fft_tables &tb, int mode, float2 *out_plane = nullptr, int ts_ld = 0)
+                  const fft_tables &tb, int mode, float2 *out_plane = nullptr, int ts_ld = 0, int run_rows = 0)
 {
     if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr, ts_ld);
     if constexpr (std::is_same<T, float>::value) {
         switch (mode) {
         case 1: return launch_rows61_m<float, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
         case 2: return launch_rows61_m<float, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
-        case 4: return launch_rows61_m<float, 4>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld);
+        case 4: return launch_rows61_m<float, 4>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
+        case 5: return launch_rows61_m<float, 5>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr, 0, run_rows);
         default: return launch_rows61_m<float, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
         }
     }
@@ -872,7 +912,18 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
     if ((rc = rows(B, nullptr, H, W, false, 1))) return rc;
     // inverse: rows (length H) of the transposed cross-power spectrum; (transposed) -> H x W; rows (length W) -> |cc|
     float2 *last = B;          // the plane the last pass reads
-    if (h61 && c->opt_fft_cross_fused) {
+    // Hermitian inverse ("fft_herm", both sides 61 M): the cross-power spectrum of two real images satisfies P(-k) = conj P(k), so the
+    // first inverse pass only runs the rows kx <= W / 2, the transpose moves half a plane and the last pass transforms two image
+    // rows per complex transform (fft61_rows_kernel mode 5) - the correlation surface comes out exactly real
+    const bool herm = w61 && h61 && c->opt_fft_cross_fused && c->opt_fft_herm && !ts;
+    if (herm) {
+        const int Wh = W / 2 + 1;
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A, 0, Wh))) return rc;       // A: Wh x H
+        const dim3 tgh((H + 63) / 64, (Wh + 63) / 64);
+        transpose_kernel<<<tgh, 256, 0, c->stream>>>(A, B, Wh, H);                                                           // B: H x Wh
+        KM_LAUNCH_CHECK(c);
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, W, H, qw, tw_w, 5, nullptr, 0, (H + 1) / 2))) return rc;
+    } else if (h61 && c->opt_fft_cross_fused) {
         // the cross-power step rides on the row load of the first inverse pass: B (= Z) -> A
         if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A, ts ? W : 0))) return rc;
         if (ts) last = A;
@@ -881,12 +932,12 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
         KM_LAUNCH_CHECK(c);
         if ((rc = rows(A, nullptr, H, W, false, 2))) return rc;
     }
-    if (!ts) {
+    if (!ts && !herm) {
         transpose_kernel<<<tg2, 256, 0, c->stream>>>(A, B, W, H);
         KM_LAUNCH_CHECK(c);
     }
     float *cc = (float *)(ts ? B : A);
-    if ((rc = rows(last, cc, W, H, true, 3))) return rc;
+    if (!herm && (rc = rows(last, cc, W, H, true, 3))) return rc;
     // largest and second-largest |cc|
     unsigned long long *k1 = &sc->argmax_key, *k2 = (unsigned long long *)&sc->valid;
     unsigned long long h1 = 0, h2 = 0;
