@@ -213,6 +213,33 @@ def test_fast_phase_correlation_equals_double_precision_path(ops, O, shape, fft_
             np.testing.assert_array_equal(got, [sy, sx])
 
 
+@pytest.mark.parametrize("shape", [(244, 183), (366, 366), (1098, 1220), (61, 122), (427, 915), (183, 1220), (1830, 854)])
+def test_hermitian_inverse_of_the_float32_phase_correlation_equals_the_full_plane_form(ops, O, shape):
+    """`fft_herm` (default): the inverse transform runs on the half plane kx <= W / 2 and packs two image rows into one complex
+    transform (k_fft.hip, mode 5) - even and odd sides, an odd number of rows (the last pair has one member): same integer shifts as
+    the full-plane form and the oracle (large_offset.py:39), peak margins within 1e-3 of each other."""
+    from karios_amd._lib import default_context
+    H, W = shape
+    ctx = default_context()
+    base, _ = synth.make_pair(H + 80, W + 80, 0.0, 0.0, seed=H + 3 * W, noise_sigma=0.0)
+    rng = np.random.default_rng(H + W)
+    try:
+        for trial in range(3):
+            sy, sx = int(rng.integers(-min(30, H // 8), min(30, H // 8) + 1)), int(rng.integers(-min(30, W // 8), min(30, W // 8) + 1))
+            a = base[40:40 + H, 40:40 + W]
+            b = base[40 - sy:40 - sy + H, 40 - sx:40 - sx + W]
+            res = {}
+            for herm in (1, 0):
+                ctx.set_option("fft_herm", herm)
+                res[herm] = (ops.phase_cross_correlation(b, a), ctx.phase_info())
+                assert res[herm][1][0] == 1
+            np.testing.assert_array_equal(res[1][0], res[0][0])
+            np.testing.assert_array_equal(res[1][0], O.phase_cross_correlation(b, a))
+            assert abs(res[1][1][1] - res[0][1][1]) < 1e-3
+    finally:
+        ctx.set_option("fft_herm", 1)
+
+
 @pytest.mark.parametrize("shape", [(61, 45), (96, 130), (1, 300), (300, 1), (2, 2), (3, 5), (11, 13), (127, 254), (131, 200), (200, 131), (257, 263),
                                    (1000, 1009), (4096, 64), (64, 4096), (4099, 37), (37, 4099), (512, 6000), (2135, 128), (122, 3721), (1830, 1098)])
 def test_double_precision_phase_correlation_for_every_kind_of_side(ops, O, shape):
