@@ -256,6 +256,18 @@ def run_aux_case(seed, ops, O, ResidentPair):
     got, want = ops.phase_cross_correlation(b, a), O.phase_cross_correlation(b, a)
     if not np.array_equal(got, want):
         fails.append(f"phase correlation {got} vs oracle {want} (true shift {sy},{sx}; {H}x{W} {np.dtype(dt).name})")
+    # ... and in the reference's complex128 whatever the side lengths (k_fft64.hip: levels, prime levels, Bluestein; ends fused or not)
+    from karios_amd._lib import default_context
+    ctx = default_context()
+    ctx.set_option("phase_fp64", 1)
+    ctx.set_option("f64_plain", int(rng.integers(2)))
+    try:
+        got64 = ops.phase_cross_correlation(b, a)
+    finally:
+        ctx.set_option("phase_fp64", 0)
+        ctx.set_option("f64_plain", 0)
+    if not np.array_equal(got64, want):
+        fails.append(f"phase correlation (float64 path) {got64} vs oracle {want} (true shift {sy},{sx}; {H}x{W} {np.dtype(dt).name})")
     # --- shift_image, also beyond the image ------------------------------------------------------------------------
     yo, xo = int(rng.integers(-H - 3, H + 4)), int(rng.integers(-W - 3, W + 4))
     if rng.random() < 0.7:
