@@ -262,6 +262,7 @@ struct km_ctx {
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
     int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
     int opt_f64_smooth_t = 0;      // "f64_smooth_t": the same for the smooth level kernel (default 8)
+    bool opt_f64_pair = true;      // "f64_pair" 1 (default): the inverse along the rows of the float64 transform packs two image rows into one complex transform
     bool opt_f64_plain = false;    // "f64_plain" 1: pack pass in front, two arg-max passes behind (instead of fusing both ends into the level kernels)
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
     bool mi_table_ready = false;   // WS_MI_TABLE holds its table

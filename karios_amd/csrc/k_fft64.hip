@@ -62,6 +62,10 @@ struct lvl_args {
     // last inverse level: the outputs are the correlation surface - every workgroup reports the largest |cc| it wrote (bit pattern)
     // and the first flat index that attains it: best[2 wg], best[2 wg + 1]  (two passes over the plane are gone)
     unsigned long long *best;
+    // the inverse along the rows runs on PAIRS of image rows (the correlation surface of two real images is real): row 2 j of the
+    // plane holds S = Q_(2j) + i Q_(2j+1) - formed by the first of these levels while it loads (pair_w = distance of the partner row,
+    // pair_h = number of image rows; 0: off) - and the last level reports |re| for row 2 j and |im| for row 2 j + 1 (best_pair_w)
+    int pair_w, pair_h, best_pair_w;
     int dbg;                         // development ("fft_dbg"): 1 skip the arithmetic, 2 skip the loads, 4 skip the stores - timing experiments, results are wrong
 };
 
@@ -177,6 +181,14 @@ struct best_t {
             if (b > bits || (b == bits && flat < idx)) { bits = b; idx = flat; }
         }
     }
+    __device__ __forceinline__ void see_abs(double v, unsigned long long flat)
+    {
+        const double m = fabs(v);
+        if (m == m) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+            if (b > bits || (b == bits && flat < idx)) { bits = b; idx = flat; }
+        }
+    }
     __device__ __forceinline__ void merge(unsigned long long ob, unsigned long long oi)
     {
         if (ob > bits || (ob == bits && oi < idx)) { bits = ob; idx = oi; }
@@ -224,6 +236,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
         else { t = e & (T - 1); i = e >> logT; }
     };
     auto addr = [&](int e, int i, int t) { return contig ? base + e : base + (long long)i * A.se + t; };
+    const bool has2 = (A.pair_w || A.best_pair_w) && 2 * (a / A.AR) + 1 < A.pair_h;   // (pairs of image rows: does this one have a second member?)
     {
         cd v[F64_SM_PER_THREAD], w[F64_SM_PER_THREAD];
         const bool pre = A.inverse && A.tw_mode;
@@ -236,7 +249,13 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
             w[u] = make_double2(1.0, 0.0);
             if (e < n * T && t < nt && !(A.dbg & 2)) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + t, i) : px_pair<IMG>(A, a, b0 + t + i * (int)A.se);
-                else v[u] = data[addr(e, i, t)];
+                else {
+                    v[u] = data[addr(e, i, t)];
+                    if (A.pair_w) {
+                        const cd q2 = has2 ? data[addr(e, i, t) + A.pair_w] : make_double2(0.0, 0.0);
+                        v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);        // Q_y1 + i Q_y2
+                    }
+                }
                 if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)(A.tw_mode == 1 ? b0 + t : qa)];
             }
         }
@@ -312,7 +331,12 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
                 else if (post) x = c_mul(x, w[u]);
                 const long long o = addr(e, i, t);
                 if (!(A.dbg & 4)) data[o] = x;
-                if (A.best) bt.see(x, (unsigned long long)o);
+                if (A.best) {
+                    if (A.best_pair_w) {
+                        bt.see_abs(x.x, (unsigned long long)o);
+                        if (has2) bt.see_abs(x.y, (unsigned long long)(o + A.best_pair_w));
+                    } else bt.see(x, (unsigned long long)o);
+                }
             }
         }
     }
@@ -335,6 +359,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
     const int q = A.tw_mode == 1 ? b0 + lane : a % A.AR;                       // (tw_mode 2: the same for the whole workgroup)
     const long long loff = (long long)lane * A.sb;
     const bool pre = A.inverse && A.tw_mode, contig = A.contiguous != 0;
+    const bool has2 = (A.pair_w || A.best_pair_w) && 2 * (a / A.AR) + 1 < A.pair_h;
     for (int u0 = 0; wave + 4 * u0 < p; u0 += F64_PR_BATCH) {
         cd v[F64_PR_BATCH], w[F64_PR_BATCH];
 #pragma unroll
@@ -344,7 +369,13 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
             w[u] = make_double2(1.0, 0.0);
             if (i < p && lane < nt && !(A.dbg & 2)) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + lane, i) : px_pair<IMG>(A, a, b0 + lane + i * (int)A.se);
-                else v[u] = data[base + (long long)i * A.se + loff];
+                else {
+                    v[u] = data[base + (long long)i * A.se + loff];
+                    if (A.pair_w) {
+                        const cd q2 = has2 ? data[base + (long long)i * A.se + loff + A.pair_w] : make_double2(0.0, 0.0);
+                        v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);
+                    }
+                }
                 if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)q];
             }
         }
@@ -372,7 +403,12 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
         else if (post) v = c_mul(v, w);
         const long long o = base + (long long)k * A.se + loff;
         if (!(A.dbg & 4)) data[o] = v;
-        if (A.best) bt.see(v, (unsigned long long)o);
+        if (A.best) {
+            if (A.best_pair_w) {
+                bt.see_abs(v.x, (unsigned long long)o);
+                if (has2) bt.see_abs(v.y, (unsigned long long)(o + A.best_pair_w));
+            } else bt.see(v, (unsigned long long)o);
+        }
     };
     auto ltw_of = [&](int k) {                                                 // W_{n R}^(q k): one coalesced row of the table per k
         return post && lane < nt ? ltw[(size_t)k * (size_t)A.ltw_R + (size_t)q] : make_double2(1.0, 0.0);
@@ -678,6 +714,8 @@ struct lvl_extra {
     const void *img_a = nullptr, *img_b = nullptr;     // first forward level along the rows: read the images
     long long img_sa = 0, img_sb = 0;
     int img_dtype = 0;
+    int pair_rows = 0;                                  // > 0: the plane's rows are PAIRS of image rows (inverse along the rows); = image rows
+    bool pair_load = false;                             //   ... and this level forms them while it loads
     bool want_best = false;                             // last inverse level: report (largest |cc|, first index) per workgroup
     unsigned long long *best = nullptr;                 //   -> WS_FFT_TOP2, `best_count` entries of two words
     size_t best_count = 0;
@@ -691,10 +729,23 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
     lvl_args A;
     A.data = data; A.tw = tabs.tw; A.ltw = tabs.ltw[level_index]; A.ptab = tabs.ptab[level_index]; A.ltw_R = L.R; A.n = L.n; A.N = N; A.inverse = inverse ? 1 : 0;
     A.img_a = A.img_b = nullptr; A.img_sa = A.img_sb = 0; A.best = nullptr; A.dbg = c->opt_fft_dbg;
+    A.pair_w = A.pair_h = A.best_pair_w = 0;
     int img = -1;
+    const bool paired = !cols && extra && extra->pair_rows > 0;     // rows of the plane = pairs of image rows at a pitch of two rows
     const long long Nl = (long long)L.n * L.R;
     long long nA;
-    if (!cols) {
+    if (paired) {
+        const int hp = (extra->pair_rows + 1) / 2;
+        A.pair_h = extra->pair_rows;
+        if (L.R > 1) {
+            A.AR = (int)(width / Nl); nA = (long long)hp * A.AR; A.s_blk = 2ll * width; A.s_r = Nl;
+            A.B = L.R; A.sb = 1; A.se = L.R; A.tw_mode = 1; A.contiguous = 0;
+        } else {
+            A.AR = 1; nA = hp; A.s_blk = 2ll * width; A.s_r = 0;
+            A.B = width / L.n; A.sb = L.n; A.se = 1; A.tw_mode = 0; A.contiguous = 1;
+        }
+        if (extra->pair_load) A.pair_w = width;
+    } else if (!cols) {
         if (L.R > 1) {
             A.AR = 1; nA = (long long)rows * (width / Nl); A.s_blk = Nl; A.s_r = 0;
             A.B = L.R; A.sb = 1; A.se = L.R; A.tw_mode = 1; A.contiguous = 0;
@@ -744,6 +795,7 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
             if (!extra->best) return KM_E_NOMEM;
             extra->best_count = (size_t)grid;
             A.best = extra->best;
+            if (paired) A.best_pair_w = width;
         }
     }
     auto launch = [&](auto ic) {
@@ -770,13 +822,20 @@ struct blue_tabs {
 };
 
 // all levels of one dimension; `first` / `last`: extras of the first forward level / the last inverse level (level 0 either way)
-int fft_levels(km_ctx *c, cd *data, const dim_tabs &tabs, const dimplan &P, bool inverse, bool cols, int rows, int width, lvl_extra *level0 = nullptr)
+// pair_rows > 0 (inverse along the rows only): the levels run on pairs of image rows, the first one forming them while it loads
+int fft_levels(km_ctx *c, cd *data, const dim_tabs &tabs, const dimplan &P, bool inverse, bool cols, int rows, int width, lvl_extra *level0 = nullptr,
+               int pair_rows = 0)
 {
     const int nl = (int)P.lv.size();
     for (int i = 0; i < nl; i++) {
         const int l = inverse ? nl - 1 - i : i;
-        const int rc = run_level(c, data, tabs, P.N, P.lv[(size_t)l], l, inverse, cols, rows, width, l == 0 ? level0 : nullptr);
+        lvl_extra ex;
+        lvl_extra *pe = nullptr;
+        if (l == 0 && level0) { ex = *level0; pe = &ex; }
+        if (pair_rows > 0) { ex.pair_rows = pair_rows; ex.pair_load = i == 0; pe = &ex; }
+        const int rc = run_level(c, data, tabs, P.N, P.lv[(size_t)l], l, inverse, cols, rows, width, pe);
         if (rc) return rc;
+        if (l == 0 && level0) { level0->best = ex.best; level0->best_count = ex.best_count; }
     }
     return KM_OK;
 }
@@ -935,7 +994,9 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
     auto along_rows = [&](bool inverse) -> int {
         if (W <= 1) return KM_OK;
         if (PX.blue) return blue_rows(c, z, H, PX, BX, inverse);
-        return fft_levels(c, z, TX, PX, inverse, false, H, W, fused_ends ? (inverse ? &last : &first) : nullptr);
+        // (inverse: the surface is real - two image rows per complex transform, half the rows through both levels)
+        const bool pairs = inverse && fused_ends && H >= 2 && c->opt_f64_pair;
+        return fft_levels(c, z, TX, PX, inverse, false, H, W, fused_ends ? (inverse ? &last : &first) : nullptr, pairs ? H : 0);
     };
     auto along_cols = [&](bool inverse) -> int {
         if (H <= 1) return KM_OK;
