@@ -142,6 +142,7 @@ int km_ctx_create(int device, km_ctx **out)
     if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_AUX_PYRAMID")) c->opt_aux_pyramid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
+    if (const char *e = getenv("KARIOS_HIP_LK_ORDER")) c->opt_lk_order = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_MM_EARLY_AT")) c->opt_mm_early_at = atoi(e);
     if (const char *e = getenv("KARIOS_HIP_TAIL_OVERLAP")) c->opt_tail_overlap = atoi(e) != 0;  // A/B switch: the scoring tail of a submitted unit beside the next unit's first kernels
     int ncu = 0;
