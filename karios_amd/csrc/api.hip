@@ -875,7 +875,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
         km_stage_timer t(c, ST_LK);
-        if (spec && !c->lk_start_valid) {
+        if (spec && !c->lk_start_valid && c->opt_mm_early_at != 3) {
             // (the next unit's early min / max starts here)
             if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
             KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
@@ -883,6 +883,12 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         }
         if ((rc = kl_track(c, A, B, d_p0, &sc->n_corners, n_max, prm->win_size, prm->max_count, prm->epsilon, true, d_p1, d_p0r)))
             return rc;
+        if (spec && !c->lk_start_valid && c->opt_mm_early_at == 3) {
+            // ("mm_early_at" 3: the next unit's min / max beside this unit's frame / ZNCC tail instead of beside LK)
+            if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
+            KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
+            c->lk_start_valid = true;
+        }
     }
     return KM_OK;
 }

@@ -257,7 +257,7 @@ struct km_ctx {
     hipEvent_t ev_front_done = nullptr, ev_tail_done = nullptr;
     bool tail_pending = false, tail_defer = false;
     int sc_parity = 0;             // which of the two scalar blocks the last overlapped unit used
-    int opt_mm_early_at = 0;       // "mm_early_at": where the next unit's early min / max may start (0 LK, 1 selection sweeps, 2 ranking)
+    int opt_mm_early_at = 0;       // "mm_early_at": where the next unit's early min / max may start (0 LK, 1 selection sweeps, 2 ranking, 3 behind LK; all but 0 measured slower)
     bool opt_tail_overlap = false; // "tail_overlap" (measured: the Laplacian kernel beside it stretches by what the tail saves - off)
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
     int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
