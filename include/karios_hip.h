@@ -129,6 +129,7 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *                  the compute stream (both issue-bound: the overlap is exact and buys nothing)
  *   "f64_pair"     1 (default): the inverse along the rows of the double-precision transform packs two image rows into one complex
  *                  transform (the correlation surface of two real images is real); 0: one row per transform
+ *   "f64_half"     1 (default): ... and its inverse column levels only run the columns kx <= W / 2; 0: all columns
  *   "f64_plain"    1: the double-precision transform packs the images in a pass of its own and finds the arg-max in two
  *                  passes behind the last level (default 0: both ends ride in the level kernels); development knobs of the
  *                  same transform: "f64_prime_t", "f64_smooth_t" (transforms per workgroup tile, 0 = default)

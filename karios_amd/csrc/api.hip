@@ -232,6 +232,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "fft_herm") == 0) { c->opt_fft_herm = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early_at") == 0) { c->opt_mm_early_at = value; return KM_OK; }
     if (strcmp(name, "tail_overlap") == 0) { c->opt_tail_overlap = value != 0; return KM_OK; }
+    if (strcmp(name, "f64_half") == 0) { c->opt_f64_half = value != 0; return KM_OK; }
     if (strcmp(name, "f64_pair") == 0) { c->opt_f64_pair = value != 0; return KM_OK; }
     if (strcmp(name, "f64_plain") == 0) { c->opt_f64_plain = value != 0; return KM_OK; }
     if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }

@@ -92,6 +92,7 @@ enum km_slot {
     WS_F64_NEGY,
     WS_F64_BLUEX,   //   ... and the tables of a Bluestein dimension
     WS_F64_BLUEY,
+    WS_F64_MASK,    //   ... which columns / column tiles the inverse needs on the Hermitian half plane
     WS_COUNT
 };
 
@@ -263,6 +264,7 @@ struct km_ctx {
     int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
     int opt_f64_smooth_t = 0;      // "f64_smooth_t": the same for the smooth level kernel (default 8)
     bool opt_f64_pair = true;      // "f64_pair" 1 (default): the inverse along the rows of the float64 transform packs two image rows into one complex transform
+    bool opt_f64_half = true;      // "f64_half" 1 (default): ... and the inverse column levels only run the columns kx <= W / 2 (the rest follows by symmetry)
     bool opt_f64_plain = false;    // "f64_plain" 1: pack pass in front, two arg-max passes behind (instead of fusing both ends into the level kernels)
     int fft_tw_n[2] = {0, 0};      // row lengths whose twiddle tables sit in WS_FFT_TW0 / WS_FFT_TW1
     bool mi_table_ready = false;   // WS_MI_TABLE holds its table

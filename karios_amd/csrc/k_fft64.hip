@@ -66,6 +66,15 @@ struct lvl_args {
     // plane holds S = Q_(2j) + i Q_(2j+1) - formed by the first of these levels while it loads (pair_w = distance of the partner row,
     // pair_h = number of image rows; 0: off) - and the last level reports |re| for row 2 j and |im| for row 2 j + 1 (best_pair_w)
     int pair_w, pair_h, best_pair_w;
+    // ... and on the Hermitian HALF of the columns (Q(y, -kx) = conj Q(y, kx)): the inverse column levels skip the tiles that hold
+    // no column with kx <= W / 2 (tile_mask, one byte per tile of T columns), the first row level reads the pairs from the plane
+    // `pair_src` (pitch pair_w), completing the columns kx > W / 2 from their mirror positions (srcx), and writes PACKED rows
+    // (pitch = row length) into `data`; the last level then adds best_row_add per packed row to get the image row's flat index
+    const unsigned char *tile_mask;
+    const cd *pair_src;
+    const int *srcx;                 // column px of a pair comes from position srcx[px] (>= 0: as it is) or ~srcx[px] (< 0: conjugated)
+    int pair_hstart;                 // elements >= pair_hstart of every transform are mirrored ones: visited in reverse, so that the reads ascend (-1: none)
+    int best_row_add;
     int dbg;                         // development ("fft_dbg"): 1 skip the arithmetic, 2 skip the loads, 4 skip the stores - timing experiments, results are wrong
 };
 
@@ -222,6 +231,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
     cd *buf0 = (cd *)smem64, *buf1 = buf0 + n * T, *twl = buf1 + n * T;       // twl[j] = exp(-2 pi i j / n)
     const int tid = threadIdx.x;
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
+    if (A.tile_mask && !A.tile_mask[tb]) return;                               // (a tile of columns nobody reads: uniform, before any barrier)
     const long long base = tile_base(A, a, b0);
     const int qa = a % A.AR;
     cd *__restrict__ data = A.data;
@@ -239,21 +249,34 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
     const bool has2 = (A.pair_w || A.best_pair_w) && 2 * (a / A.AR) + 1 < A.pair_h;   // (pairs of image rows: does this one have a second member?)
     {
         cd v[F64_SM_PER_THREAD], w[F64_SM_PER_THREAD];
+        int es[F64_SM_PER_THREAD];                                             // LDS slot of each loaded element
         const bool pre = A.inverse && A.tw_mode;
 #pragma unroll
         for (int u = 0; u < F64_SM_PER_THREAD; u++) {
-            const int e = tid + 256 * u;
+            int e = tid + 256 * u;
             int i, t;
             split(e, i, t);
+            if (A.pair_src && A.pair_hstart >= 0 && i >= A.pair_hstart) { i = A.pair_hstart + n - 1 - i; e = t * n + i; }   // (contiguous tiles: a bijection inside the transform)
+            es[u] = e;
             v[u] = make_double2(0.0, 0.0);
             w[u] = make_double2(1.0, 0.0);
             if (e < n * T && t < nt && !(A.dbg & 2)) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + t, i) : px_pair<IMG>(A, a, b0 + t + i * (int)A.se);
                 else {
-                    v[u] = data[addr(e, i, t)];
-                    if (A.pair_w) {
-                        const cd q2 = has2 ? data[addr(e, i, t) + A.pair_w] : make_double2(0.0, 0.0);
-                        v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);        // Q_y1 + i Q_y2
+                    if (A.pair_src) {
+                        // packed pairs from the half plane (contiguous tiles only): column px of image rows 2 j, 2 j + 1
+                        const int sx = A.srcx[b0 * n + e];
+                        const bool low = sx >= 0;
+                        const long long sp = (long long)(a / A.AR) * 2 * A.pair_w + (low ? sx : ~sx);
+                        const cd q1 = A.pair_src[sp], q2 = has2 ? A.pair_src[sp + A.pair_w] : make_double2(0.0, 0.0);
+                        v[u] = low ? make_double2(q1.x - q2.y, q1.y + q2.x)          // Q_y1 + i Q_y2
+                                   : make_double2(q1.x + q2.y, q2.x - q1.y);         // conj Q_y1(-kx) + i conj Q_y2(-kx)
+                    } else {
+                        v[u] = data[addr(e, i, t)];
+                        if (A.pair_w) {
+                            const cd q2 = has2 ? data[addr(e, i, t) + A.pair_w] : make_double2(0.0, 0.0);
+                            v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);        // Q_y1 + i Q_y2
+                        }
                     }
                 }
                 if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)(A.tw_mode == 1 ? b0 + t : qa)];
@@ -262,8 +285,8 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
         for (int j = tid; j < n; j += 256) twl[j] = tw[(size_t)j * (size_t)(A.N / n)];
 #pragma unroll
         for (int u = 0; u < F64_SM_PER_THREAD; u++) {
-            const int e = tid + 256 * u;
-            if (e < n * T) {
+            const int e = es[u];
+            if (tid + 256 * u < n * T) {
                 cd x = v[u];
                 if (A.inverse) {
                     x.y = -x.y;                                                // inverse DFT = conj . DFT . conj
@@ -333,8 +356,9 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
                 if (!(A.dbg & 4)) data[o] = x;
                 if (A.best) {
                     if (A.best_pair_w) {
-                        bt.see_abs(x.x, (unsigned long long)o);
-                        if (has2) bt.see_abs(x.y, (unsigned long long)(o + A.best_pair_w));
+                        const unsigned long long f1 = (unsigned long long)o + (unsigned long long)(a / A.AR) * (unsigned long long)A.best_row_add;
+                        bt.see_abs(x.x, f1);
+                        if (has2) bt.see_abs(x.y, f1 + A.best_pair_w);
                     } else bt.see(x, (unsigned long long)o);
                 }
             }
@@ -353,6 +377,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
     const int p = A.n, T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
+    if (A.tile_mask && !A.tile_mask[tb]) return;
     const long long base = tile_base(A, a, b0);
     cd *__restrict__ data = A.data;
     const cd *__restrict__ ltw = A.ltw;
@@ -370,10 +395,18 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
             if (i < p && lane < nt && !(A.dbg & 2)) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + lane, i) : px_pair<IMG>(A, a, b0 + lane + i * (int)A.se);
                 else {
-                    v[u] = data[base + (long long)i * A.se + loff];
-                    if (A.pair_w) {
-                        const cd q2 = has2 ? data[base + (long long)i * A.se + loff + A.pair_w] : make_double2(0.0, 0.0);
-                        v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);
+                    if (A.pair_src) {
+                        const int sx = A.srcx[(b0 + lane) * p + i];                    // (contiguous tiles: transform t = elements t p .. t p + p - 1)
+                        const bool low = sx >= 0;
+                        const long long sp = (long long)(a / A.AR) * 2 * A.pair_w + (low ? sx : ~sx);
+                        const cd q1 = A.pair_src[sp], q2 = has2 ? A.pair_src[sp + A.pair_w] : make_double2(0.0, 0.0);
+                        v[u] = low ? make_double2(q1.x - q2.y, q1.y + q2.x) : make_double2(q1.x + q2.y, q2.x - q1.y);
+                    } else {
+                        v[u] = data[base + (long long)i * A.se + loff];
+                        if (A.pair_w) {
+                            const cd q2 = has2 ? data[base + (long long)i * A.se + loff + A.pair_w] : make_double2(0.0, 0.0);
+                            v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);
+                        }
                     }
                 }
                 if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)q];
@@ -405,8 +438,9 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
         if (!(A.dbg & 4)) data[o] = v;
         if (A.best) {
             if (A.best_pair_w) {
-                bt.see_abs(v.x, (unsigned long long)o);
-                if (has2) bt.see_abs(v.y, (unsigned long long)(o + A.best_pair_w));
+                const unsigned long long f1 = (unsigned long long)o + (unsigned long long)(a / A.AR) * (unsigned long long)A.best_row_add;
+                bt.see_abs(v.x, f1);
+                if (has2) bt.see_abs(v.y, f1 + A.best_pair_w);
             } else bt.see(v, (unsigned long long)o);
         }
     };
@@ -716,6 +750,13 @@ struct lvl_extra {
     int img_dtype = 0;
     int pair_rows = 0;                                  // > 0: the plane's rows are PAIRS of image rows (inverse along the rows); = image rows
     bool pair_load = false;                             //   ... and this level forms them while it loads
+    // Hermitian half of the columns (inverse only): column levels skip tiles without a needed column; row levels work on PACKED pairs
+    const unsigned char *tile_mask = nullptr;           //   column level: one byte per tile of `tile_T` columns
+    int tile_T = 0;
+    bool packed = false;                                //   row level: `data` holds packed pairs (pitch = width) ...
+    const cd *pair_src = nullptr;                       //   ... which this level (pair_load) reads from here, completing kx > W / 2 by symmetry
+    const int *srcx = nullptr;
+    int pair_hstart = -1;
     bool want_best = false;                             // last inverse level: report (largest |cc|, first index) per workgroup
     unsigned long long *best = nullptr;                 //   -> WS_FFT_TOP2, `best_count` entries of two words
     size_t best_count = 0;
@@ -729,22 +770,28 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
     lvl_args A;
     A.data = data; A.tw = tabs.tw; A.ltw = tabs.ltw[level_index]; A.ptab = tabs.ptab[level_index]; A.ltw_R = L.R; A.n = L.n; A.N = N; A.inverse = inverse ? 1 : 0;
     A.img_a = A.img_b = nullptr; A.img_sa = A.img_sb = 0; A.best = nullptr; A.dbg = c->opt_fft_dbg;
-    A.pair_w = A.pair_h = A.best_pair_w = 0;
+    A.pair_w = A.pair_h = A.best_pair_w = A.best_row_add = 0;
+    A.tile_mask = nullptr; A.pair_src = nullptr; A.srcx = nullptr; A.pair_hstart = -1;
     int img = -1;
     const bool paired = !cols && extra && extra->pair_rows > 0;     // rows of the plane = pairs of image rows at a pitch of two rows
     const long long Nl = (long long)L.n * L.R;
     long long nA;
     if (paired) {
         const int hp = (extra->pair_rows + 1) / 2;
+        const long long pitch = extra->packed ? (long long)width : 2ll * width;     // in place in the rows 2 j, or packed rows
         A.pair_h = extra->pair_rows;
         if (L.R > 1) {
-            A.AR = (int)(width / Nl); nA = (long long)hp * A.AR; A.s_blk = 2ll * width; A.s_r = Nl;
+            A.AR = (int)(width / Nl); nA = (long long)hp * A.AR; A.s_blk = pitch; A.s_r = Nl;
             A.B = L.R; A.sb = 1; A.se = L.R; A.tw_mode = 1; A.contiguous = 0;
         } else {
-            A.AR = 1; nA = hp; A.s_blk = 2ll * width; A.s_r = 0;
+            A.AR = 1; nA = hp; A.s_blk = pitch; A.s_r = 0;
             A.B = width / L.n; A.sb = L.n; A.se = 1; A.tw_mode = 0; A.contiguous = 1;
         }
-        if (extra->pair_load) A.pair_w = width;
+        if (extra->pair_load) {
+            A.pair_w = width;
+            if (extra->packed) { A.pair_src = extra->pair_src; A.srcx = extra->srcx; A.pair_hstart = L.kind == 0 ? extra->pair_hstart : -1; }
+        }
+        if (extra->packed) A.best_row_add = width;
     } else if (!cols) {
         if (L.R > 1) {
             A.AR = 1; nA = (long long)rows * (width / Nl); A.s_blk = Nl; A.s_r = 0;
@@ -768,6 +815,7 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
         if (c->opt_f64_prime_t > 0) tmax = std::min(tmax, c->opt_f64_prime_t);
         const int tiles = (A.B + tmax - 1) / tmax;
         A.T = (A.B + tiles - 1) / tiles; A.logT = 0;
+        if (cols && extra && extra->tile_mask && extra->tile_T > 0) A.T = extra->tile_T;   // (chosen with the mask: half_plane_tiles)
         A.tiles_b = (A.B + A.T - 1) / A.T;
         lds = (size_t)L.n * A.T * sizeof(cd);
     } else if (A.contiguous) {
@@ -787,6 +835,10 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
     }
     const long long grid = nA * A.tiles_b;
     if (grid <= 0 || grid > 0x7fffffffll) return km_fail(c, KM_E_ARG, "phase correlation: plane too large");
+    if (cols && extra && extra->tile_mask) {
+        if (extra->tile_T != A.T) return km_fail(c, KM_E_INTERNAL, "phase correlation: tile mask of %d columns, tiles of %d", extra->tile_T, A.T);
+        A.tile_mask = extra->tile_mask;
+    }
     if (extra) {
         A.img_a = extra->img_a; A.img_b = extra->img_b; A.img_sa = extra->img_sa; A.img_sb = extra->img_sb;
         if (extra->img_a) img = extra->img_dtype;
@@ -814,6 +866,39 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
     return KM_OK;
 }
 
+// tiles of a column level (what run_level chooses for it) and, on the Hermitian half, which of them hold a needed column
+int cols_level_T(km_ctx *c, const lvl &L, int width, const std::vector<unsigned char> *lowx)
+{
+    if (L.kind == 1) {
+        int tmax = std::min(64, std::max(1, 4096 / L.n));
+        if (c->opt_f64_prime_t > 0) tmax = std::min(tmax, c->opt_f64_prime_t);
+        const int tiles = (width + tmax - 1) / tmax;
+        int best_T = (width + tiles - 1) / tiles;
+        if (lowx) {
+            // the tile width that leaves the fewest tiles to run (a tile costs the same whatever its width)
+            auto needed = [&](int T) {
+                int cnt = 0;
+                for (int t0 = 0; t0 < width; t0 += T) {
+                    bool any = false;
+                    for (int x = t0; x < std::min(width, t0 + T) && !any; x++) any = (*lowx)[(size_t)x] != 0;
+                    cnt += any;
+                }
+                return cnt;
+            };
+            int best_n = needed(best_T);
+            for (int T = tmax; T >= std::max(16, tmax / 2); T--) {
+                const int nn = needed(T);
+                if (nn < best_n) { best_n = nn; best_T = T; }
+            }
+        }
+        return best_T;
+    }
+    int T = 8;
+    while (T > 1 && (L.n * T > F64_SMOOTH_MAX || (c->opt_f64_smooth_t > 0 && T > c->opt_f64_smooth_t))) T >>= 1;
+    while (T > 1 && (T >> 1) >= width) T >>= 1;
+    return T;
+}
+
 struct blue_tabs {
     dimplan inner;                 // plan of the power-of-two length L (rows of the scratch)
     dim_tabs tabs;                 // its tables
@@ -822,16 +907,31 @@ struct blue_tabs {
 };
 
 // all levels of one dimension; `first` / `last`: extras of the first forward level / the last inverse level (level 0 either way)
+// the Hermitian half of the columns in the inverse transform (host side of lvl_args::tile_mask / pair_src)
+struct half_plane {
+    bool on = false;
+    cd *packed = nullptr;                               // the plane of packed row pairs the row levels work on
+    const cd *src = nullptr;                            // the plane the column levels left (rows 2 j, 2 j + 1 of every pair)
+    const int *srcx = nullptr;
+    int hstart = -1;
+    const unsigned char *mask[16] = {nullptr};          // per column level
+    int T[16] = {0};
+};
+
 // pair_rows > 0 (inverse along the rows only): the levels run on pairs of image rows, the first one forming them while it loads
 int fft_levels(km_ctx *c, cd *data, const dim_tabs &tabs, const dimplan &P, bool inverse, bool cols, int rows, int width, lvl_extra *level0 = nullptr,
-               int pair_rows = 0)
+               int pair_rows = 0, const half_plane *hp = nullptr)
 {
     const int nl = (int)P.lv.size();
+    const bool half = hp && hp->on && inverse;
+    if (half && !cols) data = hp->packed;
     for (int i = 0; i < nl; i++) {
         const int l = inverse ? nl - 1 - i : i;
         lvl_extra ex;
         lvl_extra *pe = nullptr;
         if (l == 0 && level0) { ex = *level0; pe = &ex; }
+        if (half && cols) { ex.tile_mask = hp->mask[l]; ex.tile_T = hp->T[l]; pe = &ex; }
+        if (half && !cols) { ex.packed = true; ex.pair_src = hp->src; ex.srcx = hp->srcx; ex.pair_hstart = hp->hstart; }
         if (pair_rows > 0) { ex.pair_rows = pair_rows; ex.pair_load = i == 0; pe = &ex; }
         const int rc = run_level(c, data, tabs, P.N, P.lv[(size_t)l], l, inverse, cols, rows, width, pe);
         if (rc) return rc;
@@ -991,16 +1091,55 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
         if (rc) return rc;
     }
 
+    // inverse: the surface is real - two image rows per complex transform, and (level kernels along the columns too) only the
+    // columns kx <= W / 2 through the inverse column levels
+    const bool pairs = fused_ends && H >= 2 && c->opt_f64_pair;
+    half_plane HP;
+    if (pairs && !PY.blue && !PY.lv.empty() && c->opt_f64_half && W >= 32) {
+        std::vector<unsigned char> lowx((size_t)W);
+        for (int pos = 0; pos < W; pos++) {
+            long long fr = 0, mult = 1;
+            for (const lvl &L : PX.lv) { fr += (long long)((pos / L.R) % L.n) * mult; mult *= L.n; }
+            lowx[(size_t)pos] = fr <= W / 2;
+        }
+        const size_t nl = PY.lv.size();
+        // [srcx: W ints] [one mask of W bytes per column level]
+        std::vector<unsigned char> h((size_t)W * (4 + nl), 0);
+        {
+            std::vector<int> ng;
+            host_negpos(PX, ng);
+            int *sx = (int *)h.data();
+            for (int pos = 0; pos < W; pos++) sx[pos] = lowx[(size_t)pos] ? pos : ~ng[(size_t)pos];
+        }
+        for (size_t l = 0; l < nl; l++) {
+            const int T = cols_level_T(c, PY.lv[l], W, &lowx);
+            HP.T[l] = T;
+            unsigned char *m = &h[(size_t)W * (4 + l)];
+            for (int t0 = 0, tb = 0; t0 < W; t0 += T, tb++)
+                for (int x = t0; x < std::min(W, t0 + T); x++) m[tb] |= lowx[(size_t)x];
+        }
+        // from which element on every transform of the first row level (the last level of the plan: contiguous) is mirrored
+        {
+            const int n0 = PX.lv.back().n;
+            int hs = 0;
+            for (int pos = 0; pos < W; pos++) if (lowx[(size_t)pos]) hs = std::max(hs, pos % n0 + 1);
+            HP.hstart = hs < n0 ? hs : -1;
+        }
+        unsigned char *d = (unsigned char *)km_ws(c, WS_F64_MASK, h.size());
+        cd *z2 = (cd *)km_ws(c, WS_FFT_B, (size_t)((H + 1) / 2) * W * sizeof(cd));
+        if (!d || !z2) return KM_E_NOMEM;
+        if ((rc = km_h2d_small(c, d, h.data(), h.size()))) return rc;
+        HP.on = true; HP.packed = z2; HP.src = z; HP.srcx = (const int *)d;
+        for (size_t l = 0; l < nl; l++) HP.mask[l] = d + (size_t)W * (4 + l);
+    }
     auto along_rows = [&](bool inverse) -> int {
         if (W <= 1) return KM_OK;
         if (PX.blue) return blue_rows(c, z, H, PX, BX, inverse);
-        // (inverse: the surface is real - two image rows per complex transform, half the rows through both levels)
-        const bool pairs = inverse && fused_ends && H >= 2 && c->opt_f64_pair;
-        return fft_levels(c, z, TX, PX, inverse, false, H, W, fused_ends ? (inverse ? &last : &first) : nullptr, pairs ? H : 0);
+        return fft_levels(c, z, TX, PX, inverse, false, H, W, fused_ends ? (inverse ? &last : &first) : nullptr, inverse && pairs ? H : 0, &HP);
     };
     auto along_cols = [&](bool inverse) -> int {
         if (H <= 1) return KM_OK;
-        if (!PY.blue) return fft_levels(c, z, TY, PY, inverse, true, H, W);
+        if (!PY.blue) return fft_levels(c, z, TY, PY, inverse, true, H, W, nullptr, 0, &HP);
         int r = transpose(c, z, zt, H, W);
         if (!r) r = blue_rows(c, zt, W, PY, BY, inverse);
         if (!r) r = transpose(c, zt, z, W, H);

@@ -266,18 +266,21 @@ def test_double_precision_phase_correlation_for_every_kind_of_side(ops, O, shape
             elif dtype == np.float32:
                 a, b = a.astype(np.float32) * np.float32(0.25), b.astype(np.float32) * np.float32(0.25)
             want = O.phase_cross_correlation(b, a)
-            for plain, pair in ((0, 1), (0, 0), (1, 1)):        # (pair: two image rows per transform in the inverse along the rows)
+            # pair: two image rows per transform in the inverse along the rows; half: only the columns kx <= W / 2 through the inverse column levels
+            for plain, pair, half in ((0, 1, 1), (0, 1, 0), (0, 0, 0), (1, 1, 1)):
                 ctx.set_option("f64_plain", plain)
                 ctx.set_option("f64_pair", pair)
+                ctx.set_option("f64_half", half)
                 got = ops.phase_cross_correlation(b, a)
                 assert ctx.phase_info()[0] == 2
-                np.testing.assert_array_equal(got, want, err_msg=f"{shape} {dtype.__name__} plain={plain} pair={pair}")
+                np.testing.assert_array_equal(got, want, err_msg=f"{shape} {dtype.__name__} plain={plain} pair={pair} half={half}")
             if min(H, W) >= 200:
                 np.testing.assert_array_equal(got, [sy, sx])
     finally:
         ctx.set_option("phase_fp64", 0)
         ctx.set_option("f64_plain", 0)
         ctx.set_option("f64_pair", 1)
+        ctx.set_option("f64_half", 1)
 
 
 def test_phase_correlation_survives_toggling_the_row_form_on_one_context(ops, O):
