@@ -348,13 +348,18 @@ def full_scoring(ctx, pair, conf, S, steps):
             take(stream.submit(pair, conf))
         take(stream.drain())
         ctx.sync()
-        rows[0] = 0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            take(stream.submit(pair, conf))
-        take(stream.drain())
-        ctx.sync()
-        dt = (time.perf_counter() - t0) / steps
+        # three windows of `steps` pairs, the median window is the figure (a 20-step window is 25 ms: one host hiccup of a few
+        # milliseconds - collector, scheduler - moved a single window from 1.16 to 1.33 ms on one box); all three are reported
+        windows = []
+        for _w in range(3):
+            rows[0] = 0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                take(stream.submit(pair, conf))
+            take(stream.drain())
+            ctx.sync()
+            windows.append((time.perf_counter() - t0) / steps)
+        dt = sorted(windows)[1]
         n_rows = rows[0] // steps
         # stage spans (untimed pass, every stage bracketed)
         ctx.set_profiling(True)
@@ -388,7 +393,8 @@ def full_scoring(ctx, pair, conf, S, steps):
         roof.update({k: v for k, v in pmc.items() if k != "traffic"})
     return {"workload": f"BASELINE config 2 pair ({S}x{S}), KLT + ZNCC + mutual_info_score + mi_score = the whole scoring of _handle_klt_results "
                         "(api/core.py:894-907) in the tile's device call; one pair in flight (FrameStream(0.4, mutual_info=True))",
-            "steps": steps, "ms_per_pair": dt * 1e3, "Mpx_per_s": S * S / 1e6 / dt, "matched_keypoints_per_sec": n_rows / dt,
+            "steps": steps, "ms_per_pair": dt * 1e3, "windows_ms_per_pair": [round(w * 1e3, 4) for w in windows], "Mpx_per_s": S * S / 1e6 / dt,
+            "matched_keypoints_per_sec": n_rows / dt,
             "matched_keypoints_per_pair": n_rows, "scored_rows_per_pair": n_scored, "columns": (None if frame is None else list(frame.columns)),
             "stage_ms": stage, "roofline": roof}, frame
 
