@@ -91,6 +91,28 @@ def test_config3_large_shift_full_size(ops, torch_dev):
     assert abs(np.median(dx) - 37.25) < 0.02 and abs(np.median(dy) + 20.75) < 0.02
 
 
+def test_config3_phase_correlation_in_both_precisions_full_size(ops, torch_dev):
+    """The same 10980 x 10980 pair through the float32 transform (Hermitian inverse and full-plane inverse) and through the complex128
+    transform of the reference (`large_offset.py:39`; every variant of its inverse: pairs of rows on the half plane, pairs, single
+    rows, the ends as passes of their own): all return the generator's shift [-21, 37]."""
+    pair, _, _ = _pair(torch_dev, 37.25, -20.75)
+    ctx = pair.ctx
+    want = np.array([-21.0, 37.0])
+    try:
+        for herm in (1, 0):
+            ctx.set_option("fft_herm", herm)
+            np.testing.assert_array_equal(pair.phase_offset(), want)
+            assert ctx.phase_info()[0] == 1 and ctx.phase_info()[1] > 0.3
+        ctx.set_option("phase_fp64", 1)
+        for plain, p2, half in ((0, 1, 1), (0, 1, 0), (0, 0, 0), (1, 1, 1)):
+            ctx.set_option("f64_plain", plain); ctx.set_option("f64_pair", p2); ctx.set_option("f64_half", half)
+            np.testing.assert_array_equal(pair.phase_offset(), want, err_msg=f"plain={plain} pair={p2} half={half}")
+            assert ctx.phase_info()[0] == 2
+    finally:
+        for k, v in (("phase_fp64", 0), ("fft_herm", 1), ("f64_plain", 0), ("f64_pair", 1), ("f64_half", 1)):
+            ctx.set_option(k, v)
+
+
 def test_config5_cross_sensor_with_user_mask(ops, O):
     """Cross-sensor stand-in (3x3 block-averaged, gamma 0.8) with a user mask, tiled; one tile compared with the oracle."""
     from karios_amd import synth
