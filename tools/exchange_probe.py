@@ -38,10 +38,11 @@ conf = KLTConfiguration()
 
 LAG = "--at-submit" not in sys.argv        # issue the exchange when the step is COLLECTED (bench.py's way) instead of at submission
 DEPTH = 2
+BATCH = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--batch=")), 4)
 
 
 def run(parts):
-    ex = RankBlockExchange(ctx, conf.maxCorners, True, device=dev, parts=parts) if parts is not None else None
+    ex = RankBlockExchange(ctx, conf.maxCorners, True, device=dev, parts=parts, batch=BATCH) if parts is not None else None
     pend_of = {}
     with FrameStream(0.4, depth=DEPTH) as stream:
         def collected(results):
