@@ -542,3 +542,14 @@ def test_phase_plan_levels_multiply_to_the_side_and_pair_every_frequency_with_it
                 assert abs(X[neg[pos]] - ref[(-f) % n]) < 1e-9 * scale
     assert lib.km_phase_plan(0, 0, levels, 16, None, None, None) < 0
     assert lib.km_phase_plan(10980, 0, levels, 1, None, None, None) < 0                 # two levels do not fit one slot
+
+
+def test_the_library_links_no_math_library():
+    """Both FFTs, the sort and the scans are hand-written (k_fft.hip, k_fft64.hip, k_sort.hip): the shared object needs the HIP runtime
+    and the C / C++ runtimes, nothing else - no rocFFT / hipFFT / rocPRIM / rocBLAS / MIOpen behind the C ABI."""
+    import subprocess
+    from karios_amd import _lib
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout.lower()
+    for name in ("rocfft", "hipfft", "rocprim", "hipcub", "rocblas", "hipblas", "miopen", "rocrand", "rocsparse", "rocsolver"):
+        assert name not in out, f"{name} in the library's dependencies:\n{out}"
+    assert "libamdhip64" in out
