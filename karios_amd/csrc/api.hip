@@ -142,6 +142,7 @@ int km_ctx_create(int device, km_ctx **out)
     if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_AUX_PYRAMID")) c->opt_aux_pyramid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
+    if (const char *e = getenv("KARIOS_HIP_DEFER_VALID")) c->opt_defer_valid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_LK_ORDER")) c->opt_lk_order = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_MM_EARLY_AT")) c->opt_mm_early_at = atoi(e);
     if (const char *e = getenv("KARIOS_HIP_TAIL_OVERLAP")) c->opt_tail_overlap = atoi(e) != 0;  // A/B switch: the scoring tail of a submitted unit beside the next unit's first kernels
@@ -230,6 +231,7 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "fft_herm") == 0) { c->opt_fft_herm = value != 0; return KM_OK; }
+    if (strcmp(name, "defer_valid") == 0) { c->opt_defer_valid = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early_at") == 0) { c->opt_mm_early_at = value; return KM_OK; }
     if (strcmp(name, "tail_overlap") == 0) { c->opt_tail_overlap = value != 0; return KM_OK; }
     if (strcmp(name, "f64_half") == 0) { c->opt_f64_half = value != 0; return KM_OK; }
@@ -508,6 +510,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE, bool defer_tail = false
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->spec_used = false; c->spec_flags = 0;
+    c->valid_job_pending = false;      // (a call that failed between the Laplacian pass and the fork)
     // early min / max (klt_tile_dev_impl): only a tile call that DIRECTLY follows a tile call may start its K1 beside the previous
     // unit's LK - any call in between may have produced the rasters on the main stream (km_shift_image_dev ...)
     c->lk_start_prev = c->lk_start_valid; c->lk_start_valid = false;
@@ -764,6 +767,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     bool spec = !d_p0_in && c->spec_allowed && c->opt_speculative && c->fused_eig && prm->max_corners > 0 && prm->min_distance >= 1 &&
                 !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor && !c->opt_select_first;
     if (!spec && (rc = tail_wait_now(c))) return rc;     // (only the sync-free form defers the wait for the previous unit's tail)
+    if (!spec && (rc = kd_run_valid_sum(c))) return rc;  // (... and the valid-pixel sum)
     if (spec) {
         const size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
         unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, capk * sizeof(unsigned long long));
@@ -795,8 +799,8 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
             hipStream_t main_stream = c->stream;
             c->stream = c->aux_stream;
-            int r;
-            {
+            int r = kd_run_valid_sum(c);                     // (the Laplacian pass's deferred valid-pixel sum: off the main stream)
+            if (r == KM_OK) {
                 km_stage_timer t(c, ST_PYRAMID);
                 r = build_pyramid_pair(c, d_ref_lap, d_mon_lap, H, W, prm->win_size, prm->max_level, &A, &B);
             }
@@ -848,6 +852,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         }
     }
     if ((rc = tail_wait_now(c))) return rc;              // (every fall-back of the block above)
+    if ((rc = kd_run_valid_sum(c))) return rc;           // (a path that never forked the second stream)
     if (spec) {
         // corners, their count and the pyramids are enqueued
     } else if (d_p0_in) {
@@ -953,9 +958,13 @@ static int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, in
     {
         km_stage_timer t(c, ST_LAPLACIAN);
         if (d_mask) { if ((rc = kd_count_nonzero(c, d_mask, n, &sc->valid))) return rc; }
-        if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, mm, prm->ksize_ref, prm->ksize_mon,
-                                            prm->invert_mon, nodata_ref, nodata_mon, lap_ref, lap_mon, mask_auto, &sc->valid)))
-            return rc;
+        // on the sync-free path with the pyramids on a second stream the valid-pixel sum goes there too (klt_track_dev: same condition)
+        c->defer_valid_sum = c->opt_defer_valid && c->spec_allowed && c->opt_speculative && c->fused_eig && c->opt_aux_pyramid && prm->max_corners > 0 &&
+                             prm->min_distance >= 1 && !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor && !c->opt_select_first;
+        rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, mm, prm->ksize_ref, prm->ksize_mon,
+                                       prm->invert_mon, nodata_ref, nodata_mon, lap_ref, lap_mon, mask_auto, &sc->valid);
+        c->defer_valid_sum = false;
+        if (rc) return rc;
     }
     // "No valid pixels" (klt.py:276-279) needs no early exit: an all-zero mask gives max-eig 0, no candidate, no corner.
     // The count itself reaches the host with the candidate count (gftt_dev), i.e. without an extra synchronisation.

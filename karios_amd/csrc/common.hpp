@@ -85,6 +85,7 @@ enum km_slot {
     WS_FFT_TW1,
     WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
     WS_MI_TABLE,    // c ln c, c = 0 .. 57^2 (k_mi.hip)
+    WS_LAP_VALID,   // k_dense.hip: per-wave counts of valid pixels of the Laplacian pass (summed later, maybe on the second stream)
     WS_FRAME_CNT,   // k_frame.hip: per-workgroup counts of the compaction (a slot of its own: the frame stage of unit k may run beside the Laplacian / eigenvalue kernels of unit k + 1, which own WS_PARTIAL)
     WS_F64_TWX,     // k_fft64.hip: exp(-2 pi i j / W), exp(-2 pi i j / H) ...
     WS_F64_TWY,
@@ -258,6 +259,12 @@ struct km_ctx {
     hipEvent_t ev_front_done = nullptr, ev_tail_done = nullptr;
     bool tail_pending = false, tail_defer = false;
     int sc_parity = 0;             // which of the two scalar blocks the last overlapped unit used
+    bool defer_valid_sum = false;  // set around the Laplacian pass of a unit on the sync-free path: the valid-pixel sum becomes a job for the second stream
+    bool valid_job_pending = false;
+    const unsigned *valid_job_partial = nullptr;
+    unsigned valid_job_n = 0;
+    unsigned long long *valid_job_out = nullptr;
+    bool opt_defer_valid = true;   // "defer_valid" 0: the sum stays behind the Laplacian pass on the main stream
     int opt_mm_early_at = 0;       // "mm_early_at": where the next unit's early min / max may start (0 LK, 1 selection sweeps, 2 ranking, 3 behind LK; all but 0 measured slower)
     bool opt_tail_overlap = false; // "tail_overlap" (measured: the Laplacian kernel beside it stretches by what the tail saves - off)
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
@@ -398,6 +405,7 @@ int kd_auto_mask(km_ctx *c, const void *d_mon, const void *d_ref, int dtype, int
                  ptrdiff_t stride_mon, ptrdiff_t stride_ref, const double *nodata_mon,
                  const double *nodata_ref, uint8_t *d_mask, unsigned long long *d_valid);
 int kd_count_nonzero(km_ctx *c, const uint8_t *d_mask, size_t n, unsigned long long *d_valid);
+int kd_run_valid_sum(km_ctx *c);
 int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, uint8_t *d_dst);
 // fused: raw ref+mon -> uint8 stretch -> Laplacians (+ auto mask when d_mask_out != null)
 int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int H,

@@ -1075,7 +1075,8 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     const size_t nwaves = SPLIT ? (size_t)nitems : (size_t)ntiles * 4;     // entries of the per-item valid counts
     unsigned *valid = nullptr;
     if (MASK) {
-        valid = (unsigned *)km_ws(c, WS_PARTIAL, ((size_t)ntiles * 4 + 4) * sizeof(unsigned));
+        // (a slot of its own: with the sum deferred to the second stream - below - the eigenvalue pass, which owns WS_PARTIAL, runs first)
+        valid = (unsigned *)km_ws(c, WS_LAP_VALID, ((size_t)ntiles * 4 + 4) * sizeof(unsigned));
         if (!valid) return KM_E_NOMEM;
     }
     switch (R) {
@@ -1086,9 +1087,25 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     }
     KM_LAUNCH_CHECK(c);
     if (MASK) {
-        sum_u32_kernel<<<1, 1024, 0, c->stream>>>(valid, (unsigned)nwaves, valid_out);
-        KM_LAUNCH_CHECK(c);
+        if (c->defer_valid_sum) {
+            // the count of valid pixels is only read at the end of the unit (frame header, statistics): its one-workgroup sum leaves
+            // the critical path - klt_track_dev launches it on the second stream in front of the pyramids (kd_run_valid_sum)
+            c->valid_job_partial = valid; c->valid_job_n = (unsigned)nwaves; c->valid_job_out = valid_out; c->valid_job_pending = true;
+        } else {
+            sum_u32_kernel<<<1, 1024, 0, c->stream>>>(valid, (unsigned)nwaves, valid_out);
+            KM_LAUNCH_CHECK(c);
+        }
     }
+    return KM_OK;
+}
+
+// the deferred sum of launch_lap_march, on whatever stream c->stream is at the moment
+int kd_run_valid_sum(km_ctx *c)
+{
+    if (!c->valid_job_pending) return KM_OK;
+    c->valid_job_pending = false;
+    sum_u32_kernel<<<1, 1024, 0, c->stream>>>(c->valid_job_partial, c->valid_job_n, c->valid_job_out);
+    KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
