@@ -35,7 +35,7 @@ class KltStats(C.Structure):
     _fields_ = [("valid_pixels", C.c_int64), ("n_candidates", C.c_int64), ("n_init", C.c_int32),
                 ("n_select_batches", C.c_int32), ("min_ref", C.c_double), ("max_ref", C.c_double),
                 ("min_mon", C.c_double), ("max_mon", C.c_double), ("max_eig", C.c_float),
-                ("emitted_ratio", C.c_float), ("path_flags", C.c_int32), ("reserved", C.c_int32)]
+                ("emitted_ratio", C.c_float), ("path_flags", C.c_int32), ("tie_rows", C.c_int32)]
 
 
 NAN_OUTSIDE_WINDOW = 0x7FF80000DEAD0000   # km_set_image_window: score of a chip outside the resident window
@@ -335,6 +335,17 @@ class Context:
         "stage_cap", "topk_factor", "select_first", "defer" (0 restores a default)."""
         self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
         self.__dict__.setdefault("_options", {})[name] = int(value)
+
+    def set_frame_sink(self, ptr: int | None, nbytes: int = 0) -> None:
+        """km_set_frame_sink: every frame block the tile entry points produce from now on is also copied to device memory at `ptr`
+        (capacity `nbytes`); None switches it off.  The current sink is remembered (`frame_sink`): the exact repeat of a flagged
+        unit (`PendingFrame.redo`) runs with the sink OFF - by then it belongs to a newer unit."""
+        self.check(self.lib.km_set_frame_sink(self.handle, C.c_void_p(ptr) if ptr else None, int(nbytes) if ptr else 0), "km_set_frame_sink")
+        self.__dict__["_frame_sink"] = (int(ptr), int(nbytes)) if ptr else (None, 0)
+
+    @property
+    def frame_sink(self) -> tuple:
+        return self.__dict__.get("_frame_sink", (None, 0))
 
     def get_option(self, name: str, default: int = 0) -> int:
         """Last value given to `set_option` (the library's own defaults are not queried)."""

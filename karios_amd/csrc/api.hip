@@ -509,6 +509,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE, bool defer_tail = false
     else { const int rct = tail_wait_now(c); if (rct) return rct; }
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
+    c->land_jobs.clear(); c->land_used = 0;   // (... and results it queued for a caller buffer that may be gone too: km_d2h_queue without its flush)
     c->spec_used = false; c->spec_flags = 0;
     c->valid_job_pending = false;      // (a call that failed between the Laplacian pass and the fork)
     // early min / max (klt_tile_dev_impl): only a tile call that DIRECTLY follows a tile call may start its K1 beside the previous
@@ -745,6 +746,7 @@ static int read_stats(km_ctx *c, km_scalars *sc)
         c->stats.n_candidates = (int64_t)h.cut[3];
         c->spec_flags = h.flags;
     }
+    c->stats.tie_rows = (int32_t)h.tie_rows;
     if (h.n_cand == 0xffffffffu) return km_fail(c, KM_E_INTERNAL, "corner grid cell overflow");
     return KM_OK;
 }
@@ -1433,6 +1435,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if (land) {
         c->stats.valid_pixels = (int64_t)land->valid;
         c->stats.n_candidates = (int64_t)land->cut[3];
+        c->stats.tie_rows = (int32_t)land->tie_rows;
         c->stats.max_eig = land->max_eig;
         c->stats.min_ref = land->mm[0]; c->stats.max_ref = land->mm[1]; c->stats.min_mon = land->mm[2]; c->stats.max_mon = land->mm[3];
         if (land->flags) {                                   // did not fit the fixed capacities: the exact path decides

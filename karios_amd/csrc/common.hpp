@@ -119,6 +119,7 @@ struct km_scalars {
     unsigned int tickets[3];       // "last workgroup finishes the job" counters of the merged launches of k_select2.hip (zeroed with the block)
     unsigned int bin_off[KM_TK_NB]; // k_select2.hip: first slot of every value bin in the kept list
     unsigned int bin_cur[KM_TK_NB]; //                fill cursors of the bins
+    unsigned int tie_rows;         // k_eig3.hip: (wavefront, row) steps that took the per-pixel emission path (a lane held two candidates)
 };
 #define KM_FLAG_SHARD_OVERFLOW 1u   // a key-buffer shard overflowed
 #define KM_FLAG_STAGE_OVERFLOW 2u   // the fused kernel's per-wave key stage overflowed (plateau image)

@@ -221,6 +221,7 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
     };
 
     float best = -INFINITY;
+    unsigned tie_rows = 0u;                           // (wave-uniform: a scalar register)
     // ---- candidate staging and the running threshold (as in eig2_item)
     unsigned cnt = 0;
     const unsigned shard = (unsigned)wave_id % KM_NSHARD;
@@ -315,6 +316,7 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
                 cnt += (unsigned)__popcll(bal);
             } else {
                 // ties: some lane holds several candidates in this row
+                tie_rows++;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     const bool is = is_cand(p);
@@ -419,6 +421,7 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
     unsigned key = best > -INFINITY ? e2_key(best) : 0u;
     for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
     if (lane == 0) max_partial[wave_id] = key;
+    if (lane == 0 && tie_rows) atomicAdd(&sc->tie_rows, tie_rows);   // (diagnostics: km_klt_stats.tie_rows)
 }
 
 // items [0, n_border): eig2_item on the two border strips (left: columns 0 .. MARGIN-1, right: W-MARGIN .. W-1), rows2 rows each;

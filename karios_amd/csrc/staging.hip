@@ -255,6 +255,15 @@ int km_d2h_flush(km_ctx *c)
     for (const km_land_job &j : c->land_jobs) copy_rows((char *)j.dst, j.bytes, (const char *)j.pinned, j.bytes, j.bytes, 1);
     c->land_jobs.clear();
     c->land_used = 0;
+    if (!c->retired.empty()) {
+        // workspace buffers replaced by larger ones (km_ws): the compute stream is idle here; once the other streams are too, nothing
+        // of this context can still use them - callers of the blocking entry points alone never reach km_ctx_sync
+        if (c->aux_stream) KM_HIP(c, hipStreamSynchronize(c->aux_stream));
+        if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
+        if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));
+        for (void *p : c->retired) (void)hipFree(p);
+        c->retired.clear();
+    }
     return km_upload_check_verify(c);
 }
 

@@ -172,6 +172,9 @@ class KLT:
         grid = self.tile_boxes(mon_img.x_size, mon_img.y_size)
         logger.info("KLT: %dx%d px in %d tile(s) of %d px, polarity %s, Laplacian kernel %s", mon_img.x_size, mon_img.y_size, len(grid),
                     self._conf.tile_size, self._describe_polarity(), self._conf.laplacian_kernel_size)
+        if self._rasters_in_hbm(mon_img, ref_img, mask):
+            yield from self._match_resident(grid, mon_img, ref_img, mask)
+            return
         upcoming = self._prefetched.pop((id(mon_img), id(ref_img), id(mask)), None) if grid else None
         for k, tile in enumerate(grid):
             session = upcoming or self._open(tile, mon_img, ref_img, mask)
@@ -213,6 +216,36 @@ class KLT:
         return tiling.tile_grid(x_size, y_size, self._conf.tile_size, self._conf.xStart)
 
     _resolve_ksize = staticmethod(tiling.kernel_sizes)
+
+    # ------------------------------------------------------------------ rasters that already live in HBM
+    def _rasters_in_hbm(self, mon_img, ref_img, mask) -> bool:
+        """Both rasters are `DeviceRasterImage`s of one pixel type the kernels read, the run uses fixed parameters and neither the
+        sigma clip nor the Laplacian dump: the tiles are boxes of ONE resident pair - nothing is read, copied or uploaded."""
+        from ..core.image import DeviceRasterImage
+        conf = self._conf
+        return (isinstance(mon_img, DeviceRasterImage) and isinstance(ref_img, DeviceRasterImage) and (mask is None or isinstance(mask, DeviceRasterImage))
+                and mon_img.dtype == ref_img.dtype and mon_img.dtype.type in _DEVICE_DTYPES and conf.laplacian_kernel_size != "auto"
+                and conf.laplacian_invert_polarity != "auto" and not getattr(conf, "outliers_filtering", False) and not self._gen_laplacian
+                and mon_img.tensor.is_contiguous() and ref_img.tensor.is_contiguous() and (mask is None or mask.tensor.is_contiguous())
+                and mon_img.tensor.shape == ref_img.tensor.shape)
+
+    def _match_resident(self, grid, mon_img, ref_img, mask) -> Iterator[DataFrame]:
+        """`match` on resident rasters: every tile of the grid is a box of the pair (pointer + stride), submitted through
+        `karios_amd.stream.FrameStream` - tile i + 1 runs on the device while tile i becomes its DataFrame; frames in tile order."""
+        import torch
+        torch.cuda.synchronize(mon_img.tensor.device)               # the library works on its own streams
+        pair = ResidentPair.from_device_pointers(mon_img.tensor.data_ptr(), ref_img.tensor.data_ptr(), mon_img.dtype, mon_img.y_size, mon_img.x_size,
+                                                 ctx=self._ctx, mask_ptr=None if mask is None else mask.tensor.data_ptr(),
+                                                 no_data_mon=getattr(mon_img, "no_data_value", None), no_data_ref=getattr(ref_img, "no_data_value", None),
+                                                 keepalive=(mon_img.tensor, ref_img.tensor, None if mask is None else mask.tensor))
+        for tile, frame in zip(grid, pair.match_pipelined(self._conf, boxes=[tuple(t) for t in grid], with_empty=True)):
+            if frame is None:
+                logger.info("tile (%d, %d): no valid pixels or no corners - skipped", tile[0], tile[1])
+                continue
+            n_init = int(frame.attrs.pop("Ninit", len(frame)))
+            frame.attrs.clear()
+            logger.info("tile (%d, %d): %d of %d corners kept", tile[0], tile[1], len(frame), n_init)
+            yield frame
 
     # ------------------------------------------------------------------ one tile
     def _match_tile(self, x_off, y_off, mon_img, ref_img, mask) -> DataFrame | None:

@@ -247,6 +247,7 @@ class RankBlockExchange:
         self.pending = deque()                     # gloo: (work, slot) issued and not waited for yet
         self.issued = 0
         self._sink_set = False
+        self.slot_step = [[None] * per for _ in range(halves)]    # RCCL: the step whose block a send slot holds until its batch has been gathered
 
     def _where(self, step: int):
         if self.on_gpu:
@@ -255,14 +256,21 @@ class RankBlockExchange:
 
     def arm(self, step: int) -> None:
         """Before submitting step `step`: its block goes to the step's send slot (RCCL).  The half's previous collective is `batch`
-        steps old at least; the check is free."""
+        steps old at least; the check is free.  A slot whose previous block has not been gathered yet is never re-armed: a half is
+        gathered when its last step is COLLECTED, i.e. `FrameStream.depth` submissions later, so the ring needs depth <= batch."""
         if not self.on_gpu or "sink" not in self.parts:
             return
         half, j = self._where(step)
+        if "wait" in self.parts:
+            old = self.slot_step[half][j]
+            if old is not None:
+                raise RuntimeError(f"RankBlockExchange: step {step} would overwrite the block of step {old}, which has not been gathered yet "
+                                   f"(steps are gathered in batches of {self.batch} when they are collected: keep the stream's depth <= batch)")
+            self.slot_step[half][j] = step
         if j == 0 and self.used[half]:
             self.done[half].synchronize()
         c = self.ctx
-        c.check(c.lib.km_set_frame_sink(c.handle, self.send[half, j].data_ptr(), self.L * 4), "km_set_frame_sink")
+        c.set_frame_sink(self.send[half, j].data_ptr(), self.L * 4)
         self._sink_set = True
 
     def _fold(self) -> None:
@@ -309,6 +317,8 @@ class RankBlockExchange:
             self.used[half] = True
         finally:
             torch.cuda.set_stream(prev)
+        for j in range(lo, hi):
+            self.slot_step[half][j] = None
         self.filled[half] = 0
 
     def issue(self, step: int, pending=None, host_block=None) -> None:
@@ -352,8 +362,7 @@ class RankBlockExchange:
             self._retire()
         if self.on_gpu:
             if self._sink_set:
-                c = self.ctx
-                c.check(c.lib.km_set_frame_sink(c.handle, None, 0), "km_set_frame_sink")
+                self.ctx.set_frame_sink(None)
                 self._sink_set = False
             for half in range(2):
                 if self.filled[half]:
@@ -446,11 +455,11 @@ def match_distributed(bands: dict, n_bands: int, x_size: int, y_size: int, conf,
         ru = ResidentUnit.load(u, src[0], src[1], src[2] if len(src) > 2 else None, halo=halo, ctx=ctx)
         if on_gpu and not getattr(conf, "outliers_filtering", False):
             # the device pipeline drops the unit's block straight into the send buffer (km_set_frame_sink)
-            ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, send[slot, 1:].data_ptr(), L * 4), "km_set_frame_sink")
+            ctx.set_frame_sink(send[slot, 1:].data_ptr(), L * 4)
             try:
                 ru.match(conf, thr)
             finally:
-                ctx.check(ctx.lib.km_set_frame_sink(ctx.handle, None, 0), "km_set_frame_sink")
+                ctx.set_frame_sink(None)
         else:
             frame = ru.match(conf, thr)
             send[slot, 1:] = torch.from_numpy(pack_frame(frame, cap, score)).to(dev)

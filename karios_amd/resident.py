@@ -459,13 +459,21 @@ class ResidentPair:
         def exact():
             before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "1") or 0))
             c.set_option("speculative", 0)
+            # the frame sink (km_set_frame_sink) now points at the slot of a NEWER unit: the repeat must not overwrite that block
+            # (the all-gather then shipped the redone block of step s - D in the place of step s's own); the caller
+            # takes the repeated block from the returned RawFrame
+            sink = c.frame_sink
+            if sink[0]:
+                c.set_frame_sink(None)
             try:
                 return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off), mutual_info=mutual_info)
             finally:
                 c.set_option("speculative", before)
+                if sink[0]:
+                    c.set_frame_sink(*sink)
         return PendingFrame(c, ticket.value, cap, n_scores, redo=exact)
 
-    def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None):
+    def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None, with_empty: bool = False):
         """`match` as a pipeline (`karios_amd.stream.FrameStream`): tile i+1 is submitted to the device (`submit_tile`) while a
         worker thread waits for tile i and builds its DataFrame.  `host_stage(frame)` (e.g. `score_frame`) runs on the CALLING
         thread when the frame is collected: a context is not thread-safe, and a stage that calls back into the library (ZNCC /
@@ -478,10 +486,10 @@ class ResidentPair:
         with FrameStream(zncc_threshold, depth=1, host_stage=stage, score_columns=False) as stream:
             for box in boxes:
                 for done in stream.submit(self, conf, box):
-                    if done.frame is not None:
+                    if done.frame is not None or with_empty:          # (with_empty: None for a tile without valid pixels / corners)
                         yield done.frame
             for done in stream.drain():
-                if done.frame is not None:
+                if done.frame is not None or with_empty:
                     yield done.frame
 
     _frame_from_block = staticmethod(frames.block_to_frame)
@@ -542,7 +550,7 @@ class ResidentPair:
             return np.empty(0, np.float64), np.empty(0, np.float64)
         # the two scores come out of ONE kernel run; the reference asks for them in two separate service calls on the same
         # key points (core.py:894-907), so the last result is remembered
-        digest = hash(b"".join(v.tobytes() for v in cols))
+        digest = b"".join(v.tobytes() for v in cols)          # the key points themselves (16 B each), compared byte for byte
         memo = self.__dict__.get("_mi_memo")
         if memo is not None and memo[0] == digest:
             return memo[1].copy(), memo[2].copy()

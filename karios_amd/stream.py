@@ -56,6 +56,7 @@ class StreamResult:
     tag: object = None           # whatever the caller passed to `submit`
     redone: bool = False         # the unit was repeated through the exact corner path
     spans: dict = field(default_factory=dict)   # stage -> ms (only with `Context.set_profiling(True)` and `want_spans`)
+    flags: int = 0               # KM_FLAG_* bits the synchronisation-free corner path raised for the unit (0: it was not repeated)
 
 
 class FrameStream:
@@ -128,7 +129,7 @@ class FrameStream:
     def _collect(self, item) -> StreamResult:
         pair, pend, tag, fut = item
         raw, spans, frame = fut.result()
-        redone = False
+        redone, flags = False, raw.flags
         if raw.flags:                      # did not fit the fixed capacities of the synchronisation-free corner path: exact repeat, here
             raw = pend.redo()
             frame = raw.to_frame(radial=self.score_columns)
@@ -138,7 +139,7 @@ class FrameStream:
             self.units_redone += 1
         if frame is not None and self.host_stage is not None:
             frame = self.host_stage(frame, pair)
-        return StreamResult(frame, raw, tag, redone, spans)
+        return StreamResult(frame, raw, tag, redone, spans, flags)
 
     # ------------------------------------------------------------------ API
     def submit(self, pair: ResidentPair, conf, box=None, origin=None, tag=None, on_submitted=None) -> list[StreamResult]:

@@ -213,3 +213,81 @@ def make_cross_sensor_pair_torch(H: int, W: int, sx: float = 0.4, sy: float = -0
         y, x = rng.integers(0, H), rng.integers(0, W)
         mask[y:y + h, x:x + w] = 0
     return mon, ref, mask
+
+
+# ---------------------------------------------------------------------------------------------------- non-best-case workloads
+# The pairs above are the friendliest content there is: every corner survives the forward-backward test and LK stops after two
+# iterations.  The reference's one real run keeps 37 448 of <= 80 000 corners (tests/end_to_end/ref_data/test_full/KLT_matcher_*.csv,
+# klt.py:134-144), and SURVEY App. A.1 warns that k = 7 Laplacians of real scenes are near-binary.  The two generators below produce
+# that kind of content; torch on any device (the CPU build serves the tests and tools/calibrate_workloads.py).
+def _smooth_field_torch(H: int, W: int, cell: int, seed: int, device):
+    """Smooth random field in [0, 1], correlation length ~`cell` px: a coarse uniform grid, bicubically enlarged."""
+    import torch
+
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    gh, gw = H // cell + 3, W // cell + 3
+    coarse = torch.rand((1, 1, gh, gw), generator=g, dtype=torch.float32).to(device)
+    big = torch.nn.functional.interpolate(coarse, size=(gh * cell, gw * cell), mode="bicubic", align_corners=False)
+    return big[0, 0, cell:cell + H, cell:cell + W].clamp_(0.0, 1.0).contiguous()
+
+
+def make_hard_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int = 20260101, mix: float = 0.45,
+                         noise_sigma: float = 120.0, warp: float = 0.6, device="cuda"):
+    """`hard_content`: the monitored image is decorrelated from the reference until about half of the tracks fail the 0.1-px round
+    trip: (1) a smooth sub-pixel warp - the content moves by (sx + u warp, sy + v warp) with u, v smooth fields in [0, 1] of ~400 px
+    correlation length (a blend of the four corner shifts with bilinear weights); (2) `mix` of an independent texture of the same
+    spectrum; (3) strong additive noise.  -> (mon, ref) int16-storage uint16 bit patterns like `make_pair_torch`."""
+    import torch
+
+    base = _base_torch(H, W, seed, device)
+    ref = _quant_torch(base[PAD:PAD + H, PAD:PAD + W]).contiguous()
+    u = _smooth_field_torch(H, W, 400, seed + 3, device)
+    v = _smooth_field_torch(H, W, 400, seed + 4, device)
+    mon_f = torch.zeros((H, W), dtype=torch.float32, device=device)
+    for du, dv, wgt in ((0.0, 0.0, (1 - u) * (1 - v)), (warp, 0.0, u * (1 - v)), (0.0, warp, (1 - u) * v), (warp, warp, u * v)):
+        mon_f += wgt * _sample_shifted_torch(base, H, W, sx + du, sy + dv)
+        del wgt
+    del base, u, v
+    if mix > 0:
+        other = _base_torch(H, W, seed + 5, device)[PAD:PAD + H, PAD:PAD + W]
+        mon_f = (1.0 - mix) * mon_f + mix * other
+        del other
+    if noise_sigma > 0:
+        g2 = torch.Generator(device=device)
+        g2.manual_seed(seed + 1)
+        mon_f = mon_f + noise_sigma * torch.randn((H, W), generator=g2, device=device, dtype=torch.float32)
+    return _quant_torch(mon_f).contiguous(), ref
+
+
+def make_tie_heavy_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed: int = 20260101, levels: int = 6,
+                              noise_sigma: float = 15.0, period: int = 96, device="cuda"):
+    """`tie_heavy`: both rasters quantised to `levels` grey levels, so that their uint8 stretch is a staircase of ~255 / levels and
+    the k = 7 Laplacian (gain 16 x 64) saturates at nearly every edge - a near-binary image; and the texture REPEATS
+    with `period` px (fields, roofs, a regular street grid: every corner of the motif recurs with exactly the same minimum eigenvalue),
+    so the candidate list is made of exact ties that only the raster index orders (App. A.2 step 6), flat maxima give several
+    candidates per 3x3 neighbourhood, and the value bins of the synchronisation-free selection are few and full.  Binary Laplacians
+    alone do not tie: a 15x15 sum of Sobel products of a 0/255 image still takes ~as many values as there are corners (measured:
+    694 distinct values among 695 corners)."""
+    import torch
+
+    base = _base_torch(min(H, period) if period else H, min(W, period) if period else W, seed, device)
+    if period:
+        cell = base[PAD:PAD + min(H, period), PAD:PAD + min(W, period)]
+        ry, rx = -(-(H + 2 * PAD) // cell.shape[0]), -(-(W + 2 * PAD) // cell.shape[1])
+        base = cell.repeat(ry, rx)[:H + 2 * PAD, :W + 2 * PAD].contiguous()
+    lo, hi = 3000.0 - 2200.0, 3000.0 + 2200.0
+    step = (hi - lo) / levels
+
+    def stair(a):
+        q = torch.floor((a - lo) / step).clamp_(0, levels - 1)
+        return _quant_torch(lo + (q + 0.5) * step).contiguous()
+
+    ref = stair(base[PAD:PAD + H, PAD:PAD + W])
+    mon_f = _sample_shifted_torch(base, H, W, sx, sy)
+    del base
+    if noise_sigma > 0:
+        g2 = torch.Generator(device=device)
+        g2.manual_seed(seed + 1)
+        mon_f = mon_f + noise_sigma * torch.randn((H, W), generator=g2, device=device, dtype=torch.float32)
+    return stair(mon_f), ref

@@ -506,8 +506,8 @@ int ko_lk_oscillates(float ddx, float pdx, float ddy, float pdy)
 /* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(w,w), maxLevel,
  * criteria=(EPS|COUNT, max_count, eps)) with flags=0, minEigThreshold=1e-4
  * (klt.py:128-140).  status/err are not produced: KARIOS
- * discards them (klt.py:142-144, 153).  iters (nullable): per-point level-0
- * iteration count, diagnostic only. */
+ * discards them (klt.py:142-144, 153).  iters (nullable): iteration counts,
+ * diagnostic only: iters[p] = level 0, iters[n + p] = level 1 (2 n entries). */
 int ko_pyrlk(const uint8_t *prev, const uint8_t *next, int H, int W,
              const float *pts, int n, int win, int max_level, int max_count,
              double eps, float *out_pts, int *iters)
@@ -561,7 +561,7 @@ int ko_pyrlk(const uint8_t *prev, const uint8_t *next, int H, int W,
                 if (level == levels) { nx = prx; ny = pry; }
                 else { nx = out_pts[2 * p] * 2.f; ny = out_pts[2 * p + 1] * 2.f; }
                 out_pts[2 * p] = nx; out_pts[2 * p + 1] = ny;
-                if (level == 0 && iters) iters[p] = 0;
+                if (level < 2 && iters) iters[(size_t)level * n + p] = 0;
                 prx -= half; pry -= half;
                 int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
                 if (ipx < -win || ipx >= I->W || ipy < -win || ipy >= I->H) continue;
@@ -617,7 +617,7 @@ int ko_pyrlk(const uint8_t *prev, const uint8_t *next, int H, int W,
                     float ddy = (A12 * b1 - A11 * b2) * D;
                     nx += ddx; ny += ddy;
                     out_pts[2 * p] = nx + half; out_pts[2 * p + 1] = ny + half;
-                    if (level == 0 && iters) iters[p] = j + 1;
+                    if (level < 2 && iters) iters[(size_t)level * n + p] = j + 1;
                     /* Point2f::ddot: double accumulation of the f32 deltas */
                     if ((double)ddx * ddx + (double)ddy * ddy <= epsilon) break;
                     /* OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 - float32 magnitude against the DOUBLE literal */

@@ -288,12 +288,14 @@ def pyr_lk(prev, nxt, pts, win=25, max_level=1, max_count=30, eps=0.03, return_i
     p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
     n = p.shape[0]
     out = np.empty_like(p)
-    it = np.zeros(max(n, 1), np.int32)
+    it = np.zeros(2 * max(n, 1), np.int32)      # [level 0 | level 1] iteration counts (diagnostic)
     rc = lib().ko_pyrlk(_p(a), _p(b), a.shape[0], a.shape[1], _p(p), n, int(win), int(max_level),
                         int(max_count), C.c_double(eps), _p(out), _p(it))
     if rc != 0:
         raise RuntimeError(f"ko_pyrlk rc={rc}")
     out = out.reshape(n, 1, 2)
+    if return_iters == "levels":
+        return out, it[:n], it[max(n, 1):max(n, 1) + n]
     return (out, it[:n]) if return_iters else out
 
 

@@ -28,6 +28,7 @@ def pytest_terminal_summary(terminalreporter):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock bounds on an MI355X - never part of -m gpu (tools/round_end.sh runs -m perf)")
 
 
 @pytest.fixture(scope="session")

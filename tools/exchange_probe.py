@@ -39,6 +39,9 @@ conf = KLTConfiguration()
 LAG = "--at-submit" not in sys.argv        # issue the exchange when the step is COLLECTED (bench.py's way) instead of at submission
 DEPTH = 2
 BATCH = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--batch=")), 4)
+if BATCH < DEPTH:
+    sys.exit(f"--batch={BATCH}: a send slot is only free once its batch has been gathered, which happens when the batch's last step is "
+             f"COLLECTED ({DEPTH} submissions later): batch >= {DEPTH} (RankBlockExchange.arm refuses anything else)")
 
 
 def run(parts):

@@ -35,6 +35,25 @@ STAGES = {   # stage key -> kernel-name fragments
 ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel", "f64": "f64_best_reduce"}
 
 
+def short_name(kernel: str) -> str:
+    """'void (anonymous namespace)::eig3_kernel<15>(unsigned char const*, ...)' -> 'eig3_kernel<15>': the full kernel name with its
+    template arguments, without return type, anonymous namespace and parameter list."""
+    n = kernel.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    n = n.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(n):          # the parameter list starts at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            n = n[:i]
+            break
+    return n.strip()[:120]
+
+
 def load(path):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
@@ -100,7 +119,7 @@ def main():
         cycles = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # the counter sums the 8 XCDs
         valu = tot.get("SQ_INSTS_VALU", 0.0)
         entry = {str(size): int(round((2 * fetch + write) * 1024)), "measured_at": commit,
-                 "_detail": {"kernels": sorted({n.split("(")[0][:60] for n in names}), "launches_per_pair": round(sum(launch_count[n] for n in names) / pairs, 2),
+                 "_detail": {"kernels": sorted({short_name(n) for n in names}), "launches_per_pair": round(sum(launch_count[n] for n in names) / pairs, 2),
                              "pairs_profiled": pairs, "FETCH_SIZE_KB": round(fetch), "WRITE_SIZE_KB": round(write),
                              "SQ_INSTS_VALU": round(valu), "SQ_INSTS_LDS": round(tot.get("SQ_INSTS_LDS", 0.0)),
                              "SQ_WAVES": round(tot.get("SQ_WAVES", 0.0)), "kernel_cycles": round(cycles),
