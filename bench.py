@@ -835,7 +835,7 @@ def sensitivity_objects(ctx, dev, S, steps):
     y0 = max(0, (S - rows) // 2)
     for name, make, note in (
             ("hard_content", lambda: synth.make_hard_pair_torch(S, S, device=dev),
-             "monitored image = smooth sub-pixel warp (0 .. 0.6 px on top of (0.5, 0.25)) of the reference texture, 55 % of an independent texture "
+             "monitored image = smooth sub-pixel warp (0 .. 0.6 px on top of (0.5, 0.25)) of the reference texture, 55.5 % of an independent texture "
              "of the same spectrum mixed in, additive noise sigma 200 DN (karios_amd.synth.make_hard_pair_torch)"),
             ("tie_heavy", lambda: synth.make_tie_heavy_pair_torch(S, S, device=dev),
              "both rasters quantised to 6 grey levels (k = 7 Laplacian 99 % saturated) and periodic with 96 px: the candidate list consists of "

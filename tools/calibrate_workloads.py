@@ -29,8 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("kind", choices=("hard", "tie", "plain"))
     ap.add_argument("--size", type=int, default=2048)
-    ap.add_argument("--mix", type=float, default=0.45)
-    ap.add_argument("--noise", type=float, default=120.0)
+    ap.add_argument("--mix", type=float, default=0.555)
+    ap.add_argument("--noise", type=float, default=200.0)
     ap.add_argument("--warp", type=float, default=0.6)
     ap.add_argument("--levels", type=int, default=6)
     ap.add_argument("--period", type=int, default=96)
