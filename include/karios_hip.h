@@ -91,53 +91,61 @@ const char *km_last_error(km_ctx *ctx);   /* ctx may be NULL: last global error 
 int km_ctx_sync(km_ctx *ctx);
 /* enable (1) / disable (0) hipEvent stage timing; read back after a call */
 int km_set_profiling(km_ctx *ctx, int enable);
-/* Knobs (no counterpart in the reference; results NEVER depend on them - tests/test_gpu_forced_paths.py):
- *   "fused_eig"    1 (default) = GFTT's minimum-eigenvalue + candidate detection fused in one pass (no eig map);
- *                  0 = eig map + candidate scan.  Initial value from the environment variable KARIOS_HIP_FUSED_EIG.
- *   "eig3"         1 (default) = the fused pass runs 8 pixels per lane (k_eig3.hip) on images at least 512 columns wide;
- *                  0 = always the 2-pixels-per-lane kernel (k_eig2.hip).  Initial value from KARIOS_HIP_EIG3.
- *   Test knobs that shrink internal capacities so that the corner detector's retry paths run on every call
- *   (0 restores the default):
+/* Options (no counterpart in the reference).  Results NEVER depend on them: every option selects between forms the parity suite
+ * holds bit-identical, or shrinks a capacity so that a retry path runs (tests/test_gpu_forced_paths.py, tests/test_gpu_parity.py).
+ * The RELEASE library accepts exactly the names below and returns KM_E_ARG for anything else (tests/test_host_logic.py checks that
+ * the development names are rejected); the development build (make DEV=1, km_is_dev_build) adds A/B switches of settled choices.
+ *  forms
+ *   "fused_eig"    1 (default): GFTT's minimum-eigenvalue + candidate detection fused in one pass (no eig map); 0: eig map + candidate
+ *                  scan.  Initial value from the environment variable KARIOS_HIP_FUSED_EIG
+ *   "eig3"         1 (default): the fused pass runs 8 pixels per lane (k_eig3.hip) on images >= 512 columns wide; 0: always the
+ *                  2-pixels-per-lane kernel (k_eig2.hip).  Initial value from KARIOS_HIP_EIG3
+ *   "lk2"          1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form (one patch per
+ *                  direction and level), which also serves deeper pyramids and row bands
+ *   "speculative"  1 (default): the tile entry points detect corners without a host synchronisation and without sorts (fixed
+ *                  capacities, k_select2.hip); a tile that does not fit is flagged (frame header word 2) and repeated through the exact
+ *                  path - inside the call for the blocking entry points, by the caller of km_frame_wait for submitted frames
+ *                  (PendingFrame.result()).  0: always the exact path (two scalar read-backs per tile, k_select.hip + k_sort.hip).
+ *                  Initial value from KARIOS_HIP_SPECULATIVE
+ *   "aux_pyramid"  1 (default): on the synchronisation-free path the two pyramids are built on a second stream beside the fused
+ *                  eigenvalue pass and joined before LK; 0: on the library's stream.  Initial value from KARIOS_HIP_AUX_PYRAMID
+ *   "mm_early"     1 (default): a unit submitted (km_klt_tile_frame_submit / km_klt_units_frame_submit) directly behind another one
+ *                  starts its min / max on the second stream as soon as the previous unit's LK launch starts (KM_PATH_MM_EARLY);
+ *                  0: on the library's stream, behind the previous unit's tail
+ *   "frame_mi"     1: frame blocks that carry the ZNCC column also carry `mutual_info_score` (MutualInfoService,
+ *                  mutual_info_service.py:73-130) and `mi_score` (ZNCCService.compute_mi, zncc_service.py:240-287) of the same rows -
+ *                  the whole scoring of KariosAPI._handle_klt_results (api/core.py:894-907) in the tile call: two more float64 columns
+ *                  of `cap` entries behind the zncc column (NaN where score < threshold or the chip leaves the image); 0 (default)
+ *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (k_fft64.hip), the reference's precision; 0 (default):
+ *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
+ *                  float32 correlation peak is not at least 1 % above every other sample
+ *   "fft61"        1 (default): rows of length 61 M of the float32 transform through the wave-local form; 0: the generic row kernel
+ *   "fft_herm"     1 (default): the inverse float32 transform works on the Hermitian half of the cross-power spectrum; 0: full plane
+ *   "f64_pair"     1 (default): the inverse along the rows of the double-precision transform packs two image rows into one complex
+ *                  transform (the correlation surface of two real images is real); 0: one row per transform
+ *   "f64_half"     1 (default): ... and its inverse column levels only run the columns kx <= W / 2; 0: all columns
+ *   "f64_plain"    1: the double-precision transform packs the images in a pass of its own and finds the arg-max in two passes behind
+ *                  the last level - the form that serves sides with a Bluestein dimension - on every shape (default 0: both ends ride in
+ *                  the level kernels where the shape allows)
+ *  test knobs that shrink internal capacities so that the corner detector's retry paths run on every call (0 = default)
  *   "key_cap"      candidate keys per shard of the first attempt          -> key-buffer overflow + regrow
  *   "stage_cap"    usable slots of the fused kernel's per-wave key stage  -> stage overflow + two-kernel repeat
  *   "topk_factor"  top-K pre-filter keeps factor * maxCorners keys (8)    -> second selection pass on all candidates
  *   "select_first" first ranked prefix of the selection sweeps (3 * maxCorners) -> prefix growth
- *   "defer"        0: pyramid jobs run after the selection's read-back waits instead of under them
- *   "speculative"  1 (default): the tile entry points detect corners without a host synchronisation and without library sorts
- *                  (fixed capacities, k_select2.hip); a tile that does not fit is flagged (frame header word 2) and repeated
- *                  through the exact path - inside the call for the blocking entry points, by the caller of km_frame_wait for
- *                  submitted frames (PendingFrame.result()).  0: always the exact path (two scalar read-backs per tile, rocPRIM
- *                  sorts).  Initial value from the environment variable KARIOS_HIP_SPECULATIVE.
- *   "aux_pyramid"  1 (default): on the synchronisation-free path the two pyramids are built on a second stream next to the
- *                  corner-selection chain and joined before LK; 0: on the library's stream.  Initial value from
- *                  KARIOS_HIP_AUX_PYRAMID.
- *   "mm_early"     1 (default): a unit submitted with km_klt_tile_frame_submit directly behind another one starts its min / max
- *                  on the second stream as soon as the previous unit's LK launch starts, and streams its two rasters beside
- *                  that instruction-bound kernel (KM_PATH_MM_EARLY); 0: on the library's stream, behind the previous unit's tail
- *   "frame_mi"     1: frame blocks that carry the ZNCC column (km_klt_tile_frame_zncc_dev, km_klt_tile_frame_submit with full images)
- *                  also carry `mutual_info_score` (MutualInfoService, mutual_info_service.py:73-130) and `mi_score`
- *                  (ZNCCService.compute_mi, zncc_service.py:240-287) of the same rows - the whole scoring of
- *                  KariosAPI._handle_klt_results (api/core.py:894-907) in the tile call: two more float64 columns of `cap`
- *                  entries behind the zncc column (NaN where score < threshold or the chip leaves the image); 0 (default): ZNCC only
- *   "spec_flag"    test knob: flag bits the speculative path raises artificially (exercises the repeat logic)
- *   "phase_fp64"   1: km_phase_shift* always evaluates in double precision (k_fft64.hip), the reference's precision; 0 (default):
- *                  hand-written float32 FFT where the image sides factor into {2,3,5,7,61}, double precision only when the
- *                  float32 correlation peak is not at least 1 % above every other sample
- *   "fft_herm"     1 (default): the inverse transform of the float32 phase correlation works on the Hermitian half of the cross-power
- *                  spectrum (sides of the form 61 M); 0: on the full plane
- *   "tail_overlap" 1: the frame / ZNCC / MI kernels of a unit SUBMITTED with km_klt_tile_frame_submit run on the block-copy
- *                  stream, beside the first kernels of the next submitted unit (klt.py:220-253: the per-tile loop); 0 (default): on
- *                  the compute stream (both issue-bound: the overlap is exact and buys nothing)
- *   "f64_pair"     1 (default): the inverse along the rows of the double-precision transform packs two image rows into one complex
- *                  transform (the correlation surface of two real images is real); 0: one row per transform
- *   "f64_half"     1 (default): ... and its inverse column levels only run the columns kx <= W / 2; 0: all columns
- *   "f64_plain"    1: the double-precision transform packs the images in a pass of its own and finds the arg-max in two
- *                  passes behind the last level (default 0: both ends ride in the level kernels); development knobs of the
- *                  same transform: "f64_prime_t", "f64_smooth_t" (transforms per workgroup tile, 0 = default)
+ *   "stash_cap"    kept keys a workgroup of the scatter launch stashes in LDS -> its second read of the keys
+ *   "spec_flag"    KM_FLAG bits the synchronisation-free path raises artificially -> the flag-and-repeat logic
+ *   "defer"        0: pyramid jobs of the exact path run after the selection's read-back waits instead of under them
+ *  profiling
  *   "profile_stage" with km_set_profiling(1): time only stage i of km_stage_name (every timed span records two events on the
  *                  library stream and the kernels either side no longer overlap: ~6 us per span); -1 (default): every stage
- * Returns KM_E_ARG for an unknown name. */
+ *   "profile_every" N: only every N-th tile call records its stage events
+ *   "roctx"        1: every stage's host-side enqueue span becomes a roctx range (rocprofv3 --marker-trace; resolved at run time)
+ * Environment variables read by the release library: KARIOS_HIP_FUSED_EIG, KARIOS_HIP_EIG3, KARIOS_HIP_AUX_PYRAMID,
+ * KARIOS_HIP_SPECULATIVE (initial option values, above) and KARIOS_HIP_UPLOAD_CHECKSUM (km_upload_check_stats). */
 int km_set_option(km_ctx *ctx, const char *name, int value);
+/* 1: development build (make -C karios_amd/csrc DEV=1): km_set_option additionally accepts A/B switches of settled choices and the
+ * library reads KARIOS_HIP_* tuning variables; 0: release build (the default; what __graft_entry__.build() produces) */
+int km_is_dev_build(void);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */
 int km_get_stage_ms(km_ctx *ctx, float *out, int cap, int *n);
 const char *km_stage_name(int i);

@@ -77,7 +77,7 @@ void *km_pinned_rb(km_ctx *c, size_t bytes)
 int km_wait_readback(km_ctx *c)
 {
     if (!c->ev_readback) KM_HIP(c, hipEventCreateWithFlags(&c->ev_readback, hipEventDisableTiming));
-    static const bool no_defer = getenv("KARIOS_HIP_NO_DEFER") != nullptr;   // A/B switch: wait first, run the jobs afterwards
+    static const bool no_defer = km_dev_env("KARIOS_HIP_NO_DEFER") != nullptr;   // A/B switch: wait first, run the jobs afterwards
     KM_HIP(c, hipEventRecord(c->ev_readback, c->stream));
     if (!c->deferred.empty() && !no_defer && !c->opt_no_defer) {
         std::function<int()> job = std::move(c->deferred.front());
@@ -142,10 +142,6 @@ int km_ctx_create(int device, km_ctx **out)
     if (const char *e = getenv("KARIOS_HIP_EIG3")) c->opt_eig3 = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_AUX_PYRAMID")) c->opt_aux_pyramid = atoi(e) != 0;
     if (const char *e = getenv("KARIOS_HIP_SPECULATIVE")) c->opt_speculative = atoi(e) != 0;   // A/B switch for the sync-free corner path
-    if (const char *e = getenv("KARIOS_HIP_DEFER_VALID")) c->opt_defer_valid = atoi(e) != 0;
-    if (const char *e = getenv("KARIOS_HIP_LK_ORDER")) c->opt_lk_order = atoi(e) != 0;
-    if (const char *e = getenv("KARIOS_HIP_MM_EARLY_AT")) c->opt_mm_early_at = atoi(e);
-    if (const char *e = getenv("KARIOS_HIP_TAIL_OVERLAP")) c->opt_tail_overlap = atoi(e) != 0;  // A/B switch: the scoring tail of a submitted unit beside the next unit's first kernels
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
@@ -181,8 +177,6 @@ int km_ctx_destroy(km_ctx *c)
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
-    if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
-    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
     if (c->ev_lk_start) (void)hipEventDestroy(c->ev_lk_start);
     if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -199,8 +193,7 @@ int km_ctx_sync(km_ctx *c)
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     KM_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks (and overlapped tails) of submitted tiles
-    c->tail_pending = false; c->tail_defer = false;
+    if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks of submitted tiles
     if (!c->retired.empty()) {
         // workspace buffers replaced by larger ones: nothing of this context uses them any more once its streams are idle
         if (c->aux_stream) KM_HIP(c, hipStreamSynchronize(c->aux_stream));
@@ -214,44 +207,52 @@ int km_ctx_sync(km_ctx *c)
 int km_set_option(km_ctx *c, const char *name, int value)
 {
     if (!c || !name) return km_fail(c, KM_E_ARG, "km_set_option: null argument");
+    // ---- the names include/karios_hip.h documents.  No option changes a result: each selects between forms that the parity suite holds
+    // bit-identical (tests/test_gpu_forced_paths.py, tests/test_gpu_parity.py), or shrinks a capacity so that a retry path runs
     if (strcmp(name, "fused_eig") == 0) { c->fused_eig = value != 0; return KM_OK; }
-    // the remaining knobs shrink internal capacities so that the retry paths of the corner detector, which otherwise fire
-    // only on unusual images or by timing, run on every call (tests / tools/fuzz_parity.py --force-paths); 0 = default
+    if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
+    if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
+    if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
+    if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
+    if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
     if (strcmp(name, "key_cap") == 0) { c->opt_key_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "stage_cap") == 0) { c->opt_stage_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "topk_factor") == 0) { c->opt_topk_factor = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "select_first") == 0) { c->opt_select_first = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "stash_cap") == 0) { c->opt_stash_cap = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "defer") == 0) { c->opt_no_defer = value == 0; return KM_OK; }
-    if (strcmp(name, "fft_dbg") == 0) { c->opt_fft_dbg = value; return KM_OK; }
-    if (strcmp(name, "roctx") == 0) { c->opt_roctx = value != 0; return KM_OK; }
-    if (strcmp(name, "fft_cross") == 0) { c->opt_fft_cross_fused = value != 0; return KM_OK; }
-    if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
-    if (strcmp(name, "fft_ts") == 0) { c->opt_fft_ts = value != 0; return KM_OK; }
     if (strcmp(name, "phase_fp64") == 0) { c->opt_phase_fp64 = value != 0; return KM_OK; }
-    if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
-    if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "fft61") == 0) { c->opt_fft61 = value != 0; return KM_OK; }
     if (strcmp(name, "fft_herm") == 0) { c->opt_fft_herm = value != 0; return KM_OK; }
-    if (strcmp(name, "defer_valid") == 0) { c->opt_defer_valid = value != 0; return KM_OK; }
-    if (strcmp(name, "mm_early_at") == 0) { c->opt_mm_early_at = value; return KM_OK; }
-    if (strcmp(name, "tail_overlap") == 0) { c->opt_tail_overlap = value != 0; return KM_OK; }
     if (strcmp(name, "f64_half") == 0) { c->opt_f64_half = value != 0; return KM_OK; }
     if (strcmp(name, "f64_pair") == 0) { c->opt_f64_pair = value != 0; return KM_OK; }
     if (strcmp(name, "f64_plain") == 0) { c->opt_f64_plain = value != 0; return KM_OK; }
-    if (strcmp(name, "speculative") == 0) { c->opt_speculative = value != 0; return KM_OK; }
-    if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
-    if (strcmp(name, "aux_early") == 0) { c->opt_aux_early = value != 0; return KM_OK; }
-    if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
-    if (strcmp(name, "eig3") == 0) { c->opt_eig3 = value != 0; return KM_OK; }
-    if (strcmp(name, "lk2") == 0) { c->opt_lk2 = value != 0; return KM_OK; }
-    if (strcmp(name, "lk_pair") == 0) { c->opt_lk_pair = value != 0; return KM_OK; }
-    if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
-    if (strcmp(name, "lk_order") == 0) { c->opt_lk_order = value != 0; return KM_OK; }
-    if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
+    if (strcmp(name, "roctx") == 0) { c->opt_roctx = value != 0; return KM_OK; }
     if (strcmp(name, "profile_every") == 0) { c->opt_profile_every = value < 1 ? 1 : value; return KM_OK; }
     if (strcmp(name, "profile_stage") == 0) { c->opt_profile_stage = (value >= 0 && value < ST_COUNT) ? value : -1; return KM_OK; }
-    if (strcmp(name, "stash_cap") == 0) { c->opt_stash_cap = value < 0 ? 0 : value; return KM_OK; }
-    if (strcmp(name, "spec_flag") == 0) { c->opt_spec_flag = value < 0 ? 0 : value; return KM_OK; }
+#ifdef KM_DEV
+    // ---- development build only (make DEV=1): A/B switches of measured-and-settled choices, tuning of the double-precision transform
+    if (strcmp(name, "fft_cross") == 0) { c->opt_fft_cross_fused = value != 0; return KM_OK; }
+    if (strcmp(name, "f64_prime_t") == 0) { c->opt_f64_prime_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "f64_smooth_t") == 0) { c->opt_f64_smooth_t = value < 0 ? 0 : value; return KM_OK; }
+    if (strcmp(name, "defer_valid") == 0) { c->opt_defer_valid = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_early") == 0) { c->opt_aux_early = value != 0; return KM_OK; }
+    if (strcmp(name, "aux_priority") == 0) { c->opt_aux_priority = value != 0; return KM_OK; }   // (before the first tile: the stream is created once)
+    if (strcmp(name, "eig3_count") == 0) { c->opt_eig3_count = value != 0; return KM_OK; }
+#endif
     return km_fail(c, KM_E_ARG, "km_set_option: unknown option '%s'", name);
+}
+
+// 1: the library was built with -DKM_DEV (development options and KARIOS_HIP_* tuning variables are live); 0: release build
+int km_is_dev_build(void)
+{
+#ifdef KM_DEV
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int km_set_profiling(km_ctx *c, int enable)
@@ -389,14 +390,7 @@ int km_upload_async(km_ctx *c, void *dst, size_t dst_pitch, const void *src, siz
     // page-locked source (km_host_alloc / hipHostMalloc / hipHostRegister): DMA'd in place, truly asynchronous.  Pageable source:
     // packed into the context's page-locked ring chunk by chunk (staging.hip) - the call returns when the source has been read,
     // the DMAs stay ordered on the copy stream; no runtime copy ever reads pageable memory
-    static const bool old_async = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;   // control soak: the ORIGINAL behaviour (rounds 1 - 3a): the runtime copies pageable rows
-    if (old_async) {
-        if (dst_pitch == width_bytes && src_pitch == width_bytes) KM_HIP(c, hipMemcpyAsync(dst, src, width_bytes * rows, hipMemcpyHostToDevice, c->copy_stream));
-        else KM_HIP(c, hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->copy_stream));
-    } else {
-        const int rcs = km_h2d_staged(c, c->copy_stream, dst, dst_pitch, src, src_pitch, width_bytes, rows);
-        if (rcs) return rcs;
-    }
+    { const int rcs = km_h2d_staged(c, c->copy_stream, dst, dst_pitch, src, src_pitch, width_bytes, rows); if (rcs) return rcs; }
     c->copy_pending = true;
     return KM_OK;
 }
@@ -487,26 +481,10 @@ int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)
 // ------------------------------------------------------------------ helpers
 // stage timers are cleared per pipeline: the KLT entry points own [ST_MINMAX, ST_LK], ZNCC owns ST_ZNCC
 enum { RESET_NONE = 0, RESET_KLT = 1, RESET_ZNCC = 2 };
-// the main stream waits for the scoring kernels of the last overlapped unit (no-op when it already has)
-static int tail_wait_now(km_ctx *c)
-{
-    if (c->tail_pending) {
-        KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail_done, 0));
-        c->tail_pending = false;
-    }
-    c->tail_defer = false;
-    return KM_OK;
-}
-
-static int begin_call(km_ctx *c, int reset = RESET_NONE, bool defer_tail = false)
+static int begin_call(km_ctx *c, int reset = RESET_NONE)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
-    // a previous submit left its frame / ZNCC / MI kernels on the copy stream: everything waits for them here, except a directly
-    // following submit, whose first kernels (min / max, Laplacians, eigenvalues) touch nothing the tail reads - it waits in front
-    // of its corner selection (klt_track_dev)
-    if (c->tail_pending && defer_tail && !getenv("KARIOS_HIP_POISON_WS")) c->tail_defer = true;
-    else { const int rct = tail_wait_now(c); if (rct) return rct; }
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->land_jobs.clear(); c->land_used = 0;   // (... and results it queued for a caller buffer that may be gone too: km_d2h_queue without its flush)
@@ -517,7 +495,7 @@ static int begin_call(km_ctx *c, int reset = RESET_NONE, bool defer_tail = false
     c->lk_start_prev = c->lk_start_valid; c->lk_start_valid = false;
     // debugging aid: KARIOS_HIP_POISON_WS=<byte> fills every workspace buffer at the start of a tile call, so a kernel that reads
     // workspace it (or its predecessors in the call) never wrote shows up as a parity failure instead of a once-in-a-while one
-    static const char *const poison = getenv("KARIOS_HIP_POISON_WS");
+    static const char *const poison = km_dev_env("KARIOS_HIP_POISON_WS");
     if (poison && reset == RESET_KLT)
         for (int i = 0; i < WS_COUNT; i++)
             if (c->ws[i].p && i != WS_AUTO && i != WS_MM_EARLY && i != WS_MM_PARTIAL) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
@@ -544,7 +522,7 @@ static int h2d_now(km_ctx *c, void *dst, const void *src, size_t bytes)
 // diagnosis (KARIOS_HIP_VERIFY_UPLOAD): read a device image back on the library stream and compare it with its host source
 static int verify_upload(km_ctx *c, const char *when, int slot, const void *host, size_t elem, int H, int W, ptrdiff_t stride, const void *d)
 {
-    static const bool verify = getenv("KARIOS_HIP_VERIFY_UPLOAD") != nullptr;
+    static const bool verify = km_dev_env("KARIOS_HIP_VERIFY_UPLOAD") != nullptr;
     if (!verify) return KM_OK;
     const size_t row = (size_t)W * elem;
     std::vector<char> back((size_t)H * row);
@@ -563,19 +541,9 @@ static int upload_image(km_ctx *c, int slot, const void *host, size_t elem, int 
 {
     void *d = km_ws(c, slot, (size_t)H * W * elem);
     if (!d) return KM_E_NOMEM;
-    // Caller memory is pageable.  Twice in ~37 000 cases of a six-process soak (images up to 1500 px, every CPU core busy with the
-    // oracles) the kernels of the blocking km_klt_tile call behind `hipMemcpy2DAsync(pageable rows)` saw partly stale destination rows
-    // (min / max of the monitored raster -32768 / 30720 where numpy says -4021 / 7987; seven of 1549 corners off; never the resident-
-    // pair path).  Round 3 completed such copies before anything else was enqueued; since round 4 the rows travel through the
-    // library's own page-locked ring (staging.hip) and the runtime never sees pageable memory.  KARIOS_HIP_ASYNC_HOST_UPLOAD=1
-    // restores the ORIGINAL behaviour for the control soak (with KARIOS_HIP_UPLOAD_CHECKSUM=1: what did the next kernel see?).
-    static const bool async_upload = getenv("KARIOS_HIP_ASYNC_HOST_UPLOAD") != nullptr;
-    if (async_upload)
-        KM_HIP(c, hipMemcpy2DAsync(d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H, hipMemcpyHostToDevice, c->stream));
-    else {
-        const int rcs = km_h2d_staged(c, c->stream, d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H);
-        if (rcs) return rcs;
-    }
+    // Caller memory is pageable: the rows travel through the library's own page-locked ring (staging.hip) - the runtime never copies
+    // from pageable memory (round 3 saw two stale-input mismatches behind hipMemcpy2DAsync(pageable rows): CHANGELOG.md, round 4)
+    { const int rcs = km_h2d_staged(c, c->stream, d, (size_t)W * elem, host, (size_t)stride * elem, (size_t)W * elem, (size_t)H); if (rcs) return rcs; }
     { const int rca = km_upload_check_arm(c, slot == WS_RAW_A ? "ref / image A" : slot == WS_RAW_B ? "mon / image B" : slot == WS_MASK_IN ? "mask" : "u8 image", host, elem, H, W, stride, d); if (rca) return rca; }
     *dptr = d;
     return verify_upload(c, "after upload", slot, host, elem, H, W, stride, d);
@@ -589,13 +557,7 @@ static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride,
     return KM_OK;
 }
 
-// two scalar blocks: the tail of an overlapped unit reads its corner count / flags while the next unit zeroes and fills its own
-#define KM_SC_STRIDE ((sizeof(km_scalars) + 255) / 256 * 256)
-static km_scalars *scalars(km_ctx *c, int which = 0)
-{
-    char *p = (char *)km_ws(c, WS_SCALARS, 2 * KM_SC_STRIDE);
-    return p ? (km_scalars *)(p + (size_t)which * KM_SC_STRIDE) : nullptr;
-}
+static km_scalars *scalars(km_ctx *c) { return (km_scalars *)km_ws(c, WS_SCALARS, sizeof(km_scalars)); }
 
 // pyramid of one image into caller-provided storage (levels >= 1 packed from `store`); returns the bytes used
 static int build_pyramid_single(km_ctx *c, const uint8_t *d_img, int H, int W, int win, int max_level, uint8_t *store, km_pyr *P, size_t *used)
@@ -768,7 +730,6 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     // caller reads sc->flags with the tile's result and repeats a flagged tile with c->spec_allowed = false.
     bool spec = !d_p0_in && c->spec_allowed && c->opt_speculative && c->fused_eig && prm->max_corners > 0 && prm->min_distance >= 1 &&
                 !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor && !c->opt_select_first;
-    if (!spec && (rc = tail_wait_now(c))) return rc;     // (only the sync-free form defers the wait for the previous unit's tail)
     if (!spec && (rc = kd_run_valid_sum(c))) return rc;  // (... and the valid-pixel sum)
     if (spec) {
         const size_t capk = (size_t)H * W / 8 + 4096 * KM_NSHARD;
@@ -779,14 +740,6 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         // memory system idle, and the ranking / selection chain behind it (small latency-bound kernels) then has the GPU to itself;
         // forked behind it (round 2) the pyramids stretched the chain's one-workgroup kernels from 8 to 36 us.
         bool forked = false;
-        // where the NEXT unit's early min / max may start ("mm_early_at": 0 in front of LK, 1 in front of the selection sweeps, 2 in
-        // front of the ranking): it must end before this unit's LK does, or the next Laplacian waits for it
-        auto mark_mm_start = [&]() -> int {
-            if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
-            KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
-            c->lk_start_valid = true;
-            return KM_OK;
-        };
         auto fork_pyramids = [&]() -> int {
             if (!c->aux_stream) {
                 // lowest priority: when a kernel of the main stream and a pyramid kernel become ready together (both wait for the
@@ -826,15 +779,10 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
         } else if (rc) return rc;
         else {
             if (c->opt_aux_pyramid && !forked && (rc = fork_pyramids())) return rc;
-            // the selection rewrites the scratch and the point lists the previous unit's frame / ZNCC / MI kernels read: they have
-            // had the Laplacian and eigenvalue passes of this unit (0.55 ms) to finish
-            if ((rc = tail_wait_now(c))) return rc;
-            if (c->opt_mm_early_at == 2 && (rc = mark_mm_start())) return rc;
             {
                 km_stage_timer t(c, ST_SORT);
                 rc = kf_rank(c, keys, capk, H, W, prm->max_corners, prm->quality_level, prm->min_distance, sc);
             }
-            if (rc == KM_OK && c->opt_mm_early_at == 1 && (rc = mark_mm_start())) return rc;
             if (rc == KM_OK) {
                 km_stage_timer t(c, ST_SELECT);
                 rc = kf_select(c, H, W, prm->max_corners, prm->min_distance, d_p0, cap, sc);
@@ -853,7 +801,6 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
             }
         }
     }
-    if ((rc = tail_wait_now(c))) return rc;              // (every fall-back of the block above)
     if ((rc = kd_run_valid_sum(c))) return rc;           // (a path that never forked the second stream)
     if (spec) {
         // corners, their count and the pyramids are enqueued
@@ -883,20 +830,15 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     const int n_max = d_p0_in ? n_p0 : (prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap);
     {
         km_stage_timer t(c, ST_LK);
-        if (spec && !c->lk_start_valid && c->opt_mm_early_at != 3) {
-            // (the next unit's early min / max starts here)
+        if (spec && !c->lk_start_valid) {
+            // (the next unit's early min / max starts here: beside LK - in front of the selection sweeps, the ranking or behind LK it
+            // measured slower, CHANGELOG.md round 4)
             if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
             KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
             c->lk_start_valid = true;
         }
         if ((rc = kl_track(c, A, B, d_p0, &sc->n_corners, n_max, prm->win_size, prm->max_count, prm->epsilon, true, d_p1, d_p0r)))
             return rc;
-        if (spec && !c->lk_start_valid && c->opt_mm_early_at == 3) {
-            // ("mm_early_at" 3: the next unit's min / max beside this unit's frame / ZNCC tail instead of beside LK)
-            if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
-            KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
-            c->lk_start_valid = true;
-        }
     }
     return KM_OK;
 }
@@ -1305,12 +1247,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     // slot != nullptr: km_klt_tile_frame_submit - the block goes to the slot's pinned buffer and the call returns without
     // waiting for the tail of the pipeline (LK, FB test, ZNCC, copy), which then overlaps the caller's next submission
     int rc;
-    // Tail overlap (submitted units, "tail_overlap"): the frame / ZNCC / MI kernels of a unit - short launches that leave most of the
-    // GPU idle, 0.09 ms of the step - run on the block-copy stream behind the unit's LK, and the main stream goes straight on to
-    // the next unit's Laplacian / eigenvalue passes.  What the two sides share is kept apart: two scalar blocks used in turn, a
-    // count buffer of the frame stage's own (WS_FRAME_CNT), and the next unit waits for this tail in front of its corner selection.
-    const bool overlap = slot != nullptr && c && c->opt_tail_overlap;
-    if ((rc = begin_call(c, RESET_KLT, overlap)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
+    if ((rc = begin_call(c, RESET_KLT)) || (rc = check_params(c, prm)) || (rc = check_image(c, d_ref, H, W, sref, "klt_tile_frame_dev")) ||
         (rc = check_image(c, d_mon, H, W, smon, "klt_tile_frame_dev")))
         return rc;
     if (with_zncc && ((rc = check_image(c, d_ref_full, Hf, Wf, sref_f, "klt_tile_frame_zncc_dev")) ||
@@ -1323,8 +1260,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
     c->evs_used[c->ev_cur][ST_ZNCC] = false; c->evs_used[c->ev_cur][ST_MI] = false;
-    if (overlap) c->sc_parity ^= 1;
-    km_scalars *sc = scalars(c, overlap ? c->sc_parity : 0);
+    km_scalars *sc = scalars(c);
     const size_t pb = (size_t)cap * 2 * sizeof(float);
     // block: header | x0 | y0 | dx | dy | score | index bits (float32) | zncc [| mutual_info_score | mi_score] (float64)
     const bool with_mi = with_zncc && c->opt_frame_mi;
@@ -1344,27 +1280,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     c->spec_allowed = false; c->mm_early_allowed = false;
     if (rc) return rc;
     const int n_max = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
-    if ((rc = tail_wait_now(c))) return rc;                 // (a path that never reached the selection)
-    // from here on the unit's tail: on the copy stream when it overlaps the next unit
-    struct stream_swap {
-        km_ctx *c; hipStream_t saved; bool active;
-        ~stream_swap() { if (active) c->stream = saved; }
-    } swap{c, c->stream, false};
-    if (overlap) {
-        if (!c->d2h_stream) {
-            KM_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-            KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
-        }
-        if (!c->ev_front_done) {
-            KM_HIP(c, hipEventCreateWithFlags(&c->ev_front_done, hipEventDisableTiming));
-            KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
-        }
-        KM_HIP(c, hipEventRecord(c->ev_front_done, c->stream));
-        KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_front_done, 0));
-        c->stream = c->d2h_stream;
-        swap.active = true;
-    }
-    if (!overlap && (rc = frame_block_free(c))) return rc;  // (on the copy stream the previous block's copy is simply ahead in the queue)
+    if ((rc = frame_block_free(c))) return rc;
     {
         km_stage_timer t(c, ST_FRAME);
         if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out, c->spec_used ? sc : nullptr))) return rc;
@@ -1419,12 +1335,6 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
         KM_HIP(c, hipEventRecord(slot->done, c->d2h_stream));
         c->frame_copy = slot->done;
         slot->bytes = ob;
-        if (overlap) {
-            // (recorded behind the copies: the next unit's selection then also finds WS_FRAME and the scalar block free)
-            KM_HIP(c, hipEventRecord(c->ev_tail_done, c->d2h_stream));
-            c->tail_pending = true;
-            c->frame_copy = nullptr;                        // (ev_tail_done covers it)
-        }
         return KM_OK;
     }
     km_scalars *land = c->spec_used ? (km_scalars *)km_pinned_rb(c, sizeof(km_scalars)) : nullptr;

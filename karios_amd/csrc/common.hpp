@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <functional>
 #include <string>
@@ -80,7 +81,6 @@ enum km_slot {
     WS_FFT_WORK,
     WS_FRAME,
     WS_AUTO,        // batched auto-ksize search: all Laplacians, pyramids, tracks
-    WS_LK_ORDER,    // spatial processing order of the key points of one LK launch
     WS_FFT_TW0,     // twiddle tables of the float32 FFT (row length of the first / second dimension), kept between calls
     WS_FFT_TW1,
     WS_FFT_TOP2,    // per-row (largest, second-largest) |cc| of the last inverse pass
@@ -225,17 +225,13 @@ struct km_ctx {
     bool spec_used = false;        // the running call went through the speculative corner path
     unsigned spec_flags = 0;       // sc->flags of the speculative run, once read back
     bool spec_allowed = false;     // set by the entry points that check sc->flags with their result (and cleared for the repeat)
-    int opt_fft_dbg = 0;           // development: bits that skip phases of the 61 M row kernel (timing experiments; results are then wrong)
     bool opt_roctx = false;        // "roctx": roctx ranges around the stages
     bool opt_fft_cross_fused = true;   // "fft_cross": the cross-power step fused into the first inverse pass's row load (61 M rows)
-    bool opt_fft_ts = false;       // "fft_ts" 1: rows of length 61 M on both sides - the two transposes are folded into the stores of the row passes in front of them (8-byte stores at a stride of one row, XCD-contiguous rows so that the lines fill up in L2): correct, the plane crosses HBM four times instead of six - and SLOWER (4.86 against 4.66 ms at 10980^2: the row kernels' store phase grows by more than the two 0.42-ms transposes cost).  0 (default): transpose kernels
     bool opt_fft_herm = true;      // "fft_herm" 1 (default): the inverse transform of the float32 phase correlation works on the Hermitian half plane (rows of length 61 M on both sides)
     bool opt_fft61 = true;         // "fft61" 1 (default): rows of length 61 M through the wave-local form (k_fft.hip, second form); 0: the Stockham kernel
     bool opt_phase_fp64 = false;   // "phase_fp64" 1: phase correlation always in double precision, k_fft64.hip (the reference's precision)
     bool opt_lk2 = true;           // "lk2" 1 (default): LK on four resident patches per key point (two-level pyramids); 0: the first form
-    int opt_lk_pair = 0;           // "lk_pair" 1: winSize 25 through the PAIR form of the second LK form (two key points per wavefront, one per 32-lane half): bit-identical, fewer per-point instructions in the template pass, and SLOWER (0.31 against 0.26 ms at 20 000 corners beside the next unit's min / max): 155 VGPRs = 3 waves per SIMD instead of 6, and the per-half address arithmetic the compiler rematerialises in the iteration loop eats what the shared per-point chain saves.  0 (default): one key point per wavefront
     bool opt_mm_early = true;      // "mm_early" 0: min / max of a submitted unit on the main stream behind the previous unit's tail (round-2 order)
-    bool opt_lk_order = false;     // "lk_order" 1: key points of a launch are processed in spatial (128-px cell) order, one contiguous eighth per XCD - halves the kernel's HBM traffic (399 -> 202 MB at 20 000 corners) but the ordering launch costs more time than the better locality returns (LK is issue-bound): off by default
     bool opt_frame_mi = false;     // "frame_mi" 1: frames scored by the tile entry points (ZNCC of the rows with score >= threshold) also carry the two mutual-information scores of those rows (core.py:894-907): two more float64 columns behind zncc
     bool opt_no_defer = false; // "defer" 0: the deferred pyramid jobs run after the read-back waits instead of under them
     // stage-timer events: set 0 serves the synchronous calls, sets 1..KM_FRAME_SLOTS the frames in flight of
@@ -253,21 +249,13 @@ struct km_ctx {
     km_klt_stats stats;
     int phase_path = 0;            // last km_phase_shift*: 1 = float32 hand-written FFT, 2 = double precision (k_fft64.hip)
     double phase_margin = 0.0;     // (max - second largest) / max of |cc| seen by the float32 path
-    // tail overlap (km_klt_tile_frame_submit): frame / ZNCC / MI of unit k run on the block-copy stream beside the first kernels of
-    // unit k + 1; ev_front_done = LK of the unit enqueued, ev_tail_done = its scoring kernels enqueued; tail_pending: the main stream
-    // has not waited for ev_tail_done yet (every entry point does at its start - a directly following submit only in front of its
-    // corner selection, the first stage that rewrites what the tail reads)
-    hipEvent_t ev_front_done = nullptr, ev_tail_done = nullptr;
-    bool tail_pending = false, tail_defer = false;
-    int sc_parity = 0;             // which of the two scalar blocks the last overlapped unit used
     bool defer_valid_sum = false;  // set around the Laplacian pass of a unit on the sync-free path: the valid-pixel sum becomes a job for the second stream
     bool valid_job_pending = false;
     const unsigned *valid_job_partial = nullptr;
     unsigned valid_job_n = 0;
     unsigned long long *valid_job_out = nullptr;
+    bool opt_eig3_count = false;   // (KM_DEV) "eig3_count": the fused 8-px eigenvalue pass counts the (wave, row, pixel slot) triples a bound could skip
     bool opt_defer_valid = true;   // "defer_valid" 0: the sum stays behind the Laplacian pass on the main stream
-    int opt_mm_early_at = 0;       // "mm_early_at": where the next unit's early min / max may start (0 LK, 1 selection sweeps, 2 ranking, 3 behind LK; all but 0 measured slower)
-    bool opt_tail_overlap = false; // "tail_overlap" (measured: the Laplacian kernel beside it stretches by what the tail saves - off)
     int f64_h = 0, f64_w = 0;      // shape whose tables sit in WS_F64_TW* / WS_F64_NEG* (k_fft64.hip)
     int opt_f64_prime_t = 0;       // "f64_prime_t": cap on the transforms per tile of the prime level kernel (0: as many as fit, <= 64)
     int opt_f64_smooth_t = 0;      // "f64_smooth_t": the same for the smooth level kernel (default 8)
@@ -280,6 +268,13 @@ struct km_ctx {
 };
 
 int km_fail(km_ctx *ctx, int code, const char *fmt, ...);
+// KARIOS_HIP_* TUNING / DEBUGGING variables (row counts of the marching kernels, grid sizes, workspace poisoning ...) only exist in the
+// development build (make DEV=1 -> -DKM_DEV); the release library reads the variables include/karios_hip.h documents and nothing else
+#ifdef KM_DEV
+static inline const char *km_dev_env(const char *name) { return getenv(name); }
+#else
+static inline const char *km_dev_env(const char *) { return nullptr; }
+#endif
 // km_set_option("roctx", 1): every stage's host-side enqueue span becomes a roctx range (rocprofv3 --marker-trace); the library
 // is looked up at run time (librocprofiler-sdk-roctx.so / libroctx64.so), nothing is linked
 void km_roctx_push(int stage);

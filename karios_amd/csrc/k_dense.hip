@@ -180,7 +180,7 @@ static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype,
 {
     // workgroups per image.  Beside LK (early min / max: ws_slot != WS_PARTIAL) the kernel is off the critical path and takes
     // fewer wave slots from the kernel it shares the GPU with
-    static const int nb_early = [] { const char *e = getenv("KARIOS_HIP_MM_EARLY_NB"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 2048 ? v : 2048; }();
+    static const int nb_early = [] { const char *e = km_dev_env("KARIOS_HIP_MM_EARLY_NB"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 2048 ? v : 2048; }();
     const int nb = ws_slot == WS_PARTIAL ? 2048 : nb_early, ni = d_b ? 2 : 1;
     double *partial = (double *)km_ws(c, ws_slot, (size_t)2 * nb * ni * sizeof(double));
     if (!partial) return KM_E_NOMEM;
@@ -1068,7 +1068,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK, SPLIT> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK, SPLIT>
                                                                                          : (const void *)lap_march_kernel<3, T, MASK, SPLIT>;
     int rows = km_pick_rows(H, (SPLIT ? 2 : 1) * nstrips, 2 * R, slots_of(fn), 32, 160);
-    if (const char *e = getenv("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
+    if (const char *e = km_dev_env("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
     const unsigned ntiles = (unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u;
     dim3 grid(km_xcd_grid(ntiles));
@@ -1486,7 +1486,7 @@ int kd_min_eigen(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, 
                  unsigned int *d_max_key)
 {
     if (block < 1 || block > 31) return km_fail(c, KM_E_UNSUPPORTED, "blockSize %d (supported 1..31)", block);
-    static const int eig_mode = getenv("KARIOS_HIP_EIG_KERNEL") ? atoi(getenv("KARIOS_HIP_EIG_KERNEL")) : 2;   // 2: two pixels per lane, 1: one
+    static const int eig_mode = km_dev_env("KARIOS_HIP_EIG_KERNEL") ? atoi(km_dev_env("KARIOS_HIP_EIG_KERNEL")) : 2;   // 2: two pixels per lane, 1: one
     if (eig_mode == 2) {
         const int rc2 = k2_min_eigen(c, d_src, d_mask, H, W, block, d_eig, d_max_key);
         if (rc2 != KM_E_UNSUPPORTED) return rc2;

@@ -64,7 +64,7 @@ int launch_eig2(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
     const int nstrips = EMIT ? (W - 1 + STRIDE - 1) / STRIDE : (W + STRIDE - 1) / STRIDE;
     // short items (several rounds of resident waves) balance best: map 0.352 ms at 48 rows, 0.38 at 128, 0.49 at 384; fused 0.464 at 64
     int rows = EMIT ? 64 : 48;
-    if (const char *e = getenv("KARIOS_HIP_EIG2_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows = v; }   // tuning override
+    if (const char *e = km_dev_env("KARIOS_HIP_EIG2_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows = v; }   // tuning override
     const int nrowblocks = EMIT ? (H - 2 + rows - 1) / rows : (H + rows - 1) / rows;
     const int nitems = nstrips * nrowblocks;
     const unsigned ntiles = (unsigned)(nitems + 3) / 4u;

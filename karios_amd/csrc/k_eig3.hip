@@ -481,7 +481,7 @@ int launch_eig3(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
     // 3 waves per SIMD are resident (168 VGPRs); the border items hold a slot each while they run.  Measured at 10980^2: 0.336 ms with
     // 96-row items (2645 + 344 items: one round), 0.341 at 48 (two rounds), 0.373 at 64 (1.4 rounds), 0.424 at 128 (slots left empty)
     int rows3 = km_pick_rows(H - 2, nstrips, 5, 1024L * 3 - n_border, 32, 192);   // (a warm-up row of an item costs about a third of a full row)
-    if (const char *e = getenv("KARIOS_HIP_EIG3_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows3 = v; }   // tuning override
+    if (const char *e = km_dev_env("KARIOS_HIP_EIG3_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows3 = v; }   // tuning override
     const int nrowblocks = (H - 2 + rows3 - 1) / rows3;
     const int nitems = n_border + nstrips * nrowblocks;
     const unsigned ntiles = (unsigned)(nitems + 3) / 4u;

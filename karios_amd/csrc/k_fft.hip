@@ -485,13 +485,9 @@ struct f61_top2 {
 template <typename T, int MC /* M at compile time (0: run time): the 61 strided reads of a butterfly then carry immediate offsets */, int mode>
 __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__ img_a, const T *__restrict__ img_b, ptrdiff_t sa, ptrdiff_t sb,
                                                            float2 *__restrict__ data, f61_top2 *__restrict__ top2, int N, int nrows, f61_plan plan,
-                                                           const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g, int dbg,
-                                                           float2 *__restrict__ out_plane, int ts_ld, int run_rows /* 0: all `nrows`; mode 4: only rows [0, run_rows); mode 5: row PAIRS */)
+                                                           const float2 *__restrict__ twM_g, const float2 *__restrict__ big_g,
+                                                           float2 *__restrict__ out_plane, int run_rows /* 0: all `nrows`; mode 4: only rows [0, run_rows); mode 5: row PAIRS */)
 {
-    // ts_ld != 0 (modes 0 and 4): the finished row r leaves TRANSPOSED - element i goes to out[i * ts_ld + r] - so that the pass behind
-    // it reads contiguous rows again and the 964-MB plane does not cross HBM twice more in a transpose kernel of its own.  Every lane
-    // then writes 8 bytes of a different 128-byte line; the lines fill up in L2 because the workgroups of an XCD (w % 8) work on 32
-    // CONSECUTIVE rows at a time (remapped below): 32 rows x 8 B = two whole lines per column.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *row = (float2 *)smem;
     float2 *twM = row + N;                                  // exp(-2 pi i n / M), n < M
@@ -578,7 +574,6 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
         }
     };
     int r = blockIdx.x;
-    if (ts_ld && (gridDim.x & 7) == 0) r = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD x: rows [32 x, 32 x + 32) of every block of gridDim.x rows
     if (r < nrun) { fetch(r); commit(r); }
     __syncthreads();
     for (; r < nrun; r += gridDim.x) {
@@ -587,7 +582,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             const int part = wave & 3, j = (wave >> 2) * 64 + lane;
             f61_acc acc;                                    // (part 3 uses 6 of the 8)
             float2 x0 = make_float2(0.f, 0.f), sum = x0;
-            if (j < M && !(dbg & 1)) {
+            if (j < M) {
                 switch (part) {
                 case 0: f61_accumulate<0, 8>(row + j, M, acc, x0, sum); break;
                 case 1: f61_accumulate<8, 8>(row + j, M, acc, x0, sum); break;
@@ -596,7 +591,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
                 }
             }
             __syncthreads();
-            if (j < M && !(dbg & 1)) {
+            if (j < M) {
                 auto put = [&](int t, float2 val) { row[j * 61 + t] = val; };
                 switch (part) {
                 case 0: f61_emit<0, 8>(acc, x0, sum, put); break;
@@ -609,9 +604,9 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
         __syncthreads();
         // ---- the next row starts its way from HBM (consumed after the store below)
         const int rn = r + gridDim.x;
-        if (!CROSS && !PAIR && rn < nrun && !(dbg & 4)) fetch(rn);     // (mode 4 holds two rows: fetched behind the transforms, where the registers are free)
+        if (!CROSS && !PAIR && rn < nrun) fetch(rn);     // (mode 4 holds two rows: fetched behind the transforms, where the registers are free)
         // ---- phase B: 61 independent length-M transforms, one wavefront each
-        for (int tp = wave; tp < ((dbg & 2) ? 0 : 61); tp += F61_T / 64) {
+        for (int tp = wave; tp < 61; tp += F61_T / 64) {
             if constexpr (MC != 0) {
                 // radix, Ns and M as constants: the stage sequence `factorize61` produces, unrolled at compile time - with run-time
                 // sizes the index arithmetic of a stage (quotients, strides, twiddle steps) cost more than its butterflies
@@ -635,7 +630,7 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             }
         }
         __syncthreads();
-        if ((CROSS || PAIR) && rn < nrun && !(dbg & 4)) fetch(rn);
+        if ((CROSS || PAIR) && rn < nrun) fetch(rn);
         // ---- the finished row leaves (natural order: X[t + 61 m] at row[t + 61 m])
         if (mode == 3 || PAIR) {
           for (int half = 0; half < (PAIR ? 2 : 1); half++) {
@@ -669,16 +664,11 @@ __global__ __launch_bounds__(F61_T) void fft61_rows_kernel(const T *__restrict__
             }
           }
         } else {
-            if (ts_ld) {
-                float2 *dst = (CROSS ? out_plane : data) + r;
-                if (!(dbg & 8)) for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2 || CROSS) x.y = -x.y; dst[(size_t)i * ts_ld] = x; }
-            } else {
-                float2 *dst = (CROSS ? out_plane : data) + (size_t)r * N;
-                if (!(dbg & 8)) for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2 || CROSS) x.y = -x.y; dst[i] = x; }
-            }
+            float2 *dst = (CROSS ? out_plane : data) + (size_t)r * N;
+            for (int i = tid; i < N; i += F61_T) { float2 x = row[i]; if (mode == 2 || CROSS) x.y = -x.y; dst[i] = x; }
         }
         __syncthreads();
-        if (rn < nrun && !(dbg & 4)) commit(rn);
+        if (rn < nrun) commit(rn);
         __syncthreads();
     }
 }
@@ -808,7 +798,7 @@ int launch_rows(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, f
 
 template <typename T, int MC, int MODE>
 int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                     const fft_tables &tb, float2 *out_plane, int ts_ld, int run_rows)
+                     const fft_tables &tb, float2 *out_plane, int run_rows)
 {
     const size_t lds = ((size_t)N + (size_t)plan.M) * sizeof(float2);
     static unsigned long long opted = 0;   // per instantiation and per DEVICE: hipFuncSetAttribute applies to the current device only
@@ -819,7 +809,7 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
     }
     const int nrun = run_rows ? run_rows : nrows;
     const int grid = nrun < c->n_cu ? nrun : c->n_cu;        // one 88-KB workgroup per CU: each walks its rows with the next one in flight
-    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, c->opt_fft_dbg, out_plane, ts_ld, run_rows);
+    fft61_rows_kernel<T, MC, MODE><<<grid, F61_T, lds, c->stream>>>(a, b, sa, sb, data, top2, N, nrows, plan, tb.twM, tb.big, out_plane, run_rows);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -828,27 +818,27 @@ int launch_rows61_as(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t 
 // as a compile-time constant: 10980 = 61 * 180 (10 m), 5490 = 61 * 90 (20 m), 1830 = 61 * 30 (60 m).
 template <typename T, int MODE>
 int launch_rows61_m(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                    const fft_tables &tb, float2 *out_plane, int ts_ld = 0, int run_rows = 0)
+                    const fft_tables &tb, float2 *out_plane, int run_rows = 0)
 {
     switch (plan.M) {
-    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
-    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
-    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
-    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
+    case 180: return launch_rows61_as<T, 180, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, run_rows);
+    case 90: return launch_rows61_as<T, 90, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, run_rows);
+    case 30: return launch_rows61_as<T, 30, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, run_rows);
+    default: return launch_rows61_as<T, 0, MODE>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, run_rows);
     }
 }
 
 template <typename T>
 int launch_rows61(km_ctx *c, const T *a, const T *b, ptrdiff_t sa, ptrdiff_t sb, float2 *data, f61_top2 *top2, int N, int nrows, const f61_plan &plan,
-                  const fft_tables &tb, int mode, float2 *out_plane = nullptr, int ts_ld = 0, int run_rows = 0)
+                  const fft_tables &tb, int mode, float2 *out_plane = nullptr, int run_rows = 0)
 {
-    if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr, ts_ld);
+    if (mode == 0) return launch_rows61_m<T, 0>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
     if constexpr (std::is_same<T, float>::value) {
         switch (mode) {
         case 1: return launch_rows61_m<float, 1>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
         case 2: return launch_rows61_m<float, 2>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
-        case 4: return launch_rows61_m<float, 4>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, ts_ld, run_rows);
-        case 5: return launch_rows61_m<float, 5>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr, 0, run_rows);
+        case 4: return launch_rows61_m<float, 4>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, out_plane, run_rows);
+        case 5: return launch_rows61_m<float, 5>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr, run_rows);
         default: return launch_rows61_m<float, 3>(c, a, b, sa, sb, data, top2, N, nrows, plan, tb, nullptr);
         }
     }
@@ -889,14 +879,12 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
         if (is_w ? w61 : h61) return launch_rows61<float>(c, nullptr, nullptr, 0, 0, data, top2, N, nrows, is_w ? qw : qh, is_w ? tw_w : tw_h, mode);
         return launch_rows<float>(c, nullptr, nullptr, 0, 0, data, mag, N, nrows, is_w ? pw : ph, (is_w ? tw_w : tw_h).tw, mode);
     };
-    // Both sides of the form 61 M (Sentinel-2: 10980 = 61 * 180) and "fft_ts" on: the two transposes ride on the stores of the row
-    // passes in front of them (the plane crosses HBM 4 times instead of 6).  Otherwise: transpose kernels between the passes.
-    const bool ts = w61 && h61 && c->opt_fft_cross_fused && c->opt_fft_ts && H >= 256 && W >= 256;
+    // (transpose kernels between the passes: folded into the row passes' stores they measured slower - CHANGELOG.md, round 4)
     // forward: rows (length W) of z = a + i b -> (transposed) -> B (W x H); rows (length H) in place
     switch (dtype) {
 #define KM_ROWS(CODE, T)                                                                                                                    \
     case CODE:                                                                                                                              \
-        rc = w61 ? launch_rows61<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, ts ? B : A, nullptr, W, H, qw, tw_w, 0, nullptr, ts ? H : 0) \
+        rc = w61 ? launch_rows61<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, A, nullptr, W, H, qw, tw_w, 0) \
                  : launch_rows<T>(c, (const T *)d_a, (const T *)d_b, stride_a, stride_b, A, nullptr, W, H, pw, tw_w.tw, 0);                 \
         break;
         KM_ROWS(KM_U8, uint8_t) KM_ROWS(KM_U16, uint16_t) KM_ROWS(KM_I16, int16_t) KM_ROWS(KM_F32, float)
@@ -905,38 +893,35 @@ int kp_phase_shift_fast(km_ctx *c, const void *d_a, const void *d_b, int dtype, 
     }
     if (rc) return rc;
     const dim3 tg((W + 63) / 64, (H + 63) / 64), tg2((H + 63) / 64, (W + 63) / 64);
-    if (!ts) {
-        transpose_kernel<<<tg, 256, 0, c->stream>>>(A, B, H, W);
-        KM_LAUNCH_CHECK(c);
-    }
+    transpose_kernel<<<tg, 256, 0, c->stream>>>(A, B, H, W);
+    KM_LAUNCH_CHECK(c);
     if ((rc = rows(B, nullptr, H, W, false, 1))) return rc;
     // inverse: rows (length H) of the transposed cross-power spectrum; (transposed) -> H x W; rows (length W) -> |cc|
     float2 *last = B;          // the plane the last pass reads
     // Hermitian inverse ("fft_herm", both sides 61 M): the cross-power spectrum of two real images satisfies P(-k) = conj P(k), so the
     // first inverse pass only runs the rows kx <= W / 2, the transpose moves half a plane and the last pass transforms two image
     // rows per complex transform (fft61_rows_kernel mode 5) - the correlation surface comes out exactly real
-    const bool herm = w61 && h61 && c->opt_fft_cross_fused && c->opt_fft_herm && !ts;
+    const bool herm = w61 && h61 && c->opt_fft_cross_fused && c->opt_fft_herm;
     if (herm) {
         const int Wh = W / 2 + 1;
-        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A, 0, Wh))) return rc;       // A: Wh x H
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A, Wh))) return rc;       // A: Wh x H
         const dim3 tgh((H + 63) / 64, (Wh + 63) / 64);
         transpose_kernel<<<tgh, 256, 0, c->stream>>>(A, B, Wh, H);                                                           // B: H x Wh
         KM_LAUNCH_CHECK(c);
-        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, W, H, qw, tw_w, 5, nullptr, 0, (H + 1) / 2))) return rc;
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, W, H, qw, tw_w, 5, nullptr, (H + 1) / 2))) return rc;
     } else if (h61 && c->opt_fft_cross_fused) {
         // the cross-power step rides on the row load of the first inverse pass: B (= Z) -> A
-        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A, ts ? W : 0))) return rc;
-        if (ts) last = A;
+        if ((rc = launch_rows61<float>(c, nullptr, nullptr, 0, 0, B, top2, H, W, qh, tw_h, 4, A))) return rc;
     } else {
         cross_power_f32_kernel<<<c->n_cu * 16, 256, 0, c->stream>>>(B, A, W, H);
         KM_LAUNCH_CHECK(c);
         if ((rc = rows(A, nullptr, H, W, false, 2))) return rc;
     }
-    if (!ts && !herm) {
+    if (!herm) {
         transpose_kernel<<<tg2, 256, 0, c->stream>>>(A, B, W, H);
         KM_LAUNCH_CHECK(c);
     }
-    float *cc = (float *)(ts ? B : A);
+    float *cc = (float *)A;
     if (!herm && (rc = rows(last, cc, W, H, true, 3))) return rc;
     // largest and second-largest |cc|
     unsigned long long *k1 = &sc->argmax_key, *k2 = (unsigned long long *)&sc->valid;

@@ -75,7 +75,6 @@ struct lvl_args {
     const int *srcx;                 // column px of a pair comes from position srcx[px] (>= 0: as it is) or ~srcx[px] (< 0: conjugated)
     int pair_hstart;                 // elements >= pair_hstart of every transform are mirrored ones: visited in reverse, so that the reads ascend (-1: none)
     int best_row_add;
-    int dbg;                         // development ("fft_dbg"): 1 skip the arithmetic, 2 skip the loads, 4 skip the stores - timing experiments, results are wrong
 };
 
 // ---------------------------------------------------------------------------------------------------------------- small DFTs
@@ -260,7 +259,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
             es[u] = e;
             v[u] = make_double2(0.0, 0.0);
             w[u] = make_double2(1.0, 0.0);
-            if (e < n * T && t < nt && !(A.dbg & 2)) {
+            if (e < n * T && t < nt) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + t, i) : px_pair<IMG>(A, a, b0 + t + i * (int)A.se);
                 else {
                     if (A.pair_src) {
@@ -300,7 +299,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
 
     cd *src = buf0, *dst = buf1;
     int Ns = 1;
-    for (int s = 0; s < ((A.dbg & 1) ? 0 : A.nst); s++) {
+    for (int s = 0; s < A.nst; s++) {
         const int R = A.radix[s], nb = n / R, twstep = n / (Ns * R);
         const unsigned magic = Ns > 1 ? (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns) : 0u;
         auto run = [&](auto rc) {
@@ -353,7 +352,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
                 if (A.inverse) x.y = -x.y;
                 else if (post) x = c_mul(x, w[u]);
                 const long long o = addr(e, i, t);
-                if (!(A.dbg & 4)) data[o] = x;
+                data[o] = x;
                 if (A.best) {
                     if (A.best_pair_w) {
                         const unsigned long long f1 = (unsigned long long)o + (unsigned long long)(a / A.AR) * (unsigned long long)A.best_row_add;
@@ -392,7 +391,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
             const int i = wave + 4 * (u0 + u);
             v[u] = make_double2(0.0, 0.0);
             w[u] = make_double2(1.0, 0.0);
-            if (i < p && lane < nt && !(A.dbg & 2)) {
+            if (i < p && lane < nt) {
                 if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + lane, i) : px_pair<IMG>(A, a, b0 + lane + i * (int)A.se);
                 else {
                     if (A.pair_src) {
@@ -435,7 +434,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
         if (A.inverse) v.y = -v.y;
         else if (post) v = c_mul(v, w);
         const long long o = base + (long long)k * A.se + loff;
-        if (!(A.dbg & 4)) data[o] = v;
+        data[o] = v;
         if (A.best) {
             if (A.best_pair_w) {
                 const unsigned long long f1 = (unsigned long long)o + (unsigned long long)(a / A.AR) * (unsigned long long)A.best_row_add;
@@ -482,7 +481,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
                 S[kk].x = fma(fb.x, cw[kk].y, S[kk].x); S[kk].y = fma(fb.y, cw[kk].y, S[kk].y);    // S = - sum (x_j - x_{p-j}) sin
             }
         };
-        const int hh = (A.dbg & 1) ? 0 : h;
+        const int hh = h;
         for (int j = 1; j <= hh; j += 2) {
             cd ya, yb, w1[F64_KB];
             fetch(j + 1, ya, yb, w1);                                          // (j + 1 = h + 1: fetched, never used)
@@ -769,7 +768,7 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
 {
     lvl_args A;
     A.data = data; A.tw = tabs.tw; A.ltw = tabs.ltw[level_index]; A.ptab = tabs.ptab[level_index]; A.ltw_R = L.R; A.n = L.n; A.N = N; A.inverse = inverse ? 1 : 0;
-    A.img_a = A.img_b = nullptr; A.img_sa = A.img_sb = 0; A.best = nullptr; A.dbg = c->opt_fft_dbg;
+    A.img_a = A.img_b = nullptr; A.img_sa = A.img_sb = 0; A.best = nullptr;
     A.pair_w = A.pair_h = A.best_pair_w = A.best_row_add = 0;
     A.tile_mask = nullptr; A.pair_src = nullptr; A.srcx = nullptr; A.pair_hstart = -1;
     int img = -1;

@@ -727,400 +727,6 @@ __global__ __launch_bounds__(64) LK2_25_OCC void lk2_kernel_win25(lk_args g, con
 }
 
 
-// ================================================================================================================
-// K7, pair form (round 4): TWO key points per wavefront, one per 32-lane half.
-//
-// What bounds the second form: a key point costs ~5 100 VALU wave-instructions, and in every iteration ~130 of ~210 are per-POINT
-// work that all 64 lanes execute on identical values - window origin, bilinear weights, the exact wave reductions of the
-// mismatch vector, the 2x2 solve, the termination tests (the window arithmetic proper is ~80).  Here the two halves of a wavefront
-// own one key point each: a lane takes four 5-px runs of its point's window instead of two, every "scalar" of the tracker is an
-// ordinary per-lane value that is uniform within its half, and the per-point instructions serve two points at once.  Control flow
-// that depends on the point (level skipped, iteration count, a patch re-centred) diverges per half like any SIMT branch; the
-// reductions stop at the half (row_bcast15 joins the two 16-lane rows of a half; lanes 31 / 63 hold the sums).
-// Arithmetic, operation order and rounding are the second form's, bit for bit (tests/test_gpu_parity.py, both forms).
-// LDS: 8 patches per wavefront (two points x two images x two levels).
-__device__ __forceinline__ int half_sum_i32_dpp(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8  -> lane 15 of every row holds the row's sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the halves' sums
-    const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
-    return (threadIdx.x & 32) ? s1 : s0;
-}
-// exact sum over the lanes of a half of an int32 of magnitude < 2^31, as a float64 (exact: |sum| < 2^37)
-__device__ __forceinline__ double half_sum_split(int v)
-{
-    const int lo = v & 0xffff, hi = v >> 16;
-    return (double)half_sum_i32_dpp(hi) * 65536.0 + (double)half_sum_i32_dpp(lo);
-}
-
-// 32 lanes stage a rows x cols byte patch (see stage_patch_*): dword loads inside the image, all in flight before the first store
-template <int MAXIT>
-__device__ __forceinline__ void stage32_issue(const uint8_t *__restrict__ img, int IW, int gx0, int gy0, int rows, int cols, lk_patch_regs<MAXIT> &rg)
-{
-    int hl = threadIdx.x & 31;
-    asm volatile("" : "+v"(hl));
-    const int nw = (cols + 3) >> 2, total = rows * nw;
-    const unsigned inv_nw = 65536u / (unsigned)nw + 1u;
-    const unsigned base = (unsigned)gy0 * (unsigned)IW + (unsigned)gx0;
-#pragma unroll
-    for (int it = 0; it < MAXIT; it++) {
-        const int i = min(hl + 32 * it, total - 1);
-        const int r = (int)(((unsigned)i * inv_nw) >> 16), d = i - r * nw;
-        const unsigned off = base + (unsigned)r * (unsigned)IW + 4u * (unsigned)d;
-        __builtin_memcpy(&rg.v[it], img + off, 4);
-    }
-}
-template <int MAXIT>
-__device__ __forceinline__ void stage32_commit(int rows, int cols, uint8_t *lds, int pitch, const lk_patch_regs<MAXIT> &rg)
-{
-    int hl = threadIdx.x & 31;
-    asm volatile("" : "+v"(hl));
-    const int nw = (cols + 3) >> 2, total = rows * nw;
-    const unsigned inv_nw = 65536u / (unsigned)nw + 1u;
-#pragma unroll
-    for (int it = 0; it < MAXIT; it++) {
-        const int i = hl + 32 * it;
-        if (i < total) {
-            const int r = (int)(((unsigned)i * inv_nw) >> 16), d = i - r * nw;
-            *(uint32_t *)(lds + r * pitch + 4 * d) = rg.v[it];
-        }
-    }
-}
-__device__ __forceinline__ bool lk_patch_inside32(int IW, int IH, int gx0, int gy0, int rows, int cols, int maxit)
-{
-    return gx0 >= 0 && gy0 >= 0 && gx0 + cols + 4 <= IW && gy0 + rows <= IH && rows * ((cols + 3) >> 2) <= 32 * maxit && rows * ((cols + 3) >> 2) < 1024 &&
-           cols <= 64;
-}
-// (re)load one patch with the lanes of the calling half (any image position: REFLECT_101 at the borders)
-template <int MAXIT, int WIN>
-__device__ __forceinline__ void lk4_restage(const uint8_t *__restrict__ img, int IW, int IH, int ox, int oy, const lk2_geo<WIN> &geo, uint8_t *patch)
-{
-    const int PS = geo.ps(), PP = geo.pp();
-    if (lk_patch_inside32(IW, IH, ox, oy, PS, PS, MAXIT)) {
-        lk_patch_regs<MAXIT> rg;
-        stage32_issue<MAXIT>(img, IW, ox, oy, PS, PS, rg);
-        stage32_commit<MAXIT>(PS, PS, patch, PP, rg);
-    } else {
-        for (int i = threadIdx.x & 31; i < PS * PS; i += 32) {
-            const int r = i / PS, cx = i - r * PS;
-            patch[r * PP + cx] = img[(size_t)km_reflect101(oy + r, IH) * IW + km_reflect101(ox + cx, IW)];
-        }
-    }
-}
-
-// One direction of the tracker for the key point of the calling half.  Every value that the second form holds once per wavefront
-// is a per-lane value here (identical in the 32 lanes of a half); `active`: the half has a key point at all.
-template <int NR, int WIN, int MAXIT>
-__device__ void lk4_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
-                                const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], bool active, float &outx, float &outy)
-{
-    const int win = geo.win;
-    const float half = (float)(win - 1) * 0.5f;
-    const float FLT_SCALE = 1.f / (1 << 20);
-    const int PP = geo.pp(), PB = geo.bytes();
-    float resx = px, resy = py;
-    int k_half9 = 1 << (14 - 5 - 1), k_half14 = 1 << 13;
-    asm volatile("" : "+v"(k_half9), "+v"(k_half14));
-#pragma unroll 1
-    for (int level = 1; level >= 0; level--) {
-        const int IW = I.W[level], IH = I.H[level], JW = J.W[level], JH = J.H[level];
-        const float sc = level ? 0.5f : 1.f;
-        float prx = px * sc, pry = py * sc;
-        float nx, ny;
-        if (level == 1) { nx = prx; ny = pry; }
-        else { nx = resx * 2.f; ny = resy * 2.f; }
-        resx = nx; resy = ny;
-        prx -= half; pry -= half;
-        const int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
-        // (the reductions below are executed by BOTH halves together: a half whose level is skipped runs the template pass on its
-        // stale patch with its results discarded - cheaper than diverging around 600 instructions, and the patch reads stay in LDS)
-        const bool level_on = active && !(ipx < -win || ipx >= IW || ipy < -win || ipy >= IH);
-        float a = prx - (float)ipx, b = pry - (float)ipy;
-        int w00, w01, w10, w11;
-        lk_weights(a, b, w00, w01, w10, w11);
-        uint8_t *X = pI + level * PB, *Y = pJ + level * PB;
-        int tx = ipx - oI[level][0], ty = ipy - oI[level][1];
-        if (level_on && (tx < 1 || tx > 2 * LK2_M - 1 || ty < 1 || ty > 2 * LK2_M - 1)) {
-            LK_WAVE_SYNC();
-            oI[level][0] = ipx - LK2_M; oI[level][1] = ipy - LK2_M;
-            lk4_restage<MAXIT>(I.img[level], IW, IH, oI[level][0], oI[level][1], geo, X);
-            LK_WAVE_SYNC();
-            tx = ty = LK2_M;
-        }
-        if (!level_on) { tx = ty = LK2_M; }       // any in-patch position: the half's results of this level are discarded
-        const bool need_mask = !(ipx >= 0 && ipy >= 0 && ipx + win <= IW - 1 && ipy + win <= IH - 1);
-        uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
-        int sA11 = 0, sA12 = 0, sA22 = 0;
-        {
-            const lk_s2 wt0 = lk_as_s2(lk_pack16(w00, w01)), wt1 = lk_as_s2(lk_pack16(w10, w11));
-            const uint8_t *xb = X + (ty - 1) * PP + (tx - 1);
-#pragma unroll
-            for (int t = 0; t < NR; t++) {
-                int rd = run_desc[t];
-                asm volatile("" : "+v"(rd));
-                const int y = rd & 0xff, x0 = (rd >> 8) & 0xff, n = rd >> 16;
-                const uint8_t *pr = xb + y * PP + x0;
-                uint2 R[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) __builtin_memcpy(&R[k], pr + k * PP, 8);
-                lk_us2 E[4][4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        E[k][j] = lk_as_us2(__builtin_amdgcn_perm(R[k].y, R[k].x, 0x0c000c00u | (uint32_t)(2 * j) | ((uint32_t)(2 * j + 1) << 16)));
-                uint32_t gx[2][3], gy[2][3];
-#pragma unroll
-                for (int d = 0; d < 2; d++) {
-                    lk_us2 S[4], V[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        S[j] = (E[d][j] + E[d + 2][j]) * (unsigned short)3 + E[d + 1][j] * (unsigned short)10;
-                        V[j] = E[d + 2][j] - E[d][j];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        gx[d][q] = lk_us_as_u(S[q + 1] - S[q]);
-                        const lk_us2 vo = lk_as_us2(__builtin_amdgcn_alignbyte(lk_us_as_u(V[q + 1]), lk_us_as_u(V[q]), 2));
-                        gy[d][q] = lk_us_as_u((V[q] + V[q + 1]) * (unsigned short)3 + vo * (unsigned short)10);
-                    }
-                }
-                if (need_mask) {
-                    const int gy0 = ipy + y, gx0 = ipx + x0;
-#pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        const uint32_t mrow = (unsigned)(gy0 + d) < (unsigned)IH ? 0xffffffffu : 0u;
-#pragma unroll
-                        for (int q = 0; q < 3; q++) {
-                            const uint32_t m = (((unsigned)(gx0 + 2 * q) < (unsigned)IW ? 0x0000ffffu : 0u) |
-                                                ((unsigned)(gx0 + 2 * q + 1) < (unsigned)IW ? 0xffff0000u : 0u)) & mrow;
-                            gx[d][q] &= m; gy[d][q] &= m;
-                        }
-                    }
-                }
-                int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
-                iv[LK_RUN] = 0; ixv[LK_RUN] = 0; iyv[LK_RUN] = 0;
-#pragma unroll
-                for (int k = 0; k < LK_RUN; k++) {
-                    const uint32_t sel = 0x0c000c00u | (uint32_t)(k + 1) | ((uint32_t)(k + 2) << 16);
-                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(R[1].y, R[1].x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(R[2].y, R[2].x, sel));
-                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, lk_dot2_k(c1, wt1, k_half9), false) >> (14 - 5);
-                    auto pair = [&](const uint32_t (&g)[3]) -> lk_s2 {
-                        return lk_as_s2((k & 1) ? __builtin_amdgcn_alignbyte(g[(k + 1) / 2], g[k / 2], 2) : g[k / 2]);
-                    };
-                    ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, lk_dot2_k(pair(gx[1]), wt1, k_half14), false) >> 14;
-                    iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, lk_dot2_k(pair(gy[1]), wt1, k_half14), false) >> 14;
-                }
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const uint32_t pm = n >= 2 * q + 2 ? 0xffffffffu : (n == 2 * q + 1 ? 0x0000ffffu : 0u);
-                    IvP[t][q] = lk_pack16(iv[2 * q], iv[2 * q + 1]) & pm;
-                    IxP[t][q] = lk_pack16(ixv[2 * q], ixv[2 * q + 1]) & pm;
-                    IyP[t][q] = lk_pack16(iyv[2 * q], iyv[2 * q + 1]) & pm;
-                    sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
-                    sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
-                    sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
-                }
-            }
-        }
-        // (float)(int64 sum): the exact sum as a float64, rounded once to float32 - the same value as the second form's int64 -> float32
-        const float A11 = (float)half_sum_split(sA11) * FLT_SCALE, A12 = (float)half_sum_split(sA12) * FLT_SCALE, A22 = (float)half_sum_split(sA22) * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
-        const float dA = A11 - A22;
-        const float q = dA * dA + 4.f * A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf(q)) / (float)(2 * win * win);
-        bool iter_on = level_on && !(minEig < 1e-4f || D < FLT_EPSILON);
-        D = 1.f / D;
-        nx -= half; ny -= half;
-        float pdx = 0.f, pdy = 0.f;
-        int jx0 = oJ[level][0], jy0 = oJ[level][1];
-        // both halves walk the iteration loop together; a half that has finished (or never started) keeps executing the window pass on
-        // its last position with its result discarded - the trip count is the larger of the two
-        for (int j = 0; j < max_count; j++) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (iter_on && (inx < -win || inx >= JW || iny < -win || iny >= JH)) iter_on = false;
-            if (!__builtin_amdgcn_ballot_w64(iter_on)) break;
-            if (iter_on && (inx < jx0 || iny < jy0 || inx > jx0 + 2 * LK2_M || iny > jy0 + 2 * LK2_M)) {
-                LK_WAVE_SYNC();
-                jx0 = inx - LK2_M; jy0 = iny - LK2_M;
-                lk4_restage<MAXIT>(J.img[level], JW, JH, jx0, jy0, geo, Y);
-                LK_WAVE_SYNC();
-            }
-            a = nx - (float)inx; b = ny - (float)iny;
-            lk_weights(a, b, w00, w01, w10, w11);
-            const lk_s2 wr0 = lk_as_s2(lk_pack16(w00, w01)), wr1 = lk_as_s2(lk_pack16(w10, w11));
-            // (a half that is off reads from the patch origin: always inside its LDS region)
-            const uint8_t *jb = Y + (iter_on ? (iny - jy0) * PP + (inx - jx0) : 0);
-            int sb1 = 0, sb2 = 0;
-#pragma unroll
-            for (int t = 0; t < NR; t++) {
-                const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
-                const uint8_t *p0 = jb + y * PP + x0;
-                uint2 r0, r1;
-                __builtin_memcpy(&r0, p0, 8);
-                __builtin_memcpy(&r1, p0 + PP, 8);
-                int val[LK_RUN + 1];
-                val[LK_RUN] = 0;
-#pragma unroll
-                for (int k = 0; k < LK_RUN; k++) {
-                    const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);
-                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
-                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, lk_dot2_k(c1, wr1, k_half9), false) >> (14 - 5);
-                }
-#pragma unroll
-                for (int q2 = 0; q2 < 3; q2++) {
-                    const lk_s2 diff = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1])) - lk_as_s2(IvP[t][q2]);
-                    sb1 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IxP[t][q2]), sb1, false);
-                    sb2 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IyP[t][q2]), sb2, false);
-                }
-            }
-            const float b1 = (float)half_sum_split(sb1) * FLT_SCALE, b2 = (float)half_sum_split(sb2) * FLT_SCALE;
-            const float ddx = (A12 * b2 - A22 * b1) * D;
-            const float ddy = (A12 * b1 - A11 * b2) * D;
-            if (iter_on) {
-                nx += ddx; ny += ddy;
-                resx = nx + half; resy = ny + half;
-                if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= epsilon) iter_on = false;
-                else if (j > 0 && lk_oscillates(ddx, pdx, ddy, pdy)) {
-                    resx -= ddx * 0.5f; resy -= ddy * 0.5f;
-                    iter_on = false;
-                }
-                pdx = ddx; pdy = ddy;
-            }
-        }
-        oJ[level][0] = jx0; oJ[level][1] = jy0;
-    }
-    outx = resx; outy = resy;
-}
-
-template <int NR, int WIN, int MAXIT>
-__device__ __forceinline__ void lk4_body(const lk_args &g, const int *__restrict__ order)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const int n = g.d_n ? min(*g.d_n, g.n_max) : g.n_max;
-    const unsigned npairs = ((unsigned)n + 1u) / 2u;
-    // workgroup w runs on XCD w % 8: every XCD takes one contiguous eighth of the (spatially ordered) list of point pairs
-    const unsigned per = (npairs + KM_XCDS - 1) / KM_XCDS, slot = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
-    if (blockIdx.x / KM_XCDS >= per || slot >= npairs) return;
-    const int hsel = (threadIdx.x >> 5) & 1, hl = threadIdx.x & 31;
-    const int li = 2 * (int)slot + hsel;
-    const bool active = li < n;
-    const int p = active ? (order ? order[li] : li) : 0;
-    const lk2_geo<WIN> geo(g.win);
-    const int win = geo.win, PS = geo.ps(), PP = geo.pp(), PB = geo.bytes();
-    uint8_t *pA = smem_all + (size_t)hsel * 4 * PB, *pB = pA + 2 * PB;      // patches of this half: [image][level]
-    const int rpr = (win + LK_RUN - 1) / LK_RUN, total = win * rpr;
-    int run_desc[NR];
-#pragma unroll
-    for (int t = 0; t < NR; t++) {
-        const int r = t * 32 + hl;
-        const int y = r / rpr, x0 = (r - y * rpr) * LK_RUN;
-        run_desc[t] = r < total ? (y | (x0 << 8) | (min(LK_RUN, win - x0) << 16)) : 0;
-    }
-    const float px = active ? g.pts_in[2 * p] : 0.f, py = active ? g.pts_in[2 * p + 1] : 0.f;
-    const float half = (float)(win - 1) * 0.5f;
-    int oA[2][2], oB[2][2];
-    bool want[2], inside = active;
-#pragma unroll
-    for (int l = 0; l < 2; l++) {
-        const float sc = l ? 0.5f : 1.f;
-        const int ipx = (int)floorf(px * sc - half), ipy = (int)floorf(py * sc - half);
-        want[l] = active && !(ipx < -win || ipx >= g.A.W[l] || ipy < -win || ipy >= g.A.H[l]);
-        oA[l][0] = oB[l][0] = want[l] ? ipx - LK2_M : LK2_INVALID;
-        oA[l][1] = oB[l][1] = want[l] ? ipy - LK2_M : LK2_INVALID;
-        inside = inside && want[l] && lk_patch_inside32(g.A.W[l], g.A.H[l], oA[l][0], oA[l][1], PS, PS, MAXIT);
-    }
-    // a half WITHOUT a key point (odd count) or with a skipped level still needs initialised patches: the template pass reads them
-    if (inside) {
-        lk_patch_regs<MAXIT> r0, r1, r2, r3;
-        stage32_issue<MAXIT>(g.A.img[1], g.A.W[1], oA[1][0], oA[1][1], PS, PS, r0);
-        stage32_issue<MAXIT>(g.B.img[1], g.B.W[1], oB[1][0], oB[1][1], PS, PS, r1);
-        stage32_issue<MAXIT>(g.A.img[0], g.A.W[0], oA[0][0], oA[0][1], PS, PS, r2);
-        stage32_issue<MAXIT>(g.B.img[0], g.B.W[0], oB[0][0], oB[0][1], PS, PS, r3);
-        stage32_commit<MAXIT>(PS, PS, pA + PB, PP, r0);
-        stage32_commit<MAXIT>(PS, PS, pB + PB, PP, r1);
-        stage32_commit<MAXIT>(PS, PS, pA, PP, r2);
-        stage32_commit<MAXIT>(PS, PS, pB, PP, r3);
-    } else {
-#pragma unroll 1
-        for (int l = 1; l >= 0; l--) {
-            if (want[l]) {
-                lk4_restage<MAXIT>(g.A.img[l], g.A.W[l], g.A.H[l], oA[l][0], oA[l][1], geo, pA + l * PB);
-                lk4_restage<MAXIT>(g.B.img[l], g.B.W[l], g.B.H[l], oB[l][0], oB[l][1], geo, pB + l * PB);
-            } else {
-                for (int i = hl; i < PB / 4; i += 32) { ((uint32_t *)(pA + l * PB))[i] = 0u; ((uint32_t *)(pB + l * PB))[i] = 0u; }
-            }
-        }
-    }
-    LK_WAVE_SYNC();
-    float fx, fy;
-    lk4_track_point<NR, WIN, MAXIT>(g.A, g.B, pA, pB, oA, oB, px, py, geo, g.max_count, g.epsilon, run_desc, active, fx, fy);
-    if (active && hl == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
-    if (g.backward) {
-        float rx, ry;
-        lk4_track_point<NR, WIN, MAXIT>(g.B, g.A, pB, pA, oB, oA, fx, fy, geo, g.max_count, g.epsilon, run_desc, active, rx, ry);
-        if (active && hl == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
-    }
-}
-
-// the reference's window (matching_winsize 25): 125 runs of 5 px = four per lane of a half.  155 VGPRs unconstrained = 3 waves per
-// SIMD = 24 key points per CU in flight (the second form: 6 waves x 1 point).  A 4-wave build (128 VGPRs) spills 20 dwords, and the
-// spill code reads inline-assembly DOT results inside their hazard window (tools/hazard_scan.py found it): not built.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void lk4_kernel_win25(lk_args g, const int *__restrict__ order)
-{
-    lk4_body<4, 25, 9>(g, order);
-}
-
-// Processing order of one launch's key points: counting sort by 2^shift-px cell (row-major), one workgroup.  Corners arrive in
-// strength order, i.e. scattered over the image: neighbouring wavefronts then share no cache line, and every 32-byte patch row
-// costs a 128-byte line from HBM.  In cell order the patches of neighbouring key points overlap in L2 (workgroup w runs on XCD
-// w % 8, so lk2_kernel hands every XCD one contiguous eighth of this list).  The order inside a cell is whatever the LDS
-// atomics produce: it only decides WHEN a key point is tracked, its result is written by index.
-#define LKO_T 1024
-template <int RPT>
-__global__ __launch_bounds__(LKO_T) void lk_order_kernel(const float *__restrict__ pts, const int *__restrict__ d_n, int n_max, int W, int H, int shift,
-                                                         int ncx, int ncells, int *__restrict__ order)
-{
-    extern __shared__ unsigned lko_cnt[];
-    __shared__ unsigned s_wave[LKO_T / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = d_n ? min(*d_n, n_max) : n_max;
-    // every thread's key points in ONE batch of loads (a loop that loads and bins per trip pays the memory latency per trip)
-    float2 pt[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; u++) pt[u] = ((const float2 *)pts)[min(u * LKO_T + tid, max(n - 1, 0))];
-    for (int b = tid; b < ncells; b += LKO_T) lko_cnt[b] = 0u;
-    int cell[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; u++) {
-        const int cx = min(max((int)pt[u].x, 0), W - 1) >> shift, cy = min(max((int)pt[u].y, 0), H - 1) >> shift;   // (points outside the image: clamped)
-        cell[u] = cy * ncx + cx;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < RPT; u++)
-        if (u * LKO_T + tid < n) atomicAdd(&lko_cnt[cell[u]], 1u);
-    __syncthreads();
-    const int per = (ncells + LKO_T - 1) / LKO_T, b0 = min(tid * per, ncells), b1 = min(b0 + per, ncells);
-    unsigned mine = 0;
-    for (int b = b0; b < b1; b++) mine += lko_cnt[b];
-    unsigned incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-    if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
-    unsigned run = incl - mine;
-    for (int w = 0; w < wv; w++) run += s_wave[w];
-    for (int b = b0; b < b1; b++) { const unsigned c2 = lko_cnt[b]; lko_cnt[b] = run; run += c2; }   // counts become fill cursors
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < RPT; u++)
-        if (u * LKO_T + tid < n) order[atomicAdd(&lko_cnt[cell[u]], 1u)] = u * LKO_T + tid;
-}
-
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
              double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {
@@ -1140,26 +746,8 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
         const lk2_geo<0> geo(win);
         const size_t sm2 = (size_t)4 * geo.bytes();
         const unsigned nblk2 = km_xcd_grid((unsigned)n_max);
-        const int *order = nullptr;
-        if (c->opt_lk_order && n_max >= 2048 && n_max <= 32 * LKO_T) {
-            int shift = 7;
-            while ((((A.W[0] - 1) >> shift) + 1) * (((A.H[0] - 1) >> shift) + 1) > 8192) shift++;
-            const int ncx = ((A.W[0] - 1) >> shift) + 1, ncells = ncx * (((A.H[0] - 1) >> shift) + 1);
-            int *d_order = (int *)km_ws(c, WS_LK_ORDER, (size_t)n_max * sizeof(int));
-            if (!d_order) return KM_E_NOMEM;
-            const size_t lds = (size_t)ncells * sizeof(unsigned);
-            if (n_max <= 8 * LKO_T) lk_order_kernel<8><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
-            else if (n_max <= 20 * LKO_T) lk_order_kernel<20><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
-            else lk_order_kernel<32><<<1, LKO_T, lds, c->stream>>>(d_pts_in, d_n, n_max, A.W[0], A.H[0], shift, ncx, ncells, d_order);
-            KM_LAUNCH_CHECK(c);
-            order = d_order;
-        }
-        if (win == 25 && c->opt_lk_pair) {
-            // pair form: two key points per wavefront (8 patches of LDS)
-            const unsigned nblk4 = km_xcd_grid(((unsigned)n_max + 1u) / 2u);
-            lk4_kernel_win25<<<nblk4, 64, 2 * sm2, c->stream>>>(g, order);
-        }
-        else if (win == 25) lk2_kernel_win25<<<nblk2, 64, sm2, c->stream>>>(g, order);
+        const int *order = nullptr;          // (processing order of the points: the batched form passes a unit-major list)
+        if (win == 25) lk2_kernel_win25<<<nblk2, 64, sm2, c->stream>>>(g, order);
         else switch (nr) {
         case 1: lk2_kernel<1, 0, 3><<<nblk2, 64, sm2, c->stream>>>(g, order); break;
         case 2: lk2_kernel<2, 0, 4><<<nblk2, 64, sm2, c->stream>>>(g, order); break;

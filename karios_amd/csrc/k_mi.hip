@@ -315,8 +315,7 @@ int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Hr
               const float *d_score, float score_thr, double *d_studholme, double *d_nmi)
 {
     if (n <= 0) return KM_OK;
-    static const bool first_form = getenv("KARIOS_HIP_MI_FIRST_FORM") != nullptr;     // A/B: the round-3 kernel for every pixel type
-    if (dtype != KM_F32 && !first_form) {
+    if (dtype != KM_F32) {
         const double *tab = mi_table(c);
         if (!tab) return KM_E_NOMEM;
         const int nbx = (int)km_xcd_grid((unsigned)((n + 3) / 4));
@@ -333,13 +332,7 @@ int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Hr
     }
     const int nb = (n + 3) / 4;
 #define KM_MI(T) mi_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_studholme, d_nmi, c->window)
-    switch (dtype) {
-    case KM_U8: KM_MI(uint8_t); break;
-    case KM_U16: KM_MI(uint16_t); break;
-    case KM_I16: KM_MI(int16_t); break;
-    case KM_F32: KM_MI(float); break;
-    default: return km_fail(c, KM_E_ARG, "mi: bad dtype %d", dtype);
-    }
+    KM_MI(float);          // (integer pixels: integer bins and table entropies above)
 #undef KM_MI
     KM_LAUNCH_CHECK(c);
     return KM_OK;

@@ -25,7 +25,7 @@ int kp_phase_shift(km_ctx *c, const void *d_a, const void *d_b, int dtype, int H
         double margin = 0.0;
         const int rc = kp_phase_shift_fast(c, d_a, d_b, dtype, H, W, stride_a, stride_b, out_rc, &margin);
         c->phase_margin = margin;
-        if (rc == KM_OK && (margin >= 0.01 || c->opt_fft_dbg)) { c->phase_path = 1; return KM_OK; }   // (fft_dbg: timing experiments, results are wrong anyway)
+        if (rc == KM_OK && margin >= 0.01) { c->phase_path = 1; return KM_OK; }
         if (rc != KM_OK && rc != KM_E_UNSUPPORTED) return rc;
     }
     return kp_phase_shift_f64(c, d_a, d_b, dtype, H, W, stride_a, stride_b, out_rc);

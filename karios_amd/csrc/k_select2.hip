@@ -497,7 +497,7 @@ int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H,
     int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
     if (rc) return rc;
     // (cell records of 8 bytes in a 16-byte aligned buffer; with an odd cell count the first two item slots behind them are zeroed too - they are written later)
-    static const int gx = [] { const char *e = getenv("KARIOS_HIP_RANK_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();   // tuning override
+    static const int gx = [] { const char *e = km_dev_env("KARIOS_HIP_RANK_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();   // tuning override
     f_hist_cut_kernel<<<dim3(gx, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, c->eig_partial, c->eig_npartial,
                                                                    (unsigned)max_corners * KF_SLICE, b.kept_cap, (unsigned)c->opt_spec_flag,
                                                                    (uint4 *)b.cell_rec, (b.cells + 1) / 2, b.acc_cnt);

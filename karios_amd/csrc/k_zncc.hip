@@ -174,8 +174,7 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
 {
     if (n <= 0) return KM_OK;
     const int nb = (int)km_xcd_grid((unsigned)((n + 3) / 4));
-    static const bool two_pass = getenv("KARIOS_HIP_ZNCC_TWO_PASS") != nullptr;     // A/B: the float64 two-pass kernel for every pixel type
-    if (dtype != KM_F32 && !two_pass) {
+    if (dtype != KM_F32) {
 #define KM_ZI(T) zncc_int_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
         switch (dtype) {
         case KM_U8: KM_ZI(uint8_t); break;
@@ -188,13 +187,7 @@ int kz_zncc_filtered(km_ctx *c, const void *d_ref, const void *d_mon, int dtype,
         return KM_OK;
     }
 #define KM_Z(T) zncc_kernel<T><<<nb, 256, 0, c->stream>>>((const T *)d_ref, (const T *)d_mon, Href, Wref, Hmon, Wmon, sref, smon, d_x0, d_y0, d_dx, d_dy, n, d_n, d_score, score_thr, d_out, c->window)
-    switch (dtype) {
-    case KM_U8: KM_Z(uint8_t); break;
-    case KM_U16: KM_Z(uint16_t); break;
-    case KM_I16: KM_Z(int16_t); break;
-    case KM_F32: KM_Z(float); break;
-    default: return km_fail(c, KM_E_ARG, "zncc: bad dtype %d", dtype);
-    }
+    KM_Z(float);           // (integer pixels: exact integer moments above)
 #undef KM_Z
     KM_LAUNCH_CHECK(c);
     return KM_OK;

@@ -85,7 +85,7 @@ int pool_threads()
 {
     std::call_once(g_pool_once, [] {
         int n = 3;                                               // + the calling thread: 45.6 GB/s on the GPU box (8 / 12 / 16 threads: 34 / 33 / 32 GB/s under its 16-CPU quota)
-        if (const char *e = getenv("KARIOS_HIP_COPY_THREADS")) n = atoi(e) - 1;
+        if (const char *e = km_dev_env("KARIOS_HIP_COPY_THREADS")) n = atoi(e) - 1;
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && n > (int)hw - 1) n = (int)hw - 1;
         if (n < 0) n = 0;
@@ -137,7 +137,7 @@ static int ring_ready(km_ctx *c)
     km_stage_ring &r = c->ring;
     if (r.slot[0].buf) return KM_OK;
     size_t chunk = (size_t)8 << 20;     // 4 x 8 MB: 50 GB/s from pageable memory on the GPU box (4 MB: 45.6, 1 - 2 MB: 30; page-locked source: 57.5)
-    if (const char *e = getenv("KARIOS_HIP_RING_CHUNK_KB")) { const long v = atol(e); if (v >= 64 && v <= (1 << 18)) chunk = (size_t)v << 10; }
+    if (const char *e = km_dev_env("KARIOS_HIP_RING_CHUNK_KB")) { const long v = atol(e); if (v >= 64 && v <= (1 << 18)) chunk = (size_t)v << 10; }
     for (int i = 0; i < KM_RING_SLOTS; i++) {
         KM_HIP(c, hipHostMalloc(&r.slot[i].buf, chunk, hipHostMallocDefault));
         KM_HIP(c, hipEventCreateWithFlags(&r.slot[i].done, hipEventDisableTiming));

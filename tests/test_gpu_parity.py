@@ -276,10 +276,9 @@ def test_lk_forward_backward_in_one_launch_with_displacements_beyond_the_patch_m
         assert (moved > 3).mean() > 0.5          # (the case really leaves the margin)
 
 
-def test_lk_many_points_are_tracked_in_spatial_order_with_identical_results(ops, O):
-    """>= 2048 key points: the launch processes them in 128-px cell order (lk_order_kernel), one contiguous eighth per XCD.  The
-    order is an implementation detail: results are written by index and equal the oracle's, with the ordering on and off; points
-    outside the image are binned into the border cells."""
+def test_lk_many_points_with_points_outside_the_image(ops, O):
+    """>= 2048 key points in one launch (every XCD takes one contiguous eighth of the list; results are written by index), four of
+    them outside the image (calcOpticalFlowPyrLK returns their start positions, App. A.3): equal to the oracle's."""
     lap_mon, lap_ref, _, _ = _lap_pair(O, 420, 520, sx=0.8, sy=-0.6, seed=20260109)
     yy, xx = np.mgrid[3:417:6, 2:518:6]
     p0 = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.float32)
@@ -288,15 +287,9 @@ def test_lk_many_points_are_tracked_in_spatial_order_with_identical_results(ops,
     conf = O.default_conf(maxCorners=len(p0))
     p1 = O.pyr_lk(lap_ref, lap_mon, p0, 25)
     p0r = O.pyr_lk(lap_mon, lap_ref, p1, 25)
-    ctx = ops._lib.default_context()
-    try:
-        for flag in (1, 0):
-            ctx.set_option("lk_order", flag)
-            got = ops.klt_track(lap_ref, lap_mon, None, conf, p0=p0)
-            np.testing.assert_array_equal(got[1], p1)
-            np.testing.assert_array_equal(got[2], p0r)
-    finally:
-        ctx.set_option("lk_order", 1)
+    got = ops.klt_track(lap_ref, lap_mon, None, conf, p0=p0)
+    np.testing.assert_array_equal(got[1], p1)
+    np.testing.assert_array_equal(got[2], p0r)
 
 
 def test_pyrlk_small_image_no_pyramid_and_identity(ops, O):
@@ -484,11 +477,9 @@ def test_submit_wait_frames_in_flight(ops, O):
 
 
 @pytest.mark.parametrize("mutual_info", [False, True])
-def test_submitted_units_with_their_scoring_tail_beside_the_next_unit(ops, O, mutual_info):
-    """`tail_overlap`: frame / ZNCC / MI of unit k on the block-copy stream while unit k + 1's min / max, Laplacians and eigenvalue
-    pass run on the compute stream (two scalar blocks in turn, the wait in front of the corner selection): twelve units of four
-    different tile boxes back to back, two in flight, equal the blocking call's frames - sync-free corner path on (the form that
-    defers the wait), then the exact path and a blocking call in between."""
+def test_submitted_units_of_different_boxes_two_in_flight(ops, O, mutual_info):
+    """Twelve submitted units of four different tile boxes back to back, two in flight, equal the blocking call's frames - with the
+    sync-free corner path, then the exact path, and a blocking call in between (klt.py:220-253: the per-tile loop, pipelined)."""
     import pandas as pd
     from karios_amd.core import KLTConfiguration
     from karios_amd.resident import ResidentPair
@@ -497,7 +488,6 @@ def test_submitted_units_with_their_scoring_tail_beside_the_next_unit(ops, O, mu
     pair = ResidentPair.upload(mon, ref)
     boxes = [(0, 0, 450, 350), (450, 0, 450, 700), (10, 350, 400, 330), None]
     want = [pair.match_tile(conf, box=b, zncc_threshold=0.4, mutual_info=mutual_info) for b in boxes]
-    pair.ctx.set_option("tail_overlap", 1)
     try:
         for spec in (1, 0):
             pair.ctx.set_option("speculative", spec)
@@ -512,7 +502,6 @@ def test_submitted_units_with_their_scoring_tail_beside_the_next_unit(ops, O, mu
             for k, p in pend:
                 pd.testing.assert_frame_equal(want[k], p.result().to_frame())
     finally:
-        pair.ctx.set_option("tail_overlap", 0)
         pair.ctx.set_option("speculative", 1)
 
 

@@ -553,3 +553,30 @@ def test_the_library_links_no_math_library():
     for name in ("rocfft", "hipfft", "rocprim", "hipcub", "rocblas", "hipblas", "miopen", "rocrand", "rocsparse", "rocsolver"):
         assert name not in out, f"{name} in the library's dependencies:\n{out}"
     assert "libamdhip64" in out
+
+
+def test_release_library_rejects_development_option_names():
+    """the release build's km_set_option accepts only the names include/karios_hip.h documents; nothing that was
+    measured-and-not-adopted (or that returned wrong results by design: `fft_dbg`) is reachable through the public ABI.  Host-only:
+    the accepted names are read from the source of km_set_option and looked up in the strings of the compiled library."""
+    import re
+    from karios_amd import _lib
+    lib = _lib.load()
+    assert lib.km_is_dev_build() == 0, "the in-tree library must be the release build (make -C karios_amd/csrc, no DEV=1)"
+    header = open(os.path.join(ROOT, "include", "karios_hip.h")).read()
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', header, re.M))
+    assert {"fused_eig", "speculative", "frame_mi", "phase_fp64", "spec_flag", "profile_stage"} <= documented
+    source = open(os.path.join(ROOT, "karios_amd", "csrc", "api.hip")).read()
+    body = source[source.index("int km_set_option("):source.index("int km_is_dev_build(")]
+    release, dev = body.split("#ifdef KM_DEV")
+    accepted = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', release))
+    assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+    dev_names = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', dev))
+    gone = {"fft_dbg", "fft_ts", "lk_pair", "lk_order", "tail_overlap", "mm_early_at"}
+    assert not (gone & (accepted | dev_names))
+    # the compiled library agrees
+    strings = open(os.path.join(ROOT, "karios_amd", "libkarios_hip.so"), "rb").read()
+    for name in sorted(gone | dev_names):
+        assert (b"\0" + name.encode() + b"\0") not in strings, f"development option name {name!r} is compiled into the release library"
+    for name in sorted(accepted):
+        assert (b"\0" + name.encode() + b"\0") in strings or name.encode() in strings, name

@@ -95,8 +95,8 @@ def make_inputs(case):
     return mon, ref, mask
 
 
-KNOB_DEFAULTS = dict(key_cap=0, stage_cap=0, topk_factor=0, select_first=0, defer=1, fused_eig=1, speculative=1, eig3=1, lk2=1, lk_order=0,
-                     stash_cap=0, aux_early=1, mm_early=1)
+KNOB_DEFAULTS = dict(key_cap=0, stage_cap=0, topk_factor=0, select_first=0, defer=1, fused_eig=1, speculative=1, eig3=1, lk2=1,
+                     stash_cap=0, mm_early=1)
 PATHS_HIT = {}   # KM_PATH_* bit -> number of library calls that went through it (coverage report of --force-paths)
 
 
@@ -107,8 +107,8 @@ def draw_knobs(seed: int) -> dict:
     return dict(key_cap=int(rng.choice([0, 48, 256, 2048])), stage_cap=int(rng.choice([0, 0, 3, 40, 200])),
                 topk_factor=int(rng.choice([0, 1, 1, 2])), select_first=int(rng.choice([0, 8, 100, 1000])),
                 defer=int(rng.choice([1, 1, 0])), fused_eig=int(rng.choice([1, 1, 1, 0])), speculative=int(rng.choice([1, 1, 0])), eig3=int(rng.choice([1, 1, 0])),
-                # round 3: both LK forms, the spatial processing order, the scatter launch's second read, the late pyramid fork
-                lk2=int(rng.choice([1, 1, 0])), lk_order=int(rng.choice([0, 1])), stash_cap=int(rng.choice([0, 0, 1, 16])), aux_early=int(rng.choice([1, 1, 0])),
+                # round 3: both LK forms, the scatter launch's second read
+                lk2=int(rng.choice([1, 1, 0])), stash_cap=int(rng.choice([0, 0, 1, 16])),
                 mm_early=int(rng.choice([1, 1, 0])))
 
 

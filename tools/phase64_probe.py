@@ -46,11 +46,8 @@ def main():
     for mode, opts in ((1, {}), (1, {"f64_half": 0}), (1, {}), (1, {"f64_half": 0}), (1, {"f64_pair": 0}), (0, {})):
         ctx.set_option("phase_fp64", mode)
         ctx.set_option("f64_plain", 0)
-        ctx.set_option("f64_prime_t", 0)
-        ctx.set_option("f64_smooth_t", 0)
         ctx.set_option("f64_pair", 1)
         ctx.set_option("f64_half", 1)
-        ctx.set_option("fft_dbg", 0)
         for k, v in opts.items():
             ctx.set_option(k, v)
         times = []

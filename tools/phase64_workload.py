@@ -14,12 +14,10 @@ side = int(sys.argv[1]) if len(sys.argv) > 1 else 10980
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = default_context()
 ctx.set_option("phase_fp64", 1)
-dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-ctx.set_option("fft_dbg", dbg)
 _, ref = synth.make_pair(side, side, 0.0, 0.0, seed=5, noise_sigma=2.0)
 mon = np.roll(ref, (-21, 37), (0, 1))
 pair = ResidentPair.upload(mon, ref)
 for _ in range(reps):
     got = pair.phase_offset()
-assert dbg or tuple(got) == (-21.0, 37.0), got
+assert tuple(got) == (-21.0, 37.0), got
 print("ok", got)
