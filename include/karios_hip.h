@@ -199,10 +199,38 @@ int km_phase_plan(int n, int along_columns, int *levels, int cap_levels, int *n_
 /* Optional device-side copy of every frame block the km_klt_tile_frame_* entry points produce (same layout), e.g. a slice of
  * the send buffer of an RCCL all-gather: the block then never bounces through host memory.  NULL switches it off. */
 int km_set_frame_sink(km_ctx *ctx, void *d_dst, size_t capacity_bytes);
+/* ... for batched submissions (km_klt_units_frame_submit): unit k's block goes to d_dst + k * pitch_bytes (pitch 0: the block size),
+ * e.g. the rows of an all-gather's send buffer that carry a unit id in front of every block */
+int km_set_frame_sink_pitch(km_ctx *ctx, void *d_dst, size_t capacity_bytes, size_t pitch_bytes);
 /* Hand-over of a SUBMITTED frame (km_klt_tile_frame_submit with a frame sink set) to a stream of the caller without the host:
  * `hip_stream` (a hipStream_t - e.g. the stream the RCCL all-gather of the per-tile blocks, klt.py:220-253 / SURVEY 8e, is issued
  * on) waits on the device until the block of frame `ticket` has reached the sink. */
 int km_stream_wait_frame(km_ctx *ctx, int ticket, void *hip_stream);
+
+/* ---- batched units ------------------------------------------------------- */
+/* One work unit of a batched submission: a tile of `KLT.match` (klt.py:220-253) - a box of a resident pair - with the rasters its
+ * ZNCC / MI chips are cut from (the whole pair, or the window of it a rank holds: win_* as km_set_image_window, win_H = 0: none). */
+typedef struct km_unit {
+    const void *d_ref, *d_mon;              /* first pixel of the box in the reference / monitored raster (device) */
+    ptrdiff_t sref, smon;                   /* row strides in elements */
+    const void *d_ref_full, *d_mon_full;    /* rasters of the score columns (NULL: bare frames; all units alike) */
+    ptrdiff_t sref_f, smon_f;
+    int32_t H, W;                           /* box size */
+    int32_t Hf, Wf;                         /* size of the full rasters */
+    float x_off, y_off;                     /* origin added to the key points (klt.py:341-342) */
+    int32_t win_ox, win_oy, win_H, win_W;
+} km_unit;
+#define KM_UNITS_PER_SUBMISSION 16
+/* km_klt_tile_frame_submit for n <= KM_UNITS_PER_SUBMISSION independent units of one pixel type and one parameter set in ONE device
+ * pipeline (csrc/api_units.hip): every dense kernel, the corner-selection chain, LK, the frame stage and the scores are launched once
+ * for all units.  The frame blocks (layout of km_klt_tile_frame_zncc_dev, unit order) are bit-identical to the unit-by-unit calls';
+ * km_frame_wait(ticket) hands out n consecutive blocks, a frame sink receives them at its pitch.  Header word 2 of a block != 0: that
+ * unit did not fit the fixed capacities of the synchronisation-free corner path - repeat it alone through km_klt_tile_frame_zncc_dev
+ * with "speculative" 0.  Returns KM_E_UNSUPPORTED (no error text) when the batch form does not cover the case (maxCorners 0,
+ * minDistance < 1, a unit narrower than 512 columns or without a level-1 pyramid, Laplacian kernels 9 / 11, float32 score columns,
+ * a shrunken test capacity): submit the units one by one then.  No user mask (automatic mask, klt.py:268-273). */
+int km_klt_units_frame_submit(km_ctx *ctx, const km_unit *units, int n_units, int dtype, const double *nodata_ref, const double *nodata_mon,
+                              const km_klt_params *prm, double zncc_threshold, int cap, int *ticket);
 
 /* ---- fine-grained mirrors (host buffers) -------------------------------- */
 /* _to_uint8 (matcher/klt.py:42-49) [+ 255-x, klt.py:419]; out_minmax[2] nullable */

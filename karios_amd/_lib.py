@@ -42,6 +42,17 @@ NAN_OUTSIDE_WINDOW = 0x7FF80000DEAD0000   # km_set_image_window: score of a chip
 PATH_KEY_REGROW, PATH_STAGE_FALLBACK, PATH_SECOND_PASS, PATH_PREFIX_GROWN = 1, 2, 4, 8
 
 
+class KmUnit(C.Structure):
+    """km_unit of include/karios_hip.h: one work unit of km_klt_units_frame_submit."""
+    _fields_ = [("d_ref", C.c_void_p), ("d_mon", C.c_void_p), ("sref", C.c_ssize_t), ("smon", C.c_ssize_t),
+                ("d_ref_full", C.c_void_p), ("d_mon_full", C.c_void_p), ("sref_f", C.c_ssize_t), ("smon_f", C.c_ssize_t),
+                ("H", C.c_int32), ("W", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32), ("x_off", C.c_float), ("y_off", C.c_float),
+                ("win_ox", C.c_int32), ("win_oy", C.c_int32), ("win_H", C.c_int32), ("win_W", C.c_int32)]
+
+
+UNITS_PER_SUBMISSION = 16      # KM_UNITS_PER_SUBMISSION
+E_UNSUPPORTED = -4             # KM_E_UNSUPPORTED
+
 _vp, _i, _d, _sz, _pd = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int)
 
@@ -70,6 +81,8 @@ SIGNATURES = {
     "km_upload_mark": (_i, [_vp, _pi]),
     "km_upload_join": (_i, [_vp, _i]),
     "km_set_frame_sink": (_i, [_vp, _vp, C.c_size_t]),
+    "km_set_frame_sink_pitch": (_i, [_vp, _vp, C.c_size_t, C.c_size_t]),
+    "km_klt_units_frame_submit": (_i, [_vp, C.POINTER(KmUnit), _i, _i, _pd, _pd, C.POINTER(KltParams), _d, _i, C.POINTER(C.c_int)]),
     "km_stream_wait_frame": (_i, [_vp, _i, _vp]),
     "km_phase_info": (_i, [_vp, _pi, _pd]),
     "km_phase_plan": (_i, [_i, _i, _vp, _i, _pi, _pi, _vp]),
@@ -337,16 +350,18 @@ class Context:
         self.check(self.lib.km_set_option(self.handle, name.encode(), int(value)), "km_set_option")
         self.__dict__.setdefault("_options", {})[name] = int(value)
 
-    def set_frame_sink(self, ptr: int | None, nbytes: int = 0) -> None:
-        """km_set_frame_sink: every frame block the tile entry points produce from now on is also copied to device memory at `ptr`
-        (capacity `nbytes`); None switches it off.  The current sink is remembered (`frame_sink`): the exact repeat of a flagged
-        unit (`PendingFrame.redo`) runs with the sink OFF - by then it belongs to a newer unit."""
-        self.check(self.lib.km_set_frame_sink(self.handle, C.c_void_p(ptr) if ptr else None, int(nbytes) if ptr else 0), "km_set_frame_sink")
-        self.__dict__["_frame_sink"] = (int(ptr), int(nbytes)) if ptr else (None, 0)
+    def set_frame_sink(self, ptr: int | None, nbytes: int = 0, pitch: int = 0) -> None:
+        """km_set_frame_sink[_pitch]: every frame block the tile entry points produce from now on is also copied to device memory at
+        `ptr` (capacity `nbytes`; a batched submission's unit k at `ptr + k * pitch`, pitch 0 = the block size); None switches it off.
+        The current sink is remembered (`frame_sink`): the exact repeat of a flagged unit (`PendingFrame.redo`) runs with the sink
+        OFF - by then it belongs to a newer unit."""
+        self.check(self.lib.km_set_frame_sink_pitch(self.handle, C.c_void_p(ptr) if ptr else None, int(nbytes) if ptr else 0, int(pitch) if ptr else 0),
+                   "km_set_frame_sink_pitch")
+        self.__dict__["_frame_sink"] = (int(ptr), int(nbytes), int(pitch)) if ptr else (None, 0, 0)
 
     @property
     def frame_sink(self) -> tuple:
-        return self.__dict__.get("_frame_sink", (None, 0))
+        return self.__dict__.get("_frame_sink", (None, 0, 0))
 
     def get_option(self, name: str, default: int = 0) -> int:
         """Last value given to `set_option` (the library's own defaults are not queried)."""

@@ -2,6 +2,7 @@
 // the device-resident KLT tile pipeline.  Nothing here computes on the CPU: every entry point
 // ends in HIP kernels on the context stream; there is no fallback path.
 #include "common.hpp"
+#include "api_internal.hpp"
 #include "fft64_plan.hpp"
 #include <vector>
 
@@ -473,15 +474,23 @@ int km_set_frame_sink(km_ctx *c, void *d_dst, size_t capacity_bytes)
     if (!c) return km_fail(c, KM_E_ARG, "null context");
     c->frame_sink = d_dst;
     c->frame_sink_cap = d_dst ? capacity_bytes : 0;
+    c->frame_sink_pitch = 0;
+    return KM_OK;
+}
+int km_set_frame_sink_pitch(km_ctx *c, void *d_dst, size_t capacity_bytes, size_t pitch_bytes)
+{
+    if (!c) return km_fail(c, KM_E_ARG, "null context");
+    c->frame_sink = d_dst;
+    c->frame_sink_cap = d_dst ? capacity_bytes : 0;
+    c->frame_sink_pitch = d_dst ? pitch_bytes : 0;
     return KM_OK;
 }
 
 }  // extern "C"
 
 // ------------------------------------------------------------------ helpers
-// stage timers are cleared per pipeline: the KLT entry points own [ST_MINMAX, ST_LK], ZNCC owns ST_ZNCC
-enum { RESET_NONE = 0, RESET_KLT = 1, RESET_ZNCC = 2 };
-static int begin_call(km_ctx *c, int reset = RESET_NONE)
+// (api_internal.hpp: RESET_* - stage timers are cleared per pipeline: the KLT entry points own [ST_MINMAX, ST_LK], ZNCC owns ST_ZNCC)
+int begin_call(km_ctx *c, int reset)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
@@ -549,7 +558,7 @@ static int upload_image(km_ctx *c, int slot, const void *host, size_t elem, int 
     return verify_upload(c, "after upload", slot, host, elem, H, W, stride, d);
 }
 
-static int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride, const char *what)
+int check_image(km_ctx *c, const void *p, int H, int W, ptrdiff_t stride, const char *what)
 {
     if (!p) return km_fail(c, KM_E_ARG, "%s: null image", what);
     if (H <= 0 || W <= 0) return km_fail(c, KM_E_ARG, "%s: empty image %dx%d", what, H, W);
@@ -843,7 +852,7 @@ static int klt_track_dev(km_ctx *c, const uint8_t *d_ref_lap, const uint8_t *d_m
     return KM_OK;
 }
 
-static int check_params(km_ctx *c, const km_klt_params *p)
+int check_params(km_ctx *c, const km_klt_params *p)
 {
     if (!p) return km_fail(c, KM_E_ARG, "null params");
     if (p->block_size < 1) return km_fail(c, KM_E_ARG, "blockSize %d < 1", p->block_size);
@@ -1230,7 +1239,7 @@ int km_klt_tile_dev(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, 
 
 // The previous submitted frame's block may still be on its way to the host (on the d2h stream): WS_FRAME may be rewritten once it
 // has left - a device-side wait that never stalls in practice (the copy takes 13 us, the next frame is written ~1 ms later).
-static int frame_block_free(km_ctx *c)
+extern "C++" int frame_block_free(km_ctx *c)
 {
     if (c->frame_copy) {
         KM_HIP(c, hipStreamWaitEvent(c->stream, c->frame_copy, 0));

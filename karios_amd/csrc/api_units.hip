@@ -1,0 +1,241 @@
+// km_klt_units_frame_submit: U independent work units - the tiles of `KLT.match` (reference karios/matcher/klt.py:220-253: no halo, per-tile
+// uint8 stretch, per-tile quality threshold and maxCorners), of one pair or of several bands - through ONE device pipeline.
+//
+// Why.  Submitted one by one, every 30-Mpx unit pays the fixed costs of 20 000 corners serially: a corner-selection chain of nine
+// latency-bound launches (0.12 ms at 4 % VALU occupancy), an LK launch with its fill + drain, three small frame launches, and dense
+// kernels whose items are too short to amortise their halo (a 5490^2 unit fills two thirds of ONE round of resident waves).  Here
+//   * min / max, stretch + Laplacians + mask, the fused eigenvalue pass and the pyramids take the unit as part of their linear item
+//     space: one launch each, items as tall as a single 10980^2 tile's;
+//   * the selection chain runs its U latency chains side by side (unit = blockIdx.z): nine launches for all units;
+//   * ONE LK launch tracks every unit's corners, one frame / ZNCC / MI launch each scores them;
+//   * the U frame blocks leave in one copy (host slot) / one strided copy (frame sink: the send buffer of the all-gather).
+// Results are the unit-by-unit results bit for bit (tests/test_gpu_units.py): every kernel runs exactly the single-unit item code on
+// the unit's own rasters, scalar block, key buffer and grid.  A unit the fixed capacities of the synchronisation-free corner path do
+// not fit is flagged in its block's header (word 2) and repeated exactly by the caller, as for km_klt_tile_frame_submit.
+#include "api_internal.hpp"
+
+#include <cstring>
+
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" {
+
+int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype, const double *nodata_ref, const double *nodata_mon,
+                              const km_klt_params *prm, double zncc_threshold, int cap, int *ticket)
+{
+    int rc;
+    if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
+    if (!ticket || !units) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: null argument");
+    if (n < 1 || n > KM_UNITS_MAX) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: %d units (1 .. %d per submission)", n, KM_UNITS_MAX);
+    if ((rc = check_params(c, prm))) return rc;
+    if (!km_dtype_size(dtype)) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: bad dtype %d", dtype);
+    if (cap <= 0 || prm->max_corners <= 0 || cap < prm->max_corners) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: capacity %d / maxCorners %d", cap, prm->max_corners);
+    // the batch form IS the synchronisation-free corner path: whatever that path does not cover goes unit by unit (no message)
+    if (!(prm->min_distance >= 1) || !c->opt_speculative || !c->fused_eig || c->opt_key_cap || c->opt_stage_cap || c->opt_topk_factor || c->opt_select_first ||
+        prm->max_level != 1 || cap > 32768)
+        return KM_E_UNSUPPORTED;
+    const bool with_zncc = units[0].d_ref_full != nullptr;
+    const bool with_mi = with_zncc && c->opt_frame_mi;
+    if (with_zncc && dtype == KM_F32) return KM_E_UNSUPPORTED;
+    for (int u = 0; u < n; u++) {
+        const km_unit &q = units[u];
+        if ((rc = check_image(c, q.d_ref, q.H, q.W, q.sref, "klt_units_frame_submit")) || (rc = check_image(c, q.d_mon, q.H, q.W, q.smon, "klt_units_frame_submit")))
+            return rc;
+        if ((q.d_ref_full != nullptr) != with_zncc) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: either every unit carries full rasters or none");
+        if (with_zncc && ((rc = check_image(c, q.d_ref_full, q.Hf, q.Wf, q.sref_f, "klt_units_frame_submit")) ||
+                          (rc = check_image(c, q.d_mon_full, q.Hf, q.Wf, q.smon_f, "klt_units_frame_submit"))))
+            return rc;
+        if (q.W > 65535) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: unit of %d columns (the device-side frame ordering holds at most 65535)", q.W);
+        if (q.W < 512 || q.H < 2 * prm->block_size + 8 || (q.W + 1) / 2 <= prm->win_size || (q.H + 1) / 2 <= prm->win_size) return KM_E_UNSUPPORTED;
+    }
+    const int k = c->fslot_next;
+    km_frame_slot *slot = &c->fslot[k];
+    if (slot->pending.load(std::memory_order_acquire)) {   // never waited for: its block is about to be overwritten
+        KM_HIP(c, hipEventSynchronize(slot->done));
+        slot->pending.store(0, std::memory_order_release);
+    }
+    c->ev_cur = 1 + k;
+    struct ev_reset { km_ctx *c; ~ev_reset() { c->ev_cur = 0; } } ev_guard{c};
+    if ((rc = begin_call(c, RESET_KLT))) return rc;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->evs_used[c->ev_cur][ST_ZNCC] = false; c->evs_used[c->ev_cur][ST_MI] = false;
+
+    // ---- layout: unit u's slices of the context's workspace slots
+    km_units U;
+    U.n = n; U.dtype = dtype;
+    size_t px_total = 0, pyr_total = 0, max_px = 0;
+    size_t px_off[KM_UNITS_MAX], pyr_off[KM_UNITS_MAX];
+    for (int u = 0; u < n; u++) {
+        const km_unit &q = units[u];
+        U.H[u] = q.H; U.W[u] = q.W; U.ref[u] = q.d_ref; U.mon[u] = q.d_mon; U.sref[u] = q.sref; U.smon[u] = q.smon; U.x_off[u] = q.x_off; U.y_off[u] = q.y_off;
+        U.ref_full[u] = q.d_ref_full; U.mon_full[u] = q.d_mon_full; U.Hf[u] = q.Hf; U.Wf[u] = q.Wf; U.sref_f[u] = q.sref_f; U.smon_f[u] = q.smon_f;
+        U.win[u].ox = q.win_ox; U.win[u].oy = q.win_oy; U.win[u].H = q.win_H; U.win[u].W = q.win_W;
+        const size_t px = (size_t)q.H * q.W;
+        px_off[u] = px_total; px_total += up256(px);
+        max_px = px > max_px ? px : max_px;
+        pyr_off[u] = pyr_total; pyr_total += up256((size_t)((q.H + 1) / 2) * ((q.W + 1) / 2));
+    }
+    U.capk = max_px / 8 + 4096 * KM_NSHARD;
+    const size_t sc_stride = up256(sizeof(km_scalars)), pb = up256((size_t)cap * 2 * sizeof(float));
+    const size_t fb = 16 + (size_t)cap * 6 * sizeof(float), ob = fb + (with_zncc ? (size_t)cap * sizeof(double) : 0) + (with_mi ? (size_t)cap * 2 * sizeof(double) : 0);
+    const size_t ob_al = up256(ob);
+    uint8_t *lap_ref = (uint8_t *)km_ws(c, WS_U8_A, px_total), *lap_mon = (uint8_t *)km_ws(c, WS_U8_B, px_total), *mask = (uint8_t *)km_ws(c, WS_MASK, px_total);
+    unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, U.capk * sizeof(unsigned long long) * n);
+    char *sc = (char *)km_ws(c, WS_SCALARS, sc_stride * n);
+    char *p0 = (char *)km_ws(c, WS_PTS0, pb * n), *p1 = (char *)km_ws(c, WS_PTS1, pb * n), *p0r = (char *)km_ws(c, WS_PTS2, pb * n);
+    uint8_t *pyr_a = (uint8_t *)km_ws(c, WS_PYR_A, pyr_total), *pyr_b = (uint8_t *)km_ws(c, WS_PYR_B, pyr_total);
+    char *d_out = (char *)km_ws(c, WS_FRAME, ob_al * n);
+    if (!lap_ref || !lap_mon || !mask || !keys || !sc || !p0 || !p1 || !p0r || !pyr_a || !pyr_b || !d_out) return KM_E_NOMEM;
+    for (int u = 0; u < n; u++) {
+        U.lap_ref[u] = lap_ref + px_off[u]; U.lap_mon[u] = lap_mon + px_off[u]; U.mask[u] = mask + px_off[u];
+        U.keys[u] = keys + U.capk * u;
+        U.sc[u] = (km_scalars *)(sc + sc_stride * u);
+        U.mm[u] = U.sc[u]->mm;
+        U.p0[u] = (float *)(p0 + pb * u); U.p1[u] = (float *)(p1 + pb * u); U.p0r[u] = (float *)(p0r + pb * u);
+        U.frame[u] = d_out + ob_al * u;
+        U.eig_partial[u] = nullptr; U.eig_npartial[u] = 0;
+        km_pyr &A = U.A[u], &B = U.B[u];
+        A.img[0] = U.lap_ref[u]; B.img[0] = U.lap_mon[u];
+        A.H[0] = B.H[0] = U.H[u]; A.W[0] = B.W[0] = U.W[u];
+        A.img[1] = pyr_a + pyr_off[u]; B.img[1] = pyr_b + pyr_off[u];
+        A.H[1] = B.H[1] = (U.H[u] + 1) / 2; A.W[1] = B.W[1] = (U.W[u] + 1) / 2;
+        A.levels = B.levels = 1;
+    }
+    KM_HIP(c, hipMemsetAsync(sc, 0, sc_stride * n, c->stream));
+    const int n_max = prm->max_corners < cap ? prm->max_corners : cap;
+    if ((rc = kl_units_prepare(c, U, n_max, prm->win_size, prm->max_count, prm->epsilon))) return rc;   // (the table's small copy: off the critical path here)
+
+    // ---- K1: min / max of every raster.  A batch submitted directly behind another submission streams its rasters on the second
+    // stream beside the previous one's LK (instruction-bound kernels of short-lived waves leave HBM idle), as single units do
+    if (!c->aux_stream) {
+        KM_HIP(c, hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, 0));
+        KM_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        KM_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    if (dtype != KM_U8) {
+        double *out[KM_UNITS_MAX];
+        if (c->opt_mm_early && c->lk_start_prev) {
+            double *early = (double *)km_ws(c, WS_UNITS_MM, (size_t)4 * KM_UNITS_MAX * sizeof(double));
+            if (!early) return KM_E_NOMEM;
+            for (int u = 0; u < n; u++) { out[u] = early + 4 * u; U.mm[u] = out[u]; }
+            if (!c->ev_mm) KM_HIP(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
+            KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_lk_start, 0));
+            hipStream_t main_stream = c->stream;
+            c->stream = c->aux_stream;
+            {
+                km_stage_timer t(c, ST_MINMAX);
+                rc = kd_minmax_units(c, U, out, WS_MM_PARTIAL);
+            }
+            if (rc == KM_OK && hipEventRecord(c->ev_mm, c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(min/max)");
+            c->stream = main_stream;
+            if (rc) return rc;
+            KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_mm, 0));
+            c->stats.path_flags |= KM_PATH_MM_EARLY;
+        } else {
+            for (int u = 0; u < n; u++) out[u] = U.sc[u]->mm;
+            km_stage_timer t(c, ST_MINMAX);
+            if ((rc = kd_minmax_units(c, U, out, WS_PARTIAL))) return rc;
+        }
+    }
+    // ---- K2: stretch + Laplacians + automatic mask
+    km_valid_units vjob;
+    {
+        km_stage_timer t(c, ST_LAPLACIAN);
+        if ((rc = kd_stretch_laplacian_units(c, U, prm->ksize_ref, prm->ksize_mon, prm->invert_mon, nodata_ref, nodata_mon, &vjob))) return rc;
+    }
+    // ---- K3 + K4 fused; the valid-pixel sums and the pyramids (they depend on the Laplacians only) on the second stream beside it
+    {
+        km_stage_timer t(c, ST_EIGEN);
+        KM_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        KM_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        hipStream_t main_stream = c->stream;
+        c->stream = c->aux_stream;
+        rc = kd_valid_sum_units(c, vjob);
+        if (rc == KM_OK) {
+            km_stage_timer tp(c, ST_PYRAMID);
+            rc = kd_pyrdown_units(c, U, 1);
+        }
+        if (rc == KM_OK && hipEventRecord(c->ev_join, c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(join)");
+        c->stream = main_stream;
+        if (rc) return rc;
+        rc = k3_eig_candidates_units(c, U, prm->block_size, prm->quality_level);
+    }
+    if (rc) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); return rc; }
+    // ---- K5: ranking + greedy selection, every unit's chain side by side
+    {
+        km_stage_timer t(c, ST_SELECT);
+        rc = kf_rank_select_units(c, U, prm->max_corners, prm->quality_level, prm->min_distance, cap);
+    }
+    KM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (rc) return rc;
+    c->spec_used = true;
+    // ---- K7: LK forward + backward of every unit's corners in one launch (the next submission's early min / max starts here)
+    {
+        km_stage_timer t(c, ST_LK);
+        if (!c->ev_lk_start) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lk_start, hipEventDisableTiming));
+        KM_HIP(c, hipEventRecord(c->ev_lk_start, c->stream));
+        c->lk_start_valid = true;
+        if ((rc = kl_units_launch(c, n, n_max, prm->win_size))) return rc;
+    }
+    // ---- K8: FB test, score, (x0, y0) order; K9 / K12: scores of the confident rows
+    if ((rc = frame_block_free(c))) return rc;
+    {
+        km_stage_timer t(c, ST_FRAME);
+        if ((rc = kf_frame_units(c, U, n_max, cap, 0.1f))) return rc;
+    }
+    if (with_zncc) {
+        km_score_units S;
+        for (int u = 0; u < n; u++) {
+            km_score_unit &s = S.u[u];
+            const float *f = (const float *)(U.frame[u] + 16);
+            s.ref = U.ref_full[u]; s.mon = U.mon_full[u]; s.Href = s.Hmon = U.Hf[u]; s.Wref = s.Wmon = U.Wf[u]; s.sref = U.sref_f[u]; s.smon = U.smon_f[u];
+            s.x0 = f; s.y0 = f + cap; s.dx = f + 2 * (size_t)cap; s.dy = f + 3 * (size_t)cap; s.score = f + 4 * (size_t)cap;
+            s.d_n = (const int *)U.frame[u];
+            s.out = (double *)(U.frame[u] + fb); s.out2 = nullptr;
+            s.win = U.win[u];
+        }
+        {
+            km_stage_timer t(c, ST_ZNCC);
+            if ((rc = kz_zncc_units(c, S, n, dtype, n_max, (float)zncc_threshold))) return rc;
+        }
+        if (with_mi) {
+            for (int u = 0; u < n; u++) { S.u[u].out = (double *)(U.frame[u] + fb) + cap; S.u[u].out2 = S.u[u].out + cap; }
+            km_stage_timer t(c, ST_MI);
+            if ((rc = kmi_units(c, S, n, dtype, n_max, (float)zncc_threshold))) return rc;
+        }
+    }
+    // ---- the blocks leave: one strided device copy into the frame sink, one copy into the slot's page-locked buffer
+    const size_t pitch = c->frame_sink_pitch ? c->frame_sink_pitch : ob;
+    if (c->frame_sink && (pitch < ob || c->frame_sink_cap < pitch * (size_t)(n - 1) + ob))
+        return km_fail(c, KM_E_ARG, "frame sink of %zu bytes (pitch %zu) is smaller than %d frame blocks of %zu bytes", c->frame_sink_cap, pitch, n, ob);
+    if (slot->cap < ob * n) {
+        if (slot->host) KM_HIP(c, hipHostFree(slot->host));
+        slot->host = nullptr; slot->cap = 0;
+        KM_HIP(c, hipHostMalloc(&slot->host, ob * n + ob / 8, hipHostMallocDefault));
+        slot->cap = ob * n + ob / 8;
+    }
+    if (!slot->done) KM_HIP(c, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+    if (!c->d2h_stream) {
+        KM_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+        KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    }
+    KM_HIP(c, hipEventRecord(c->ev_tail, c->stream));
+    KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_tail, 0));
+    slot->sunk_valid = false;
+    if (c->frame_sink) {
+        KM_HIP(c, hipMemcpy2DAsync(c->frame_sink, pitch, d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToDevice, c->d2h_stream));
+        if (!slot->sunk) KM_HIP(c, hipEventCreateWithFlags(&slot->sunk, hipEventDisableTiming));
+        KM_HIP(c, hipEventRecord(slot->sunk, c->d2h_stream));
+        slot->sunk_valid = true;
+    }
+    KM_HIP(c, hipMemcpy2DAsync(slot->host, ob, d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToHost, c->d2h_stream));
+    KM_HIP(c, hipEventRecord(slot->done, c->d2h_stream));
+    c->frame_copy = slot->done;
+    slot->bytes = ob * n;
+    slot->pending.store(1, std::memory_order_release);
+    c->fslot_next = (k + 1) % KM_FRAME_SLOTS;
+    *ticket = k;
+    return KM_OK;
+}
+
+}  // extern "C"

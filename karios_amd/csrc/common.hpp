@@ -17,6 +17,7 @@
 // counter caps the whole kernel at the ~90 atomics/us one address sustains
 #define KM_NSHARD 16
 #define KM_TK_NB 2048   // bins of the top-K pre-filter histogram
+#define KM_UNITS_MAX 16 // work units one batched submission holds (km_klt_units_frame_submit)
 
 // OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
 __host__ __device__ __forceinline__ int km_reflect101(int p, int len)
@@ -94,6 +95,8 @@ enum km_slot {
     WS_F64_BLUEX,   //   ... and the tables of a Bluestein dimension
     WS_F64_BLUEY,
     WS_F64_MASK,    //   ... which columns / column tiles the inverse needs on the Hermitian half plane
+    WS_UNITS_LK,    // k_lk.hip: the per-unit argument table of a batched LK launch
+    WS_UNITS_MM,    // api_units.hip: early min / max results of a batch ({min_ref, max_ref, min_mon, max_mon} per unit)
     WS_COUNT
 };
 
@@ -183,6 +186,7 @@ struct km_ctx {
     bool band_fused = false;             //   ... emitted by the fused kernel (else: eig map in WS_EIG, candidates still to be scanned)
     void *frame_sink = nullptr;          // km_set_frame_sink: device-side copy of every frame block
     size_t frame_sink_cap = 0;
+    size_t frame_sink_pitch = 0;         // km_set_frame_sink_pitch: distance between the blocks of a batched submission (0: block size)
     km_buf ws[WS_COUNT];
     std::vector<void *> retired;         // workspace buffers replaced by larger ones (km_ws): freed at the next km_ctx_sync / destroy
     km_stage_ring ring;                  // host -> device staging (staging.hip)
@@ -388,6 +392,20 @@ static inline size_t km_any_dtype_size(int dtype)
     return dtype == KM_F64 ? 8 : (dtype == KM_I32 || dtype == KM_U32) ? 4 : km_dtype_size(dtype);
 }
 
+// per-unit arguments of the batched scoring kernels (k_zncc.hip, k_mi.hip): by value in the kernel arguments
+struct km_score_unit {
+    const void *ref, *mon;                // rasters the chips are cut from
+    const float *x0, *y0, *dx, *dy, *score;
+    const int *d_n;
+    double *out, *out2;                   // ZNCC: out; MI: out = mutual_info_score, out2 = mi_score
+    ptrdiff_t sref, smon;
+    int Href, Wref, Hmon, Wmon;
+    km_window win;
+};
+struct km_score_units {
+    km_score_unit u[KM_UNITS_MAX];
+};
+
 // ---- launchers implemented in the kernel translation units (all asynchronous) ----
 // k_dense.hip
 int kd_minmax(km_ctx *c, const void *d_img, int dtype, int H, int W, ptrdiff_t stride,
@@ -458,6 +476,56 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
              int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
              float *d_p0r, int *d_left_band = nullptr);
 int kl_oscillation_probe(km_ctx *c, const float *d_q, int n, uint8_t *d_out);   // test hook of the LK kernels' oscillation predicate
+// ---- batched units (km_klt_units_frame_submit, api_units.hip): U independent work units - tiles of one or several pairs, klt.py:220-253 -
+// through ONE set of launches: the dense kernels take the unit as part of their linear work-item space (items tall enough to amortise
+// their halo, one launch's worth of waves instead of U thin ones), the corner-selection chain runs its U latency chains side by side
+// (unit = blockIdx.z), LK / frame / ZNCC / MI take the unit as blockIdx.y.  The per-unit tables travel BY VALUE in the kernel
+// arguments (<= 4 KB), so nothing has to be uploaded or kept alive.
+struct km_units {
+    int n = 0;                                   // units of the batch (<= KM_UNITS_MAX)
+    int dtype = 0;
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX];
+    const void *ref[KM_UNITS_MAX], *mon[KM_UNITS_MAX];      // the unit's box in the two rasters
+    ptrdiff_t sref[KM_UNITS_MAX], smon[KM_UNITS_MAX];
+    float x_off[KM_UNITS_MAX], y_off[KM_UNITS_MAX];
+    // per-unit workspace (slices of the context's slots)
+    km_scalars *sc[KM_UNITS_MAX];
+    const double *mm[KM_UNITS_MAX];              // {min_ref, max_ref, min_mon, max_mon} the stretch reads (sc->mm, or the early slot)
+    uint8_t *lap_ref[KM_UNITS_MAX], *lap_mon[KM_UNITS_MAX], *mask[KM_UNITS_MAX];
+    unsigned long long *keys[KM_UNITS_MAX];      // candidate keys (KM_NSHARD regions of capk / KM_NSHARD slots)
+    size_t capk = 0;                             // ... the same capacity for every unit (sized for the largest)
+    const unsigned *eig_partial[KM_UNITS_MAX];   // per-wave maxima the fused eigenvalue pass leaves for the ranking's first launch
+    unsigned eig_npartial[KM_UNITS_MAX];
+    km_pyr A[KM_UNITS_MAX], B[KM_UNITS_MAX];     // pyramids (ref, mon Laplacians)
+    float *p0[KM_UNITS_MAX], *p1[KM_UNITS_MAX], *p0r[KM_UNITS_MAX];
+    char *frame[KM_UNITS_MAX];                   // frame block (header | 6 cap float32 | score columns)
+    // scoring (rasters the chips are cut from; window of km_set_image_window per unit)
+    const void *ref_full[KM_UNITS_MAX], *mon_full[KM_UNITS_MAX];
+    int Hf[KM_UNITS_MAX], Wf[KM_UNITS_MAX];
+    ptrdiff_t sref_f[KM_UNITS_MAX], smon_f[KM_UNITS_MAX];
+    km_window win[KM_UNITS_MAX];
+};
+
+// deferred per-unit sums of the valid-pixel counts of the batched Laplacian pass
+struct km_valid_units {
+    int n = 0;
+    const unsigned *partial[KM_UNITS_MAX];
+    unsigned n_partial[KM_UNITS_MAX];
+    unsigned long long *out[KM_UNITS_MAX];
+};
+// batched launchers (KM_E_UNSUPPORTED without a message: the batch form does not cover the case - the caller submits the units one by one)
+int kd_minmax_units(km_ctx *c, const km_units &U, double *const *d_out, int ws_slot);
+int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int ksize_mon, int invert_mon, const double *nodata_ref,
+                               const double *nodata_mon, km_valid_units *job);
+int kd_valid_sum_units(km_ctx *c, const km_valid_units &J);
+int k3_eig_candidates_units(km_ctx *c, km_units &U, int block, double quality);
+int kd_pyrdown_units(km_ctx *c, const km_units &U, int level);
+int kf_rank_select_units(km_ctx *c, const km_units &U, int max_corners, double quality, double min_distance, int cap);
+int kl_units_prepare(km_ctx *c, const km_units &U, int n_max, int win, int max_count, double epsilon);
+int kl_units_launch(km_ctx *c, int n_units, int n_max, int win);
+int kf_frame_units(km_ctx *c, const km_units &U, int n_max, int cap, float back_thr);
+int kz_zncc_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, int n, float score_thr);
+int kmi_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, int n, float score_thr);
 // k_frame.hip
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
              float x_off, float y_off, void *d_out, const km_scalars *d_sc_header = nullptr);   // d_sc_header: header words 2 / 3 = flags, candidate count

@@ -75,14 +75,12 @@ __device__ __forceinline__ unsigned stretch_u8(T v, double mn, double range, boo
 }
 
 // ------------------------------------------------------------------ K1 min/max
-// blockIdx.y selects the image (kd_minmax_pair: both rasters of a pair in one launch); partials of image y start at 2 * gridDim.x * y
+// One image (or one box of a larger raster: stride > W) reduced by the `nth` threads of a launch that share it: 16-byte vector loads
+// over the aligned body of every contiguous span - the whole image when its rows are dense, else row by row (a box of a larger
+// raster: the tiles of `KLT.match` on a resident pair; byte loads there cost 0.27 ms per 30-Mpx tile) - packed 16-bit min / max.
 template <typename T>
-__global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
-                                                             ptrdiff_t stride0, ptrdiff_t stride1, double *partial)
+__device__ __forceinline__ void minmax_image(const T *__restrict__ img, int H, int W, ptrdiff_t stride, unsigned blk, unsigned nblk, double *partial_out)
 {
-    const T *__restrict__ img = blockIdx.y ? img1 : img0;
-    const ptrdiff_t stride = blockIdx.y ? stride1 : stride0;
-    partial += (size_t)2 * gridDim.x * blockIdx.y;
     using A = typename px_traits<T>::acc;
     A mn, mx;
     if constexpr (px_traits<T>::code == KM_F32) { mn = INFINITY; mx = -INFINITY; }
@@ -91,57 +89,55 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict
         if constexpr (px_traits<T>::code == KM_F32) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
         else { mn = min(mn, (A)v); mx = max(mx, (A)v); }
     };
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nth = (size_t)gridDim.x * blockDim.x;
-    if (stride == W) {
-        // flat, 16-byte vector loads over the aligned body
-        const size_t n = (size_t)H * W;
-        constexpr int V = 16 / sizeof(T);
-        const uintptr_t base = (uintptr_t)img;
+    constexpr int V = 16 / sizeof(T);
+    // 16-bit pixels: packed minimum / maximum of the dwords as loaded (v_pk_min/max_u16|i16: 2 instructions per pixel pair
+    // where widening each pixel took 6), folded into mn / mx after the loop
+    typedef typename std::conditional<std::is_signed<T>::value, short, unsigned short>::type P16;
+    typedef P16 pk2 __attribute__((ext_vector_type(2)));
+    constexpr bool PACKED = sizeof(T) == 2 && px_traits<T>::code != KM_F32;
+    pk2 pmn, pmx;
+    pmn.x = pmn.y = std::is_signed<T>::value ? (P16)0x7fff : (P16)0xffff;
+    pmx.x = pmx.y = std::is_signed<T>::value ? (P16)0x8000 : (P16)0;
+    bool packed_used = false;
+    auto take = [&](const uint4 &q) {
+        if constexpr (PACKED) {
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                pk2 v;
+                __builtin_memcpy(&v, &w[k], 4);
+                pmn = __builtin_elementwise_min(pmn, v);
+                pmx = __builtin_elementwise_max(pmx, v);
+            }
+            packed_used = true;
+        } else {
+            T e[V];
+            __builtin_memcpy(e, &q, 16);
+#pragma unroll
+            for (int k = 0; k < V; k++) upd(e[k]);
+        }
+    };
+    // span of n contiguous pixels, shared by threads tid of nth
+    auto span = [&](const T *p, size_t n, size_t tid, size_t nth) {
+        const uintptr_t base = (uintptr_t)p;
         size_t head = ((16 - (base & 15)) & 15) / sizeof(T);
         if (head > n) head = n;
         const size_t nvec = (n - head) / V;
-        const uint4 *vp = (const uint4 *)(img + head);
-        // 16-bit pixels: packed minimum / maximum of the dwords as loaded (v_pk_min/max_u16|i16: 2 instructions per pixel pair
-        // where widening each pixel took 6), folded into mn / mx after the loop
-        typedef typename std::conditional<std::is_signed<T>::value, short, unsigned short>::type P16;
-        typedef P16 pk2 __attribute__((ext_vector_type(2)));
-        constexpr bool PACKED = sizeof(T) == 2 && px_traits<T>::code != KM_F32;
-        pk2 pmn, pmx;
-        pmn.x = pmn.y = std::is_signed<T>::value ? (P16)0x7fff : (P16)0xffff;
-        pmx.x = pmx.y = std::is_signed<T>::value ? (P16)0x8000 : (P16)0;
-        auto take = [&](const uint4 &q) {
-            if constexpr (PACKED) {
-                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    pk2 v;
-                    __builtin_memcpy(&v, &w[k], 4);
-                    pmn = __builtin_elementwise_min(pmn, v);
-                    pmx = __builtin_elementwise_max(pmx, v);
-                }
-            } else {
-                T e[V];
-                __builtin_memcpy(e, &q, 16);
-#pragma unroll
-                for (int k = 0; k < V; k++) upd(e[k]);
-            }
-        };
-        size_t i = tid;
-        for (; i < nvec; i += nth) take(vp[i]);
-        if constexpr (PACKED) {
-            if (nvec > 0) {      // (every lane's packed accumulators hold real pixels or their neutral start values)
-                mn = min(mn, min((A)pmn.x, (A)pmn.y));
-                mx = max(mx, max((A)pmx.x, (A)pmx.y));
-            }
-        }
-        if (tid < head) upd(img[tid]);
+        const uint4 *vp = (const uint4 *)(p + head);
+        for (size_t i = tid; i < nvec; i += nth) take(vp[i]);
+        if (tid < head) upd(p[tid]);
         const size_t tail0 = head + nvec * V;
-        if (tail0 + tid < n && tid < V) upd(img[tail0 + tid]);
+        if (tail0 + tid < n && tid < (size_t)V) upd(p[tail0 + tid]);
+    };
+    if (stride == W) {
+        span(img, (size_t)H * W, (size_t)blk * blockDim.x + threadIdx.x, (size_t)nblk * blockDim.x);
     } else {
-        for (int y = blockIdx.x; y < H; y += gridDim.x) {
-            const T *row = img + (size_t)y * stride;
-            for (int x = threadIdx.x; x < W; x += blockDim.x) upd(row[x]);
+        for (int y = (int)blk; y < H; y += (int)nblk) span(img + (size_t)y * stride, (size_t)W, threadIdx.x, blockDim.x);
+    }
+    if constexpr (PACKED) {
+        if (packed_used) {      // (the packed accumulators hold real pixels or their neutral start values)
+            mn = min(mn, min((A)pmn.x, (A)pmn.y));
+            mx = max(mx, max((A)pmx.x, (A)pmx.y));
         }
     }
     double dmn = wave_min((double)mn), dmx = wave_max((double)mx);
@@ -150,15 +146,37 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict
     if (lane == 0) { s[0][w] = dmn; s[1][w] = dmx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
-        partial[2 * blockIdx.x + 1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
+        partial_out[0] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
+        partial_out[1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
     }
 }
 
-__global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial, int nb, double *out)
+// blockIdx.y selects the image (kd_minmax_pair: both rasters of a pair in one launch); partials of image y start at 2 * gridDim.x * y
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                                             ptrdiff_t stride0, ptrdiff_t stride1, double *partial)
 {
-    partial += (size_t)2 * nb * blockIdx.x;     // (one block per image)
-    out += 2 * blockIdx.x;
+    minmax_image<T>(blockIdx.y ? img1 : img0, H, W, blockIdx.y ? stride1 : stride0, blockIdx.x, gridDim.x,
+                    partial + (size_t)2 * gridDim.x * blockIdx.y + 2 * blockIdx.x);
+}
+
+// batched units: blockIdx.z = unit, blockIdx.y = raster (0 ref, 1 mon)
+struct mm_units_args {
+    const void *img[2][KM_UNITS_MAX];
+    ptrdiff_t stride[2][KM_UNITS_MAX];
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX];
+    double *out[KM_UNITS_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_partial_units_kernel(mm_units_args U, double *partial)
+{
+    const unsigned u = blockIdx.z, im = blockIdx.y;
+    minmax_image<T>((const T *)U.img[im][u], U.H[u], U.W[u], U.stride[im][u], blockIdx.x, gridDim.x,
+                    partial + (size_t)2 * gridDim.x * (2 * u + im) + 2 * blockIdx.x);
+}
+
+__device__ __forceinline__ void minmax_final(const double *partial, int nb, double *out)
+{
     double mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         mn = fmin(mn, partial[2 * i]);
@@ -173,6 +191,14 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial
         out[0] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
         out[1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
     }
+}
+__global__ __launch_bounds__(256) void minmax_final_kernel(const double *partial, int nb, double *out)
+{
+    minmax_final(partial + (size_t)2 * nb * blockIdx.x, nb, out + 2 * blockIdx.x);     // (one block per image)
+}
+__global__ __launch_bounds__(256) void minmax_final_units_kernel(const double *partial, int nb, mm_units_args U)
+{
+    minmax_final(partial + (size_t)2 * nb * (2 * blockIdx.y + blockIdx.x), nb, U.out[blockIdx.y] + 2 * blockIdx.x);   // grid (2, units)
 }
 
 // min / max of one image (d_b == nullptr) or of the two rasters of a pair in one launch: d_mm[0..1] (and d_mm[2..3])
@@ -194,6 +220,31 @@ static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype,
     }
     KM_LAUNCH_CHECK(c);
     minmax_final_kernel<<<ni, 256, 0, c->stream>>>(partial, nb, d_mm);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// both rasters of every unit of a batch in ONE launch (+ one final launch): out[u] = {min_ref, max_ref, min_mon, max_mon}
+int kd_minmax_units(km_ctx *c, const km_units &U, double *const *d_out, int ws_slot)
+{
+    mm_units_args A;
+    for (int u = 0; u < U.n; u++) {
+        A.img[0][u] = U.ref[u]; A.img[1][u] = U.mon[u]; A.stride[0][u] = U.sref[u]; A.stride[1][u] = U.smon[u];
+        A.H[u] = U.H[u]; A.W[u] = U.W[u]; A.out[u] = d_out[u];
+    }
+    const int nb = U.n >= 8 ? 256 : U.n >= 4 ? 512 : 1024;          // workgroups per raster: ~4096 - 8192 in flight over the batch
+    double *partial = (double *)km_ws(c, ws_slot, (size_t)2 * nb * 2 * U.n * sizeof(double));
+    if (!partial) return KM_E_NOMEM;
+    const dim3 grid(nb, 2, U.n);
+    switch (U.dtype) {
+    case KM_U8: minmax_partial_units_kernel<uint8_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
+    case KM_U16: minmax_partial_units_kernel<uint16_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
+    case KM_I16: minmax_partial_units_kernel<int16_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
+    case KM_F32: minmax_partial_units_kernel<float><<<grid, 256, 0, c->stream>>>(A, partial); break;
+    default: return km_fail(c, KM_E_ARG, "minmax: bad dtype %d", U.dtype);
+    }
+    KM_LAUNCH_CHECK(c);
+    minmax_final_units_kernel<<<dim3(2, U.n), 256, 0, c->stream>>>(partial, nb, A);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
@@ -805,20 +856,16 @@ __device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
 // SPLIT: the two images of a work item go to two different wavefronts (wave parity) - half the register ring per wave
 // (76 instead of 123 VGPRs: 6 instead of 4 waves per SIMD); the image-0 wave also loads image 1's raw row for the mask.
 template <int R, typename T, bool MASK, bool SPLIT>
-__global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
-                                                        ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
-                                                        lap_coef cf, int invert1, nodata_t nd,
-                                                        uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
-                                                        uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips,
-                                                        int rows_per_item, int nitems)
+__device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                               ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
+                                               const lap_coef &cf, int invert1, const nodata_t &nd,
+                                               uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
+                                               uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips,
+                                               int rows_per_item, int nitems, int wave_lin /* wave-uniform: this wavefront's work item (x 2 with SPLIT) */)
 {
     typedef short short2v __attribute__((ext_vector_type(2)));
     constexpr int NR = 2 * R + 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    // work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
-    unsigned tile;
-    if (!km_xcd_tile((unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u, tile)) return;
-    const int wave_lin = (int)tile * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);   // readfirstlane: the compiler must know it is wave-uniform
     const int wave_id = SPLIT ? wave_lin >> 1 : wave_lin;           // work item (row arithmetic, loop control and row bases stay scalar)
     const int img_sel = SPLIT ? __builtin_amdgcn_readfirstlane(wave_lin & 1) : -1;
     if (wave_id >= nitems) { if (!SPLIT && MASK && lane == 0) valid_partial[wave_id] = 0u; return; }
@@ -1052,6 +1099,48 @@ __global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__r
     }
 }
 
+// work item = (row block, column strip), strips fastest: the 4 waves of a workgroup take 4 consecutive items
+template <int R, typename T, bool MASK, bool SPLIT>
+__global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_kernel(const T *__restrict__ img0, const T *__restrict__ img1, int H, int W,
+                                                        ptrdiff_t stride0, ptrdiff_t stride1, const double *__restrict__ mm,
+                                                        lap_coef cf, int invert1, nodata_t nd,
+                                                        uint8_t *__restrict__ out0, uint8_t *__restrict__ out1,
+                                                        uint8_t *__restrict__ mask_out, unsigned *__restrict__ valid_partial, int nstrips,
+                                                        int rows_per_item, int nitems)
+{
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)((SPLIT ? 2 : 1) * nitems + 3) / 4u, tile)) return;
+    const int wave_lin = (int)tile * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // readfirstlane: the compiler must know it is wave-uniform
+    lap_march_item<R, T, MASK, SPLIT>(img0, img1, H, W, stride0, stride1, mm, cf, invert1, nd, out0, out1, mask_out, valid_partial, nstrips, rows_per_item,
+                                      nitems, wave_lin);
+}
+
+// batched units: the units' work items form ONE linear item space (unit u owns [item0[u], item0[u + 1])): a wavefront finds its unit
+// with a scalar scan of <= 16 bounds and then runs exactly the item of the single-unit kernel on that unit's rasters
+struct lapm_units_args {
+    const void *img0[KM_UNITS_MAX], *img1[KM_UNITS_MAX];
+    ptrdiff_t s0[KM_UNITS_MAX], s1[KM_UNITS_MAX];
+    const double *mm[KM_UNITS_MAX];
+    uint8_t *out0[KM_UNITS_MAX], *out1[KM_UNITS_MAX], *mask[KM_UNITS_MAX];
+    unsigned *valid[KM_UNITS_MAX];
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX], nstrips[KM_UNITS_MAX];
+    int item0[KM_UNITS_MAX + 1];
+    int n, rows;
+};
+template <int R, typename T, bool MASK>
+__global__ __launch_bounds__(256) KM_LAPM_OCC void lap_march_units_kernel(lapm_units_args U, lap_coef cf, int invert1, nodata_t nd)
+{
+    const int total = U.item0[U.n];
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(total + 3) / 4u, tile)) return;
+    const int wave_lin = (int)tile * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave_lin >= total) return;
+    int u = 0;
+    while (u + 1 < U.n && wave_lin >= U.item0[u + 1]) u++;
+    lap_march_item<R, T, MASK, false>((const T *)U.img0[u], (const T *)U.img1[u], U.H[u], U.W[u], U.s0[u], U.s1[u], U.mm[u], cf, invert1, nd, U.out0[u], U.out1[u],
+                                      U.mask[u], U.valid[u], U.nstrips[u], U.rows, U.item0[u + 1] - U.item0[u], wave_lin - U.item0[u]);
+}
+
 template <typename T, bool MASK>
 static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int W, ptrdiff_t sa, ptrdiff_t sb, const double *mm,
                             const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob,
@@ -1110,6 +1199,106 @@ int kd_run_valid_sum(km_ctx *c)
 }
 
 static int lap_radius(int ksize) { return ksize == 1 ? 1 : ksize / 2; }
+
+// ---- batched units: stretch + Laplacians + automatic mask of every unit in ONE launch; the per-item counts of valid pixels are summed
+// per unit by kd_valid_sum_units (one workgroup per unit, on whatever stream c->stream is: the caller puts it beside the pyramids)
+__global__ __launch_bounds__(1024) void valid_sum_units_kernel(km_valid_units J)
+{
+    const unsigned *partial = J.partial[blockIdx.x];
+    const unsigned n = J.n_partial[blockIdx.x];
+    unsigned long long s = 0;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) s += partial[i];
+    s = wave_sum_u64(s);
+    __shared__ unsigned long long sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; i++) t += sh[i];
+        *J.out[blockIdx.x] = t;
+    }
+}
+
+int kd_valid_sum_units(km_ctx *c, const km_valid_units &J)
+{
+    if (J.n <= 0) return KM_OK;
+    valid_sum_units_kernel<<<J.n, 1024, 0, c->stream>>>(J);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+template <typename T>
+static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap_coef &cf, int invert1, const nodata_t &nd, km_valid_units *job)
+{
+    lapm_units_args A;
+    A.n = U.n;
+    for (int u = 0; u < U.n; u++) {
+        A.img0[u] = U.ref[u]; A.img1[u] = U.mon[u]; A.s0[u] = U.sref[u]; A.s1[u] = U.smon[u]; A.mm[u] = U.mm[u];
+        A.out0[u] = U.lap_ref[u]; A.out1[u] = U.lap_mon[u]; A.mask[u] = U.mask[u];
+        A.H[u] = U.H[u]; A.W[u] = U.W[u]; A.nstrips[u] = (U.W[u] + LAPM_VALID - 1) / LAPM_VALID;
+    }
+    int wg_per_cu = 0;
+    const void *fn = R == 1 ? (const void *)lap_march_units_kernel<1, T, true> : R == 2 ? (const void *)lap_march_units_kernel<2, T, true>
+                                                                                       : (const void *)lap_march_units_kernel<3, T, true>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, fn, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 4;
+    const long slots = (long)c->n_cu * 4 * wg_per_cu;
+    // rows per item: the value in [32, 160] that minimises whole rounds of resident waves x the work of one item, over ALL units' strips
+    int rows = 32;
+    {
+        double best = 1e300;
+        for (int r = 32; r <= 160; r++) {
+            long items = 0;
+            for (int u = 0; u < U.n; u++) items += (long)A.nstrips[u] * ((U.H[u] + r - 1) / r);
+            const long rounds = (items + slots - 1) / slots;
+            const double last = (double)(items - (rounds - 1) * slots) / (double)slots;
+            const double cost = ((double)(rounds - 1) + 0.5 + 0.5 * last) * (double)(r + 2 * R);
+            if (cost < best) { best = cost; rows = r; }
+        }
+    }
+    A.rows = rows;
+    A.item0[0] = 0;
+    for (int u = 0; u < U.n; u++) A.item0[u + 1] = A.item0[u] + A.nstrips[u] * ((U.H[u] + rows - 1) / rows);
+    const int total = A.item0[U.n];
+    unsigned *valid = (unsigned *)km_ws(c, WS_LAP_VALID, ((size_t)total + 4 * KM_UNITS_MAX) * sizeof(unsigned));
+    if (!valid) return KM_E_NOMEM;
+    job->n = U.n;
+    for (int u = 0; u < U.n; u++) {
+        A.valid[u] = valid + A.item0[u];
+        job->partial[u] = A.valid[u]; job->n_partial[u] = (unsigned)(A.item0[u + 1] - A.item0[u]); job->out[u] = &U.sc[u]->valid;
+    }
+    const dim3 grid(km_xcd_grid((unsigned)(total + 3) / 4u));
+    switch (R) {
+    case 1: lap_march_units_kernel<1, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+    case 2: lap_march_units_kernel<2, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+    case 3: lap_march_units_kernel<3, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+    default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+// KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (kernel sizes 9 / 11, tiny units): the caller submits the
+// units one by one instead
+int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int ksize_mon, int invert_mon, const double *nodata_ref,
+                               const double *nodata_mon, km_valid_units *job)
+{
+    lap_coef cf;
+    const int R = lap_radius(ksize_ref) > lap_radius(ksize_mon) ? lap_radius(ksize_ref) : lap_radius(ksize_mon);
+    auto okk = [](int k) { return k >= 1 && k <= 11 && (k & 1); };
+    if (!okk(ksize_ref) || !okk(ksize_mon) || !fill_coef(ksize_ref, R, cf.kd[0], cf.ks[0]) || !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
+        return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
+    if (R > 3) return KM_E_UNSUPPORTED;
+    for (int u = 0; u < U.n; u++)
+        if (U.W[u] < 8 || U.H[u] < 8) return KM_E_UNSUPPORTED;
+    const nodata_t nd = make_nodata(nodata_mon, nodata_ref);
+    switch (U.dtype) {
+    case KM_U8: return launch_lap_march_units<uint8_t>(c, R, U, cf, invert_mon, nd, job);
+    case KM_U16: return launch_lap_march_units<uint16_t>(c, R, U, cf, invert_mon, nd, job);
+    case KM_I16: return launch_lap_march_units<int16_t>(c, R, U, cf, invert_mon, nd, job);
+    case KM_F32: return launch_lap_march_units<float>(c, R, U, cf, invert_mon, nd, job);
+    default: return km_fail(c, KM_E_ARG, "stretch_laplacian: bad dtype %d", U.dtype);
+    }
+}
 
 int kd_laplacian_u8(km_ctx *c, const uint8_t *d_src, int H, int W, int ksize, uint8_t *d_dst)
 {
@@ -1694,13 +1883,12 @@ __device__ __forceinline__ void pyr_hsum(const uint32_t (&w)[4], int (&h)[4])
     h[3] = (int)__builtin_amdgcn_udot4(w[2], coef, w[3] & 0xffu, false);          // bytes 8..11 + byte 12
 }
 
-__global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
+__device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H, int W, int dh, int dw, int nquads)
 {
-    const uint8_t *__restrict__ src = pp.src[blockIdx.z];
-    uint8_t *__restrict__ dst = pp.dst[blockIdx.z];
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nquads) return;
     const int y0 = blockIdx.y * PYR_RS, y1 = min(dh, y0 + PYR_RS);
+    if (y0 >= dh) return;
     const int sx0 = 8 * q - 4;                                  // first source byte loaded
     const bool fast = (W % 4 == 0) && ((uintptr_t)src % 4 == 0) && sx0 >= 0 && sx0 + 16 <= W;
     auto load_row = [&](int sy, uint32_t (&w)[4]) {
@@ -1745,6 +1933,45 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W,
 #pragma unroll
         for (int j = 0; j < 4; j++) { h0[j] = h2[j]; h1[j] = h3[j]; h2[j] = h4[j]; }
     }
+}
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
+{
+    pyrdown_item(pp.src[blockIdx.z], pp.dst[blockIdx.z], H, W, dh, dw, nquads);
+}
+
+// batched units: blockIdx.z = 2 * unit + image; the grid covers the largest unit, the others leave their surplus workgroups at once
+struct pyr_units_args {
+    const uint8_t *src[2 * KM_UNITS_MAX];
+    uint8_t *dst[2 * KM_UNITS_MAX];
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX];
+};
+__global__ __launch_bounds__(256) void pyrdown_units_kernel(pyr_units_args P)
+{
+    const int u = blockIdx.z >> 1, H = P.H[u], W = P.W[u], dh = (H + 1) / 2, dw = (W + 1) / 2;
+    pyrdown_item(P.src[blockIdx.z], P.dst[blockIdx.z], H, W, dh, dw, (dw + 3) / 4);
+}
+
+// level l of both pyramids of every unit from level l - 1 (units whose pyramid ends below l are skipped by the caller: H = 0)
+int kd_pyrdown_units(km_ctx *c, const km_units &U, int level)
+{
+    pyr_units_args P;
+    int max_dh = 0, max_q = 0, n = 0;
+    for (int u = 0; u < U.n; u++) {
+        if (U.A[u].levels < level) continue;
+        P.src[2 * n] = U.A[u].img[level - 1]; P.src[2 * n + 1] = U.B[u].img[level - 1];
+        P.dst[2 * n] = (uint8_t *)U.A[u].img[level]; P.dst[2 * n + 1] = (uint8_t *)U.B[u].img[level];
+        P.H[n] = U.A[u].H[level - 1]; P.W[n] = U.A[u].W[level - 1];
+        const int dh = (P.H[n] + 1) / 2, dw = (P.W[n] + 1) / 2;
+        max_dh = dh > max_dh ? dh : max_dh;
+        max_q = (dw + 3) / 4 > max_q ? (dw + 3) / 4 : max_q;
+        n++;
+    }
+    if (n == 0) return KM_OK;
+    const dim3 grid((max_q + 255) / 256, (max_dh + PYR_RS - 1) / PYR_RS, 2 * n);
+    pyrdown_units_kernel<<<grid, 256, 0, c->stream>>>(P);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
 }
 
 static int launch_pyrdown(km_ctx *c, const pyr_pair &pp, int nimg, int H, int W)

@@ -456,6 +456,96 @@ __global__ __launch_bounds__(256, 3) void eig3_kernel(const uint8_t *__restrict_
     eig3_item<BLOCK>(src, mask, H, W, scale2, max_partial, quality, sc, keys, cap, stage_cap3, wave_id, xs, col_lo, col_hi, ye0, ye1, stage[wv]);
 }
 
+// batched units: one linear item space over the units (unit u owns [item0[u], item0[u + 1]): its border items first, then its strips,
+// exactly the items of the single-unit launch); shards, running-threshold words and per-wave maxima are the unit's own
+struct e3_units_args {
+    const uint8_t *src[KM_UNITS_MAX], *mask[KM_UNITS_MAX];
+    unsigned *max_partial[KM_UNITS_MAX];
+    km_scalars *sc[KM_UNITS_MAX];
+    unsigned long long *keys[KM_UNITS_MAX];
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX], n_border[KM_UNITS_MAX], nstrips[KM_UNITS_MAX];
+    int item0[KM_UNITS_MAX + 1];
+    int n, rows2, rows3;
+};
+template <int BLOCK>
+__global__ __launch_bounds__(256, 3) void eig3_units_kernel(e3_units_args U, double scale2, double quality, size_t cap, unsigned stage_cap2, unsigned stage_cap3)
+{
+    __shared__ int xs_scratch[4][3][128];
+    __shared__ unsigned long long stage[4][EIG3_STAGE + 64];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = U.item0[U.n];
+    unsigned tile;
+    if (!km_xcd_tile((unsigned)(total + 3) / 4u, tile)) return;
+    const int wave_lin = (int)tile * 4 + wv;
+    if (wave_lin >= total) return;
+    int u = 0;
+    while (u + 1 < U.n && wave_lin >= U.item0[u + 1]) u++;
+    const int wave_id = wave_lin - U.item0[u];
+    const uint8_t *src = U.src[u], *mask = U.mask[u];
+    const int H = U.H[u], W = U.W[u], n_border = U.n_border[u], nstrips = U.nstrips[u];
+    unsigned *max_partial = U.max_partial[u];
+    km_scalars *sc = U.sc[u];
+    unsigned long long *keys = U.keys[u];
+    if (wave_id < n_border) {
+        const int rowblock = wave_id >> 1;
+        const bool right = wave_id & 1;
+        constexpr int ML2 = eig2_geom<BLOCK, true>::ML;
+        eig2_item<BLOCK, true>(src, mask, H, W, scale2, nullptr, max_partial, U.rows2, quality, sc, keys, cap, stage_cap2, wave_id, rowblock,
+                               right ? W - EIG3_MARGIN - ML2 : -ML2, right ? W - EIG3_MARGIN : 0, right ? W : EIG3_MARGIN, &xs_scratch[wv][0][0], stage[wv]);
+        return;
+    }
+    const int j = wave_id - n_border;
+    const int rowblock = j / nstrips, strip = j - rowblock * nstrips;
+    const int xs = min(strip * EIG3_STRIDE, W - 512);
+    const int col_lo = EIG3_MARGIN + strip * EIG3_STRIDE, col_hi = min(col_lo + EIG3_STRIDE, W - EIG3_MARGIN);
+    const int ye0 = rowblock * U.rows3, ye1 = min(H - 1, ye0 + U.rows3 + 1);
+    eig3_item<BLOCK>(src, mask, H, W, scale2, max_partial, quality, sc, keys, cap, stage_cap3, wave_id, xs, col_lo, col_hi, ye0, ye1, stage[wv]);
+}
+
+template <int BLOCK>
+int launch_eig3_units(km_ctx *c, km_units &U, double scale2, double quality)
+{
+    e3_units_args A;
+    A.n = U.n; A.rows2 = 64;
+    long border_total = 0;
+    for (int u = 0; u < U.n; u++) {
+        A.src[u] = U.lap_ref[u]; A.mask[u] = U.mask[u]; A.sc[u] = U.sc[u]; A.keys[u] = U.keys[u];
+        A.H[u] = U.H[u]; A.W[u] = U.W[u];
+        A.nstrips[u] = (U.W[u] - 2 * EIG3_MARGIN + EIG3_STRIDE - 1) / EIG3_STRIDE;
+        A.n_border[u] = 2 * ((U.H[u] - 2 + A.rows2 - 1) / A.rows2);
+        border_total += A.n_border[u];
+    }
+    // rows per strip item: whole rounds of 3 resident waves per SIMD x the work of one item (5 warm-up rows' worth), over ALL units
+    const long slots = 1024L * 3 - (border_total < 1024 ? border_total : 1024);
+    int rows3 = 32;
+    {
+        double best = 1e300;
+        for (int r = 32; r <= 192; r++) {
+            long items = 0;
+            for (int u = 0; u < U.n; u++) items += (long)A.nstrips[u] * ((U.H[u] - 2 + r - 1) / r);
+            const long rounds = (items + slots - 1) / slots;
+            const double last = (double)(items - (rounds - 1) * slots) / (double)slots;
+            const double cost = ((double)(rounds - 1) + 0.5 + 0.5 * last) * (double)(r + 5);
+            if (cost < best) { best = cost; rows3 = r; }
+        }
+    }
+    A.rows3 = rows3;
+    A.item0[0] = 0;
+    for (int u = 0; u < U.n; u++) A.item0[u + 1] = A.item0[u] + A.n_border[u] + A.nstrips[u] * ((U.H[u] - 2 + rows3 - 1) / rows3);
+    const int total = A.item0[U.n];
+    unsigned *partial = (unsigned *)km_ws(c, WS_PARTIAL, ((size_t)total + 16) * sizeof(unsigned));
+    if (!partial) return KM_E_NOMEM;
+    for (int u = 0; u < U.n; u++) {
+        A.max_partial[u] = partial + A.item0[u];
+        U.eig_partial[u] = A.max_partial[u]; U.eig_npartial[u] = (unsigned)(A.item0[u + 1] - A.item0[u]);
+    }
+    const unsigned cap2 = c->opt_stage_cap > 0 && c->opt_stage_cap < EIG2_STAGE ? (unsigned)c->opt_stage_cap : (unsigned)EIG2_STAGE;
+    const unsigned cap3 = c->opt_stage_cap > 0 && c->opt_stage_cap < EIG3_STAGE ? (unsigned)c->opt_stage_cap : (unsigned)EIG3_STAGE;
+    eig3_units_kernel<BLOCK><<<km_xcd_grid((unsigned)(total + 3) / 4u), 256, 0, c->stream>>>(A, scale2, quality, U.capk, cap2, cap3);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
 __global__ __launch_bounds__(1024) void eig3_max_kernel(const unsigned *__restrict__ partial, unsigned n, unsigned *out)
 {
     unsigned m = 0;
@@ -503,6 +593,22 @@ int launch_eig3(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
 }
 
 }  // namespace
+
+// Batched units (api_units.hip): the fused pass of every unit in ONE launch; the per-wave maxima stay in U.eig_partial[u] for the
+// ranking's first launch.  KM_E_UNSUPPORTED (no message): a unit the 8-px kernel does not cover.
+int k3_eig_candidates_units(km_ctx *c, km_units &U, int block, double quality)
+{
+    if (block < 1 || block > 15 || (block & 1) == 0 || !c->opt_eig3) return KM_E_UNSUPPORTED;
+    for (int u = 0; u < U.n; u++)
+        if (U.W[u] < 512 || U.H[u] < 2 * block + 8) return KM_E_UNSUPPORTED;
+    const double scale = 1.0 / (4.0 * (double)block * 255.0), s2 = scale * scale;
+    switch (block) {
+#define KM_EIG3_CASE(B) case B: return launch_eig3_units<B>(c, U, s2, quality);
+        KM_EIG3_CASE(1) KM_EIG3_CASE(3) KM_EIG3_CASE(5) KM_EIG3_CASE(7) KM_EIG3_CASE(9) KM_EIG3_CASE(11) KM_EIG3_CASE(13) KM_EIG3_CASE(15)
+#undef KM_EIG3_CASE
+    default: return KM_E_UNSUPPORTED;
+    }
+}
 
 // Fused minimum-eigenvalue + candidate pass, 8 pixels per lane.  Same contract as k2_eig_candidates (k_eig2.hip), which
 // forwards here; KM_E_UNSUPPORTED (no message) when the case is not covered (narrow images, even block sizes).

@@ -18,15 +18,34 @@
 
 #define FB_T 1024
 
+// What differs between the units of a batch (blockIdx.y = unit; km_klt_units_frame_submit); the single-unit entry point passes one
+struct fb_unit {
+    const float *p0, *p1, *p0r;
+    const int *d_n;
+    unsigned long long *keys;
+    unsigned *ranks, *counts;
+    float *tmp /* 5*cap */, *out /* 6*cap */;
+    int *hdr;
+    const km_scalars *sc_hdr;
+    float x_off, y_off;
+};
+struct fb_units_args {
+    fb_unit u[KM_UNITS_MAX];
+};
+
 // stable compaction of the kept points (rank = position in p0 order): pass 1 counts per workgroup, pass 2 writes
 template <bool WRITE>
-__global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
-                                                          const float *__restrict__ p0r, const int *__restrict__ d_n, int n_max,
-                                                          float back_thr, float x_off, float y_off, unsigned long long *__restrict__ keys,
-                                                          unsigned *__restrict__ ranks, float *__restrict__ tmp /* 5*cap */, int cap,
-                                                          int *__restrict__ hdr, unsigned *__restrict__ counts, int n_sort,
-                                                          const km_scalars *__restrict__ sc_hdr)
+__global__ __launch_bounds__(FB_T) void fb_compact_kernel(fb_units_args A, int n_max, float back_thr, int cap, int n_sort)
 {
+    const fb_unit &U = A.u[blockIdx.y];
+    const float *__restrict__ p0 = U.p0, *__restrict__ p1 = U.p1, *__restrict__ p0r = U.p0r;
+    const int *__restrict__ d_n = U.d_n;
+    const float x_off = U.x_off, y_off = U.y_off;
+    unsigned long long *__restrict__ keys = U.keys;
+    unsigned *__restrict__ ranks = U.ranks, *__restrict__ counts = U.counts;
+    float *__restrict__ tmp = U.tmp;
+    int *__restrict__ hdr = U.hdr;
+    const km_scalars *__restrict__ sc_hdr = U.sc_hdr;
     __shared__ int s_wave[FB_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(d_n ? *d_n : n_max, n_max);
@@ -71,9 +90,12 @@ __global__ __launch_bounds__(FB_T) void fb_compact_kernel(const float *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void fb_gather_kernel(const unsigned *__restrict__ order, const float *__restrict__ tmp, int cap,
-                                                        const int *__restrict__ hdr, float *__restrict__ out /* 6*cap */)
+__global__ __launch_bounds__(256) void fb_gather_kernel(fb_units_args A, const unsigned *__restrict__ order, int cap)
 {
+    const fb_unit &U = A.u[blockIdx.y];
+    const float *__restrict__ tmp = U.tmp;
+    const int *__restrict__ hdr = U.hdr;
+    float *__restrict__ out = U.out;
     const int m = hdr[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const unsigned r = order[i];
@@ -91,9 +113,13 @@ __global__ __launch_bounds__(256) void fb_gather_kernel(const unsigned *__restri
 // distance, so a bucket holds a handful of rows.  One launch, no global synchronisation.
 #define FBP_T 1024
 template <int RPT>
-__global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long long *__restrict__ keys, const float *__restrict__ tmp, int cap,
-                                                         const int *__restrict__ hdr, float *__restrict__ out /* 6*cap */, int shift, int nbins)
+__global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int cap, int shift, int nbins)
 {
+    const fb_unit &U = A.u[blockIdx.y];
+    const unsigned long long *__restrict__ keys = U.keys;
+    const float *__restrict__ tmp = U.tmp;
+    const int *__restrict__ hdr = U.hdr;
+    float *__restrict__ out = U.out;
     extern __shared__ unsigned fbp_smem[];
     unsigned *cnt = fbp_smem, *start = fbp_smem + nbins;          // start: nbins + 1 entries
     unsigned short *items = (unsigned short *)(start + nbins + 1);
@@ -154,32 +180,43 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(const unsigned long lon
     }
 }
 
-// d_out: [header 4 ints: n_rows, n_init, 0, 0][6 * cap floats: x0 | y0 | dx | dy | score | index bits]
-int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
-             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header)
+// d_out: [header 4 ints: n_rows, n_init, flags, candidates][6 * cap floats: x0 | y0 | dx | dy | score | index bits]
+// n units at once (n = 1: kf_frame): scratch = unit k's slices of WS_MISC0 / WS_MISC1 / WS_MISC2 / WS_FRAME_CNT
+static int frame_launch(km_ctx *c, int n, const float *const *d_p0, const float *const *d_p1, const float *const *d_p0r, const int *const *d_n, int n_max,
+                        int cap, float back_thr, const float *x_off, const float *y_off, void *const *d_out, const km_scalars *const *d_sc_header)
 {
     if (cap <= 0 || n_max <= 0) return km_fail(c, KM_E_ARG, "frame: empty capacity");
     // the tile origin is added to the corner coordinates and the sum becomes the (x0, y0) ordering key: a pair of non-negative
     // integers.  The reference's origins are tile offsets (klt.py:341-342); anything else is refused instead of mis-ordered.
-    if (!(x_off >= 0.f && x_off <= 1073741824.f && y_off >= 0.f && y_off <= 1073741824.f))
-        return km_fail(c, KM_E_ARG, "frame: tile origin (%g, %g) must be finite and within [0, 2^30]", (double)x_off, (double)y_off);
-    int *hdr = (int *)d_out;
-    float *out = (float *)((char *)d_out + 16);
-    unsigned long long *keys = (unsigned long long *)km_ws(c, WS_MISC0, (size_t)cap * 2 * sizeof(unsigned long long));
-    unsigned *ranks = (unsigned *)km_ws(c, WS_MISC1, (size_t)cap * 2 * sizeof(unsigned));
-    float *tmp = (float *)km_ws(c, WS_MISC2, (size_t)cap * 5 * sizeof(float));
-    if (!keys || !ranks || !tmp) return KM_E_NOMEM;
+    float x_hi = 0.f;
+    for (int k = 0; k < n; k++) {
+        if (!(x_off[k] >= 0.f && x_off[k] <= 1073741824.f && y_off[k] >= 0.f && y_off[k] <= 1073741824.f))
+            return km_fail(c, KM_E_ARG, "frame: tile origin (%g, %g) must be finite and within [0, 2^30]", (double)x_off[k], (double)y_off[k]);
+        x_hi = fmaxf(x_hi, x_off[k]);
+    }
     const int nblk = (n_max + FB_T - 1) / FB_T;
     const unsigned n_sort = (unsigned)(n_max < cap ? n_max : cap);   // fixed sort length: sentinel keys behind the kept rows
-    unsigned *counts = (unsigned *)km_ws(c, WS_FRAME_CNT, (size_t)nblk * sizeof(unsigned));
-    if (!counts) return KM_E_NOMEM;
-    fb_compact_kernel<false><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort, d_sc_header);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t kb = up((size_t)cap * 2 * sizeof(unsigned long long)), rb = up((size_t)cap * 2 * sizeof(unsigned)), tb = up((size_t)cap * 5 * sizeof(float)),
+                 cb = up((size_t)nblk * sizeof(unsigned));
+    char *keys = (char *)km_ws(c, WS_MISC0, kb * n), *ranks = (char *)km_ws(c, WS_MISC1, rb * n), *tmp = (char *)km_ws(c, WS_MISC2, tb * n);
+    char *counts = (char *)km_ws(c, WS_FRAME_CNT, cb * n);
+    if (!keys || !ranks || !tmp || !counts) return KM_E_NOMEM;
+    fb_units_args A;
+    for (int k = 0; k < n; k++) {
+        fb_unit &u = A.u[k];
+        u.p0 = d_p0[k]; u.p1 = d_p1[k]; u.p0r = d_p0r[k]; u.d_n = d_n[k]; u.x_off = x_off[k]; u.y_off = y_off[k];
+        u.keys = (unsigned long long *)(keys + kb * k); u.ranks = (unsigned *)(ranks + rb * k); u.tmp = (float *)(tmp + tb * k);
+        u.counts = (unsigned *)(counts + cb * k);
+        u.hdr = (int *)d_out[k]; u.out = (float *)((char *)d_out[k] + 16); u.sc_hdr = d_sc_header ? d_sc_header[k] : nullptr;
+    }
+    fb_compact_kernel<false><<<dim3(nblk, n), FB_T, 0, c->stream>>>(A, n_max, back_thr, cap, (int)n_sort);
     KM_LAUNCH_CHECK(c);
-    fb_compact_kernel<true><<<nblk, FB_T, 0, c->stream>>>(d_p0, d_p1, d_p0r, d_n, n_max, back_thr, x_off, y_off, keys, ranks, tmp, cap, hdr, counts, (int)n_sort, d_sc_header);
+    fb_compact_kernel<true><<<dim3(nblk, n), FB_T, 0, c->stream>>>(A, n_max, back_thr, cap, (int)n_sort);
     KM_LAUNCH_CHECK(c);
     if (n_sort <= 32768u) {
         // up to a few 10^4 rows (maxCorners of a tile): one workgroup, buckets of x0 in LDS (<= 64 KB of buckets + 2 B per row)
-        const unsigned x_max = (unsigned)fmaxf(x_off, 0.f) + 70000u;          // x0 = corner column + tile offset, columns < 65536
+        const unsigned x_max = (unsigned)x_hi + 70000u;          // x0 = corner column + tile offset, columns < 65536
         int shift = 0;
         while (((x_max >> shift) + 1u) > 8192u) shift++;
         const int nbins = (int)(x_max >> shift) + 1;
@@ -192,7 +229,7 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
                 KM_HIP(c, hipFuncSetAttribute((const void *)fb_place_kernel<RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
                 opted |= 1ull << (c->device & 63);
             }
-            fb_place_kernel<RPT><<<32, FBP_T, smem, c->stream>>>(keys, tmp, cap, hdr, out, shift, nbins);
+            fb_place_kernel<RPT><<<dim3(32, n), FBP_T, smem, c->stream>>>(A, cap, shift, nbins);   // (32 x 1024 threads: one row per thread)
             return KM_OK;
         };
         int rl;
@@ -205,10 +242,28 @@ int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r
         return KM_OK;
     }
     // maxCorners = 0 on a large tile: hundreds of thousands of rows - radix sort of (key, rank) pairs (k_sort.hip) + gather
-    { const int rs = km_sort_u64(c, keys, keys + cap, ranks, ranks + cap, n_sort, false); if (rs) return rs; }
-    fb_gather_kernel<<<32, 256, 0, c->stream>>>(ranks, tmp, cap, hdr, out);
+    if (n != 1) return km_fail(c, KM_E_UNSUPPORTED, "frame: batched units hold at most 32768 rows each");
+    { const int rs = km_sort_u64(c, A.u[0].keys, A.u[0].keys + cap, A.u[0].ranks, A.u[0].ranks + cap, n_sort, false); if (rs) return rs; }
+    fb_gather_kernel<<<32, 256, 0, c->stream>>>(A, A.u[0].ranks, cap);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
+}
+
+int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
+             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header)
+{
+    return frame_launch(c, 1, &d_p0, &d_p1, &d_p0r, &d_n, n_max, cap, back_thr, &x_off, &y_off, &d_out, d_sc_header ? &d_sc_header : nullptr);
+}
+
+// FB test + frame of every unit of a batch: three launches for all of them
+int kf_frame_units(km_ctx *c, const km_units &U, int n_max, int cap, float back_thr)
+{
+    const float *p0[KM_UNITS_MAX], *p1[KM_UNITS_MAX], *p0r[KM_UNITS_MAX];
+    const int *dn[KM_UNITS_MAX];
+    void *out[KM_UNITS_MAX];
+    const km_scalars *sc[KM_UNITS_MAX];
+    for (int k = 0; k < U.n; k++) { p0[k] = U.p0[k]; p1[k] = U.p1[k]; p0r[k] = U.p0r[k]; dn[k] = &U.sc[k]->n_corners; out[k] = U.frame[k]; sc[k] = U.sc[k]; }
+    return frame_launch(c, U.n, p0, p1, p0r, dn, n_max, cap, back_thr, U.x_off, U.y_off, out, sc);
 }
 
 // ---- K13: DN-value filter of KariosAPI._filter_by_dn_values (reference karios/api/core.py:650-737): a key point is

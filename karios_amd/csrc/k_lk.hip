@@ -727,6 +727,63 @@ __global__ __launch_bounds__(64) LK2_25_OCC void lk2_kernel_win25(lk_args g, con
 }
 
 
+// ---- batched units (api_units.hip): ONE launch tracks the corners of every unit (blockIdx.y = unit): a launch pays one wave
+// lifetime of fill + drain (~30 us) whatever its size, and sixteen units' 320 000 corners keep the GPU in steady state throughout
+// The per-unit arguments are the single-unit kernel's own `lk_args`, in a table in device memory (sixteen of them exceed the 4 KB of
+// kernel arguments): the tracker indexes the pyramids by level at run time, which wants them in addressable memory, not in registers.
+template <int NR, int WIN, int MAXIT>
+__global__ __launch_bounds__(64) KM_LK_OCC void lk2_units_kernel(const lk_args *__restrict__ table)
+{
+    lk2_body<NR, WIN, MAXIT>(table[blockIdx.y], nullptr);
+}
+__global__ __launch_bounds__(64) LK2_25_OCC void lk2_units_kernel_win25(const lk_args *__restrict__ table)
+{
+    lk2_body<2, 25, 4>(table[blockIdx.y], nullptr);
+}
+
+// kl_units_prepare: validate + upload the table (early in the call: the small copy is then off the critical path);
+// kl_units_launch: the launch itself.  KM_E_UNSUPPORTED (no message): a unit without a level-1 pyramid (the first LK form serves it:
+// units one by one)
+int kl_units_prepare(km_ctx *c, const km_units &U, int n_max, int win, int max_count, double epsilon)
+{
+    if (n_max <= 0 || U.n <= 0) return KM_OK;
+    if (win <= 2) return km_fail(c, KM_E_ARG, "winSize %d must be > 2", win);
+    if (win > 40) return km_fail(c, KM_E_UNSUPPORTED, "winSize %d (supported 3..40)", win);
+    if (!c->opt_lk2) return KM_E_UNSUPPORTED;
+    lk_args host[KM_UNITS_MAX];
+    const double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
+    for (int u = 0; u < U.n; u++) {
+        if (U.A[u].levels != 1 || U.B[u].levels != 1) return KM_E_UNSUPPORTED;
+        lk_args &g = host[u];
+        g.A = U.A[u]; g.B = U.B[u]; g.pts_in = U.p0[u]; g.d_n = &U.sc[u]->n_corners; g.n_max = n_max; g.win = win;
+        g.max_count = max_count < 0 ? 0 : max_count > 100 ? 100 : max_count;
+        g.backward = 1; g.epsilon = e * e; g.p1 = U.p1[u]; g.p0r = U.p0r[u]; g.left_band = nullptr;
+    }
+    lk_args *table = (lk_args *)km_ws(c, WS_UNITS_LK, sizeof(lk_args) * KM_UNITS_MAX);
+    if (!table) return KM_E_NOMEM;
+    return km_h2d_small(c, table, host, sizeof(lk_args) * (size_t)U.n);
+}
+
+int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
+{
+    if (n_max <= 0 || n_units <= 0) return KM_OK;
+    const lk_args *table = (const lk_args *)c->ws[WS_UNITS_LK].p;
+    const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;
+    const lk2_geo<0> geo(win);
+    const size_t sm2 = (size_t)4 * geo.bytes();
+    const dim3 grid(km_xcd_grid((unsigned)n_max), n_units);
+    if (win == 25) lk2_units_kernel_win25<<<grid, 64, sm2, c->stream>>>(table);
+    else switch (nr) {
+    case 1: lk2_units_kernel<1, 0, 3><<<grid, 64, sm2, c->stream>>>(table); break;
+    case 2: lk2_units_kernel<2, 0, 4><<<grid, 64, sm2, c->stream>>>(table); break;
+    case 3: lk2_units_kernel<3, 0, 6><<<grid, 64, sm2, c->stream>>>(table); break;
+    case 4: lk2_units_kernel<4, 0, 8><<<grid, 64, sm2, c->stream>>>(table); break;
+    default: lk2_units_kernel<5, 0, 9><<<grid, 64, sm2, c->stream>>>(table); break;
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
              double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {

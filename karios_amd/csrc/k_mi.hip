@@ -169,13 +169,13 @@ __global__ __launch_bounds__(256) void mi_kernel(const T *__restrict__ ref, cons
 // Results agree with the first form (and the oracle's numpy) to ~1e-15; the gate is 1e-9.
 // (144 - 168 VGPRs = 3 waves per SIMD; 128 for a fourth wave spills ~70 bytes - measured as built: 0.097 ms at 20 000 points)
 template <typename T>
-__global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
-                                                     ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
-                                                     const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
-                                                     const float *__restrict__ score, float score_thr, double *__restrict__ out_studholme,
-                                                     double *__restrict__ out_nmi, km_window win, const double *__restrict__ clogc)
+__device__ __forceinline__ void mi_int_item(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                            ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                            const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                            const float *__restrict__ score, float score_thr, double *__restrict__ out_studholme,
+                                            double *__restrict__ out_nmi, const km_window &win, const double *__restrict__ clogc,
+                                            unsigned (&s_hist)[4][MI_BINS * MI_BINS])
 {
-    __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
     const int n_rows = d_n ? min(*d_n, n) : n;
     const unsigned per = ((unsigned)(n_rows + 3) / 4 + KM_XCDS - 1) / KM_XCDS, blk = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -296,6 +296,26 @@ __global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, 
 }
 
 // c ln c for c = 0 .. 57^2 (float64, host libm), in a workspace slot of the context
+template <typename T>
+__global__ __launch_bounds__(256) void mi_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                                     ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                                     const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                                     const float *__restrict__ score, float score_thr, double *__restrict__ out_studholme,
+                                                     double *__restrict__ out_nmi, km_window win, const double *__restrict__ clogc)
+{
+    __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
+    mi_int_item<T>(ref, mon, Href, Wref, Hmon, Wmon, sref, smon, x0, y0, dx, dy, n, d_n, score, score_thr, out_studholme, out_nmi, win, clogc, s_hist);
+}
+// batched units: blockIdx.y = unit
+template <typename T>
+__global__ __launch_bounds__(256) void mi_int_units_kernel(km_score_units A, int n, float score_thr, const double *__restrict__ clogc)
+{
+    __shared__ unsigned s_hist[4][MI_BINS * MI_BINS];
+    const km_score_unit &U = A.u[blockIdx.y];
+    mi_int_item<T>((const T *)U.ref, (const T *)U.mon, U.Href, U.Wref, U.Hmon, U.Wmon, U.sref, U.smon, U.x0, U.y0, U.dx, U.dy, n, U.d_n, U.score, score_thr,
+                   U.out, U.out2, U.win, clogc, s_hist);
+}
+
 static const double *mi_table(km_ctx *c)
 {
     double *d = (double *)km_ws(c, WS_MI_TABLE, (size_t)(MI_NPX + 1) * sizeof(double));
@@ -308,6 +328,23 @@ static const double *mi_table(km_ctx *c)
         c->mi_table_ready = true;
     }
     return d;
+}
+
+// both mutual-information scores of the confident rows of every unit's frame (integer pixels): one launch
+int kmi_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, int n, float score_thr)
+{
+    if (n <= 0 || n_units <= 0) return KM_OK;
+    const double *tab = mi_table(c);
+    if (!tab) return KM_E_NOMEM;
+    const dim3 grid(km_xcd_grid((unsigned)((n + 3) / 4)), n_units);
+    switch (dtype) {
+    case KM_U8: mi_int_units_kernel<uint8_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr, tab); break;
+    case KM_U16: mi_int_units_kernel<uint16_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr, tab); break;
+    case KM_I16: mi_int_units_kernel<int16_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr, tab); break;
+    default: return KM_E_UNSUPPORTED;
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
 }
 
 int kmi_batch(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,

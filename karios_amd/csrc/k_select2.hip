@@ -29,6 +29,25 @@ namespace {
 
 enum { S_UNDECIDED = 0, S_ACCEPT = 1, S_REJECT = 2 };
 
+// Every kernel of the chain serves a BATCH of independent units (blockIdx.z = unit; km_klt_units_frame_submit) - the chain is bound by
+// the latency of dependent loads and leaves the GPU idle (VALU 4 % busy), so U units' chains run side by side in the time of one.  What
+// differs between units travels by value in the kernel arguments; the single-unit entry points pass a table of one.
+struct kf_unit {
+    const unsigned long long *keys;       // candidate keys the fused eigenvalue pass emitted (KM_NSHARD regions)
+    km_scalars *sc;
+    const unsigned *max_partial;          // its per-wave maxima (nullptr: sc->max_eig_key is final)
+    unsigned long long *kept, *acc_keys;
+    uint2 *cell_rec;
+    unsigned *cell_items, *state, *acc_cnt, *acc_cur, *acc_off, *chunk_off;
+    float *out_xy;
+    size_t n_zero16;
+    unsigned n_partial;
+    int W, gw, gh;
+};
+struct kf_units_args {
+    kf_unit u[KM_UNITS_MAX];
+};
+
 __device__ __forceinline__ unsigned kf_bin(unsigned long long key, unsigned top)
 {
     const unsigned b = (unsigned)(key >> (32 + KF_SHIFT));
@@ -74,11 +93,17 @@ __device__ __forceinline__ bool kf_last_workgroup(unsigned *ticket, unsigned n_w
 // between; workgroup 0 publishes the result); histogram of its keys by value bin.  The LAST workgroup then cuts:
 // hist[KF_NB] -> cut[0] = D (last kept bin), cut[1] = kept keys, cut[3] = exact candidate count, bin_off[b] = first slot of
 // bin b in the kept list; overflow flags of the emission stage.
-__global__ __launch_bounds__(1024) void f_hist_cut_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
-                                                          const unsigned *__restrict__ max_partial, unsigned n_partial, unsigned k_target,
-                                                          unsigned kept_cap, unsigned test_flags, uint4 *__restrict__ zero16, size_t n_zero16,
-                                                          unsigned *__restrict__ acc_zero)
+__global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsigned cap, double quality, unsigned k_target, unsigned kept_cap,
+                                                          unsigned test_flags)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ keys = U.keys;
+    km_scalars *sc = U.sc;
+    const unsigned *__restrict__ max_partial = U.max_partial;
+    const unsigned n_partial = U.n_partial;
+    uint4 *__restrict__ zero16 = (uint4 *)U.cell_rec;
+    const size_t n_zero16 = U.n_zero16;
+    unsigned *__restrict__ acc_zero = U.acc_cnt;
     __shared__ unsigned h[KF_NB];
     __shared__ unsigned s_wave[16];
     __shared__ unsigned s_first, s_maxkey;
@@ -178,11 +203,16 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(const unsigned long lo
 // candidates on 1.2 million cells), and the sweeps then reach a neighbour's key with two dependent loads instead of three.
 // (The cell records were zeroed by launch 1.)
 #define KF_STASH 3072
-__global__ __launch_bounds__(1024) void f_scatter_cells_kernel(const unsigned long long *__restrict__ keys, unsigned cap, km_scalars *sc, double quality,
-                                                               unsigned long long *__restrict__ out, unsigned kept_cap, int W, int cell, int gw,
-                                                               uint2 *__restrict__ cell_rec, unsigned *__restrict__ cell_items, unsigned *__restrict__ state,
+__global__ __launch_bounds__(1024) void f_scatter_cells_kernel(kf_units_args A, unsigned cap, double quality, unsigned kept_cap, int cell,
                                                                unsigned stash_cap /* <= KF_STASH (test knob: small values force the second read) */)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ keys = U.keys;
+    km_scalars *sc = U.sc;
+    unsigned long long *__restrict__ out = U.kept;
+    const int W = U.W, gw = U.gw;
+    uint2 *__restrict__ cell_rec = U.cell_rec;
+    unsigned *__restrict__ cell_items = U.cell_items, *__restrict__ state = U.state;
     __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
     __shared__ unsigned long long s_stash[KF_STASH];
     __shared__ unsigned s_n;
@@ -241,10 +271,15 @@ __global__ __launch_bounds__(1024) void f_scatter_cells_kernel(const unsigned lo
 // of its neighbourhood at once, then the keys of their first candidates at once, keeps the few higher-ranked neighbours within the
 // minimum distance (0.2 on average) in registers, and the sweeps only poll those neighbours' states.
 #define KF_NBR 6
-__global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *__restrict__ keys, km_scalars *sc, int W, int cell, int gw, int gh,
-                                                      double md2, const uint2 *__restrict__ cell_rec, const unsigned *__restrict__ cell_items,
-                                                      unsigned *state, unsigned *n_undecided, unsigned kept_cap)
+__global__ __launch_bounds__(256) void f_sweep_kernel(kf_units_args A, int cell, double md2, int und_slot, unsigned kept_cap)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ keys = U.kept;
+    km_scalars *sc = U.sc;
+    const int W = U.W, gw = U.gw, gh = U.gh;
+    const uint2 *__restrict__ cell_rec = U.cell_rec;
+    const unsigned *__restrict__ cell_items = U.cell_items;
+    unsigned *state = U.state, *n_undecided = &sc->und[und_slot];
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     bool undecided = false;
@@ -338,11 +373,13 @@ __global__ __launch_bounds__(256) void f_sweep_kernel(const unsigned long long *
 // accepted corners per value bin.  Workgroup-aggregated like the scatter: thousands of accepted corners share a handful of bins
 // (equal eigenvalues), and one device-scope atomic per corner on the same address took 300 us.  The LAST workgroup then scans:
 // acc_off = exclusive scan of acc_cnt, chunk_off = exclusive scan of the bins' 64-corner chunks; corner count, flags.
-__global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
-                                                                km_scalars *sc, unsigned *__restrict__ acc_cnt, unsigned kept_cap,
-                                                                unsigned *__restrict__ acc_off, unsigned *__restrict__ chunk_off, int max_corners,
-                                                                unsigned und_slot)
+__global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(kf_units_args A, unsigned kept_cap, int max_corners, unsigned und_slot)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ keys = U.kept;
+    const unsigned *__restrict__ state = U.state;
+    km_scalars *sc = U.sc;
+    unsigned *__restrict__ acc_cnt = U.acc_cnt, *__restrict__ acc_off = U.acc_off, *__restrict__ chunk_off = U.chunk_off;
     __shared__ unsigned s_cnt[KF_NB];
     __shared__ unsigned s_wave[16], s_wave2[16];
     const unsigned n = kf_count(sc, kept_cap);
@@ -386,10 +423,15 @@ __global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(const unsigned l
 }
 
 // accepted keys grouped by bin (any order inside a bin)
-__global__ __launch_bounds__(1024) void f_acc_fill_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ state,
-                                                          const km_scalars *sc, const unsigned *__restrict__ acc_off, unsigned *__restrict__ acc_cur,
-                                                          unsigned long long *__restrict__ acc_keys, unsigned kept_cap)
+__global__ __launch_bounds__(1024) void f_acc_fill_kernel(kf_units_args A, unsigned kept_cap)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ keys = U.kept;
+    const unsigned *__restrict__ state = U.state;
+    const km_scalars *sc = U.sc;
+    const unsigned *__restrict__ acc_off = U.acc_off;
+    unsigned *__restrict__ acc_cur = U.acc_cur;
+    unsigned long long *__restrict__ acc_keys = U.acc_keys;
     __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
@@ -417,10 +459,13 @@ __global__ __launch_bounds__(1024) void f_acc_fill_kernel(const unsigned long lo
 // its 16 wavefronts compares the 64 corners (one per lane) with a sixteenth of the bin - keys at wave-uniform addresses, scalar
 // loads, eight per instruction - and the partial counts meet in LDS.  (One wavefront walking a 10 000-corner bin alone - equal
 // eigenvalues are common in a quantised Laplacian image - took 73 us.)
-__global__ __launch_bounds__(1024) void f_acc_emit_kernel(const unsigned long long *__restrict__ acc_keys, const unsigned *__restrict__ acc_off,
-                                                          const unsigned *__restrict__ chunk_off, int W, int max_corners, int cap,
-                                                          float *__restrict__ out_xy)
+__global__ __launch_bounds__(1024) void f_acc_emit_kernel(kf_units_args A, int max_corners, int cap)
 {
+    const kf_unit &U = A.u[blockIdx.z];
+    const unsigned long long *__restrict__ acc_keys = U.acc_keys;
+    const unsigned *__restrict__ acc_off = U.acc_off, *__restrict__ chunk_off = U.chunk_off;
+    const int W = U.W;
+    float *__restrict__ out_xy = U.out_xy;
     __shared__ unsigned s_part[16][64];
     const unsigned chunk = blockIdx.x;
     if (chunk >= chunk_off[KF_NB]) return;
@@ -459,32 +504,82 @@ __global__ __launch_bounds__(1024) void f_acc_emit_kernel(const unsigned long lo
 
 size_t kf_kept_capacity(int max_corners) { return (size_t)max_corners * 2 * KF_SLICE; }
 
-struct kf_buffers {
-    unsigned long long *kept;
-    unsigned long long *acc_keys;
-    uint2 *cell_rec;
-    unsigned *cell_items, *state, *acc_cnt, *acc_cur, *acc_off, *chunk_off;
+// Workspace of ONE unit's chain (byte sizes: kf_bytes): kept keys + accepted keys | cell records + further slots | states, counters
+struct kf_sizes {
+    size_t kept, grid, per;
     unsigned kept_cap;
-    int cell, gw, gh;
-    size_t cells;
+    int cell;
 };
-
-static int kf_layout(km_ctx *c, int H, int W, int max_corners, double min_distance, kf_buffers *b)
+static int kf_sizes_of(int max_corners, double min_distance, int H_max, int W_max, kf_sizes *z)
 {
     if (!(max_corners > 0) || !(min_distance >= 1)) return KM_E_UNSUPPORTED;
-    b->kept_cap = (unsigned)kf_kept_capacity(max_corners);
-    b->cell = (int)lrint(min_distance);
-    b->gw = (W + b->cell - 1) / b->cell; b->gh = (H + b->cell - 1) / b->cell;
-    b->cells = (size_t)b->gw * b->gh;
-    if (b->cells * KF_CELL > 0x7fffffffull) return KM_E_UNSUPPORTED;
-    b->kept = (unsigned long long *)km_ws(c, WS_MISC3, (2 * (size_t)b->kept_cap + 32) * sizeof(unsigned long long));
-    b->cell_rec = (uint2 *)km_ws(c, WS_GRID, b->cells * (2 + KF_CELL) * sizeof(unsigned));
-    unsigned *per = (unsigned *)km_ws(c, WS_MISC2, ((size_t)b->kept_cap + 4 * KF_NB + 16) * sizeof(unsigned));
-    if (!b->kept || !b->cell_rec || !per) return KM_E_NOMEM;
-    b->acc_keys = b->kept + b->kept_cap + 16;
-    b->cell_items = (unsigned *)(b->cell_rec + b->cells); b->state = per;
-    b->acc_cnt = per + b->kept_cap; b->acc_cur = b->acc_cnt + KF_NB; b->acc_off = b->acc_cur + KF_NB;   // acc_off, chunk_off: KF_NB + 1 entries
-    b->chunk_off = b->acc_off + KF_NB + 4;
+    z->kept_cap = (unsigned)kf_kept_capacity(max_corners);
+    z->cell = (int)lrint(min_distance);
+    const size_t cells = (size_t)((W_max + z->cell - 1) / z->cell) * (size_t)((H_max + z->cell - 1) / z->cell);
+    if (cells * KF_CELL > 0x7fffffffull) return KM_E_UNSUPPORTED;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    z->kept = up((2 * (size_t)z->kept_cap + 32) * sizeof(unsigned long long));
+    z->grid = up((cells + 1) * (2 + KF_CELL) * sizeof(unsigned));
+    z->per = up(((size_t)z->kept_cap + 4 * KF_NB + 16) * sizeof(unsigned));
+    return KM_OK;
+}
+static void kf_carve(const kf_sizes &z, char *kept, char *grid, char *per, int H, int W, kf_unit *u)
+{
+    u->gw = (W + z.cell - 1) / z.cell; u->gh = (H + z.cell - 1) / z.cell; u->W = W;
+    const size_t cells = (size_t)u->gw * u->gh;
+    u->kept = (unsigned long long *)kept; u->acc_keys = u->kept + z.kept_cap + 16;
+    u->cell_rec = (uint2 *)grid; u->cell_items = (unsigned *)(u->cell_rec + cells);
+    u->n_zero16 = (cells + 1) / 2;   // (cell records of 8 bytes in a 16-byte aligned buffer; with an odd cell count the first two item slots behind them are zeroed too - they are written later)
+    unsigned *p = (unsigned *)per;
+    u->state = p; u->acc_cnt = p + z.kept_cap; u->acc_cur = u->acc_cnt + KF_NB; u->acc_off = u->acc_cur + KF_NB;   // acc_off, chunk_off: KF_NB + 1 entries
+    u->chunk_off = u->acc_off + KF_NB + 4;
+}
+
+// the tables of a batch: unit k's slices of WS_MISC3 / WS_GRID / WS_MISC2 (sized for the largest unit)
+static int kf_layout_units(km_ctx *c, int n, const int *H, const int *W, int max_corners, double min_distance, kf_units_args *A, kf_sizes *z)
+{
+    int Hm = 0, Wm = 0;
+    for (int k = 0; k < n; k++) { Hm = H[k] > Hm ? H[k] : Hm; Wm = W[k] > Wm ? W[k] : Wm; }
+    const int rc = kf_sizes_of(max_corners, min_distance, Hm, Wm, z);
+    if (rc) return rc;
+    char *kept = (char *)km_ws(c, WS_MISC3, z->kept * n), *grid = (char *)km_ws(c, WS_GRID, z->grid * n), *per = (char *)km_ws(c, WS_MISC2, z->per * n);
+    if (!kept || !grid || !per) return KM_E_NOMEM;
+    for (int k = 0; k < n; k++) kf_carve(*z, kept + z->kept * k, grid + z->grid * k, per + z->per * k, H[k], W[k], &A->u[k]);
+    return KM_OK;
+}
+
+static int kf_rank_launch(km_ctx *c, const kf_units_args &A, int n, size_t cap_keys, int max_corners, double quality, const kf_sizes &z)
+{
+    static const int gx = [] { const char *e = km_dev_env("KARIOS_HIP_RANK_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();   // tuning override
+    // (a batch keeps ~256 workgroups per launch in flight: 16 x 16 per unit alone, fewer columns per unit as the units multiply)
+    const int gxu = n >= 8 ? (gx + 3) / 4 : n >= 3 ? (gx + 1) / 2 : gx;
+    f_hist_cut_kernel<<<dim3(gxu, KM_NSHARD, n), 1024, 0, c->stream>>>(A, (unsigned)cap_keys, quality, (unsigned)max_corners * KF_SLICE, z.kept_cap,
+                                                                     (unsigned)c->opt_spec_flag);
+    KM_LAUNCH_CHECK(c);
+    f_scatter_cells_kernel<<<dim3(gxu, KM_NSHARD, n), 1024, 0, c->stream>>>(A, (unsigned)cap_keys, quality, z.kept_cap, z.cell,
+                                                                          c->opt_stash_cap > 0 && c->opt_stash_cap < KF_STASH ? (unsigned)c->opt_stash_cap : (unsigned)KF_STASH);
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
+#define KF_LAUNCHES 4          // sweep launches (42 + 6 + 2 + 2 us: the last two find nothing left to do on a GPU of their own; with several
+                               // contexts sharing the GPU the polling sweeps give up earlier and three launches left tiles unconverged - flagged, repeated)
+static int kf_select_launch(km_ctx *c, const kf_units_args &A, int n, int max_corners, double min_distance, int cap, const kf_sizes &z)
+{
+    const double md2 = min_distance * min_distance;
+    const unsigned g256 = (z.kept_cap + 255) / 256;
+    for (int g = 0; g < KF_LAUNCHES; g++) {
+        f_sweep_kernel<<<dim3(g256, 1, n), 256, 0, c->stream>>>(A, z.cell, md2, g, z.kept_cap);
+        KM_LAUNCH_CHECK(c);
+    }
+    const int gb = n >= 8 ? 8 : n >= 3 ? 16 : 32;
+    f_acc_count_scan_kernel<<<dim3(gb, 1, n), 1024, 0, c->stream>>>(A, z.kept_cap, max_corners, (unsigned)(KF_LAUNCHES - 1));
+    KM_LAUNCH_CHECK(c);
+    f_acc_fill_kernel<<<dim3(gb, 1, n), 1024, 0, c->stream>>>(A, z.kept_cap);
+    KM_LAUNCH_CHECK(c);
+    // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
+    f_acc_emit_kernel<<<dim3(z.kept_cap / 64 + KF_NB, 1, n), 1024, 0, c->stream>>>(A, max_corners, cap);
+    KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
@@ -493,44 +588,37 @@ static int kf_layout(km_ctx *c, int H, int W, int max_corners, double min_distan
 // start of the call.
 int kf_rank(km_ctx *c, const unsigned long long *d_keys, size_t cap_keys, int H, int W, int max_corners, double quality, double min_distance, km_scalars *sc)
 {
-    kf_buffers b;
-    int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
+    kf_units_args A;
+    kf_sizes z;
+    const int rc = kf_layout_units(c, 1, &H, &W, max_corners, min_distance, &A, &z);
     if (rc) return rc;
-    // (cell records of 8 bytes in a 16-byte aligned buffer; with an odd cell count the first two item slots behind them are zeroed too - they are written later)
-    static const int gx = [] { const char *e = km_dev_env("KARIOS_HIP_RANK_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();   // tuning override
-    f_hist_cut_kernel<<<dim3(gx, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, c->eig_partial, c->eig_npartial,
-                                                                   (unsigned)max_corners * KF_SLICE, b.kept_cap, (unsigned)c->opt_spec_flag,
-                                                                   (uint4 *)b.cell_rec, (b.cells + 1) / 2, b.acc_cnt);
-    KM_LAUNCH_CHECK(c);
+    A.u[0].keys = d_keys; A.u[0].sc = sc; A.u[0].max_partial = c->eig_partial; A.u[0].n_partial = c->eig_npartial; A.u[0].out_xy = nullptr;
     c->eig_partial = nullptr; c->eig_npartial = 0;
-    f_scatter_cells_kernel<<<dim3(gx, KM_NSHARD), 1024, 0, c->stream>>>(d_keys, (unsigned)cap_keys, sc, quality, b.kept, b.kept_cap, W, b.cell, b.gw,
-                                                                        b.cell_rec, b.cell_items, b.state,
-                                                                        c->opt_stash_cap > 0 && c->opt_stash_cap < KF_STASH ? (unsigned)c->opt_stash_cap : (unsigned)KF_STASH);
-    KM_LAUNCH_CHECK(c);
-    return KM_OK;
+    return kf_rank_launch(c, A, 1, cap_keys, max_corners, quality, z);
 }
 
 // Greedy minimum-distance selection on the ranked keys of kf_rank: corners in d_xy, their count in sc->n_corners.
-#define KF_LAUNCHES 4          // sweep launches (42 + 6 + 2 + 2 us: the last two find nothing left to do on a GPU of their own; with several
-                               // contexts sharing the GPU the polling sweeps give up earlier and three launches left tiles unconverged - flagged, repeated)
 int kf_select(km_ctx *c, int H, int W, int max_corners, double min_distance, float *d_xy, int cap, km_scalars *sc)
 {
-    kf_buffers b;
-    int rc = kf_layout(c, H, W, max_corners, min_distance, &b);
+    kf_units_args A;
+    kf_sizes z;
+    const int rc = kf_layout_units(c, 1, &H, &W, max_corners, min_distance, &A, &z);
     if (rc) return rc;
-    const double md2 = min_distance * min_distance;
-    const unsigned g256 = (b.kept_cap + 255) / 256;
-    for (int g = 0; g < KF_LAUNCHES; g++) {
-        f_sweep_kernel<<<g256, 256, 0, c->stream>>>(b.kept, sc, W, b.cell, b.gw, b.gh, md2, b.cell_rec, b.cell_items, b.state, &sc->und[g], b.kept_cap);
-        KM_LAUNCH_CHECK(c);
+    A.u[0].keys = nullptr; A.u[0].sc = sc; A.u[0].max_partial = nullptr; A.u[0].n_partial = 0; A.u[0].out_xy = d_xy;
+    return kf_select_launch(c, A, 1, max_corners, min_distance, cap, z);
+}
+
+// The whole chain for a batch of units (api_units.hip): nine launches for ALL of them.  KM_E_UNSUPPORTED: see kf_sizes_of.
+int kf_rank_select_units(km_ctx *c, const km_units &U, int max_corners, double quality, double min_distance, int cap)
+{
+    kf_units_args A;
+    kf_sizes z;
+    const int rc = kf_layout_units(c, U.n, U.H, U.W, max_corners, min_distance, &A, &z);
+    if (rc) return rc;
+    for (int k = 0; k < U.n; k++) {
+        A.u[k].keys = U.keys[k]; A.u[k].sc = U.sc[k]; A.u[k].max_partial = U.eig_partial[k]; A.u[k].n_partial = U.eig_npartial[k]; A.u[k].out_xy = U.p0[k];
     }
-    f_acc_count_scan_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_cnt, b.kept_cap, b.acc_off, b.chunk_off, max_corners,
-                                                        (unsigned)(KF_LAUNCHES - 1));
-    KM_LAUNCH_CHECK(c);
-    f_acc_fill_kernel<<<32, 1024, 0, c->stream>>>(b.kept, b.state, sc, b.acc_off, b.acc_cur, b.acc_keys, b.kept_cap);
-    KM_LAUNCH_CHECK(c);
-    // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
-    f_acc_emit_kernel<<<b.kept_cap / 64 + KF_NB, 1024, 0, c->stream>>>(b.acc_keys, b.acc_off, b.chunk_off, W, max_corners, cap, d_xy);
-    KM_LAUNCH_CHECK(c);
-    return KM_OK;
+    int r = kf_rank_launch(c, A, U.n, U.capk, max_corners, quality, z);
+    if (r) return r;
+    return kf_select_launch(c, A, U.n, max_corners, min_distance, cap, z);
 }

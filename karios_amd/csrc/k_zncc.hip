@@ -98,10 +98,10 @@ __global__ __launch_bounds__(256) void zncc_kernel(const T *__restrict__ ref, co
 // The float64 two-pass kernel above cost ~1 100 issue slots per key point (58 float64 registers of pixels, index arithmetic per pixel);
 // this one ~420.
 template <typename T>
-__global__ __launch_bounds__(256) void zncc_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
-                                                       ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
-                                                       const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
-                                                       const float *__restrict__ score, float score_thr, double *__restrict__ out, km_window win)
+__device__ __forceinline__ void zncc_int_item(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                              ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                              const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                              const float *__restrict__ score, float score_thr, double *__restrict__ out, const km_window &win)
 {
     const int n_rows = d_n ? min(*d_n, n) : n;
     const unsigned per = ((unsigned)(n_rows + 3) / 4 + KM_XCDS - 1) / KM_XCDS, blk = (blockIdx.x % KM_XCDS) * per + blockIdx.x / KM_XCDS;
@@ -160,6 +160,38 @@ __global__ __launch_bounds__(256) void zncc_int_kernel(const T *__restrict__ ref
         const long long v1 = N * (long long)daa - Sa * Sa, v2 = N * (long long)dbb - Sb * Sb, cv = N * (long long)dab - Sa * Sb;
         out[k] = (v1 == 0 || v2 == 0) ? nan : (double)cv / (sqrt((double)v1) * sqrt((double)v2));
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zncc_int_kernel(const T *__restrict__ ref, const T *__restrict__ mon, int Href, int Wref, int Hmon, int Wmon,
+                                                       ptrdiff_t sref, ptrdiff_t smon, const float *__restrict__ x0, const float *__restrict__ y0,
+                                                       const float *__restrict__ dx, const float *__restrict__ dy, int n, const int *__restrict__ d_n,
+                                                       const float *__restrict__ score, float score_thr, double *__restrict__ out, km_window win)
+{
+    zncc_int_item<T>(ref, mon, Href, Wref, Hmon, Wmon, sref, smon, x0, y0, dx, dy, n, d_n, score, score_thr, out, win);
+}
+// batched units: blockIdx.y = unit
+template <typename T>
+__global__ __launch_bounds__(256) void zncc_int_units_kernel(km_score_units A, int n, float score_thr)
+{
+    const km_score_unit &U = A.u[blockIdx.y];
+    zncc_int_item<T>((const T *)U.ref, (const T *)U.mon, U.Href, U.Wref, U.Hmon, U.Wmon, U.sref, U.smon, U.x0, U.y0, U.dx, U.dy, n, U.d_n, U.score, score_thr,
+                     U.out, U.win);
+}
+
+// ZNCC of the confident rows of every unit's frame (integer pixels): one launch.  KM_E_UNSUPPORTED: float32 rasters (units one by one)
+int kz_zncc_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, int n, float score_thr)
+{
+    if (n <= 0 || n_units <= 0) return KM_OK;
+    const dim3 grid(km_xcd_grid((unsigned)((n + 3) / 4)), n_units);
+    switch (dtype) {
+    case KM_U8: zncc_int_units_kernel<uint8_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr); break;
+    case KM_U16: zncc_int_units_kernel<uint16_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr); break;
+    case KM_I16: zncc_int_units_kernel<int16_t><<<grid, 256, 0, c->stream>>>(A, n, score_thr); break;
+    default: return KM_E_UNSUPPORTED;
+    }
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
 }
 
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref, int Hmon, int Wmon, ptrdiff_t sref,

@@ -139,6 +139,99 @@ class PendingFrame:
         return {c.lib.km_stage_name(i).decode(): float(buf[i]) for i in range(n.value)}
 
 
+class PendingBatch:
+    """Units submitted together with `submit_units` (km_klt_units_frame_submit): ONE device pipeline for all of them.
+    `wait()` (any thread) -> the units' `RawFrame`s in submission order; `redo(i)` repeats unit i alone through the exact path."""
+
+    def __init__(self, ctx: Context, ticket: int, cap: int, with_zncc, redos):
+        self.ctx, self.ticket, self.cap, self.with_zncc = ctx, ticket, cap, with_zncc
+        self._redos = redos
+        self._raws = None
+
+    def __len__(self):
+        return len(self._redos)
+
+    def wait(self) -> "list[RawFrame]":
+        if self._raws is None:
+            c = self.ctx
+            blk, nbytes = C.c_void_p(), C.c_size_t()
+            rc = c.lib.km_frame_wait(c.handle, self.ticket, C.byref(blk), C.byref(nbytes))
+            if rc != 0:
+                raise KariosHipError(f"km_frame_wait(ticket {self.ticket}) failed with status {rc}")
+            n32 = frames.block_words(self.cap, self.with_zncc)
+            n = len(self._redos)
+            pinned = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_float)), shape=(n * n32,))
+            own = pinned.copy()                                   # the pinned slot is reused 3 submissions later
+            self._raws = [RawFrame(own[k * n32:(k + 1) * n32], self.cap, self.with_zncc) for k in range(n)]
+        return self._raws
+
+    def redo(self, i: int) -> "RawFrame":
+        """Unit i through the exact (synchronising) corner path (submitting thread only)."""
+        self._raws[i] = self._redos[i]()
+        return self._raws[i]
+
+    def stage_ms(self) -> dict:
+        """Stage spans of the whole batch (after `wait`, with `Context.set_profiling(True)`)."""
+        return PendingFrame.stage_ms(self)
+
+
+def submit_units(units, conf, zncc_threshold=None, mutual_info: bool = False) -> "PendingBatch | None":
+    """`ResidentPair.submit_tile` for up to 16 independent units at once - `units` = [(pair, box | None, origin | None), ...], all on
+    ONE context, one pixel type, no user mask: the tiles of `KLT.match` (klt.py:220-253), of one pair or of several bands.  Every
+    dense kernel, the corner-selection chain, LK, the frame stage and the scores are launched ONCE for all units
+    (csrc/api_units.hip); the frames are the unit-by-unit frames bit for bit.  Returns None when the batch form does not cover the
+    case (the library answers KM_E_UNSUPPORTED: maxCorners 0, a unit narrower than 512 columns, Laplacian kernels 9 / 11 ...) or the
+    units do not share a context / pixel type / carry a user mask - submit them one by one then."""
+    if not units or len(units) > _lib.UNITS_PER_SUBMISSION:
+        return None
+    if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False) or conf.maxCorners <= 0:
+        return None
+    first = units[0][0]
+    c = first.ctx
+    if any(p.ctx is not c or p.code != first.code or p.mask_ptr or p.no_data_mon != first.no_data_mon or p.no_data_ref != first.no_data_ref for p, _, _ in units):
+        return None
+    with_zncc = zncc_threshold is not None
+    n_scores = 0 if not with_zncc else (3 if mutual_info else 1)
+    prm = ResidentPair._params(conf)
+    cap = prm.max_corners
+    arr = (_lib.KmUnit * len(units))()
+    redos = []
+    for k, (pair, box, origin) in enumerate(units):
+        bx_off, by_off, bx, by, off = pair._box(box)
+        x_off, y_off = origin if origin is not None else (bx_off, by_off)
+        es = pair.dtype.itemsize
+        u = arr[k]
+        u.d_ref, u.d_mon, u.sref, u.smon, u.H, u.W = pair.ref_ptr + off * es, pair.mon_ptr + off * es, pair.x_size, pair.x_size, by, bx
+        u.x_off, u.y_off = float(x_off), float(y_off)
+        if with_zncc:
+            u.d_ref_full, u.d_mon_full, u.sref_f, u.smon_f, u.Hf, u.Wf = pair.ref_ptr, pair.mon_ptr, pair.x_size, pair.x_size, pair.y_size, pair.x_size
+        if pair.window is not None:
+            u.win_ox, u.win_oy, u.win_H, u.win_W = (int(v) for v in pair.window)
+
+        def exact(pair=pair, box=box, origin=(x_off, y_off)):
+            before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "1") or 0))
+            c.set_option("speculative", 0)
+            sink = c.frame_sink
+            if sink[0]:
+                c.set_frame_sink(None)
+            try:
+                return pair.match_tile_raw(conf, box, zncc_threshold, origin=origin, mutual_info=mutual_info)
+            finally:
+                c.set_option("speculative", before)
+                if sink[0]:
+                    c.set_frame_sink(*sink)
+        redos.append(exact)
+    nr = C.byref(C.c_double(float(first.no_data_ref))) if first.no_data_ref is not None else None
+    nm = C.byref(C.c_double(float(first.no_data_mon))) if first.no_data_mon is not None else None
+    ticket = C.c_int(-1)
+    with first._frame_mi(n_scores == 3):
+        rc = c.lib.km_klt_units_frame_submit(c.handle, arr, len(units), first.code, nr, nm, C.byref(prm), float(zncc_threshold or 0.0), cap, C.byref(ticket))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    c.check(rc, "km_klt_units_frame_submit")
+    return PendingBatch(c, ticket.value, cap, n_scores, redos)
+
+
 class ResidentPair:
     """A monitored / reference image pair (plus optional user mask) resident in HBM."""
 
@@ -484,10 +577,10 @@ class ResidentPair:
             boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
         stage = None if host_stage is None else (lambda frame, _pair: host_stage(frame))
         with FrameStream(zncc_threshold, depth=1, host_stage=stage, score_columns=False) as stream:
-            for box in boxes:
-                for done in stream.submit(self, conf, box):
-                    if done.frame is not None or with_empty:          # (with_empty: None for a tile without valid pixels / corners)
-                        yield done.frame
+            # the tiles travel as batched submissions (one set of device launches per <= 16 tiles) where the batch form covers them
+            for done in stream.submit_many([(self, box, None) for box in boxes], conf):
+                if done.frame is not None or with_empty:              # (with_empty: None for a tile without valid pixels / corners)
+                    yield done.frame
             for done in stream.drain():
                 if done.frame is not None or with_empty:
                     yield done.frame
@@ -654,4 +747,4 @@ def forget_shared_pairs() -> None:
     _SHARED.clear()
 
 
-__all__ = ["ResidentPair", "DeviceBuffer", "shared_pair", "forget_shared_pairs", "_lib"]
+__all__ = ["ResidentPair", "DeviceBuffer", "PendingBatch", "submit_units", "shared_pair", "forget_shared_pairs", "_lib"]

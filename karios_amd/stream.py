@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 from pandas import DataFrame
 
-from .resident import PendingFrame, RawFrame, ResidentPair
+from .resident import PendingBatch, PendingFrame, RawFrame, ResidentPair, submit_units
 
 
 # The interpreter's switch interval is process-global: open streams are counted, the original value is saved by the FIRST one
@@ -126,7 +126,45 @@ class FrameStream:
                 frame = pair.score_frame(frame, self.threshold, mutual_info=self.mutual_info)     # every column is in place: pure numpy, no library call
         return raw, spans, frame
 
-    def _collect(self, item) -> StreamResult:
+    def _batch_host_half(self, pairs, pend: PendingBatch):
+        """Worker thread, batched submission: the units' blocks arrive together."""
+        raws = pend.wait()
+        spans = pend.stage_ms() if self.want_spans else {}
+        out = []
+        for pair, raw in zip(pairs, raws):
+            frame = None
+            if not raw.flags:
+                frame = raw.to_frame(radial=self.score_columns)
+                if frame is not None and self.score_columns and raw.with_zncc:
+                    frame = pair.score_frame(frame, self.threshold, mutual_info=self.mutual_info)
+            out.append((raw, frame))
+        return out, spans
+
+    def _collect_batch(self, item) -> list[StreamResult]:
+        pairs, pend, tags, fut = item
+        done, spans = fut.result()
+        out = []
+        for i, (pair, (raw, frame), tag) in enumerate(zip(pairs, done, tags)):
+            redone, flags = False, raw.flags
+            if raw.flags:                  # this unit alone through the exact path (the others of the batch stand)
+                raw = pend.redo(i)
+                frame = raw.to_frame(radial=self.score_columns)
+                if frame is not None and self.score_columns and self.threshold is not None:
+                    frame = pair.score_frame(frame, self.threshold, mutual_info=self.mutual_info)
+                redone = True
+                self.units_redone += 1
+            if frame is not None and self.host_stage is not None:
+                frame = self.host_stage(frame, pair)
+            # the batch's stage spans are attached to its FIRST unit (they cover all units: one set of launches)
+            out.append(StreamResult(frame, raw, tag, redone, spans if i == 0 else {}, flags))
+        return out
+
+    def _collect(self, item):
+        if isinstance(item[1], PendingBatch):
+            return self._collect_batch(item)
+        return [self._collect_one(item)]
+
+    def _collect_one(self, item) -> StreamResult:
         pair, pend, tag, fut = item
         raw, spans, frame = fut.result()
         redone, flags = False, raw.flags
@@ -158,13 +196,42 @@ class FrameStream:
         self._pending.append((pair, pend, tag, self._pool.submit(self._host_half, pair, pend)))
         out = []
         while len(self._pending) > self.depth:
-            out.append(self._collect(self._pending.popleft()))
+            out += self._collect(self._pending.popleft())
+        return out
+
+    def submit_many(self, units, conf, tags=None, on_submitted=None) -> list[StreamResult]:
+        """Queue several independent units - `units` = [(pair, box | None, origin | None), ...], e.g. the tiles of one `KLT.match`
+        (klt.py:220-253) or a rank's share of a multi-band job - as BATCHED submissions (`karios_amd.resident.submit_units`: one set
+        of device launches per <= 16 units; a batch counts as one pending submission for `depth`).  Units the batch form does not
+        cover (another context, a user mask, maxCorners 0 ...) go one by one through `submit`, in order.  Returns the collected
+        results like `submit`; `on_submitted(pending_batch_or_frame, first_unit_index)` runs behind every submission."""
+        from ._lib import UNITS_PER_SUBMISSION
+        if self._pool is None:
+            raise RuntimeError("FrameStream is closed")
+        tags = list(tags) if tags is not None else [None] * len(units)
+        out = []
+        i = 0
+        while i < len(units):
+            chunk, chunk_tags = units[i:i + UNITS_PER_SUBMISSION], tags[i:i + UNITS_PER_SUBMISSION]
+            pend = submit_units(chunk, conf, self.threshold, self.mutual_info) if len(chunk) > 1 else None
+            if pend is None:               # not batchable: unit by unit
+                for (pair, box, origin), tag in zip(chunk, chunk_tags):
+                    out += self.submit(pair, conf, box, origin, tag, None if on_submitted is None else (lambda p, k=i: on_submitted(p, k)))
+                    i += 1
+                continue
+            if on_submitted is not None:
+                on_submitted(pend, i)
+            pairs = [u[0] for u in chunk]
+            self._pending.append((pairs, pend, chunk_tags, self._pool.submit(self._batch_host_half, pairs, pend)))
+            while len(self._pending) > self.depth:
+                out += self._collect(self._pending.popleft())
+            i += len(chunk)
         return out
 
     def drain(self) -> list[StreamResult]:
         out = []
         while self._pending:
-            out.append(self._collect(self._pending.popleft()))
+            out += self._collect(self._pending.popleft())
         return out
 
 

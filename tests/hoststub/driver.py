@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from karios_amd._lib import SIGNATURES, KltParams, KltStats  # noqa: E402  (signatures only: the product library is NOT loaded)
+from karios_amd._lib import SIGNATURES, KltParams, KltStats, KmUnit  # noqa: E402  (signatures only: the product library is NOT loaded)
 
 lib = C.CDLL(os.path.join(ROOT, "tests", "hoststub", "_build", "libkarios_host_asan.so"))
 for name, (res, args) in SIGNATURES.items():
@@ -224,6 +224,44 @@ t = C.c_int()
 err(lib.km_klt_tile_frame_submit(ctx, dr, dm, 1, H, W, W, W, None, 0, None, None, C.byref(prm), 0.0, 0.0, dr, dm, H, W, W, W, 0.4, cap, C.byref(t)), "sink too small", KM_E_ARG)
 ok(lib.km_set_frame_sink(ctx, None, 0), "sink off")
 ok(lib.km_ctx_sync(ctx), "ctx_sync")
+
+# ---- batched units (api_units.hip): three boxes of the resident pair in one submission, blocks into a pitched sink
+es = 2
+units = (KmUnit * 3)()
+boxes = [(0, 0, 520, 300), (8, 40, 512, 200), (4, 100, 516, 300)]
+for u, (bx, by, bw, bh) in zip(units, boxes):
+    u.d_ref, u.d_mon, u.sref, u.smon, u.H, u.W = dr.value + (by * W + bx) * es, dm.value + (by * W + bx) * es, W, W, bh, bw
+    u.d_ref_full, u.d_mon_full, u.sref_f, u.smon_f, u.Hf, u.Wf = dr.value, dm.value, W, W, H, W
+    u.x_off, u.y_off = float(bx), float(by)
+pitch = blk_bytes + 16
+sink3 = C.c_void_p()
+ok(lib.km_dev_alloc(ctx, 3 * pitch, C.byref(sink3)), "dev_alloc sink3")
+ok(lib.km_set_frame_sink_pitch(ctx, sink3, 2 * pitch + blk_bytes, pitch), "sink pitch")
+for k in range(5):
+    t = C.c_int(-1)
+    ok(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units submit")
+    assert t.value == (k + 2) % 3, t.value                    # (the ring went on from the five single submissions above)
+    assert lib.km_frame_wait(ctx, t.value, C.byref(blk), C.byref(nb)) == 0 and nb.value == 3 * blk_bytes
+    got3 = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_float)), shape=(3 * blk_bytes // 4,)).copy().reshape(3, -1)
+    h3 = got3[:, :4].view(np.int32)
+    assert (h3[:, 1] == [40, 41, 42]).all() and (h3[:, 0] > 0).all() and (h3[:, 3] == [1000, 1001, 1002]).all(), h3
+sunk3 = np.zeros(3 * pitch // 4, np.float32)
+ok(lib.km_d2h(ctx, P(sunk3), sink3, 3 * pitch), "d2h sink3")
+for k in range(3):
+    assert np.array_equal(sunk3[k * pitch // 4:k * pitch // 4 + blk_bytes // 4].view(np.int32), got3[k].view(np.int32))
+ok(lib.km_set_frame_sink_pitch(ctx, sink3, 2 * pitch, pitch), "sink too small for three")
+err(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: sink too small", KM_E_ARG)
+ok(lib.km_set_frame_sink(ctx, None, 0), "sink off")
+err(lib.km_klt_units_frame_submit(ctx, units, 0, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: none", KM_E_ARG)
+err(lib.km_klt_units_frame_submit(ctx, units, 17, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: too many", KM_E_ARG)
+err(lib.km_klt_units_frame_submit(ctx, None, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: null", KM_E_ARG)
+units[1].W = 300                                                # narrower than the 8-px eigenvalue kernel serves: not an error, "one by one"
+assert lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)) == -4
+units[1].W = 512
+units[2].d_ref_full = None
+err(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: mixed score columns", KM_E_ARG)
+ok(lib.km_ctx_sync(ctx), "ctx_sync")
+ok(lib.km_dev_free(ctx, sink3), "dev_free sink3")
 
 # ---- scores / filters on host key points
 n = 300

@@ -348,3 +348,92 @@ int kp_phase_shift(km_ctx *c, const void *a, const void *b, int dtype, int H, in
 }
 void kp_destroy(km_ctx *) {}
 int kd_run_valid_sum(km_ctx *c) { c->valid_job_pending = false; return KM_OK; }
+
+// ---- batched units (api_units.hip): every stage touches the first and last byte / element of what the host laid out for it
+int kd_minmax_units(km_ctx *, const km_units &U, double *const *out, int)
+{
+    for (int u = 0; u < U.n; u++) {
+        minmax_of(U.ref[u], U.dtype, U.H[u], U.W[u], U.sref[u], out[u]);
+        minmax_of(U.mon[u], U.dtype, U.H[u], U.W[u], U.smon[u], out[u] + 2);
+    }
+    return KM_OK;
+}
+int kd_stretch_laplacian_units(km_ctx *, const km_units &U, int, int, int, const double *, const double *, km_valid_units *job)
+{
+    job->n = U.n;
+    for (int u = 0; u < U.n; u++) {
+        const size_t n = (size_t)U.H[u] * U.W[u];
+        for (size_t i = 0; i < n; i++) { U.lap_ref[u][i] = (uint8_t)i; U.lap_mon[u][i] = (uint8_t)(i + 1); U.mask[u][i] = 1; }
+        volatile double m = U.mm[u][0] + U.mm[u][3];
+        (void)m;
+        job->partial[u] = nullptr; job->n_partial[u] = 0; job->out[u] = &U.sc[u]->valid;
+    }
+    return KM_OK;
+}
+int kd_valid_sum_units(km_ctx *, const km_valid_units &J)
+{
+    for (int u = 0; u < J.n; u++) *J.out[u] = 12345ull;
+    return KM_OK;
+}
+int k3_eig_candidates_units(km_ctx *, km_units &U, int, double)
+{
+    for (int u = 0; u < U.n; u++) { U.keys[u][0] = 1ull; U.keys[u][U.capk - 1] = 2ull; U.eig_partial[u] = nullptr; U.eig_npartial[u] = 0; }
+    return KM_OK;
+}
+int kd_pyrdown_units(km_ctx *, const km_units &U, int level)
+{
+    for (int u = 0; u < U.n; u++) {
+        uint8_t *a = (uint8_t *)U.A[u].img[level], *b = (uint8_t *)U.B[u].img[level];
+        const size_t n = (size_t)U.A[u].H[level] * U.A[u].W[level];
+        memset(a, 3, n); memset(b, 4, n);
+    }
+    return KM_OK;
+}
+int kf_rank_select_units(km_ctx *, const km_units &U, int max_corners, double, double, int cap)
+{
+    for (int u = 0; u < U.n; u++) {
+        const int n = std::min(std::min(max_corners, cap), 40 + u);
+        for (int i = 0; i < n; i++) { U.p0[u][2 * i] = (float)(20 + 7 * i % (U.W[u] - 40)); U.p0[u][2 * i + 1] = (float)(20 + 11 * i % (U.H[u] - 40)); }
+        U.p0[u][2 * (size_t)cap - 1] = 0.f;
+        U.sc[u]->n_corners = n; U.sc[u]->cut[3] = 1000u + (unsigned)u;
+    }
+    return KM_OK;
+}
+static km_units g_lk_units;
+int kl_units_prepare(km_ctx *, const km_units &U, int, int, int, double) { g_lk_units = U; return KM_OK; }
+int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
+{
+    const km_units &U = g_lk_units;
+    for (int u = 0; u < n_units; u++) {
+        const int rc = kl_track(c, U.A[u], U.B[u], U.p0[u], &U.sc[u]->n_corners, n_max, win, 30, 0.03, true, U.p1[u], U.p0r[u], nullptr);
+        if (rc) return rc;
+    }
+    return KM_OK;
+}
+int kf_frame_units(km_ctx *c, const km_units &U, int n_max, int cap, float thr)
+{
+    for (int u = 0; u < U.n; u++) {
+        const int rc = kf_frame(c, U.p0[u], U.p1[u], U.p0r[u], &U.sc[u]->n_corners, n_max, cap, thr, U.x_off[u], U.y_off[u], U.frame[u], U.sc[u]);
+        if (rc) return rc;
+    }
+    return KM_OK;
+}
+int kz_zncc_units(km_ctx *, const km_score_units &A, int n_units, int, int n, float thr)
+{
+    for (int u = 0; u < n_units; u++) {
+        const km_score_unit &s = A.u[u];
+        const int m = std::min(*s.d_n, n);
+        for (int i = 0; i < m; i++) s.out[i] = s.score[i] >= thr ? (double)s.x0[i] : NAN;
+        s.out[n - 1] = s.out[n - 1];
+    }
+    return KM_OK;
+}
+int kmi_units(km_ctx *, const km_score_units &A, int n_units, int, int n, float)
+{
+    for (int u = 0; u < n_units; u++) {
+        const km_score_unit &s = A.u[u];
+        const int m = std::min(*s.d_n, n);
+        for (int i = 0; i < m; i++) { s.out[i] = s.x0[i]; s.out2[i] = -s.x0[i]; }
+    }
+    return KM_OK;
+}

@@ -1,0 +1,137 @@
+"""Batched units (km_klt_units_frame_submit, csrc/api_units.hip): U independent tiles (reference karios/matcher/klt.py:220-253: no halo,
+per-tile stretch / threshold / maxCorners) through ONE set of device launches.  The contract is bit-identity with the unit-by-unit
+submission - every kernel runs the single-unit item code on the unit's own rasters, scalar block, key buffer and grid - including the
+score columns, units of different shape, units of different pairs, flagged units and the frame sink."""
+import numpy as np
+import pytest
+
+from karios_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(ops):
+    from karios_amd.resident import ResidentPair
+    ctx = ops._lib.default_context()
+    mon_a, ref_a = synth.make_pair(1400, 1500, 0.5, 0.25, seed=11, nodata_wedge=True)
+    mon_b, ref_b = synth.make_pair(900, 1100, -0.3, 0.4, seed=12)
+    return ctx, ResidentPair.upload(mon_a, ref_a, ctx=ctx), ResidentPair.upload(mon_b, ref_b, ctx=ctx), (mon_a, ref_a)
+
+
+UNITS_A = [(0, 0, 700, 600), (700, 0, 800, 600), (0, 600, 1500, 800), (300, 200, 640, 512), None]
+
+
+@pytest.mark.parametrize("scores", [None, "zncc", "full"])
+def test_units_submitted_together_equal_units_submitted_one_by_one(ops, O, scores):
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import submit_units
+    ctx, pa, pb, _ = _pairs(ops)
+    conf = KLTConfiguration(maxCorners=1200)
+    thr = None if scores is None else 0.4
+    mi = scores == "full"
+    units = [(pa, b, None) for b in UNITS_A] + [(pb, None, None), (pb, (100, 50, 900, 700), (5100, 7050))]
+    want = [p.submit_tile(conf, box=b, zncc_threshold=thr, origin=o, mutual_info=mi).result() for p, b, o in units]
+    assert all(w.n_rows > 200 for w in want)
+    for rep in range(3):                                   # (slot ring, workspace reuse, the early min / max behind another submission)
+        batch = submit_units(units, conf, thr, mi)
+        assert batch is not None and len(batch) == len(units)
+        got = batch.wait()
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert g.flags == 0 and g.n_rows == w.n_rows, (rep, k)
+            assert np.array_equal(g.block.view(np.int32), w.block.view(np.int32)), (rep, k)
+    # one unit against the oracle: the batch is not merely self-consistent
+    exp = O.klt_tile(*_pairs_host(3), O.default_conf(maxCorners=1200))
+    f = got[3].to_frame()
+    np.testing.assert_array_equal(f["x0"].to_numpy(), exp["x0"] + 300)
+    np.testing.assert_array_equal(f["y0"].to_numpy(), exp["y0"] + 200)
+    np.testing.assert_array_equal(f["dx"].to_numpy(), exp["dx"])
+
+
+def _pairs_host(k):
+    mon_a, ref_a = synth.make_pair(1400, 1500, 0.5, 0.25, seed=11, nodata_wedge=True)
+    x, y, w, h = UNITS_A[k]
+    return mon_a[y:y + h, x:x + w], ref_a[y:y + h, x:x + w]
+
+
+def test_a_flagged_unit_of_a_batch_is_repeated_alone_and_the_sink_receives_every_block(ops):
+    import ctypes as C
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import DeviceBuffer
+    from karios_amd.stream import FrameStream
+    from karios_amd import frames
+    ctx, pa, pb, _ = _pairs(ops)
+    conf = KLTConfiguration(maxCorners=900)
+    units = [(pa, b, None) for b in UNITS_A[:4]]
+    with FrameStream(0.4, depth=1) as s:
+        want = []
+        for p, b, o in units:
+            want += s.submit(p, conf, b, o)
+        want += s.drain()
+    words = frames.block_words(conf.maxCorners, 1)
+    pitch = 4 * words + 64
+    sink = DeviceBuffer(ctx, pitch * len(units))
+    ctx.set_frame_sink(sink.ptr, pitch * len(units), pitch)
+    try:
+        with FrameStream(0.4, depth=1) as s:
+            got = s.submit_many(units, conf, tags=list("abcd")) + s.drain()
+            ctx.sync()
+            blocks = sink.download((len(units), pitch // 4), np.float32)
+            ctx.set_option("spec_flag", 32)
+            flagged = s.submit_many(units, conf) + s.drain()
+            ctx.set_option("spec_flag", 0)
+    finally:
+        ctx.set_option("spec_flag", 0)
+        ctx.set_frame_sink(None)
+    assert [d.tag for d in got] == list("abcd") and not any(d.redone for d in got)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g.raw.block.view(np.int32), w.raw.block.view(np.int32)), k
+        assert np.array_equal(blocks[k, :words].view(np.int32), w.raw.block.view(np.int32)), k     # the sink holds unit k's block at k * pitch
+        assert g.frame.equals(w.frame)
+    assert all(d.redone and d.flags & 32 for d in flagged)
+    for k, (g, w) in enumerate(zip(flagged, want)):
+        assert g.raw.flags == 0 and g.frame.equals(w.frame), k
+
+
+def test_klt_match_on_resident_rasters_goes_through_batched_tiles(ops, O):
+    """`KLT.match` (klt.py:198-234) on rasters that live in HBM: the tile grid - unequal edge tiles included - is one batched submission;
+    frames in x-outer / y-inner order, each equal to the oracle's tile."""
+    import torch
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.core.image import DeviceRasterImage
+    from karios_amd.matcher import KLT
+    dev = torch.device("cuda", 0)
+    mon_t, ref_t = synth.make_pair_torch(1300, 1700, 0.4, -0.2, seed=9, device=dev)
+    torch.cuda.synchronize()
+    conf = KLTConfiguration(tile_size=900, maxCorners=800, laplacian_kernel_size=5)
+    klt = KLT(conf)
+    frames_ = list(klt.match(DeviceRasterImage(mon_t, np.uint16), DeviceRasterImage(ref_t, np.uint16), None))
+    grid = klt.tile_boxes(1700, 1300)
+    assert [tuple(t) for t in grid] == [(0, 0, 900, 900), (0, 900, 900, 400), (900, 0, 800, 900), (900, 900, 800, 400)] and len(frames_) == 4
+    mon, ref = mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16)
+    oc = O.default_conf(maxCorners=800, laplacian_kernel_size=5, tile_size=900)
+    for t, f in zip(grid, frames_):
+        exp = O.klt_tile(mon[t.y_off:t.y_off + t.y_size, t.x_off:t.x_off + t.x_size], ref[t.y_off:t.y_off + t.y_size, t.x_off:t.x_off + t.x_size], oc,
+                         x_off=t.x_off, y_off=t.y_off)
+        for col in ("x0", "y0", "dx", "dy", "score"):
+            np.testing.assert_array_equal(f[col].to_numpy(), exp[col], err_msg=f"{tuple(t)} {col}")
+        assert list(f.columns) == ["x0", "y0", "dx", "dy", "score"] and f["x0"].dtype == np.float32
+
+
+def test_what_the_batch_form_does_not_cover_goes_one_by_one(ops):
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import submit_units
+    from karios_amd.stream import FrameStream
+    ctx, pa, pb, _ = _pairs(ops)
+    narrow = [(pa, (0, 0, 400, 600), None), (pa, (400, 0, 500, 600), None)]          # narrower than 512 columns
+    assert submit_units(narrow, KLTConfiguration(maxCorners=500)) is None
+    assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=0)) is None
+    assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=500, laplacian_kernel_size=9)) is None
+    conf = KLTConfiguration(maxCorners=500)
+    with FrameStream(None, depth=1) as s:
+        a = s.submit_many(narrow, conf) + s.drain()
+    with FrameStream(None, depth=1) as s:
+        b = []
+        for p, bx, o in narrow:
+            b += s.submit(p, conf, bx, o)
+        b += s.drain()
+    assert len(a) == 2 and all(x.frame.equals(y.frame) for x, y in zip(a, b))
