@@ -442,10 +442,12 @@ def in_flight(dev, conf, S, first_pair, n_ctx=3, pairs=60):
 
 
 # ---------------------------------------------------------------------------------------------------- config 4
-def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3):
+def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False):
     """4 bands x tile_size 5490 = 16 work units of 10980^2 pairs (seeds 20260101 + 10 b), split round-robin over the ranks;
-    every rank keeps only its units' regions (box + ZNCC halo) resident and deals them to `n_ctx_max` library contexts (units in
-    flight fill each other's latency-bound stretches); a step = all 16 units + ONE all-gather of their blocks."""
+    every rank keeps only its units' regions (box + ZNCC halo) resident; a step = all 16 units + ONE all-gather of their blocks.
+    `batched` (the object's value since round 5): a rank's units go through ONE batched submission (km_klt_units_frame_submit: one set of
+    device launches for all of them, blocks straight into the send buffer at its row pitch); else unit by unit on `n_ctx_max` library
+    contexts (units in flight fill each other's latency-bound stretches): the A/B in `contexts_in_flight_ab`."""
     import torch
     import torch.distributed as dist
     from karios_amd import synth
@@ -460,7 +462,7 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3):
     per_rank = (len(units) + world - 1) // world
     send = torch.zeros((per_rank, 1 + L), dtype=torch.float32, device=dev)
     send[:, 0] = -1
-    n_ctx = max(1, min(n_ctx_max, len(mine)))
+    n_ctx = 1 if batched else max(1, min(n_ctx_max, len(mine)))
     ctxs = [Context(dev.index or 0) for _ in range(n_ctx)]
     resident = []
     for b in sorted({u.band for u in mine}):
@@ -484,12 +486,33 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3):
     def sink(c, slot):
         c.set_frame_sink(None if slot is None else send[slot, 1:].data_ptr(), 0 if slot is None else L * 4)
 
+    from karios_amd.resident import submit_units
+
+    class _one:                                        # (a unit of a batch behaves like a submitted tile for the repeat below)
+        def __init__(self, batch, i):
+            self.batch, self.i = batch, i
+
+        def redo(self):
+            self.batch.wait()
+            return self.batch.redo(self.i)
+
     def step():
         pend = []
-        for slot, (u, pair, box) in enumerate(resident):
-            sink(pair.ctx, slot)
-            pend.append(pair.submit_tile(conf, box=box, zncc_threshold=0.4, origin=(u.x_off, u.y_off)))
-            sink(pair.ctx, None)
+        if batched and resident:
+            c0 = ctxs[0]
+            for lo in range(0, len(resident), 16):
+                chunk = resident[lo:lo + 16]
+                c0.set_frame_sink(send[lo, 1:].data_ptr(), (len(chunk) - 1) * (1 + L) * 4 + L * 4, (1 + L) * 4)
+                batch = submit_units([(pair, box, (u.x_off, u.y_off)) for u, pair, box in chunk], conf, 0.4)
+                c0.set_frame_sink(None)
+                if batch is None:
+                    raise SystemExit("config 4: the batch form refused the units")
+                pend += [_one(batch, i) for i in range(len(chunk))]
+        else:
+            for slot, (u, pair, box) in enumerate(resident):
+                sink(pair.ctx, slot)
+                pend.append(pair.submit_tile(conf, box=box, zncc_threshold=0.4, origin=(u.x_off, u.y_off)))
+                sink(pair.ctx, None)
         for c in ctxs:
             c.sync()
         # a unit outside the fixed capacities of the sync-free corner path comes back flagged (header word 2): exact repeat, into the
@@ -541,6 +564,7 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3):
                         "each rank holds only its units' regions (box + 128 px halo); one all-gather of the 16 frame blocks per step",
             "scaling": "strong", "n_gpus": world, "units": len(units), "units_gathered": got,
             "units_per_rank": [len(units_of_rank(units, r, world)) for r in range(world)], "contexts_in_flight_per_rank": n_ctx,
+            "submission": "batched: one km_klt_units_frame_submit per rank and step" if batched else f"unit by unit on {n_ctx} context(s)",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": 4 * S * S / 1e6 / (dt / steps), "unit": "Mpx/s",
             "matched_keypoints_per_step": rows, "matched_keypoints_per_sec": rows / (dt / steps), "units_repeated_exactly_on_this_rank": redone[0]}
 
@@ -1331,15 +1355,16 @@ def main():
         out.update(sensitivity_objects(ctx, dev, S, max(6, min(12, a.steps))))
         torch.cuda.empty_cache()
     if not a.no_config4 and S == 10980:
-        c4 = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)))
+        c4 = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)), batched=True)
         if solo:
-            # A/B of the one tuning choice of this workload: the rank's units on ONE library context against up to three
+            # A/B: the rank's units through ONE batched submission against unit by unit on one / three library contexts
             c4_one = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)), n_ctx_max=1)
-            c4["contexts_in_flight_ab"] = {"1": {"ms_per_step": c4_one["ms_per_step"], "units_repeated_exactly": c4_one["units_repeated_exactly_on_this_rank"]},
-                                           str(c4["contexts_in_flight_per_rank"]): {"ms_per_step": c4["ms_per_step"], "units_repeated_exactly": c4["units_repeated_exactly_on_this_rank"]},
-                                           "note": "same 16 units, same box, back to back; the object's value is the three-context run (round 4, with the frame "
-                                                   "sink's copy off the compute stream: 10.9 - 11.3 against 12.3 - 12.6 ms on one context; with the copy on the "
-                                                   "compute stream the order was the reverse, 13.6 - 13.8 against 12.7 - 13.3)"}
+            c4_three = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)), n_ctx_max=3)
+            c4["contexts_in_flight_ab"] = {"batched": {"ms_per_step": c4["ms_per_step"], "units_repeated_exactly": c4["units_repeated_exactly_on_this_rank"]},
+                                           "1": {"ms_per_step": c4_one["ms_per_step"], "units_repeated_exactly": c4_one["units_repeated_exactly_on_this_rank"]},
+                                           "3": {"ms_per_step": c4_three["ms_per_step"], "units_repeated_exactly": c4_three["units_repeated_exactly_on_this_rank"]},
+                                           "note": "same 16 units, same box, back to back; the object's value is the batched run (round 4: 10.8 ms per 16 units on "
+                                                   "three contexts, 12.2 on one)"}
         if rank == 0:
             out["config4"] = c4
     if solo and not a.no_cpu_baseline:      # reported baseline: rank 0 at N=1 only

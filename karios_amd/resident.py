@@ -215,7 +215,8 @@ def submit_units(units, conf, zncc_threshold=None, mutual_info: bool = False) ->
             if sink[0]:
                 c.set_frame_sink(None)
             try:
-                return pair.match_tile_raw(conf, box, zncc_threshold, origin=origin, mutual_info=mutual_info)
+                raw = pair.match_tile_raw(conf, box, zncc_threshold, origin=origin, mutual_info=mutual_info)
+                return RawFrame(raw.block.copy(), raw.cap, raw.with_zncc)      # (match_tile_raw's blocks rotate through a ring of three)
             finally:
                 c.set_option("speculative", before)
                 if sink[0]:
@@ -559,7 +560,8 @@ class ResidentPair:
             if sink[0]:
                 c.set_frame_sink(None)
             try:
-                return self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off), mutual_info=mutual_info)
+                raw = self.match_tile_raw(conf, box, zncc_threshold, origin=(x_off, y_off), mutual_info=mutual_info)
+                return RawFrame(raw.block.copy(), raw.cap, raw.with_zncc)      # (match_tile_raw's blocks rotate through a ring of three)
             finally:
                 c.set_option("speculative", before)
                 if sink[0]:
