@@ -545,12 +545,57 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(2):
-        rows, got = step()
+    # ---- batched mode: the steps are PIPELINED like the headline's (FrameStream): step k + 1 is submitted before step k is collected - its
+    # blocks arrive in the page-locked slot (header flags on the host: no read-back of the send buffer), flagged units are repeated,
+    # the step's send buffer (two alternate) is gathered.  The device never waits for the host between steps.
+    send2 = [send, send.clone()] if batched else None
+
+    def submit_step(k):
+        buf = send2[k % 2]
+        out = []
+        c0 = ctxs[0]
+        for lo in range(0, len(resident), 16):
+            chunk = resident[lo:lo + 16]
+            c0.set_frame_sink(buf[lo, 1:].data_ptr(), (len(chunk) - 1) * (1 + L) * 4 + L * 4, (1 + L) * 4)
+            batch = submit_units([(pair, box, (u.x_off, u.y_off)) for u, pair, box in chunk], conf, 0.4)
+            c0.set_frame_sink(None)
+            if batch is None:
+                raise SystemExit("config 4: the batch form refused the units")
+            out.append((lo, batch))
+        return out
+
+    def collect_step(k, batches):
+        buf = send2[k % 2]
+        for lo, batch in batches:
+            for i, raw in enumerate(batch.wait()):           # (the blocks have left the device: the sink's copy is ahead of the host slot's)
+                if raw.flags:
+                    raw = batch.redo(i)
+                    buf[lo + i, 1:1 + len(raw.block)] = torch.from_numpy(raw.block).to(dev)
+                    redone[0] += 1
+        blocks = gather_block_tensor(buf if coll_dev.type == "cuda" else buf.cpu(), len(units))
+        hdr = blocks[:, :3].contiguous().view(torch.int32).cpu()             # ONE read-back per step: rows, Ninit, flags of every unit
+        if int((hdr[:, 2] != 0).sum()):
+            raise SystemExit("config 4: a unit is still flagged after the exact repeat")
+        return int(hdr[:, 0].sum()), int((hdr[:, 1] != 0).sum())
+
+    def run(n):
+        if not batched:
+            r = (0, 0)
+            for _ in range(n):
+                r = step()
+            return r
+        prev, r = None, (0, 0)
+        for k in range(n):
+            cur = submit_step(k) if resident else []
+            if prev is not None:
+                r = collect_step(k - 1, prev)
+            prev = cur
+        return collect_step(n - 1, prev)
+
+    rows, got = run(2)
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        rows, got = step()
+    rows, got = run(steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -564,7 +609,8 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False):
                         "each rank holds only its units' regions (box + 128 px halo); one all-gather of the 16 frame blocks per step",
             "scaling": "strong", "n_gpus": world, "units": len(units), "units_gathered": got,
             "units_per_rank": [len(units_of_rank(units, r, world)) for r in range(world)], "contexts_in_flight_per_rank": n_ctx,
-            "submission": "batched: one km_klt_units_frame_submit per rank and step" if batched else f"unit by unit on {n_ctx} context(s)",
+            "submission": ("batched: one km_klt_units_frame_submit per rank and step, steps pipelined (step k + 1 submitted before step k is collected and gathered)"
+                           if batched else f"unit by unit on {n_ctx} context(s), a host synchronisation per step (round 4's loop)"),
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": 4 * S * S / 1e6 / (dt / steps), "unit": "Mpx/s",
             "matched_keypoints_per_step": rows, "matched_keypoints_per_sec": rows / (dt / steps), "units_repeated_exactly_on_this_rank": redone[0]}
 

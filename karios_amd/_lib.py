@@ -163,12 +163,15 @@ def load():
     global _lib
     with _lib_lock:
         if _lib is None:
-            if not os.path.exists(LIB_PATH):
+            # KARIOS_HIP_LIB: another build of the same library, e.g. the development build karios_amd/libkarios_hip_dev.so
+            # (make -C karios_amd/csrc DEV=1) for tools/ A-B measurements; the product loads the release library
+            path = os.environ.get("KARIOS_HIP_LIB") or LIB_PATH
+            if not os.path.exists(path):
                 raise KariosHipError(
-                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(karios_amd has no CPU fallback)")
             _preload_shared_hip_runtime()
-            lib = C.CDLL(LIB_PATH)
+            lib = C.CDLL(path)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args

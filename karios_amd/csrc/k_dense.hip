@@ -939,10 +939,8 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
         const T *r0 = img0 + (size_t)r * stride0, *r1 = img1 + (size_t)r * stride1;
         const unsigned lx = opaque_lane_offset(ugx_load * (unsigned)sizeof(T));   // byte offset of the lane's first column
         if (!LOAD0) {
-        } else if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic
-            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 4); }
-            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 8); }
-            else { uint4 q = *(const uint4 *)((const char *)r0 + lx); __builtin_memcpy(v[0], &q, 16); }
+        } else if (FAST) {   // uniform row base + unsigned 32-bit lane offset: no per-lane 64-bit address arithmetic; any row alignment
+            __builtin_memcpy(v[0], (const char *)r0 + lx, 4 * sizeof(T));
         } else if (vec0) {
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r0 + gx0); __builtin_memcpy(v[0], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r0 + gx0); __builtin_memcpy(v[0], &q, 8); }
@@ -953,9 +951,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
         }
         if (!LOAD1) {
         } else if (FAST) {
-            if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 4); }
-            else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 8); }
-            else { uint4 q = *(const uint4 *)((const char *)r1 + lx); __builtin_memcpy(v[1], &q, 16); }
+            __builtin_memcpy(v[1], (const char *)r1 + lx, 4 * sizeof(T));
         } else if (vec1) {
             if constexpr (sizeof(T) == 1) { uint32_t q = *(const uint32_t *)(r1 + gx0); __builtin_memcpy(v[1], &q, 4); }
             else if constexpr (sizeof(T) == 2) { uint2 q = *(const uint2 *)(r1 + gx0); __builtin_memcpy(v[1], &q, 8); }
@@ -1007,7 +1003,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                     };
                     const uint32_t mp = __builtin_amdgcn_perm(nz2(qm.y, qr.y), nz2(qm.x, qr.x), 0x06040200u);
                     cnt += (unsigned)__popc(mp);
-                    *(uint32_t *)((mask_out + (size_t)m * W) + opaque_lane_offset(ugx)) = mp;
+                    __builtin_memcpy((mask_out + (size_t)m * W) + opaque_lane_offset(ugx), &mp, 4);
                 }
             } else if constexpr (MASK && IMG != 1) {
                 if (m >= y0 && m < y1 && out_lane) {
@@ -1019,7 +1015,8 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                         cnt += ok;
                     }
                     const size_t o = (size_t)m * W + gx0;
-                    if (FAST || (gx0 + 3 < W && (o & 3) == 0)) *(uint32_t *)(mask_out + o) = mp;
+                    if (FAST) __builtin_memcpy(mask_out + o, &mp, 4);
+                    else if (gx0 + 3 < W && (o & 3) == 0) *(uint32_t *)(mask_out + o) = mp;
                     else {
                         for (int j = 0; j < 4 && gx0 + j < W; j++) mask_out[o + j] = (uint8_t)((mp >> (8 * j)) & 1u);
                     }
@@ -1071,7 +1068,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                         packed |= (uint32_t)min(max(acc, 0), 255) << (8 * o);
                     }
                     const size_t off = (size_t)y * W + gx0;
-                    if (FAST) *(uint32_t *)((outs[i] + (size_t)y * W) + opaque_lane_offset(ugx)) = packed;
+                    if (FAST) __builtin_memcpy((outs[i] + (size_t)y * W) + opaque_lane_offset(ugx), &packed, 4);
                     else if (gx0 + 3 < W && (off & 3) == 0) *(uint32_t *)(outs[i] + off) = packed;
                     else {
                         for (int j = 0; j < 4 && gx0 + j < W; j++) outs[i][off + j] = (uint8_t)(packed >> (8 * j));
@@ -1081,9 +1078,11 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
         }
     }
     };  // march
-    const bool fast = (W % 4 == 0) && (stride0 % 4 == 0) && (stride1 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0) &&
-                      ((uintptr_t)img1 % (4 * sizeof(T)) == 0) && ((uintptr_t)out0 % 4 == 0) && ((uintptr_t)out1 % 4 == 0) &&
-                      (!MASK || (uintptr_t)mask_out % 4 == 0);   // wave-uniform
+    // FAST: every lane of the item either lies inside the image with its 4 columns or is a whole-lane mirror of its in-image neighbour
+    // (wave-uniform).  Rows need no alignment - loads and stores are 4-column accesses at whatever address the row has (a 5490-column
+    // tile: every other row sits off the dword grid; the per-pixel path there cost 1.75x).  Only a width that is no multiple of 4 sends
+    // the strips that reach the right border through the general path (their border lane straddles the edge).
+    const bool fast = (W % 4 == 0) || (strip * LAPM_VALID - 4 + 4 * 64 <= W);
     if constexpr (SPLIT) {
         if (img_sel == 0) { if (fast) march(std::true_type{}, std::integral_constant<int, 0>{}); else march(std::false_type{}, std::integral_constant<int, 0>{}); }
         else { if (fast) march(std::true_type{}, std::integral_constant<int, 1>{}); else march(std::false_type{}, std::integral_constant<int, 1>{}); }
@@ -1255,6 +1254,7 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
             if (cost < best) { best = cost; rows = r; }
         }
     }
+    if (const char *e = km_dev_env("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     A.rows = rows;
     A.item0[0] = 0;
     for (int u = 0; u < U.n; u++) A.item0[u + 1] = A.item0[u] + A.nstrips[u] * ((U.H[u] + rows - 1) / rows);
@@ -1890,12 +1890,13 @@ __device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, ui
     const int y0 = blockIdx.y * PYR_RS, y1 = min(dh, y0 + PYR_RS);
     if (y0 >= dh) return;
     const int sx0 = 8 * q - 4;                                  // first source byte loaded
-    const bool fast = (W % 4 == 0) && ((uintptr_t)src % 4 == 0) && sx0 >= 0 && sx0 + 16 <= W;
+    // interior threads: one 16-byte load per source row at whatever alignment the row has (a level of odd width - 5490 -> 2745 - puts three
+    // rows in four off the dword grid; per-byte loads there made the kernel five times slower: the hardware reads unaligned just as well)
+    const bool fast = sx0 >= 0 && sx0 + 16 <= W;
     auto load_row = [&](int sy, uint32_t (&w)[4]) {
         const uint8_t *row = src + (size_t)km_reflect101(sy, H) * W;
         if (fast) {
-            const uint32_t *p = (const uint32_t *)(row + sx0);
-            w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+            __builtin_memcpy(w, row + sx0, 16);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1926,7 +1927,7 @@ __device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, ui
         }
         const int ox = 4 * q;
         const size_t o = (size_t)y * dw + ox;
-        if (ox + 3 < dw && (((uintptr_t)dst + o) & 3) == 0) *(uint32_t *)(dst + o) = packed;
+        if (ox + 3 < dw) __builtin_memcpy(dst + o, &packed, 4);          // (one dword store, aligned or not)
         else {
             for (int j = 0; j < 4 && ox + j < dw; j++) dst[o + j] = (uint8_t)(packed >> (8 * j));
         }

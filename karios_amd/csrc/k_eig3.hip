@@ -529,6 +529,7 @@ int launch_eig3_units(km_ctx *c, km_units &U, double scale2, double quality)
             if (cost < best) { best = cost; rows3 = r; }
         }
     }
+    if (const char *e = km_dev_env("KARIOS_HIP_EIG3_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows3 = v; }   // tuning override
     A.rows3 = rows3;
     A.item0[0] = 0;
     for (int u = 0; u < U.n; u++) A.item0[u + 1] = A.item0[u] + A.n_border[u] + A.nstrips[u] * ((U.H[u] - 2 + rows3 - 1) / rows3);

@@ -29,6 +29,7 @@ struct lk_args {
     const float *pts_in;
     const int *d_n;
     int n_max, win, max_count, backward;
+    int general_templates;   // (development build, KARIOS_HIP_LK_GENERAL: every template through the general two-row form - A/B of the degenerate-weight forms)
     double epsilon;
     float *p1, *p0r;
     int *left_band;   // row-band mode: raised when a point's window needs rows outside the resident band
@@ -461,7 +462,7 @@ __device__ __forceinline__ int lk_dot2_k(lk_s2 a, lk_s2 b, int k)
 
 template <int NR, int WIN, int MAXIT>
 __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
-                                const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], float &outx, float &outy)
+                                const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], float &outx, float &outy, int general_templates)
 {
     const int win = geo.win;
     const float half = (float)(win - 1) * 0.5f;
@@ -501,7 +502,15 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
         const bool need_mask = !(ipx >= 0 && ipy >= 0 && ipx + win <= IW - 1 && ipy + win <= IH - 1);
         uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
         int sA11 = 0, sA12 = 0, sA22 = 0;
-        {
+        // The bilinear weights of the TEMPLATE are often degenerate: a key point of the forward pass is an integer position (a corner
+        // of goodFeaturesToTrack) and winSize is odd, so at level 0 the weights are exactly (16384, 0, 0, 0) and at level 1 multiples of
+        // 4096 - I = 32 p, Ix / Iy = the Scharr values themselves, CV_DESCALE changes nothing.  MODE 2 (w01 = w10 =
+        // w11 = 0): no interpolation at all, one bilinear row; MODE 1 (w10 = w11 = 0): one bilinear row, horizontal interpolation only;
+        // MODE 0: the general two-row form (the backward pass, whose start positions are the forward pass's sub-pixel results).  The
+        // values are the general form's bit for bit: a zero weight contributes a zero to an exact integer sum.
+        auto build_templates = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr int ROWS = MODE == 0 ? 4 : 3, ND = MODE == 0 ? 2 : 1;
             const lk_s2 wt0 = lk_as_s2(lk_pack16(w00, w01)), wt1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
             const uint8_t *xb = X + (ty - 1) * PP + (tx - 1);
 #pragma unroll
@@ -513,17 +522,18 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                 const uint8_t *pr = xb + y * PP + x0;
                 uint2 R[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) __builtin_memcpy(&R[k], pr + k * PP, 8);
+                for (int k = 0; k < ROWS; k++) __builtin_memcpy(&R[k], pr + k * PP, 8);
+                if constexpr (ROWS == 3) R[3] = R[2];
                 // columns as 16-bit pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7)
                 lk_us2 E[4][4];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int k = 0; k < ROWS; k++)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         E[k][j] = lk_as_us2(__builtin_amdgcn_perm(R[k].y, R[k].x, 0x0c000c00u | (uint32_t)(2 * j) | ((uint32_t)(2 * j + 1) << 16)));
                 uint32_t gx[2][3], gy[2][3];      // derivative pairs of the two bilinear rows: positions (0,1) (2,3) (4,5)
 #pragma unroll
-                for (int d = 0; d < 2; d++) {
+                for (int d = 0; d < ND; d++) {
                     lk_us2 S[4], V[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -540,7 +550,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                 if (need_mask) {
                     const int gy0 = ipy + y, gx0 = ipx + x0;
 #pragma unroll
-                    for (int d = 0; d < 2; d++) {
+                    for (int d = 0; d < ND; d++) {
                         const uint32_t mrow = (unsigned)(gy0 + d) < (unsigned)IH ? 0xffffffffu : 0u;
 #pragma unroll
                         for (int q = 0; q < 3; q++) {
@@ -550,19 +560,41 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                         }
                     }
                 }
+                if constexpr (MODE == 2) {
+                    // weights (16384, 0, 0, 0): I = 32 p (bytes 1 .. 6 of patch row y), Ix / Iy = the Scharr pairs as they are
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const uint32_t pm = n >= 2 * q + 2 ? 0xffffffffu : (n == 2 * q + 1 ? 0x0000ffffu : 0u);
+                        const uint32_t pp2 = __builtin_amdgcn_perm(R[1].y, R[1].x, 0x0c000c00u | (uint32_t)(2 * q + 1) | ((uint32_t)(2 * q + 2) << 16));
+                        IvP[t][q] = (pp2 << 5) & pm;                    // (two values <= 255: the shift does not cross the halves)
+                        IxP[t][q] = gx[0][q] & pm;
+                        IyP[t][q] = gy[0][q] & pm;
+                        sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
+                        sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
+                        sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
+                    }
+                } else {
                 int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
                 iv[LK_RUN] = 0; ixv[LK_RUN] = 0; iyv[LK_RUN] = 0;
 #pragma unroll
                 for (int k = 0; k < LK_RUN; k++) {
                     // intensities: bytes k+1, k+2 of patch rows y, y+1
                     const uint32_t sel = 0x0c000c00u | (uint32_t)(k + 1) | ((uint32_t)(k + 2) << 16);
-                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(R[1].y, R[1].x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(R[2].y, R[2].x, sel));
-                    iv[k] = __builtin_amdgcn_sdot2(c0, wt0, lk_dot2_k(c1, wt1, k_half9), false) >> (14 - 5);
+                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(R[1].y, R[1].x, sel));
                     auto pair = [&](const uint32_t (&g)[3]) -> lk_s2 {
                         return lk_as_s2((k & 1) ? __builtin_amdgcn_alignbyte(g[(k + 1) / 2], g[k / 2], 2) : g[k / 2]);
                     };
-                    ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, lk_dot2_k(pair(gx[1]), wt1, k_half14), false) >> 14;
-                    iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, lk_dot2_k(pair(gy[1]), wt1, k_half14), false) >> 14;
+                    if constexpr (MODE == 1) {
+                        // (the compiler's own dot: its result is read by a shift, and a DOT result behind inline assembly gets no hazard padding)
+                        iv[k] = __builtin_amdgcn_sdot2(c0, wt0, k_half9, false) >> (14 - 5);
+                        ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, k_half14, false) >> 14;
+                        iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, k_half14, false) >> 14;
+                    } else {
+                        const lk_s2 c1 = lk_as_s2(__builtin_amdgcn_perm(R[2].y, R[2].x, sel));
+                        iv[k] = __builtin_amdgcn_sdot2(c0, wt0, lk_dot2_k(c1, wt1, k_half9), false) >> (14 - 5);
+                        ixv[k] = __builtin_amdgcn_sdot2(pair(gx[0]), wt0, lk_dot2_k(pair(gx[1]), wt1, k_half14), false) >> 14;
+                        iyv[k] = __builtin_amdgcn_sdot2(pair(gy[0]), wt0, lk_dot2_k(pair(gy[1]), wt1, k_half14), false) >> 14;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -574,7 +606,15 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                     sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
                     sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
                 }
+                }
             }
+        };
+        {
+            // (wave-uniform: every lane holds the key point's scalars; readfirstlane makes the branch a scalar one)
+            const int z01 = __builtin_amdgcn_readfirstlane(w01), z1 = __builtin_amdgcn_readfirstlane(w10 | w11) | general_templates;
+            if (z1 == 0 && z01 == 0) build_templates(std::integral_constant<int, 2>{});
+            else if (z1 == 0) build_templates(std::integral_constant<int, 1>{});
+            else build_templates(std::integral_constant<int, 0>{});
         }
         const long long iA11 = wave_sum_split(sA11), iA12 = wave_sum_split(sA12), iA22 = wave_sum_split(sA22);
         const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
@@ -696,11 +736,11 @@ __device__ __forceinline__ void lk2_body(const lk_args &g, const int *__restrict
     }
     LK_WAVE_SYNC();
     float fx, fy;
-    lk2_track_point<NR, WIN, MAXIT>(g.A, g.B, pA, pB, oA, oB, px, py, geo, g.max_count, g.epsilon, run_desc, fx, fy);
+    lk2_track_point<NR, WIN, MAXIT>(g.A, g.B, pA, pB, oA, oB, px, py, geo, g.max_count, g.epsilon, run_desc, fx, fy, g.general_templates);
     if ((threadIdx.x & 63) == 0) { g.p1[2 * p] = fx; g.p1[2 * p + 1] = fy; }
     if (g.backward) {
         float rx, ry;
-        lk2_track_point<NR, WIN, MAXIT>(g.B, g.A, pB, pA, oB, oA, fx, fy, geo, g.max_count, g.epsilon, run_desc, rx, ry);
+        lk2_track_point<NR, WIN, MAXIT>(g.B, g.A, pB, pA, oB, oA, fx, fy, geo, g.max_count, g.epsilon, run_desc, rx, ry, g.general_templates);
         if ((threadIdx.x & 63) == 0) { g.p0r[2 * p] = rx; g.p0r[2 * p + 1] = ry; }
     }
 }
@@ -758,6 +798,7 @@ int kl_units_prepare(km_ctx *c, const km_units &U, int n_max, int win, int max_c
         g.A = U.A[u]; g.B = U.B[u]; g.pts_in = U.p0[u]; g.d_n = &U.sc[u]->n_corners; g.n_max = n_max; g.win = win;
         g.max_count = max_count < 0 ? 0 : max_count > 100 ? 100 : max_count;
         g.backward = 1; g.epsilon = e * e; g.p1 = U.p1[u]; g.p0r = U.p0r[u]; g.left_band = nullptr;
+        g.general_templates = km_dev_env("KARIOS_HIP_LK_GENERAL") ? 1 : 0;
     }
     lk_args *table = (lk_args *)km_ws(c, WS_UNITS_LK, sizeof(lk_args) * KM_UNITS_MAX);
     if (!table) return KM_E_NOMEM;
@@ -794,6 +835,7 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
     g.A = A; g.B = B; g.pts_in = d_pts_in; g.d_n = d_n; g.n_max = n_max; g.win = win;
     g.max_count = max_count < 0 ? 0 : max_count > 100 ? 100 : max_count;
     g.backward = backward_too ? 1 : 0;
+    g.general_templates = km_dev_env("KARIOS_HIP_LK_GENERAL") ? 1 : 0;
     double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
     g.epsilon = e * e;
     g.p1 = d_p1; g.p0r = d_p0r; g.left_band = d_left_band;
