@@ -836,8 +836,7 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
 
     with FrameStream(0.4, depth=2, want_spans=True) as stream:
         for _ in range(4):
-            for b in boxes:
-                take(stream.submit(pair, conf, b))
+            take(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
         take(stream.drain())
         ctx.sync()
         windows = []
@@ -846,8 +845,7 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
                 acc[k] = 0
             t0 = time.perf_counter()
             for _ in range(steps):
-                for b in boxes:
-                    take(stream.submit(pair, conf, b))
+                take(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
             take(stream.drain())
             ctx.sync()
             windows.append((time.perf_counter() - t0) / steps)
@@ -866,12 +864,11 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
                         spans[k] = spans.get(k, 0.0) + v
 
         for _ in range(4):
-            for b in boxes:
-                take_spans(stream.submit(pair, conf, b))
+            take_spans(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
         take_spans(stream.drain())
         ctx.set_profiling(False)
     dt = sorted(windows)[1]
-    per_pair = max(1, n // len(boxes))
+    per_pair = max(1, n)           # (a batched submission reports ONE set of spans for all its units)
     stage = {k: round(v / per_pair, 4) for k, v in spans.items() if v > 0}
     units = max(1, keep["units"])
     return {"ms_per_pair": dt * 1e3, "windows_ms_per_pair": [round(w * 1e3, 4) for w in windows], "Mpx_per_s": S * S / 1e6 / dt,
@@ -952,7 +949,8 @@ def sensitivity_objects(ctx, dev, S, steps):
     o["with_zncc_through_framestream"] = {k: st_e[k] for k in ("ms_per_pair", "windows_ms_per_pair", "stage_ms", "lk_span_ms", "selection_span_ms",
                                                                "units_repeated_exactly", "speculative_flags_seen", "forward_backward_survival",
                                                                "corners_per_pair", "matched_keypoints_per_pair")}
-    o["with_zncc_through_framestream"]["stage_ms_note"] = "spans summed over the four tiles of a pair"
+    o["with_zncc_through_framestream"]["stage_ms_note"] = ("the four tiles of a pair as ONE batched submission (FrameStream.submit_many -> km_klt_units_frame_submit), "
+                                                           "pairs pipelined (depth 2), ZNCC of the confident rows included; spans of the batch")
     t = grid[-1]                                                        # the smallest tile, whole: 4980 x 4980
     o["gate"] = _band_gate(O, pair, mon_t, ref_t, conf_e, t.y_off, t.y_size, t.x_off, t.x_size, with_iters=False, same_as=frames[-1])
     o["gate"]["passed"] = bool(o["gate"]["passed"] and o["gate"]["frame_of_klt_match_identical"] and len(frames) == len(grid))
@@ -1273,6 +1271,7 @@ def main():
         ex.finish()                    # (everything issued so far is accounted for ...)
         ex.reset_counts()              # ... and the counters restart with the timed region
     fence()
+    cpu0 = (time.thread_time(), stream.worker_cpu_s, time.process_time())
     t0 = time.perf_counter()
     marks = [t0]
     for _ in range(a.steps):
@@ -1295,6 +1294,12 @@ def main():
                     "steps_exchanged": a.steps}
     fence()
     dt = time.perf_counter() - t0
+    # host CPU a rank spends per step: the submitting thread (library calls, exchange enqueues, collecting frames),
+    # the stream's worker thread (block -> DataFrame), and the whole process (copy pool, runtime threads): eight ranks' worth must fit
+    # the box's CPU quota (this pool grants 16 CPUs) or the host becomes the 8-GPU bottleneck before xGMI does
+    host_cpu = {"submit_thread_ms_per_step": round((time.thread_time() - cpu0[0]) / a.steps * 1e3, 4),
+                "worker_thread_ms_per_step": round((stream.worker_cpu_s - cpu0[1]) / a.steps * 1e3, 4),
+                "process_ms_per_step": round((time.process_time() - cpu0[2]) / a.steps * 1e3, 4)}
     gc.enable()
     # (where the region's time went, step by step: `value` is the whole region; a single slow step - another tenant of the host, a
     # page fault - shows here as max >> median instead of hiding in the mean)
@@ -1332,6 +1337,17 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
     mpx_per_s = world * S * S / 1e6 / (dt / a.steps)
+    host_cpu_ranks = [host_cpu["process_ms_per_step"]]
+    if world > 1:
+        mine_cpu = torch.tensor([host_cpu["process_ms_per_step"]], device=coll_dev, dtype=torch.float64)
+        all_cpu = torch.empty(world, device=coll_dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(all_cpu, mine_cpu)
+        host_cpu_ranks = [round(float(v), 4) for v in all_cpu.tolist()]
+    host_cpu["process_ms_per_step_per_rank"] = host_cpu_ranks
+    host_cpu["cpus_this_process_may_use"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    host_cpu["note"] = ("time.thread_time / time.process_time over the timed steps; process = every thread of the rank (submit, FrameStream worker, the "
+                        "library's copy pool, runtime threads).  Sum over the ranks / ms_per_step = CPUs the job keeps busy")
+    host_cpu["cpus_busy_all_ranks"] = round(sum(host_cpu_ranks) / ms_per_step, 3)
     stats = ctx.stats()
     mm_early = bool(int(stats.path_flags) & 32)      # KM_PATH_MM_EARLY: the last unit's min / max ran beside its predecessor's LK
     stats.n_init = totals["n_init"]       # asynchronous submissions: the count travels in the frame block's header
@@ -1358,6 +1374,7 @@ def main():
             "world": world, "launcher": os.environ.get("KARIOS_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "single process"),
             "backend": (backend if (world > 1 or force_exchange) else None), "rccl_ranks_seen": ranks_seen, "devices": devices, "exchange": exchange,
             "matched_keypoints_per_sec": n_kp_total / dt,
+            "host_cpu_ms_per_step": host_cpu,
             "matched_keypoints_per_pair": (0 if frame is None else len(frame)),
             "n_init": int(stats.n_init), "n_candidates": n_cand,
             "speculative_tiles_redone": int(redone_timed),

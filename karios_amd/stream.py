@@ -91,6 +91,7 @@ class FrameStream:
             _gil_interval_acquire(gil_switch_interval)
             self._holds_interval = True
         self.units_redone = 0
+        self.worker_cpu_s = 0.0        # CPU time of the worker thread's host halves (time.thread_time): what a rank's frames cost its host
 
     # ------------------------------------------------------------------ context manager
     def __enter__(self):
@@ -117,6 +118,14 @@ class FrameStream:
     # ------------------------------------------------------------------ the two halves
     def _host_half(self, pair: ResidentPair, pend):
         """Worker thread: touches the frame slot (km_frame_wait) and numpy / pandas only."""
+        import time
+        t_cpu = time.thread_time()
+        try:
+            return self._host_half_body(pair, pend)
+        finally:
+            self.worker_cpu_s += time.thread_time() - t_cpu
+
+    def _host_half_body(self, pair: ResidentPair, pend):
         raw = pend.wait() if isinstance(pend, PendingFrame) else pend
         spans = pend.stage_ms() if self.want_spans and isinstance(pend, PendingFrame) else {}
         frame = None
@@ -128,6 +137,14 @@ class FrameStream:
 
     def _batch_host_half(self, pairs, pend: PendingBatch):
         """Worker thread, batched submission: the units' blocks arrive together."""
+        import time
+        t_cpu = time.thread_time()
+        try:
+            return self._batch_host_half_body(pairs, pend)
+        finally:
+            self.worker_cpu_s += time.thread_time() - t_cpu
+
+    def _batch_host_half_body(self, pairs, pend: PendingBatch):
         raws = pend.wait()
         spans = pend.stage_ms() if self.want_spans else {}
         out = []

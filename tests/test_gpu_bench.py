@@ -34,6 +34,21 @@ def test_bench_gpus_2_launches_two_ranks_and_gathers_sixteen_units():
     assert line["cpu_baseline"] is None and "in_flight" not in line and "config3" not in line     # rank-0, N = 1 legs only
 
 
+def test_bench_gpus_8_shares_the_gpu_between_eight_ranks_two_units_each():
+    """the launch an 8-GPU node would see - eight ranks, ports, the rendezvous, config 4's sixteen units dealt two per
+    rank and gathered, no rank starved - with the ranks time-slicing the one GPU a builder has (gloo collectives: RCCL wants a device
+    per rank).  What it cannot show is xGMI; what it does show is that eight ranks' worth of host work fits the box."""
+    line = _bench(["--gpus", "8", "--share-gpu", "--steps", "4", "--warmup", "1", "--no-sensitivity"], timeout=1500)
+    assert line["n_gpus"] == 8 and line["world"] == 8 and line["rccl_ranks_seen"] == 8 and line["backend"] == "gloo"
+    assert sorted(d["rank"] for d in line["devices"]) == list(range(8))
+    assert line["config"]["pairs_per_step"] == 8
+    c4 = line["config4"]
+    assert c4["n_gpus"] == 8 and c4["units"] == 16 and c4["units_gathered"] == 16 and c4["units_per_rank"] == [2] * 8
+    assert c4["matched_keypoints_per_step"] > 16 * 10000
+    cpu = line["host_cpu_ms_per_step"]
+    assert len(cpu["process_ms_per_step_per_rank"]) == 8 and all(v > 0 for v in cpu["process_ms_per_step_per_rank"])       # every rank worked
+
+
 def test_bench_default_line_carries_config3_in_flight_and_labels_precomputed_parts():
     line = _bench(["--steps", "6", "--warmup", "2", "--cpu-runs", "1"])
     assert line["n_gpus"] == 1 and line["launcher"] == "single process"
@@ -43,7 +58,11 @@ def test_bench_default_line_carries_config3_in_flight_and_labels_precomputed_par
     fs = line["full_scoring"]       # the whole scoring of _handle_klt_results in the tile call, gated against the oracle on every row
     assert fs["parity"]["passed"] is True and fs["parity"]["rows"] == fs["matched_keypoints_per_pair"] > 10000
     assert {"zncc_score", "mutual_info_score", "mi_score"} <= set(fs["columns"]) and fs["roofline"]["frac"] > 0
-    assert set(line["config4"]["contexts_in_flight_ab"]) >= {"1", "3"}
+    assert set(line["config4"]["contexts_in_flight_ab"]) >= {"1", "3", "batched"}
+    for key in ("hard_content", "tie_heavy", "e2e_shape"):          # the step on content that is not the best case, gated inside the run
+        assert line[key]["gate"]["passed"] is True and line[key]["gate"]["keypoints_identical_and_in_order"] is True, key
+    assert 0.4 <= line["hard_content"]["forward_backward_survival"] <= 0.6
+    assert line["e2e_shape"]["tiles"] == 4 and line["host_cpu_ms_per_step"]["process_ms_per_step"] > 0
     g = line["config3"]["gate"]
     assert g["passed"] is True and g["gpu_crop_row_col"] == g["oracle_crop_row_col"]
     assert line["config3"]["detected_offset_row_col"] == [-21.0, 37.0]
