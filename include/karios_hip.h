@@ -146,6 +146,8 @@ int km_set_option(km_ctx *ctx, const char *name, int value);
 /* 1: development build (make -C karios_amd/csrc DEV=1): km_set_option additionally accepts A/B switches of settled choices and the
  * library reads KARIOS_HIP_* tuning variables; 0: release build (the default; what __graft_entry__.build() produces) */
 int km_is_dev_build(void);
+/* development build only (KM_E_UNSUPPORTED otherwise): counters of the "eig3_count" option after a blocking tile call */
+int km_dev_counters(km_ctx *ctx, unsigned long long out[2]);
 /* stage times (ms) of the last pipeline call; names via km_stage_name(i) */
 int km_get_stage_ms(km_ctx *ctx, float *out, int cap, int *n);
 const char *km_stage_name(int i);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "km_set_profiling": (_i, [_vp, _i]),
     "km_set_option": (_i, [_vp, C.c_char_p, _i]),
     "km_is_dev_build": (_i, []),
+    "km_dev_counters": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "km_get_stage_ms": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
     "km_stage_name": (C.c_char_p, [_i]),
     "km_get_klt_stats": (_i, [_vp, C.POINTER(KltStats)]),

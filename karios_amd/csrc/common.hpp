@@ -123,6 +123,9 @@ struct km_scalars {
     unsigned int bin_off[KM_TK_NB]; // k_select2.hip: first slot of every value bin in the kept list
     unsigned int bin_cur[KM_TK_NB]; //                fill cursors of the bins
     unsigned int tie_rows;         // k_eig3.hip: (wavefront, row) steps that took the per-pixel emission path (a lane held two candidates)
+    unsigned int pad1;
+    unsigned long long skip_total; // development build, "eig3_count": (wavefront, row, pixel slot) triples of the fused 8-px eigenvalue pass ...
+    unsigned long long skip_hit;   //   ... of which every lane satisfies min(S_xx, S_yy) scale^2 <= the running lower bound of the threshold
 };
 #define KM_FLAG_SHARD_OVERFLOW 1u   // a key-buffer shard overflowed
 #define KM_FLAG_STAGE_OVERFLOW 2u   // the fused kernel's per-wave key stage overflowed (plateau image)

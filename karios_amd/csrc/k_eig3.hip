@@ -89,7 +89,7 @@ template <int BLOCK>
 __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, double scale2,
                                           unsigned *__restrict__ max_partial, double quality, km_scalars *sc, unsigned long long *__restrict__ keys,
                                           size_t cap, unsigned stage_cap, int wave_id, int xs, int col_lo, int col_hi, int ye0, int ye1,
-                                          unsigned long long *st /* [EIG3_STAGE + 64] */)
+                                          unsigned long long *st /* [EIG3_STAGE + 64] */, int count_skips = 0)
 {
     constexpr int L = BLOCK / 2, Rr = BLOCK - 1 - L;
     static_assert(L <= 7 && Rr <= 7, "the box window must stay within the two neighbouring lanes");
@@ -222,6 +222,9 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
 
     float best = -INFINITY;
     unsigned tie_rows = 0u;                           // (wave-uniform: a scalar register)
+#ifdef KM_DEV
+    unsigned skip_total = 0u, skip_hit = 0u;          // "eig3_count" (VERDICT r4 item 5): how often could the eigenvalue formula be skipped?
+#endif
     // ---- candidate staging and the running threshold (as in eig2_item)
     unsigned cnt = 0;
     const unsigned shard = (unsigned)wave_id % KM_NSHARD;
@@ -284,6 +287,19 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
                             "+v"(V[1][0]), "+v"(V[1][1]), "+v"(V[1][2]), "+v"(V[1][3]), "+v"(V[1][4]), "+v"(V[1][5]), "+v"(V[1][6]), "+v"(V[1][7]),
                             "+v"(V[2][0]), "+v"(V[2][1]), "+v"(V[2][2]), "+v"(V[2][3]), "+v"(V[2][4]), "+v"(V[2][5]), "+v"(V[2][6]), "+v"(V[2][7]));
             // (a pixel's eigenvalue is formed as soon as its three window sums exist: the 24 sums of a row never coexist)
+#ifdef KM_DEV
+            if (count_skips) {
+                // lambda_min <= min(c_xx, c_yy) = min(S_xx, S_yy) scale^2: when that bound is <= the running lower bound of the threshold
+                // for ALL 64 lanes, TOZERO zeroes the pixel slot whatever the formula returns (the bound only rises): the fp64-scaled,
+                // individually rounded formula with its correctly rounded sqrt (44 % of the kernel's instructions) could be skipped
+                windows([&](auto pt, int sxx, int sxy, int syy) {
+                    E[C][decltype(pt)::value] = lambda_min(sxx, sxy, syy);
+                    const float bound = (float)__dmul_rn((double)min(sxx, syy), scale2);
+                    skip_total++;
+                    skip_hit += __ballot(!(bound <= thr_run)) == 0ull ? 1u : 0u;
+                });
+            } else
+#endif
             windows([&](auto pt, int sxx, int sxy, int syy) { E[C][decltype(pt)::value] = lambda_min(sxx, sxy, syy); });
         }
         if (cand) {
@@ -422,6 +438,9 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
     for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
     if (lane == 0) max_partial[wave_id] = key;
     if (lane == 0 && tie_rows) atomicAdd(&sc->tie_rows, tie_rows);   // (diagnostics: km_klt_stats.tie_rows)
+#ifdef KM_DEV
+    if (lane == 0 && count_skips) { atomicAdd(&sc->skip_total, (unsigned long long)skip_total); atomicAdd(&sc->skip_hit, (unsigned long long)skip_hit); }
+#endif
 }
 
 // items [0, n_border): eig2_item on the two border strips (left: columns 0 .. MARGIN-1, right: W-MARGIN .. W-1), rows2 rows each;
@@ -430,7 +449,7 @@ template <int BLOCK>
 __global__ __launch_bounds__(256, 3) void eig3_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ mask, int H, int W, double scale2,
                                                    unsigned *__restrict__ max_partial, int n_border, int rows2, int nstrips, int rows3, int nitems,
                                                    double quality, km_scalars *sc, unsigned long long *__restrict__ keys, size_t cap, unsigned stage_cap2,
-                                                   unsigned stage_cap3)
+                                                   unsigned stage_cap3, int count_skips)
 {
     __shared__ int xs_scratch[4][3][128];
     __shared__ unsigned long long stage[4][EIG3_STAGE + 64];
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256, 3) void eig3_kernel(const uint8_t *__restrict_
     const int xs = min(strip * EIG3_STRIDE, W - 512);
     const int col_lo = EIG3_MARGIN + strip * EIG3_STRIDE, col_hi = min(col_lo + EIG3_STRIDE, W - EIG3_MARGIN);
     const int ye0 = rowblock * rows3, ye1 = min(H - 1, ye0 + rows3 + 1);
-    eig3_item<BLOCK>(src, mask, H, W, scale2, max_partial, quality, sc, keys, cap, stage_cap3, wave_id, xs, col_lo, col_hi, ye0, ye1, stage[wv]);
+    eig3_item<BLOCK>(src, mask, H, W, scale2, max_partial, quality, sc, keys, cap, stage_cap3, wave_id, xs, col_lo, col_hi, ye0, ye1, stage[wv], count_skips);
 }
 
 // batched units: one linear item space over the units (unit u owns [item0[u], item0[u + 1]): its border items first, then its strips,
@@ -582,7 +601,7 @@ int launch_eig3(km_ctx *c, const uint8_t *d_src, const uint8_t *d_mask, int H, i
     const unsigned cap2 = c->opt_stage_cap > 0 && c->opt_stage_cap < EIG2_STAGE ? (unsigned)c->opt_stage_cap : (unsigned)EIG2_STAGE;
     const unsigned cap3 = c->opt_stage_cap > 0 && c->opt_stage_cap < EIG3_STAGE ? (unsigned)c->opt_stage_cap : (unsigned)EIG3_STAGE;
     eig3_kernel<BLOCK><<<km_xcd_grid(ntiles), 256, 0, c->stream>>>(d_src, d_mask, H, W, scale2, partial, n_border, rows2, nstrips, rows3, nitems, quality, sc,
-                                                                   d_keys, cap, cap2, cap3);
+                                                                   d_keys, cap, cap2, cap3, c->opt_eig3_count ? 1 : 0);
     KM_LAUNCH_CHECK(c);
     if (c->eig_defer_max) {          // speculative corner path: kf_rank's first launch takes the maximum of the partials itself
         c->eig_partial = partial; c->eig_npartial = ntiles * 4;
