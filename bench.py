@@ -689,9 +689,14 @@ def config3_object(ctx, dev, S, steps, warmup, with_gate=True):
         finally:
             ctx.set_option("phase_fp64", 0)
         a64 = PHASE_BYTES_PER_PX_F64 * S * S
+        step64_ms = dt / steps * 1e3 - phase_ms + ms64
         out["phase_fp64"] = {"ms": round(ms64, 3), "path": "float64 hand-written FFT" if p64 == 2 else "?", "detected_offset_row_col": [float(off64[0]), float(off64[1])],
                              "equals_float32_path": bool(np.array_equal(off64, off)), "algorithmic_bytes": a64,
-                             "roofline_frac": a64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "roofline_frac": a64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             # the figure to quote beside the reference (large_offset.py:39 computes in complex128): the same step with the
+                             # float32 correlation's time replaced by the complex128 one's
+                             "config3_ms_per_step_at_reference_precision": round(step64_ms, 3),
+                             "config3_value_at_reference_precision_Mpx_s": round(S * S / 1e6 / (step64_ms * 1e-3), 1)}
     if with_gate:
         # gate: the detected offset equals the generator's truth, and - on a 1098^2 crop of the SAME pair, small enough for the
         # fp64 numpy oracle - the GPU's answer equals the oracle's

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   mkdir -p $out/$name
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$name -o p -- python3 $script $ARGS > $out/$name/run.log 2>&1
+  timeout 280 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$name -o p -- python3 $script $ARGS > $out/$name/run.log 2>&1
 }
 ARGS="$*"
 run_pass f FETCH_SIZE

@@ -16,13 +16,13 @@ import sys
 
 STAGES = {   # stage key -> kernel-name fragments
     "minmax": ("minmax_partial", "minmax_final"),
-    "stretch_laplacian_mask": ("lap_march", "lap_kernel", "sum_u32"),
+    "stretch_laplacian_mask": ("lap_march", "lap_kernel", "sum_u32", "valid_sum_units"),
     "min_eigen_candidates_fused": ("eig3_kernel", "eig2_kernel", "eig3_max"),
     "rank_select": ("f_hist_cut", "f_scatter_cells", "f_sweep", "f_acc_", "tk_hist", "f_cut", "f_cells"),
-    "pyramid": ("pyrdown_kernel",),
-    "lk_fwd_bwd": ("lk2_kernel", "lk_kernel", "lk_order"),
+    "pyramid": ("pyrdown_kernel", "pyrdown_units_kernel"),
+    "lk_fwd_bwd": ("lk2_kernel", "lk2_units_kernel", "lk_kernel"),
     "fb_frame": ("fb_compact", "fb_place", "fb_gather"),
-    "zncc": ("zncc_kernel", "zncc_int_kernel"),
+    "zncc": ("zncc_kernel", "zncc_int_kernel", "zncc_int_units_kernel"),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
     "mi_kernel": ("mi_kernel", "mi_int_kernel"),
