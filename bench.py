@@ -88,10 +88,15 @@ def parse(argv=None):
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-one-pair", action="store_true", help="skip the one_pair_per_submission object (profiler runs: only the headline's kernels)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the hard_content / tie_heavy / e2e_shape objects")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--depth", type=int, default=2, help="units of the headline loop still pending when submit() returns (FrameStream depth; <= 2 on one context: "
                     "three frame slots).  Same throughput as 1 on a quiet box (1.082 against 1.083 ms, three runs each); a host hiccup of up to a step no longer idles the GPU")
+    ap.add_argument("--pairs-per-submission", type=int, default=4, choices=(1, 2, 4),
+                    help="band pairs of the headline loop that travel in ONE batched submission (FrameStream.submit_many -> km_klt_units_frame_submit: "
+                         "one device pipeline for all of them; 4 = the 10 m bands of a Sentinel-2 product).  1: one pair per submission (rounds 1 - 4); "
+                         "the line reports that loop too (`one_pair_per_submission`)")
     ap.add_argument("--timed-stage", default="auto", help="stage bracketed by HIP events inside the timed region (auto: the largest kernel; none)")
     return ap.parse_args(argv)
 
@@ -1143,18 +1148,40 @@ def main():
     # the path's only exchange step: one all-gather of every rank's key-point block per step.  RCCL: issued on a side stream
     # behind a DEVICE-side wait for the block, counted on the device, read once behind the last step - the submitting thread never
     # waits for a collective (round 3 staged the block through the host and read a count back in every step)
-    ex = RankBlockExchange(ctx, conf.maxCorners, True, device=coll_dev) if (world > 1 or force_exchange) else None
+    G = max(1, int(a.pairs_per_submission))
+    depth = max(0, min(2, a.depth))
+    ex = RankBlockExchange(ctx, conf.maxCorners, True, device=coll_dev, halves=depth + 1) if (world > 1 or force_exchange) else None
     step_no = [0, 0]                    # units submitted / (gloo) units handed to the exchange
+    pend_of = {}                        # RCCL exchange: first step of a submission -> (its pending frame / batch, units)
+    group_size = {}                     # first step of a submission -> pairs it carries (its stage spans cover all of them)
 
-    def submit_step():
-        if ex is not None and ex.on_gpu:
-            k = step_no[0]
-            step_no[0] += 1
-            ex.arm(k)
-            return stream.submit(pair, conf, tag=k, on_submitted=lambda pend, k=k: pend_of.__setitem__(k, pend))
-        return stream.submit(pair, conf)
+    def submit_group(n):
+        """`n` consecutive steps (band pairs) as ONE submission: n = 1 the single-unit entry point, else a batched submission."""
+        on_gpu = ex is not None and ex.on_gpu
+        k = step_no[0]
+        step_no[0] += n
+        group_size[k] = n
+        if n == 1:
+            if on_gpu:
+                ex.arm(k)
+                return stream.submit(pair, conf, tag=k, on_submitted=lambda pend, k=k: pend_of.__setitem__(k, (pend, 1)))
+            return stream.submit(pair, conf, tag=k)
+        if on_gpu:
+            ex.arm_many(k, n)
+        return stream.submit_many([(pair, None, None)] * n, conf, tags=list(range(k, k + n)),
+                                  on_submitted=(lambda pend, _i, k=k, n=n: pend_of.__setitem__(k, (pend, n))) if on_gpu else None)
 
-    pend_of = {}
+    def run_steps(n, marks=None):
+        """n steps in groups of G pairs per submission (the last group may be smaller); `marks`: host time after every submission."""
+        done = 0
+        while done < n:
+            g = min(G, n - done)
+            if ex is not None and ex.on_gpu and g > 1:
+                g = min(g, ex.batch - step_no[0] % ex.batch)       # (a batched submission fills slots of ONE group of the send ring)
+            take(submit_group(g))
+            done += g
+            if marks is not None:
+                marks.append((time.perf_counter(), g))
 
     def take(results):
         """Finished steps: their frames, and the exchange of their blocks - ISSUED here, when the step has been collected (its block
@@ -1165,7 +1192,12 @@ def main():
         for d in results:
             n_rows = d.raw.n_rows
             if ex is not None and ex.on_gpu:
-                ex.issue(d.tag, pend_of.pop(d.tag))
+                if d.tag in pend_of:                       # the first step of a submission: the whole submission has been collected
+                    pend, n_units = pend_of.pop(d.tag)
+                    if n_units == 1:
+                        ex.issue(d.tag, pend)
+                    else:
+                        ex.issue_many(d.tag, n_units, pend)
             elif ex is not None:
                 ex.issue(step_no[1], host_block=d.raw.block)
                 step_no[1] += 1
@@ -1177,10 +1209,12 @@ def main():
             totals["n_candidates"] = d.raw.n_candidates
             totals["redone"] += int(d.redone)
             totals["last"] = d.frame
+            gs = group_size.pop(d.tag, 1)
             for k, v in d.spans.items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
             if any(v > 0 for v in d.spans.values()):
                 totals["span_samples"] = totals.get("span_samples", 0) + 1
+                totals["span_units"] = totals.get("span_units", 0) + gs         # (a batched submission's spans cover all its pairs)
 
     def fence():
         ctx.sync()
@@ -1189,9 +1223,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    stream = FrameStream(0.4, depth=max(0, min(2, a.depth)), want_spans=True)
-    for _ in range(a.warmup):
-        take(submit_step())
+    stream = FrameStream(0.4, depth=depth, want_spans=True)
+    run_steps(a.warmup)
     take(stream.drain())
     # settle (untimed, on top of the W warm-up steps): a fresh box ramps its clocks over the first few hundred milliseconds of
     # load - windows of 20 steps are repeated until two consecutive ones agree within 2 % (at least 1 s, at most 3 s of work: the first
@@ -1201,8 +1234,7 @@ def main():
     while True:
         fence()
         t_w = time.perf_counter()
-        for _ in range(20):
-            take(submit_step())
+        run_steps(20)
         take(stream.drain())
         fence()
         cur = time.perf_counter() - t_w
@@ -1234,8 +1266,7 @@ def main():
     ctx.set_option("profile_stage", -1)
     ctx.set_profiling(True)
     stage_sum.clear()
-    for _ in range(8):
-        take(submit_step())
+    run_steps(8)
     take(stream.drain())
     fence()
     probe = {k: v for k, v in stage_sum.items() if k in ("stretch_laplacian_mask", "min_eigen", "lk_fwd_bwd") and v > 0}
@@ -1253,8 +1284,7 @@ def main():
     while True:
         fence()
         t_w = time.perf_counter()
-        for _ in range(10):
-            take(submit_step())
+        run_steps(12)
         take(stream.drain())
         fence()
         cur2 = time.perf_counter() - t_w
@@ -1269,19 +1299,17 @@ def main():
             break
         prev2 = cur2
     settle["post_gc_seconds"] = round(time.perf_counter() - t_s2, 3)
-    settle["post_gc_last_window_ms_per_step"] = round(cur2 / 10 * 1e3, 4)
+    settle["post_gc_last_window_ms_per_step"] = round(cur2 / 12 * 1e3, 4)
     stage_sum.clear()
-    totals.update(rows=0, frames=0, redone=0, redone_rows=0, span_samples=0)
+    totals.update(rows=0, frames=0, redone=0, redone_rows=0, span_samples=0, span_units=0)
     if ex is not None:
         ex.finish()                    # (everything issued so far is accounted for ...)
         ex.reset_counts()              # ... and the counters restart with the timed region
     fence()
     cpu0 = (time.thread_time(), stream.worker_cpu_s, time.process_time())
     t0 = time.perf_counter()
-    marks = [t0]
-    for _ in range(a.steps):
-        take(submit_step())
-        marks.append(time.perf_counter())
+    marks = [(t0, 0)]
+    run_steps(a.steps, marks)
     take(stream.drain())              # the last pair's frame: part of the timed region
     exchange = None
     if ex is not None:
@@ -1308,27 +1336,28 @@ def main():
     gc.enable()
     # (where the region's time went, step by step: `value` is the whole region; a single slow step - another tenant of the host, a
     # page fault - shows here as max >> median instead of hiding in the mean)
-    gaps_in_order = [round(1e3 * (b - a_), 3) for a_, b in zip(marks, marks[1:])]
-    gaps = sorted(1e3 * (b - a_) for a_, b in zip(marks, marks[1:]))
+    gaps_in_order = [round(1e3 * (b[0] - a_[0]) / max(1, b[1]), 3) for a_, b in zip(marks, marks[1:])]
+    gaps = sorted(gaps_in_order)
     step_spread = {"median_ms": round(gaps[len(gaps) // 2], 4), "p90_ms": round(gaps[min(len(gaps) - 1, int(0.9 * len(gaps)))], 4),
-                   "max_ms": round(gaps[-1], 4), "drain_ms": round(1e3 * (dt - (marks[-1] - t0)), 4),
+                   "max_ms": round(gaps[-1], 4), "drain_ms": round(1e3 * (dt - (marks[-1][0] - t0)), 4),
                    "in_order_ms": gaps_in_order,
-                   "note": "host-side intervals between consecutive submit() returns inside the timed region (one context)"}
+                   "note": "host-side intervals between consecutive submissions inside the timed region, per PAIR (a submission carries "
+                           f"{G} pair(s); one context)"}
     assert totals["frames"] == a.steps
     n_kp_total = totals["rows"] if exchange is None else exchange["rows_from_gathered_blocks"] + exchange["rows_of_exactly_repeated_units"]
     frame = last_frame = totals["last"]   # (the parity gate of the cpu_baseline leg compares it with the oracle's result for the same pair)
     timed_samples = totals.get("span_samples", 0)
-    timed_ms = stage_sum.get(timed_stage, 0.0) / max(1, timed_samples)
+    timed_ms = stage_sum.get(timed_stage, 0.0) / max(1, totals.get("span_units", 0))       # per PAIR (a launch serves the pairs of its submission)
+    timed_launch_ms = stage_sum.get(timed_stage, 0.0) / max(1, timed_samples)
     redone_timed = totals["redone"]
     # untimed pass: every stage bracketed
     ctx.set_profiling(True)
     ctx.set_option("profile_stage", -1)
     ctx.set_option("profile_every", 1)
-    stage_steps = max(3, min(a.steps, 12))
+    stage_steps = max(G, min(a.steps, 12) // G * G)
     stage_sum.clear()
     keep = dict(totals)
-    for _ in range(stage_steps):
-        take(submit_step())
+    run_steps(stage_steps)
     take(stream.drain())
     fence()
     totals.update(keep)
@@ -1366,6 +1395,16 @@ def main():
         n_zncc = 0 if frame is None else int((frame["score"].to_numpy() >= 0.4).sum())
         roof = roofline_of(stage_ms, S, int(stats.n_init), n_cand, n_zncc, "min_eigen_candidates_fused" if timed_stage == "min_eigen" else timed_stage,
                            minmax_early=mm_early)
+        if G > 1:
+            # a launch of the batched pipeline serves the G pairs of its submission: bytes and duration both scale by G, `achieved` is
+            # bytes per launch / launch duration either way; `kernel_ms` (and the stage table) are quoted per PAIR
+            roof["pairs_per_launch"] = G
+            roof["launch_ms"] = round(timed_launch_ms, 4) if timed_launch_ms > 0 else round(roof["kernel_ms"] * G, 4)
+            roof["algorithmic_bytes_per_launch"] = roof["algorithmic_bytes_per_launch"] * G
+            if roof.get("traffic"):
+                roof["traffic"] = roof["traffic"] * G
+            roof["note"] = (f"one launch = the kernel's work for the {G} pairs of a batched submission (km_klt_units_frame_submit): achieved = "
+                            "algorithmic_bytes_per_launch / launch_ms; kernel_ms and the `kernels` table are per pair")
         out = {
             "metric": "Mpixels/sec (+ matched keypoints/sec), Sentinel-2 10980^2 pair, KLT + ZNCC",
             "value": mpx_per_s, "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1374,7 +1413,10 @@ def main():
             "config": {"workload": f"BASELINE config 2: synthetic Sentinel-2 10 m band pair {S}x{S} uint16, shift (0.5, 0.25) px, "
                                    "KLT only (Laplacian k=7, maxCorners 20000, one tile), ZNCC of rows with score>=0.4, "
                                    "inputs resident in HBM; host DataFrame stage of pair i overlaps the device stage of the pairs behind it "
-                                   f"(karios_amd.stream.FrameStream, depth {max(0, min(2, a.depth))}: pairs queued on ONE context execute one after the other)", "pairs_per_step": world,
+                                   f"(karios_amd.stream.FrameStream, depth {depth}); a stream of independent band pairs, {G} pair(s) per "
+                                   "submission" + (" (FrameStream.submit_many -> km_klt_units_frame_submit: ONE device pipeline for the pairs of a submission, e.g. the "
+                                                   "four 10 m bands of a product; frames bit-identical to one pair per submission, which `one_pair_per_submission` times)"
+                                                   if G > 1 else ""), "pairs_per_step": world, "pairs_per_submission": G,
                        "parallelism": f"{world} independent band pair(s), 1 per GPU" + (", RCCL all-gather of key-point frames" if world > 1 else "")},
             "world": world, "launcher": os.environ.get("KARIOS_BENCH_LAUNCHER", "external (torch.distributed.run)" if "WORLD_SIZE" in os.environ else "single process"),
             "backend": (backend if (world > 1 or force_exchange) else None), "rccl_ranks_seen": ranks_seen, "devices": devices, "exchange": exchange,
@@ -1385,9 +1427,10 @@ def main():
             "speculative_tiles_redone": int(redone_timed),
             "median_dx_dy": (None if frame is None else [float(np.median(frame["dx"])), float(np.median(frame["dy"]))]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_note": f"{timed_stage}: HIP events on {timed_samples} of the {a.steps} timed steps (every fourth: an event record is a point where "
-                             "consecutive kernels may not overlap); the other stages: an untimed pass of "
-                             f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
+            "stage_ms_note": f"per PAIR.  {timed_stage}: HIP events on {timed_samples} submissions of the timed region (every fourth call: an event record is a "
+                             "point where consecutive kernels may not overlap); the other stages: an untimed pass of "
+                             f"{stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)"
+                             + ("; rank + select of a batched submission are one span (`select`)" if G > 1 else ""),
             "roofline": roof,
             "synth_seconds": round(t_gen, 2), "settle": settle, "step_spread": step_spread, "python_gc": "disabled during the timed steps (collected in front of the 8 untimed probe steps that precede them)",
         }
@@ -1403,6 +1446,13 @@ def main():
     host_pair = None
     if solo and not (a.no_cpu_baseline and a.no_end_to_end):
         host_pair = (mon_t.cpu().numpy().view(np.uint16), ref_t.cpu().numpy().view(np.uint16))
+    if solo and G > 1 and not a.no_one_pair:
+        # the loop of rounds 1 - 4 for continuity: ONE pair per submission (km_klt_tile_frame_submit), same pair, same stream depth
+        one = _stream_timing(ctx, pair, conf, S, max(8, min(20, a.steps)))
+        out["one_pair_per_submission"] = {k: one[k] for k in ("ms_per_pair", "windows_ms_per_pair", "Mpx_per_s", "matched_keypoints_per_sec", "stage_ms",
+                                                                "lk_span_ms", "selection_span_ms", "units_repeated_exactly")}
+        out["one_pair_per_submission"]["note"] = ("FrameStream.submit(pair) per step (rounds 1 - 4's headline loop): every unit pays its corner-selection chain, "
+                                                  "its LK fill + drain and its frame launches alone")
     scored_frame = None
     if solo and not a.no_full_scoring:
         out["full_scoring"], scored_frame = full_scoring(ctx, pair, conf, S, max(6, min(20, a.steps)))

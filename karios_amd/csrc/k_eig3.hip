@@ -534,20 +534,17 @@ int launch_eig3_units(km_ctx *c, km_units &U, double scale2, double quality)
         A.n_border[u] = 2 * ((U.H[u] - 2 + A.rows2 - 1) / A.rows2);
         border_total += A.n_border[u];
     }
-    // rows per strip item: whole rounds of 3 resident waves per SIMD x the work of one item (5 warm-up rows' worth), over ALL units
-    const long slots = 1024L * 3 - (border_total < 1024 ? border_total : 1024);
-    int rows3 = 32;
-    {
-        double best = 1e300;
-        for (int r = 32; r <= 192; r++) {
-            long items = 0;
-            for (int u = 0; u < U.n; u++) items += (long)A.nstrips[u] * ((U.H[u] - 2 + r - 1) / r);
-            const long rounds = (items + slots - 1) / slots;
-            const double last = (double)(items - (rounds - 1) * slots) / (double)slots;
-            const double cost = ((double)(rounds - 1) + 0.5 + 0.5 * last) * (double)(r + 5);
-            if (cost < best) { best = cost; rows3 = r; }
-        }
+    // rows per strip item: what the single-unit launch picks for the LARGEST unit alone (one round of 3 resident waves per SIMD: ~96 rows
+    // for a 10980^2 tile), clamped to [48, 96].  A batch is several rounds anyway, and measured at four 10980^2 units the item height, not
+    // the number of rounds, decides: 0.357 ms per unit at 96 rows, 0.347 at 64, 0.381 at 128, 0.423 at the ~192 rows a rounds x height
+    // cost model prefers (long items drain the last round slowly); 16 units of 5490^2 are flat between 48 and 128 rows.
+    (void)border_total;
+    int rows3 = 48;
+    for (int u = 0; u < U.n; u++) {
+        const int r = km_pick_rows(U.H[u] - 2, A.nstrips[u], 5, 1024L * 3 - A.n_border[u], 32, 192);
+        rows3 = r > rows3 ? r : rows3;
     }
+    rows3 = rows3 > 96 ? 96 : rows3;
     if (const char *e = km_dev_env("KARIOS_HIP_EIG3_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 8192) rows3 = v; }   // tuning override
     A.rows3 = rows3;
     A.item0[0] = 0;

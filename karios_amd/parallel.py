@@ -220,7 +220,8 @@ class RankBlockExchange:
     """
     HISTORY = 4096                    # gathered headers kept on the device before they are folded into the counters (in steps)
 
-    def __init__(self, ctx, cap: int, with_zncc=True, device=None, batch: int = 4, slots: int | None = None, parts: str = "sink,wait,gather,account"):
+    def __init__(self, ctx, cap: int, with_zncc=True, device=None, batch: int = 4, slots: int | None = None, parts: str = "sink,wait,gather,account",
+                 halves: int = 2):
         import torch
         from collections import deque
         self.ctx, self.cap, self.L = ctx, cap, block_len(cap, with_zncc)
@@ -229,9 +230,10 @@ class RankBlockExchange:
         self.device = _collective_device(ctx, device)
         self.on_gpu = self.device.type == "cuda"
         self.batch = max(1, int(batch)) if self.on_gpu else 1
-        self.slots = 2 * self.batch if self.on_gpu else max(2, int(slots or 4))
+        self.halves = max(2, int(halves))     # groups of `batch` send slots (RCCL): with batched submissions of `batch` steps and a stream depth d, d + 1 groups
+        self.slots = self.halves * self.batch if self.on_gpu else max(2, int(slots or 4))
         self.parts = set(parts.split(","))          # (tools/exchange_probe.py switches stages off to price them; everything on otherwise)
-        halves = 2 if self.on_gpu else self.slots
+        halves = self.halves if self.on_gpu else self.slots
         per = self.batch if self.on_gpu else 1
         self.send = torch.zeros((halves, per, self.L), dtype=torch.float32, device=self.device)
         self.recv = torch.zeros((halves, self.ws, per, self.L), dtype=torch.float32, device=self.device)
@@ -251,7 +253,7 @@ class RankBlockExchange:
 
     def _where(self, step: int):
         if self.on_gpu:
-            return (step // self.batch) % 2, step % self.batch
+            return (step // self.batch) % self.halves, step % self.batch
         return step % self.slots, 0
 
     def arm(self, step: int) -> None:
@@ -272,6 +274,43 @@ class RankBlockExchange:
         c = self.ctx
         c.set_frame_sink(self.send[half, j].data_ptr(), self.L * 4)
         self._sink_set = True
+
+    def arm_many(self, first_step: int, n: int) -> None:
+        """Before a BATCHED submission of the steps `first_step .. first_step + n - 1` (`FrameStream.submit_many`: one device pipeline
+        for n units): their blocks go to n consecutive send slots of ONE half (pitch = the block size), so `(first_step % batch) + n
+        <= batch`."""
+        if not self.on_gpu or "sink" not in self.parts:
+            return
+        half, j = self._where(first_step)
+        if j + n > self.batch:
+            raise ValueError(f"RankBlockExchange.arm_many: steps {first_step} .. {first_step + n - 1} straddle a half of {self.batch} slots")
+        if "wait" in self.parts:
+            for k in range(n):
+                old = self.slot_step[half][j + k]
+                if old is not None:
+                    raise RuntimeError(f"RankBlockExchange: step {first_step + k} would overwrite the block of step {old}, which has not been gathered yet "
+                                       f"(keep the stream's depth x units per submission <= the ring's {2 * self.batch} slots)")
+                self.slot_step[half][j + k] = first_step + k
+        if j == 0 and self.used[half]:
+            self.done[half].synchronize()
+        self.ctx.set_frame_sink(self.send[half, j].data_ptr(), n * self.L * 4, self.L * 4)
+        self._sink_set = True
+
+    def issue_many(self, first_step: int, n: int, pending) -> None:
+        """The collected steps `first_step .. first_step + n - 1` of ONE batched submission (`pending`: its PendingBatch): one device-side
+        wait covers all n blocks."""
+        if not self.on_gpu:
+            raise RuntimeError("issue_many: RCCL path only (host blocks go through issue(step, host_block=...) one by one)")
+        half, j = self._where(first_step)
+        c = self.ctx
+        if "wait" in self.parts and "sink" in self.parts:
+            c.check(c.lib.km_stream_wait_frame(c.handle, pending.ticket, self.side.cuda_stream), "km_stream_wait_frame")
+            if self.filled[half] == 0:
+                self.first[half] = j
+            self.filled[half] = j + n
+            if j + n == self.batch:
+                self._gather_half(half)
+        self.issued += n
 
     def _fold(self) -> None:
         """History of headers -> counters (a handful of small device ops, once per HISTORY steps and at the end)."""
@@ -364,7 +403,7 @@ class RankBlockExchange:
             if self._sink_set:
                 self.ctx.set_frame_sink(None)
                 self._sink_set = False
-            for half in range(2):
+            for half in range(self.halves):
                 if self.filled[half]:
                     self._gather_half(half)
             with torch.cuda.stream(self.side):

@@ -12,7 +12,8 @@ prof() {   # prof <tag> <script> [args]: rocprofv3 kernel statistics (csv) of `p
   t=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$t -o $t -- python3 "$@" > $R/gpurun_out/prof_${TAG}_$t.log 2>&1
 }
-prof c2 $R/bench.py --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-sensitivity --steps 20 --warmup 5
+prof c2 $R/bench.py --no-one-pair --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-sensitivity --steps 20 --warmup 5
+prof c2one $R/bench.py --pairs-per-submission 1 --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-sensitivity --no-full-scoring --steps 20 --warmup 5
 prof alone $R/tools/blocking_workload.py 12
 prof c4 $R/tools/units_probe.py config4 4
 prof e2e $R/tools/units_probe.py e2e 4
@@ -23,12 +24,13 @@ cd $R
 sumr() { f=$(find gpurun_out/prof_${TAG}_$1 -name "$1_kernel_stats.csv" | head -1); [ -n "$f" ] && python3 tools/summarize_rocprof.py $f gpurun_out/${TAG}_kernel_stats_$2.md $3; }
 sumr f64 phase_fp64 5
 sumr c2 config2
+sumr c2one config2_one_pair_per_submission
 sumr alone kernels_alone 12
 sumr c4 config4_batched
 sumr e2e e2e_shape_batched
 sumr c3 config3 6
 sumr ep entry_points
-PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c2 bench.py --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-full-scoring --no-sensitivity --steps 12 --warmup 3
+PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c2 bench.py --no-one-pair --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-full-scoring --no-sensitivity --steps 12 --warmup 3
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_ep tools/entry_points_workload.py 10980 scoring,dn
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c3 bench.py --config 3 --steps 4 --warmup 1
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_f64 tools/phase64_workload.py 10980 3

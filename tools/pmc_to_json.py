@@ -15,9 +15,9 @@ import os
 import sys
 
 STAGES = {   # stage key -> kernel-name fragments
-    "minmax": ("minmax_partial", "minmax_final"),
+    "minmax": ("minmax_partial", "minmax_final"),            # (incl. the *_units_kernel forms of a batched submission)
     "stretch_laplacian_mask": ("lap_march", "lap_kernel", "sum_u32", "valid_sum_units"),
-    "min_eigen_candidates_fused": ("eig3_kernel", "eig2_kernel", "eig3_max"),
+    "min_eigen_candidates_fused": ("eig3_kernel", "eig3_units_kernel", "eig2_kernel", "eig3_max"),
     "rank_select": ("f_hist_cut", "f_scatter_cells", "f_sweep", "f_acc_", "tk_hist", "f_cut", "f_cells"),
     "pyramid": ("pyrdown_kernel", "pyrdown_units_kernel"),
     "lk_fwd_bwd": ("lk2_kernel", "lk2_units_kernel", "lk_kernel"),
@@ -25,14 +25,14 @@ STAGES = {   # stage key -> kernel-name fragments
     "zncc": ("zncc_kernel", "zncc_int_kernel", "zncc_int_units_kernel"),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
     "shift_image": ("shift_kernel",),
-    "mi_kernel": ("mi_kernel", "mi_int_kernel"),
+    "mi_kernel": ("mi_kernel", "mi_int_kernel", "mi_int_units_kernel"),
     "dn_keep": ("dn_keep_kernel",),
     "phase_correlation_f64": ("f64_prime_kernel", "f64_smooth_kernel", "f64_cross_kernel", "f64_best_reduce", "f64_pack", "f64_absmax", "f64_first_index"),
     "phase_f64_prime_level": ("f64_prime_kernel",),
     "phase_f64_smooth_level": ("f64_smooth_kernel",),
     "phase_f64_cross_power": ("f64_cross_kernel",),
 }
-ONCE_PER_PAIR = {"config2": "lk2_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel", "f64": "f64_best_reduce"}
+ONCE_PER_PAIR = {"config2": "lk2_kernel", "config2_batched": "lk2_units_kernel", "config3": "f61_top2_reduce", "scoring": "mi_int_kernel", "dn": "dn_keep_kernel", "f64": "f64_best_reduce"}
 
 
 def short_name(kernel: str) -> str:
@@ -79,6 +79,7 @@ def main():
     for arg in sys.argv[3:]:
         if arg.startswith("--mode="):
             mode = arg.split("=", 1)[1]          # which kernel counts the units profiled (ONCE_PER_PAIR)
+    units_per_launch = next((int(a.split("=", 1)[1]) for a in sys.argv[3:] if a.startswith("--units-per-launch=")), 1)   # batched submissions: pairs one marker launch serves
     only = [a.split("=", 1)[1].split(",") for a in sys.argv[3:] if a.startswith("--only=")]
     only = only[0] if only else None
     commit = open(os.path.join(root, "commit.txt")).read().strip()
@@ -96,7 +97,7 @@ def main():
                 launch_count[name] = max(launch_count[name], k)
     dur, dn = durations(os.path.join(root, "v", "p_kernel_trace.csv"))
     marker = next((n for n in launch_count if ONCE_PER_PAIR[mode] in n), None)
-    pairs = launch_count[marker] if marker else 1
+    pairs = launch_count[marker] * units_per_launch if marker else 1
     for name in list(merged):                       # mean per launch -> per unit (pair / call)
         scale = launch_count.get(name, 0) / pairs
         for c in merged[name]:
