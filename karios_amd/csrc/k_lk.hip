@@ -460,6 +460,21 @@ __device__ __forceinline__ int lk_dot2_k(lk_s2 a, lk_s2 b, int k)
     return d;
 }
 
+// Eight patch bytes from a byte-aligned LDS address as three ALIGNED dwords + two v_alignbyte.  A ds_read_b64 whose address is
+// not a multiple of 8 takes the LDS unit's unaligned path: ~55 cycles per wave instruction against ~4 aligned (PMC, round 5:
+// SQ_LDS_UNALIGNED_STALL = 96 % of SQ_LDS_IDX_ACTIVE, the LDS unit busy 83 % of the kernel - the tracker was LDS-bound on it).
+// Reads up to 3 bytes in front of p (same patch: its base is 16-byte aligned) and 4 behind p + 8 (the pitch / tail slack of lk2_geo).
+__device__ __forceinline__ uint2 lk_lds_read8(const uint8_t *p, unsigned sh)
+{
+    const uint32_t *q = (const uint32_t *)(p - sh);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    uint2 r;
+    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return r;
+}
+__device__ __forceinline__ unsigned lk_lds_shift(const uint8_t *p) { return (unsigned)(size_t)p & 3u; }
+
 template <int NR, int WIN, int MAXIT>
 __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
                                 const lk2_geo<WIN> &geo, int max_count, double epsilon, const int (&run_desc)[NR], float &outx, float &outy, int general_templates)
@@ -521,8 +536,9 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                 // patch rows y-1 .. y+2 (window coordinates), bytes x0-1 .. x0+6
                 const uint8_t *pr = xb + y * PP + x0;
                 uint2 R[4];
+                const unsigned rsh = lk_lds_shift(pr);          // (the pitch is a multiple of 4: one shift for all rows)
 #pragma unroll
-                for (int k = 0; k < ROWS; k++) __builtin_memcpy(&R[k], pr + k * PP, 8);
+                for (int k = 0; k < ROWS; k++) R[k] = lk_lds_read8(pr + k * PP, rsh);
                 if constexpr (ROWS == 3) R[3] = R[2];
                 // columns as 16-bit pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7)
                 lk_us2 E[4][4];
@@ -646,9 +662,8 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
             for (int t = 0; t < NR; t++) {
                 const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
                 const uint8_t *p0 = jb + y * PP + x0;
-                uint2 r0, r1;                         // bytes x0 .. x0+7 of the two patch rows (unaligned LDS reads)
-                __builtin_memcpy(&r0, p0, 8);
-                __builtin_memcpy(&r1, p0 + PP, 8);
+                const unsigned jsh = lk_lds_shift(p0);
+                const uint2 r0 = lk_lds_read8(p0, jsh), r1 = lk_lds_read8(p0 + PP, jsh);   // bytes x0 .. x0+7 of the two patch rows
                 int val[LK_RUN + 1];
                 val[LK_RUN] = 0;
 #pragma unroll
