@@ -73,8 +73,8 @@ typedef struct km_klt_stats {
     float max_eig;            /* maxVal of minMaxLoc */
     float emitted_ratio;      /* candidate keys emitted by the fused eig kernel / exact candidate count */
     int32_t path_flags;       /* KM_PATH_* bits: which retry paths of the corner detector the call went through */
-    int32_t tie_rows;         /* (wavefront, row) steps of the fused 8-px eigenvalue pass in which a lane held more than one candidate
-                                 (exact ties / plateaus): the per-pixel emission path; diagnostics of the blocking tile entry points */
+    int32_t tie_rows;         /* (wavefront, row) steps of the fused 8-px eigenvalue pass in which a lane held more than two candidates
+                                 of its 8 pixels (ties / plateaus): the per-pixel emission path; diagnostics of the blocking tile entry points */
 } km_klt_stats;
 #define KM_PATH_KEY_REGROW 1      /* a key-buffer shard overflowed: buffer regrown, detection repeated */
 #define KM_PATH_STAGE_FALLBACK 2  /* the fused kernel's key stage overflowed: eig map + candidate kernel instead */

@@ -12,9 +12,9 @@
 //   * the box filter (<= 15 wide) of a pixel spans this lane and its two neighbours only: it slides along the lane's pixels,
 //     W(p+1) = W(p) + V(p+1+R) - V(p-L), with the neighbours' vertical sums as DPP operands of the add / subtract itself -
 //     no scan, no LDS;
-//   * a lane rarely holds more than one candidate per row (3x3 local maxima cannot touch unless they tie): the candidate of
-//     the lane is selected while the pixels are tested and appended ONCE per row; rows where some lane holds two take a
-//     per-pixel path;
+//   * a lane seldom holds more than two candidates per row: the last candidate of the lane is selected while the pixels are
+//     tested and appended once per row, a second append takes the first candidates of the lanes that hold two (their tests
+//     stay in scalar registers as wave masks); rows where some lane holds three or more take a per-pixel path (tie_rows);
 //   * 24 of 512 columns are halo, and an item is ~120 rows tall (2-3 waves per SIMD hide the latencies: eight independent
 //     pixels per lane give the scheduler what four more resident waves gave the 2-px kernel).
 // The strips that touch the left / right image border (12 columns each) run eig2_item inside the same launch.
@@ -315,27 +315,41 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
             };
             float selval = 0.f;
             unsigned selp = 0u, ncand = 0u;
+            bool isv[8];                                  // (wave masks: scalar registers)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const bool is = is_cand(p);
+                const bool is = isv[p] = is_cand(p);
                 selval = is ? EM[p] : selval;
                 selp = is ? (unsigned)p : selp;
                 ncand += is ? 1u : 0u;
             }
             const unsigned rowidx = (unsigned)(y - 1) * (unsigned)W + (unsigned)c0;
             const unsigned long long multi = __ballot(ncand > 1u);
-            if (__builtin_expect(multi == 0ull, 1)) {
-                const unsigned long long bal = __ballot(ncand != 0u);
+            auto append = [&](unsigned long long bal, bool mine, float v, unsigned p) {
                 const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                st[min(ncand ? slot : ~0u, EIG3_STAGE + (unsigned)lane)] =
-                    ((unsigned long long)__float_as_uint(selval) << 32) | (unsigned long long)(rowidx + selp);
+                st[min(mine ? slot : ~0u, EIG3_STAGE + (unsigned)lane)] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(rowidx + p);
                 cnt += (unsigned)__popcll(bal);
+            };
+            if (__builtin_expect(multi == 0ull, 1)) {
+                append(__ballot(ncand != 0u), ncand != 0u, selval, selp);
+            } else if (__ballot(ncand > 2u) == 0ull) {
+                // some lane holds two candidates (local maxima two or more pixels apart inside its 8: the common case on textured
+                // content - 83 % of the row steps of the headline pair): the lanes' LAST candidates, then the first ones of those lanes
+                float fval = selval;
+                unsigned fp = selp;
+#pragma unroll
+                for (int p = 6; p >= 0; p--) {
+                    fval = isv[p] ? EM[p] : fval;
+                    fp = isv[p] ? (unsigned)p : fp;
+                }
+                append(__ballot(ncand != 0u), ncand != 0u, selval, selp);
+                append(multi, ncand > 1u, fval, fp);
             } else {
-                // ties: some lane holds several candidates in this row
+                // three or more candidates in one lane
                 tie_rows++;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
-                    const bool is = is_cand(p);
+                    const bool is = isv[p];
                     const unsigned long long bal = __ballot(is);
                     const unsigned slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                     st[min(is ? slot : ~0u, EIG3_STAGE + (unsigned)lane)] =

@@ -37,7 +37,9 @@ __device__ __forceinline__ cd c_add(cd a, cd b) { return make_double2(a.x + b.x,
 __device__ __forceinline__ cd c_sub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ cd c_mul(cd a, cd b) { return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)); }
 
-#define F64_KB 8              // output pairs per wavefront pass of the prime kernel
+#define F64_KB 4              // output pairs per wavefront pass of the prime kernel
+#define F64_PR_NW 8           // wavefronts per workgroup of the prime kernel: 8 x 4 pairs cover h <= 32 in one pass (p = 61: h = 30), and a
+                              // wavefront fills its 8 of the 61 tile rows in ONE batch of loads (4 x 8: 1.00 -> ? ms on the column level)
 
 struct lvl_args {
     cd *data;
@@ -140,23 +142,27 @@ template <int R> __device__ __forceinline__ void dft_r(cd *v)
     }
 }
 
-// one Stockham butterfly: radix R, Ns = product of the radices done; element i of transform t at buf[i * lsi + toff]
+// one Stockham butterfly: radix R, Ns = product of the radices done; element i of transform t at buf[i * lsi + toff].  In two halves
+// with the workgroup's barrier between them - every butterfly of a stage is read before any is written, so the stage runs in ONE buffer
+// (half the LDS of a source / destination pair: twice the resident workgroups to hide a tile's loads and stores behind).
 template <int R>
-__device__ __forceinline__ void bfly(const cd *__restrict__ src, cd *__restrict__ dst, int b, int nb, int Ns, unsigned magic, int lsi, int toff,
-                                     const cd *__restrict__ twl, int twstep)
+__device__ __forceinline__ int bfly_read(const cd *__restrict__ buf, cd (&v)[R], int b, int nb, int Ns, unsigned magic, int lsi, int toff,
+                                         const cd *__restrict__ twl, int twstep)
 {
     const int q = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic), k = b - q * Ns;     // b / Ns, b % Ns (exact: b Ns < 2^32)
-    cd v[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) v[r] = src[(b + r * nb) * lsi + toff];
+    for (int r = 0; r < R; r++) v[r] = buf[(b + r * nb) * lsi + toff];
     if (Ns > 1) {
 #pragma unroll
         for (int r = 1; r < R; r++) v[r] = c_mul(v[r], twl[r * k * twstep]);
     }
     dft_r<R>(v);
-    const int j0 = q * Ns * R + k;
+    return (q * Ns * R + k) * lsi + toff;
+}
+template <int R> __device__ __forceinline__ void bfly_write(cd *__restrict__ buf, const cd (&v)[R], int at, int Ns, int lsi)
+{
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[(j0 + r * Ns) * lsi + toff] = v[r];
+    for (int r = 0; r < R; r++) buf[at + r * Ns * lsi] = v[r];
 }
 
 __device__ __forceinline__ long long tile_base(const lvl_args &A, int a, int b0)
@@ -172,6 +178,13 @@ template <int IMG> __device__ __forceinline__ double px_f64(const void *p, size_
     else if constexpr (IMG == KM_U16) return (double)((const uint16_t *)p)[off];
     else if constexpr (IMG == KM_I16) return (double)((const int16_t *)p)[off];
     else return (double)((const float *)p)[off];
+}
+template <int IMG> __device__ __forceinline__ float px_f32(const void *p, size_t off)
+{
+    if constexpr (IMG == KM_U8) return (float)((const uint8_t *)p)[off];
+    else if constexpr (IMG == KM_U16) return (float)((const uint16_t *)p)[off];
+    else if constexpr (IMG == KM_I16) return (float)((const int16_t *)p)[off];
+    else return ((const float *)p)[off];
 }
 template <int IMG> __device__ __forceinline__ cd px_pair(const lvl_args &A, int y, int x)
 {
@@ -202,7 +215,7 @@ struct best_t {
         if (ob > bits || (ob == bits && oi < idx)) { bits = ob; idx = oi; }
     }
 };
-__device__ __forceinline__ void best_publish(best_t bt, unsigned long long *out, unsigned long long *s_b /* 8 words of LDS */)
+__device__ __forceinline__ void best_publish(best_t bt, unsigned long long *out, unsigned long long *s_b /* 2 words of LDS per wavefront */, int nwaves = 4)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -214,7 +227,7 @@ __device__ __forceinline__ void best_publish(best_t bt, unsigned long long *out,
     __syncthreads();
     if (threadIdx.x == 0) {
         best_t r;
-        for (int w = 0; w < 4; w++) r.merge(s_b[2 * w], s_b[2 * w + 1]);
+        for (int w = 0; w < nwaves; w++) r.merge(s_b[2 * w], s_b[2 * w + 1]);
         out[2 * (size_t)blockIdx.x] = r.bits; out[2 * (size_t)blockIdx.x + 1] = r.idx;
     }
 }
@@ -227,7 +240,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     __shared__ unsigned long long s_b[8];
     const int n = A.n, T = A.T, logT = A.logT;
-    cd *buf0 = (cd *)smem64, *buf1 = buf0 + n * T, *twl = buf1 + n * T;       // twl[j] = exp(-2 pi i j / n)
+    cd *buf0 = (cd *)smem64, *twl = buf0 + n * T;                              // twl[j] = exp(-2 pi i j / n)
     const int tid = threadIdx.x;
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
     if (A.tile_mask && !A.tile_mask[tb]) return;                               // (a tile of columns nobody reads: uniform, before any barrier)
@@ -297,23 +310,33 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
     }
     __syncthreads();
 
-    cd *src = buf0, *dst = buf1;
     int Ns = 1;
     for (int s = 0; s < A.nst; s++) {
         const int R = A.radix[s], nb = n / R, twstep = n / (Ns * R);
         const unsigned magic = Ns > 1 ? (unsigned)((0x100000000ull + (unsigned)Ns - 1) / (unsigned)Ns) : 0u;
         auto run = [&](auto rc) {
             constexpr int RR = decltype(rc)::value;
-            if (contig) {
-                // (flat over the tile like the strided form: one wavefront per transform left 64 - n / R lanes idle)
-                const unsigned magic_nb = (unsigned)((0x100000000ull + (unsigned)nb - 1) / (unsigned)nb);
-                for (int idx = tid; idx < nb * nt; idx += 256) {
-                    const int t = nb > 1 ? (int)__umulhi((unsigned)idx, magic_nb) : idx;
-                    bfly<RR>(src, dst, idx - t * nb, nb, Ns, magic, 1, t * n, twl, twstep);
+            constexpr int MAXB = (F64_SMOOTH_MAX / RR + 255) / 256;            // butterflies of a stage per thread
+            cd v[MAXB][RR];
+            int at[MAXB];
+            // (contiguous tiles: flat over the tile like the strided form - one wavefront per transform left 64 - n / R lanes idle)
+            const unsigned magic_nb = (unsigned)((0x100000000ull + (unsigned)nb - 1) / (unsigned)nb);
+            const int count = contig ? nb * nt : nb * T;
+#pragma unroll
+            for (int k = 0; k < MAXB; k++) {
+                const int idx = tid + 256 * k;
+                at[k] = -1;
+                if (idx < count) {
+                    if (contig) {
+                        const int t = nb > 1 ? (int)__umulhi((unsigned)idx, magic_nb) : idx;
+                        at[k] = bfly_read<RR>(buf0, v[k], idx - t * nb, nb, Ns, magic, 1, t * n, twl, twstep);
+                    } else at[k] = bfly_read<RR>(buf0, v[k], idx >> logT, nb, Ns, magic, lsi, idx & (T - 1), twl, twstep);
                 }
-            } else {
-                for (int idx = tid; idx < nb * T; idx += 256) bfly<RR>(src, dst, idx >> logT, nb, Ns, magic, lsi, idx & (T - 1), twl, twstep);
             }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MAXB; k++)
+                if (at[k] >= 0) bfly_write<RR>(buf0, v[k], at[k], Ns, lsi);
         };
         switch (R) {
         case 7: run(std::integral_constant<int, 7>{}); break;
@@ -324,9 +347,9 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
         default: run(std::integral_constant<int, 2>{}); break;
         }
         __syncthreads();
-        cd *tmp = src; src = dst; dst = tmp;
         Ns *= R;
     }
+    cd *src = buf0;
 
     best_t bt;
     {
@@ -367,12 +390,24 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_smooth_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------- prime level
-#define F64_PR_BATCH 8     // rows of the tile a wavefront has in flight at once while it fills the LDS
-template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const lvl_args A)
+#define F64_PR_BATCH 8     // rows of the tile a wavefront has in flight at once while it fills the LDS (16 measured slower on the plane: 1.06 against 0.97 ms)
+// The level that reads the IMAGES keeps its tile as float pairs (every pixel type is exact in float32): 8 bytes per element instead of
+// 16, five workgroups per CU instead of two - that level was bound by the latency of its loads (ablation, round 5: 0.80 of its 1.48 ms
+// went when the loads were removed, 0.22 when the arithmetic was).
+template <int IMG> struct pr_lds { typedef cd type; };
+template <> struct pr_lds<KM_U8> { typedef float2 type; };
+template <> struct pr_lds<KM_U16> { typedef float2 type; };
+template <> struct pr_lds<KM_I16> { typedef float2 type; };
+template <> struct pr_lds<KM_F32> { typedef float2 type; };
+__device__ __forceinline__ cd pr_value(cd v) { return v; }
+__device__ __forceinline__ cd pr_value(float2 v) { return make_double2((double)v.x, (double)v.y); }
+
+template <int IMG> __global__ __launch_bounds__(64 * F64_PR_NW) void f64_prime_kernel(const lvl_args A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
-    __shared__ unsigned long long s_b[8];
-    cd *sm = (cd *)smem64;                                                     // [i][t], t < T <= 64
+    __shared__ unsigned long long s_b[2 * F64_PR_NW];
+    typedef typename pr_lds<IMG>::type sm_t;
+    sm_t *sm = (sm_t *)smem64;                                                 // [i][t], t < T <= 64
     const int p = A.n, T = A.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x, a = wg / A.tiles_b, tb = wg - a * A.tiles_b, b0 = tb * T, nt = min(T, A.B - b0);
@@ -384,28 +419,87 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
     const long long loff = (long long)lane * A.sb;
     const bool pre = A.inverse && A.tw_mode, contig = A.contiguous != 0;
     const bool has2 = (A.pair_w || A.best_pair_w) && 2 * (a / A.AR) + 1 < A.pair_h;
-    for (int u0 = 0; wave + 4 * u0 < p; u0 += F64_PR_BATCH) {
+    // 8- and 16-bit pixels: a row of the tile is nt consecutive pixels of an image row - read as whole DWORDS, a lane taking 2 or 4
+    // neighbouring transforms' pixels of both images and writing them as float pairs (sub-dword global loads go through the address
+    // unit one lane at a time: the 2-byte gathers of this level cost 0.8 of its 1.49 ms).  Needs every row start 4-byte aligned.
+    bool img_dwords = false;
+    if constexpr (IMG == KM_U8 || IMG == KM_U16 || IMG == KM_I16) {
+        typedef typename std::conditional<IMG == KM_U8, uint8_t, typename std::conditional<IMG == KM_U16, uint16_t, int16_t>::type>::type px_t;
+        constexpr int ES = (int)sizeof(px_t), PPD = 4 / ES;
+        img_dwords = !contig && nt % PPD == 0 && nt >= 2 * PPD && T % PPD == 0 && (int)A.se % PPD == 0 && A.img_sa % PPD == 0 && A.img_sb % PPD == 0 &&
+                     (((unsigned long long)A.img_a | (unsigned long long)A.img_b) & 3ull) == 0;
+        if (img_dwords) {
+            const int dpr = nt / PPD, nrows = (p - wave + F64_PR_NW - 1) / F64_PR_NW, total = nrows * dpr;      // this wavefront's rows: i = wave + NW u
+            const unsigned magic = (unsigned)((0x100000000ull + (unsigned)dpr - 1) / (unsigned)dpr);   // f / dpr for f < 4096
+            const px_t *ia = (const px_t *)A.img_a + (size_t)a * (size_t)A.img_sa + (size_t)b0;
+            const px_t *ib = (const px_t *)A.img_b + (size_t)a * (size_t)A.img_sb + (size_t)b0;
+            for (int f0 = 0; f0 < total; f0 += 64 * F64_PR_BATCH) {
+                uint32_t da[F64_PR_BATCH], db[F64_PR_BATCH];
+                int slot[F64_PR_BATCH];
+#pragma unroll
+                for (int u = 0; u < F64_PR_BATCH; u++) {
+                    const int f = f0 + 64 * u + lane;
+                    const int r = (int)__umulhi((unsigned)f, magic), d = f - r * dpr, i = wave + F64_PR_NW * r;
+                    slot[u] = -1; da[u] = db[u] = 0u;
+                    if (f < total) {
+                        const size_t off = (size_t)i * (size_t)A.se + (size_t)(d * PPD);
+                        da[u] = *(const uint32_t *)(ia + off);
+                        db[u] = *(const uint32_t *)(ib + off);
+                        slot[u] = i * T + d * PPD;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < F64_PR_BATCH; u++) {
+                    if (slot[u] < 0) continue;
+#pragma unroll
+                    for (int k = 0; k < PPD; k++) {
+                        const px_t pa = (px_t)(da[u] >> (8 * ES * k)), pb = (px_t)(db[u] >> (8 * ES * k));
+                        sm[slot[u] + k] = make_float2((float)pa, (float)pb);
+                    }
+                }
+            }
+            if (nt < T)                                                         // (the lanes behind a short last tile transform zeros)
+                for (int e = tid; e < p * (T - nt); e += 64 * F64_PR_NW) { const int i = e / (T - nt); sm[i * T + nt + (e - i * (T - nt))] = make_float2(0.f, 0.f); }
+        }
+    }
+    for (int u0 = 0; wave + F64_PR_NW * u0 < p; u0 += F64_PR_BATCH) {
+        if constexpr (IMG >= 0) {
+            // (the first forward level: no conjugation, no twiddle in front)
+            if (img_dwords) break;
+            float2 v[F64_PR_BATCH];
+#pragma unroll
+            for (int u = 0; u < F64_PR_BATCH; u++) {
+                const int i = wave + F64_PR_NW * (u0 + u);
+                v[u] = make_float2(0.f, 0.f);
+                if (i < p && lane < nt) {
+                    const size_t y = contig ? (size_t)(b0 + lane) : (size_t)a, x = contig ? (size_t)i : (size_t)(b0 + lane + i * (int)A.se);
+                    v[u] = make_float2(px_f32<IMG>(A.img_a, y * (size_t)A.img_sa + x), px_f32<IMG>(A.img_b, y * (size_t)A.img_sb + x));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < F64_PR_BATCH; u++) {
+                const int i = wave + F64_PR_NW * (u0 + u);
+                if (i < p && lane < T) sm[i * T + lane] = v[u];
+            }
+        } else {
         cd v[F64_PR_BATCH], w[F64_PR_BATCH];
 #pragma unroll
         for (int u = 0; u < F64_PR_BATCH; u++) {
-            const int i = wave + 4 * (u0 + u);
+            const int i = wave + F64_PR_NW * (u0 + u);
             v[u] = make_double2(0.0, 0.0);
             w[u] = make_double2(1.0, 0.0);
             if (i < p && lane < nt) {
-                if constexpr (IMG >= 0) v[u] = contig ? px_pair<IMG>(A, b0 + lane, i) : px_pair<IMG>(A, a, b0 + lane + i * (int)A.se);
-                else {
-                    if (A.pair_src) {
-                        const int sx = A.srcx[(b0 + lane) * p + i];                    // (contiguous tiles: transform t = elements t p .. t p + p - 1)
-                        const bool low = sx >= 0;
-                        const long long sp = (long long)(a / A.AR) * 2 * A.pair_w + (low ? sx : ~sx);
-                        const cd q1 = A.pair_src[sp], q2 = has2 ? A.pair_src[sp + A.pair_w] : make_double2(0.0, 0.0);
-                        v[u] = low ? make_double2(q1.x - q2.y, q1.y + q2.x) : make_double2(q1.x + q2.y, q2.x - q1.y);
-                    } else {
-                        v[u] = data[base + (long long)i * A.se + loff];
-                        if (A.pair_w) {
-                            const cd q2 = has2 ? data[base + (long long)i * A.se + loff + A.pair_w] : make_double2(0.0, 0.0);
-                            v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);
-                        }
+                if (A.pair_src) {
+                    const int sx = A.srcx[(b0 + lane) * p + i];                    // (contiguous tiles: transform t = elements t p .. t p + p - 1)
+                    const bool low = sx >= 0;
+                    const long long sp = (long long)(a / A.AR) * 2 * A.pair_w + (low ? sx : ~sx);
+                    const cd q1 = A.pair_src[sp], q2 = has2 ? A.pair_src[sp + A.pair_w] : make_double2(0.0, 0.0);
+                    v[u] = low ? make_double2(q1.x - q2.y, q1.y + q2.x) : make_double2(q1.x + q2.y, q2.x - q1.y);
+                } else {
+                    v[u] = data[base + (long long)i * A.se + loff];
+                    if (A.pair_w) {
+                        const cd q2 = has2 ? data[base + (long long)i * A.se + loff + A.pair_w] : make_double2(0.0, 0.0);
+                        v[u] = make_double2(v[u].x - q2.y, v[u].y + q2.x);
                     }
                 }
                 if (pre) w[u] = ltw[(size_t)i * (size_t)A.ltw_R + (size_t)q];
@@ -413,7 +507,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
         }
 #pragma unroll
         for (int u = 0; u < F64_PR_BATCH; u++) {
-            const int i = wave + 4 * (u0 + u);
+            const int i = wave + F64_PR_NW * (u0 + u);
             if (i < p && lane < T) {
                 cd x = v[u];
                 if (A.inverse) {
@@ -422,6 +516,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
                 }
                 sm[i * T + lane] = x;
             }
+        }
         }
     }
     __syncthreads();
@@ -453,7 +548,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
     typedef const __attribute__((address_space(4))) double *scalar_f64_ptr;
     const scalar_f64_ptr ptab = (scalar_f64_ptr)(unsigned long long)A.ptab;
     const size_t prow = 2 * (size_t)(h + 7);                                   // doubles per table row
-    for (int g0 = wave * F64_KB; g0 < h; g0 += 4 * F64_KB) {                   // (uniform per wavefront)
+    for (int g0 = wave * F64_KB; g0 < h; g0 += F64_PR_NW * F64_KB) {                   // (uniform per wavefront)
         cd C[F64_KB], S[F64_KB], w[F64_KB];
         const scalar_f64_ptr col = ptab + 2 * (size_t)g0;                      // k = g0 + 1 .. g0 + 8
 #pragma unroll
@@ -461,14 +556,14 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
             C[kk] = S[kk] = make_double2(0.0, 0.0);
             w[kk] = make_double2(col[2 * kk], col[2 * kk + 1]);                // j = 1
         }
-        const cd x0 = sm[l];
+        const cd x0 = pr_value(sm[l]);
         cd sum = x0;
-        cd xa = sm[T + l], xb = sm[(p - 1) * T + l];
+        cd xa = pr_value(sm[T + l]), xb = pr_value(sm[(p - 1) * T + l]);
         // two steps of j per trip, the inputs and coefficients of the next step travelling while the current one is accumulated
         // (registers alternate: no copies; a wavefront issues one instruction per four cycles whatever its kind, so every
         // instruction that is not one of the 32 FMAs of a step counts)
         auto fetch = [&](int j, cd &na, cd &nb, cd *nw) {                      // step j (its table column is j - 1)
-            na = sm[j * T + l]; nb = sm[(p - j) * T + l];
+            na = pr_value(sm[j * T + l]); nb = pr_value(sm[(p - j) * T + l]);
 #pragma unroll
             for (int kk = 0; kk < F64_KB; kk++) nw[kk] = make_double2(col[(size_t)(j - 1) * prow + 2 * kk], col[(size_t)(j - 1) * prow + 2 * kk + 1]);
         };
@@ -518,7 +613,7 @@ template <int IMG> __global__ __launch_bounds__(256) void f64_prime_kernel(const
         }
         if (g0 == 0) put(0, sum, make_double2(1.0, 0.0));                      // (k = 0: W^0)
     }
-    if (A.best) best_publish(bt, A.best, s_b);
+    if (A.best) best_publish(bt, A.best, s_b, F64_PR_NW);
 }
 
 // every workgroup's (bits, first index) -> the plane's: out[0] = first flat index of the largest |cc| (~0: none, e.g. all NaN)
@@ -816,21 +911,21 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
         A.T = (A.B + tiles - 1) / tiles; A.logT = 0;
         if (cols && extra && extra->tile_mask && extra->tile_T > 0) A.T = extra->tile_T;   // (chosen with the mask: half_plane_tiles)
         A.tiles_b = (A.B + A.T - 1) / A.T;
-        lds = (size_t)L.n * A.T * sizeof(cd);
+        lds = (size_t)L.n * A.T * (extra && extra->img_a ? sizeof(float2) : sizeof(cd));   // (the level that reads the images: float pairs)
     } else if (A.contiguous) {
         int T = std::max(1, std::min(8, F64_SMOOTH_MAX / L.n));
         if (c->opt_f64_smooth_t > 0) T = std::min(T, c->opt_f64_smooth_t);
         T = std::min(T, A.B);
         A.T = T; A.logT = 0;
         A.tiles_b = (A.B + T - 1) / T;
-        lds = ((size_t)2 * L.n * T + L.n) * sizeof(cd);
+        lds = ((size_t)L.n * T + L.n) * sizeof(cd);
     } else {
         int T = 8, lg = 3;
         while (T > 1 && (L.n * T > F64_SMOOTH_MAX || (c->opt_f64_smooth_t > 0 && T > c->opt_f64_smooth_t))) { T >>= 1; lg--; }
         while (T > 1 && (T >> 1) >= A.B) { T >>= 1; lg--; }
         A.T = T; A.logT = lg;
         A.tiles_b = (A.B + T - 1) / T;
-        lds = ((size_t)2 * L.n * T + L.n) * sizeof(cd);
+        lds = ((size_t)L.n * T + L.n) * sizeof(cd);
     }
     const long long grid = nA * A.tiles_b;
     if (grid <= 0 || grid > 0x7fffffffll) return km_fail(c, KM_E_ARG, "phase correlation: plane too large");
@@ -851,7 +946,7 @@ int run_level(km_ctx *c, cd *data, const dim_tabs &tabs, int N, const lvl &L, in
     }
     auto launch = [&](auto ic) {
         constexpr int IMG = decltype(ic)::value;
-        if (L.kind == 1) f64_prime_kernel<IMG><<<(unsigned)grid, 256, lds, c->stream>>>(A);
+        if (L.kind == 1) f64_prime_kernel<IMG><<<(unsigned)grid, 64 * F64_PR_NW, lds, c->stream>>>(A);
         else f64_smooth_kernel<IMG><<<(unsigned)grid, 256, lds, c->stream>>>(A);
     };
     switch (img) {
