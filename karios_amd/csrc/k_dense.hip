@@ -2000,30 +2000,40 @@ int kd_pyrdown_u8_pair(km_ctx *c, const uint8_t *d_src_a, const uint8_t *d_src_b
 }
 
 // ------------------------------------------------------------------ K11 integer shift
-template <typename T>
-__global__ __launch_bounds__(256) void shift_kernel(const T *__restrict__ img, int H, int W, ptrdiff_t stride, int y_off, int x_off,
-                                                    T *__restrict__ out)
+// out(y, x) = img(y + y_off, x + x_off), zero outside (reference large_offset.py `_shift_image`): a row is a byte copy at an offset -
+// 16 bytes per lane with unaligned loads and stores, whatever the element size (one element per lane with a 64-bit division each
+// ran at 2.5 TB/s; sub-dword global accesses pass the address unit a lane at a time).  Chunks that touch an edge go byte by byte.
+__global__ __launch_bounds__(256) void shift_rows_kernel(const uint8_t *__restrict__ img, int H, long long rowbytes, long long stride_bytes, int y_off,
+                                                         long long xoff_bytes, uint8_t *__restrict__ out)
 {
-    const size_t n = (size_t)H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        const long sy = (long)y + y_off, sx = (long)x + x_off;
-        T v = (T)0;
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = img[(size_t)sy * stride + sx];
-        out[i] = v;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const long long sy = (long long)y + y_off;
+        const bool row_in = sy >= 0 && sy < H;
+        const uint8_t *src = img + (size_t)(row_in ? sy : 0) * (size_t)stride_bytes;
+        uint8_t *o = out + (size_t)y * (size_t)rowbytes;
+        for (long long b = ((long long)blockIdx.x * 256 + threadIdx.x) * 16; b < rowbytes; b += (long long)gridDim.x * 256 * 16) {
+            const long long sb = b + xoff_bytes;
+            if (row_in && sb >= 0 && sb + 16 <= rowbytes && b + 16 <= rowbytes) {
+                uint4 v;
+                __builtin_memcpy(&v, src + sb, 16);
+                __builtin_memcpy(o + b, &v, 16);
+            } else {
+                for (int k = 0; k < 16 && b + k < rowbytes; k++) {
+                    const long long sx = sb + k;
+                    o[b + k] = row_in && sx >= 0 && sx < rowbytes ? src[sx] : (uint8_t)0;
+                }
+            }
+        }
     }
 }
 
 int kd_shift_image(km_ctx *c, const void *d_img, int elem_size, int H, int W, ptrdiff_t stride, int y_off, int x_off, void *d_out)
 {
-    const int nb = 4096;
-    switch (elem_size) {
-    case 1: shift_kernel<uint8_t><<<nb, 256, 0, c->stream>>>((const uint8_t *)d_img, H, W, stride, y_off, x_off, (uint8_t *)d_out); break;
-    case 2: shift_kernel<uint16_t><<<nb, 256, 0, c->stream>>>((const uint16_t *)d_img, H, W, stride, y_off, x_off, (uint16_t *)d_out); break;
-    case 4: shift_kernel<uint32_t><<<nb, 256, 0, c->stream>>>((const uint32_t *)d_img, H, W, stride, y_off, x_off, (uint32_t *)d_out); break;
-    case 8: shift_kernel<uint64_t><<<nb, 256, 0, c->stream>>>((const uint64_t *)d_img, H, W, stride, y_off, x_off, (uint64_t *)d_out); break;
-    default: return km_fail(c, KM_E_ARG, "shift_image: elem_size %d", elem_size);
-    }
+    if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8) return km_fail(c, KM_E_ARG, "shift_image: elem_size %d", elem_size);
+    if (H <= 0 || W <= 0) return KM_OK;
+    const long long rowbytes = (long long)W * elem_size;
+    const dim3 grid((unsigned)std::min<long long>((rowbytes + 16 * 256 - 1) / (16 * 256), 64), (unsigned)std::min(H, 65535));
+    shift_rows_kernel<<<grid, 256, 0, c->stream>>>((const uint8_t *)d_img, H, rowbytes, (long long)stride * elem_size, y_off, (long long)x_off * elem_size, (uint8_t *)d_out);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

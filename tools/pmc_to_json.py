@@ -24,7 +24,7 @@ STAGES = {   # stage key -> kernel-name fragments
     "fb_frame": ("fb_compact", "fb_place", "fb_gather"),
     "zncc": ("zncc_kernel", "zncc_int_kernel", "zncc_int_units_kernel"),
     "phase_correlation_f32": ("fft_rows", "fft61_", "transpose_kernel", "cross_power_f32", "argmax_f32", "fft_"),
-    "shift_image": ("shift_kernel",),
+    "shift_image": ("shift_kernel", "shift_rows_kernel"),
     "mi_kernel": ("mi_kernel", "mi_int_kernel", "mi_int_units_kernel"),
     "dn_keep": ("dn_keep_kernel",),
     "phase_correlation_f64": ("f64_prime_kernel", "f64_smooth_kernel", "f64_cross_kernel", "f64_best_reduce", "f64_pack", "f64_absmax", "f64_first_index"),

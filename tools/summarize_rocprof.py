@@ -9,7 +9,7 @@ import re
 import sys
 
 OURS = ("lk2_", "valid_sum_units", "pyrdown_units", "fft61", "f61_", "eig3_", "f_", "kf_header", "fb_place", "eig2_", "eigc_", "dn_keep", "fb_count", "mi_kernel", "mi_int_kernel", "row_checksum", "lap_kernel", "lap_march", "eig_kernel", "eig_march", "tk_", "fb_", "pyr_", "cand_kernel", "lk_kernel", "pyrdown_kernel", "minmax_", "zncc_kernel", "zncc_int_kernel", "sel_", "select_kernel",
-        "take_first", "sum_u32", "max_u32", "to_uint8", "auto_mask", "count_nonzero", "shift_kernel", "rocprim", "cross_power",
+        "take_first", "sum_u32", "max_u32", "to_uint8", "auto_mask", "count_nonzero", "shift_kernel", "shift_rows_kernel", "rocprim", "cross_power",
         "absmax", "first_index", "to_f64", "f64_", "blue_", "fft", "stretch", "lut_", "transpose_kernel", "argmax_f32", "zncc_win")
 
 
