@@ -828,11 +828,19 @@ def _band_gate(O, pair, mon_t, ref_t, conf, y0, rows, x0=0, cols=None, with_iter
     return out
 
 
-def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
+def _stream_timing(ctx, pair, conf, S, steps, boxes=None, group=1):
     """ms per pair of `pair` through FrameStream (depth 2, ZNCC of the confident rows), median of three windows of `steps` pairs; the
-    stage table from an untimed pass with every stage bracketed; flags the synchronisation-free corner path raised and units repeated."""
+    stage table from an untimed pass with every stage bracketed; flags the synchronisation-free corner path raised and units repeated.
+    `group`: pairs per batched submission (the headline's --pairs-per-submission: the sensitivity workloads are timed in the headline's form)."""
     from karios_amd.stream import FrameStream
     boxes = boxes or [None]
+    group = max(1, int(group))
+    units_of_submission = [(pair, b, None) for _ in range(group) for b in boxes]
+    nsub = max(1, steps // group)
+    steps = nsub * group
+
+    def submit_one(stream):
+        return stream.submit_many(units_of_submission, conf) if len(units_of_submission) > 1 else stream.submit(pair, conf, boxes[0])
     acc = {"rows": 0, "n_init": 0, "redone": 0, "units": 0, "flags": 0, "cand": 0}
 
     def take(res):
@@ -846,7 +854,7 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
 
     with FrameStream(0.4, depth=2, want_spans=True) as stream:
         for _ in range(4):
-            take(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
+            take(submit_one(stream))
         take(stream.drain())
         ctx.sync()
         windows = []
@@ -854,8 +862,8 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
             for k in acc:
                 acc[k] = 0
             t0 = time.perf_counter()
-            for _ in range(steps):
-                take(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
+            for _ in range(nsub):
+                take(submit_one(stream))
             take(stream.drain())
             ctx.sync()
             windows.append((time.perf_counter() - t0) / steps)
@@ -874,15 +882,15 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
                         spans[k] = spans.get(k, 0.0) + v
 
         for _ in range(4):
-            take_spans(stream.submit_many([(pair, b, None) for b in boxes], conf) if len(boxes) > 1 else stream.submit(pair, conf, boxes[0]))
+            take_spans(submit_one(stream))
         take_spans(stream.drain())
         ctx.set_profiling(False)
     dt = sorted(windows)[1]
-    per_pair = max(1, n)           # (a batched submission reports ONE set of spans for all its units)
+    per_pair = max(1, n) * (group if len(units_of_submission) > 1 else 1)      # (a batched submission reports ONE set of spans for all its units)
     stage = {k: round(v / per_pair, 4) for k, v in spans.items() if v > 0}
     units = max(1, keep["units"])
     return {"ms_per_pair": dt * 1e3, "windows_ms_per_pair": [round(w * 1e3, 4) for w in windows], "Mpx_per_s": S * S / 1e6 / dt,
-            "units_per_pair": len(boxes), "steps": steps,
+            "units_per_pair": len(boxes), "pairs_per_submission": group, "steps": steps,
             "corners_per_pair": keep["n_init"] // steps, "matched_keypoints_per_pair": keep["rows"] // steps,
             "forward_backward_survival": round(keep["rows"] / max(1, keep["n_init"]), 4), "candidates_per_pair": keep["cand"] // steps,
             "matched_keypoints_per_sec": keep["rows"] / steps / dt,
@@ -890,7 +898,7 @@ def _stream_timing(ctx, pair, conf, S, steps, boxes=None):
             "stage_ms": stage, "lk_span_ms": stage.get("lk_fwd_bwd"), "selection_span_ms": round(stage.get("sort", 0.0) + stage.get("select", 0.0), 4)}
 
 
-def sensitivity_objects(ctx, dev, S, steps):
+def sensitivity_objects(ctx, dev, S, steps, group=1):
     """the step on content that is NOT the best case, next to the headline (whose every corner survives the
     forward-backward test after ~2 LK iterations per level-0 pass).  Three resident 10980^2 workloads, each with ms per pair through
     FrameStream, the stage table, the flags / repeats of the synchronisation-free corner path and an in-run oracle gate on a box of
@@ -921,7 +929,7 @@ def sensitivity_objects(ctx, dev, S, steps):
         torch.cuda.synchronize()
         pair = ResidentPair.from_device_pointers(mon_t.data_ptr(), ref_t.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon_t, ref_t))
         o = {"workload": f"{S}x{S} uint16 pair resident in HBM, default configuration (one tile, k = 7, maxCorners 20000), KLT + ZNCC; " + note}
-        o.update(_stream_timing(ctx, pair, conf, S, steps))
+        o.update(_stream_timing(ctx, pair, conf, S, steps, group=group))     # (the headline's form: `group` pairs per batched submission)
         whole = pair.match_tile_raw(conf, zncc_threshold=0.4)            # blocking call: the library's diagnostics of the whole pair
         st = ctx.stats()
         o["whole_pair_blocking_call"] = {"path_flags": _bits(st.path_flags, KM_PATH_NAMES), "tie_rows_of_fused_eigen_pass": int(st.tie_rows),
@@ -1470,7 +1478,7 @@ def main():
         out["config5"] = config5_object(ctx, dev, S, max(4, min(10, a.steps // 2)))
         torch.cuda.empty_cache()
     if solo and not a.no_sensitivity:
-        out.update(sensitivity_objects(ctx, dev, S, max(6, min(12, a.steps))))
+        out.update(sensitivity_objects(ctx, dev, S, max(8, min(24, a.steps)), group=G))
         torch.cuda.empty_cache()
     if not a.no_config4 and S == 10980:
         c4 = config4(dev, rank, world, coll_dev, max(3, min(8, a.steps // 3)), batched=True)

@@ -30,7 +30,8 @@ sumr c4 config4_batched
 sumr e2e e2e_shape_batched
 sumr c3 config3 6
 sumr ep entry_points
-PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c2 bench.py --no-one-pair --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-full-scoring --no-sensitivity --steps 12 --warmup 3
+# (the bench loop also runs gates and settle phases with other shapes: the PMC of the batched headline uses a stream of EXACTLY four pairs per submission)
+PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c2 tools/pairs_batched_probe.py 4
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_ep tools/entry_points_workload.py 10980 scoring,dn
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c3 bench.py --config 3 --steps 4 --warmup 1
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_f64 tools/phase64_workload.py 10980 3
