@@ -992,8 +992,15 @@ def pmc_traffic(kernel: str, S: int) -> dict:
     ent = db.get(kernel)
     if not isinstance(ent, dict) or str(S) not in ent:
         return {"traffic": None}
-    return {"traffic": ent[str(S)], "traffic_source": f"precomputed: {PMC_FILE}"
-            + (f" (measured at commit {ent['measured_at']})" if ent.get("measured_at") else " (round-1 counters)")}
+    out = {"traffic": ent[str(S)], "traffic_source": f"precomputed: {PMC_FILE}"
+           + (f" (measured at commit {ent['measured_at']})" if ent.get("measured_at") else " (round-1 counters)")}
+    busy = (ent.get("_detail") or {}).get("valu_pipe_busy")
+    if busy is not None:
+        # what actually bounds the stencil / tracker kernels: instruction issue.  4 cycles per VALU wave-instruction over the 1024 SIMDs'
+        # cycles of the launch, from the same precomputed passes
+        out["valu_pipe_busy"] = busy
+        out["valu_pipe_busy_note"] = "4 * SQ_INSTS_VALU / (1024 SIMDs * kernel cycles), kernels serialised by the counter run (precomputed)"
+    return out
 
 
 def roofline_of(stage_ms: dict, S: int, n_init: int, n_cand: int, n_zncc: int, timed_stage: str | None, minmax_early: bool = False) -> dict:
