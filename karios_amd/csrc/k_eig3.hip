@@ -311,7 +311,7 @@ __device__ __forceinline__ void eig3_item(const uint8_t *__restrict__ src, const
             auto is_cand = [&](int p) {
                 const float left = p == 0 ? m3l : m3[(p + 7) & 7], right = p == 7 ? m3r : m3[(p + 1) & 7];
                 const float nb = fmaxf(fmaxf(left, right), m3[p]);
-                return EM[p] > thr_run && EM[p] != 0.f && EM[p] >= nb;
+                return EM[p] > thr_run && EM[p] >= nb;   // (thr_run >= +0 - qualityLevel > 0 is checked on entry - so OpenCV's `val != 0` is implied)
             };
             float selval = 0.f;
             unsigned selp = 0u, ncand = 0u;

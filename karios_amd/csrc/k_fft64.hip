@@ -650,7 +650,9 @@ __global__ __launch_bounds__(256) void f64_pack_kernel(const T *__restrict__ a, 
 
 // Z = spectrum of a + i b at permuted positions; neg*[pos] = position of the negated frequency.  In place, a pair (k, -k) per thread:
 // A = (Z(k) + conj Z(-k)) / 2, B = (Z(k) - conj Z(-k)) / 2i, P = A conj(B) / max(|A conj(B)|, 100 eps); P(-k) = conj P(k) (real images)
-__global__ __launch_bounds__(256) void f64_cross_kernel(cd *__restrict__ Z, const int *__restrict__ negx, const int *__restrict__ negy, int H, int W)
+// `keepx` (Hermitian half of the inverse): only the columns it marks are read afterwards - the others are not written (0.97 of 3.9 GB).
+__global__ __launch_bounds__(256) void f64_cross_kernel(cd *__restrict__ Z, const int *__restrict__ negx, const int *__restrict__ negy, int H, int W,
+                                                        const unsigned char *__restrict__ keepx)
 {
     const double floor_ = 100.0 * 2.220446049250313e-16;
     for (int py = blockIdx.y; py < H; py += gridDim.y) {
@@ -668,8 +670,8 @@ __global__ __launch_bounds__(256) void f64_cross_kernel(cd *__restrict__ Z, cons
             const double re = fa.x * fb.x + fa.y * fb.y, im = fa.y * fb.x - fa.x * fb.y;       // fa conj(fb)
             const double mag = fmax(hypot(re, im), floor_);
             const cd P = make_double2(re / mag, im / mag);
-            Z[i0] = P;
-            if (i1 != i0) Z[i1] = make_double2(P.x, -P.y);
+            if (!keepx || keepx[px]) Z[i0] = P;
+            if (i1 != i0 && (!keepx || keepx[nx])) Z[i1] = make_double2(P.x, -P.y);
         }
     }
 }
@@ -1009,6 +1011,7 @@ struct half_plane {
     const int *srcx = nullptr;
     int hstart = -1;
     const unsigned char *mask[16] = {nullptr};          // per column level
+    const unsigned char *keepx = nullptr;               // per column position: kx <= W / 2 (the cross-power pass writes only these)
     int T[16] = {0};
 };
 
@@ -1197,8 +1200,8 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
             lowx[(size_t)pos] = fr <= W / 2;
         }
         const size_t nl = PY.lv.size();
-        // [srcx: W ints] [one mask of W bytes per column level]
-        std::vector<unsigned char> h((size_t)W * (4 + nl), 0);
+        // [srcx: W ints] [one mask of W bytes per column level] [lowx: W bytes]
+        std::vector<unsigned char> h((size_t)W * (4 + nl + 1), 0);
         {
             std::vector<int> ng;
             host_negpos(PX, ng);
@@ -1219,12 +1222,14 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
             for (int pos = 0; pos < W; pos++) if (lowx[(size_t)pos]) hs = std::max(hs, pos % n0 + 1);
             HP.hstart = hs < n0 ? hs : -1;
         }
+        std::copy(lowx.begin(), lowx.end(), h.begin() + (size_t)W * (4 + nl));
         unsigned char *d = (unsigned char *)km_ws(c, WS_F64_MASK, h.size());
         cd *z2 = (cd *)km_ws(c, WS_FFT_B, (size_t)((H + 1) / 2) * W * sizeof(cd));
         if (!d || !z2) return KM_E_NOMEM;
         if ((rc = km_h2d_small(c, d, h.data(), h.size()))) return rc;
         HP.on = true; HP.packed = z2; HP.src = z; HP.srcx = (const int *)d;
         for (size_t l = 0; l < nl; l++) HP.mask[l] = d + (size_t)W * (4 + l);
+        HP.keepx = d + (size_t)W * (4 + nl);
     }
     auto along_rows = [&](bool inverse) -> int {
         if (W <= 1) return KM_OK;
@@ -1243,7 +1248,7 @@ int kp_phase_shift_f64(km_ctx *c, const void *d_a, const void *d_b, int dtype, i
     if ((rc = along_cols(false))) return rc;
     {
         const dim3 g((unsigned)std::min((W + 255) / 256, 64), (unsigned)std::min(H, 8192));
-        f64_cross_kernel<<<g, 256, 0, c->stream>>>(z, negx, negy, H, W);
+        f64_cross_kernel<<<g, 256, 0, c->stream>>>(z, negx, negy, H, W, HP.on ? HP.keepx : nullptr);
         KM_LAUNCH_CHECK(c);
     }
     if ((rc = along_cols(true))) return rc;
