@@ -71,4 +71,5 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new stub_event{0};
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { if (!e) return hipErrorInvalidValue; e->recorded++; return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipEventQuery(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }   // (the stand-in executes everything at once: always complete)
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = 0.f; return a && b ? hipSuccess : hipErrorInvalidValue; }
