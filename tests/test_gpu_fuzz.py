@@ -36,3 +36,14 @@ def test_random_aux_case_matches_oracle(ops, O, seed):
     from karios_amd.resident import ResidentPair
     fails = fuzz.run_aux_case(seed, ops, O, ResidentPair)
     assert not fails, fails
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 17))
+def test_random_batched_submission_matches_oracle_unit_by_unit(ops, O, seed):
+    """2 .. 16 random units (boxes of one or two resident pairs, widths off the dword grid) through km_klt_units_frame_submit, every
+    unit's frame against the oracle on its box (flagged units through the exact repeat, as FrameStream does); a submission the batch
+    form declines for a documented reason counts as covered by the unit-by-unit tests."""
+    from karios_amd.resident import ResidentPair
+    fails = fuzz.run_units_case(seed, ops, O, ResidentPair)
+    assert not fails, fails
