@@ -155,6 +155,21 @@ __device__ __forceinline__ long long wave_sum_split(int v)
     return ((long long)wave_sum_i32_dpp(hi) << 16) + (long long)wave_sum_i32_dpp(lo);
 }
 
+// Eight patch bytes from a byte-aligned LDS address as three ALIGNED dwords + two v_alignbyte.  A ds_read_b64 whose address is
+// not a multiple of 8 takes the LDS unit's unaligned path: ~55 cycles per wave instruction against ~4 aligned (PMC, round 5:
+// SQ_LDS_UNALIGNED_STALL = 96 % of SQ_LDS_IDX_ACTIVE, the LDS unit busy 83 % of the kernel - the tracker was LDS-bound on it).
+// Reads up to 3 bytes in front of p (same patch: its base is 16-byte aligned) and 4 behind p + 8 (the pitch / tail slack of lk2_geo).
+__device__ __forceinline__ uint2 lk_lds_read8(const uint8_t *p, unsigned sh)
+{
+    const uint32_t *q = (const uint32_t *)(p - sh);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    uint2 r;
+    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return r;
+}
+__device__ __forceinline__ unsigned lk_lds_shift(const uint8_t *p) { return (unsigned)(size_t)p & 3u; }
+
 // Window pixels are dealt to the lanes as horizontal RUNS of LK_RUN pixels (run r = t * 64 + lane covers columns
 // [x0, x0 + n) of window row y).  A run needs LK_RUN + 1 consecutive bytes from each of two rows of the search patch:
 // two (unaligned) 8-byte LDS reads per run and iteration instead of four byte reads per pixel, the byte pairs are cut out
@@ -340,9 +355,8 @@ __device__ void lk_track_point(const km_pyr &I, const km_pyr &J, float px, float
             for (int t = 0; t < NR; t++) {
                 const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
                 const uint8_t *p0 = jb + y * JP + x0;
-                uint2 r0, r1;                         // bytes x0 .. x0+7 of the two patch rows (unaligned LDS reads)
-                __builtin_memcpy(&r0, p0, 8);
-                __builtin_memcpy(&r1, p0 + JP, 8);
+                const unsigned jsh = lk_lds_shift(p0);
+                const uint2 r0 = lk_lds_read8(p0, jsh), r1 = lk_lds_read8(p0 + JP, jsh);   // bytes x0 .. x0+7 of the two patch rows
                 int val[LK_RUN + 1];
                 val[LK_RUN] = 0;
 #pragma unroll
@@ -459,21 +473,6 @@ __device__ __forceinline__ int lk_dot2_k(lk_s2 a, lk_s2 b, int k)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
     return d;
 }
-
-// Eight patch bytes from a byte-aligned LDS address as three ALIGNED dwords + two v_alignbyte.  A ds_read_b64 whose address is
-// not a multiple of 8 takes the LDS unit's unaligned path: ~55 cycles per wave instruction against ~4 aligned (PMC, round 5:
-// SQ_LDS_UNALIGNED_STALL = 96 % of SQ_LDS_IDX_ACTIVE, the LDS unit busy 83 % of the kernel - the tracker was LDS-bound on it).
-// Reads up to 3 bytes in front of p (same patch: its base is 16-byte aligned) and 4 behind p + 8 (the pitch / tail slack of lk2_geo).
-__device__ __forceinline__ uint2 lk_lds_read8(const uint8_t *p, unsigned sh)
-{
-    const uint32_t *q = (const uint32_t *)(p - sh);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    uint2 r;
-    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    return r;
-}
-__device__ __forceinline__ unsigned lk_lds_shift(const uint8_t *p) { return (unsigned)(size_t)p & 3u; }
 
 template <int NR, int WIN, int MAXIT>
 __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, uint8_t *pJ, int (&oI)[2][2], int (&oJ)[2][2], float px, float py,
@@ -655,7 +654,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
             }
             a = nx - (float)inx; b = ny - (float)iny;
             lk_weights(a, b, w00, w01, w10, w11);
-            const lk_s2 wr0 = lk_as_s2(lk_pack16(w00, w01)), wr1 = lk_as_s2(lk_pack16(w10, w11));   // signed: w11 may be -1
+            const lk_s2 wc0 = lk_as_s2(lk_pack16(w00, w10)), wc1 = lk_as_s2(lk_pack16(w01, w11));   // (column k, column k + 1); signed: w11 may be -1
             const uint8_t *jb = Y + (iny - jy0) * PP + (inx - jx0);
             int sb1 = 0, sb2 = 0;
 #pragma unroll
@@ -666,12 +665,17 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                 const uint2 r0 = lk_lds_read8(p0, jsh), r1 = lk_lds_read8(p0 + PP, jsh);   // bytes x0 .. x0+7 of the two patch rows
                 int val[LK_RUN + 1];
                 val[LK_RUN] = 0;
+                // VERTICAL byte pairs (row y, row y + 1) of columns 0 .. 5: six v_perm serve the five interpolated values (the horizontal
+                // pairs (k, k + 1) of either row took ten); the integer sum w00 p(k) + w10 q(k) + w01 p(k+1) + w11 q(k+1) is the same
+                lk_s2 V[LK_RUN + 1];
 #pragma unroll
-                for (int k = 0; k < LK_RUN; k++) {
-                    const uint32_t sel = 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 1) << 16);   // (byte k, byte k+1) as 16-bit values
-                    const lk_s2 c0 = lk_as_s2(__builtin_amdgcn_perm(r0.y, r0.x, sel)), c1 = lk_as_s2(__builtin_amdgcn_perm(r1.y, r1.x, sel));
-                    val[k] = __builtin_amdgcn_sdot2(c0, wr0, lk_dot2_k(c1, wr1, k_half9), false) >> (14 - 5);
+                for (int k = 0; k <= LK_RUN; k++) {
+                    const uint32_t sel = 0x0c000c00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16);
+                    V[k] = lk_as_s2(k < 4 ? __builtin_amdgcn_perm(r1.x, r0.x, sel) : __builtin_amdgcn_perm(r1.y, r0.y, sel));
                 }
+#pragma unroll
+                for (int k = 0; k < LK_RUN; k++)
+                    val[k] = __builtin_amdgcn_sdot2(V[k], wc0, lk_dot2_k(V[k + 1], wc1, k_half9), false) >> (14 - 5);
 #pragma unroll
                 for (int q2 = 0; q2 < 3; q2++) {
                     const lk_s2 diff = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1])) - lk_as_s2(IvP[t][q2]);
