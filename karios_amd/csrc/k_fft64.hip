@@ -18,7 +18,7 @@
 // another.  Two level kernels:
 //     * smooth  n (prime factors 2, 3, 5, 7; <= 2048): Stockham stages in LDS, radices 7 / 5 / 4 / 3 / 2;
 //     * prime   p (11 <= p <= 127, e.g. the 61 of Sentinel-2's 10980): lane = transform, the p inputs stream from LDS once per
-//       group of 8 output pairs (X_k, X_{p-k} share the folded inputs x_j +- x_{p-j}), coefficients through the scalar path.
+//       group of F64_KB = 4 output pairs per wavefront (X_k, X_{p-k} share the folded inputs x_j +- x_{p-j}; 8 wavefronts per tile), coefficients through the scalar path.
 // A side with a prime factor above 127 goes through Bluestein's chirp-z on top of the same kernels (power-of-two length >= 2 N - 1).
 // The unnormalised inverse is used (the arg-max does not depend on a factor).
 #include "common.hpp"
@@ -39,7 +39,7 @@ __device__ __forceinline__ cd c_mul(cd a, cd b) { return make_double2(fma(a.x, b
 
 #define F64_KB 4              // output pairs per wavefront pass of the prime kernel
 #define F64_PR_NW 8           // wavefronts per workgroup of the prime kernel: 8 x 4 pairs cover h <= 32 in one pass (p = 61: h = 30), and a
-                              // wavefront fills its 8 of the 61 tile rows in ONE batch of loads (4 x 8: 1.00 -> ? ms on the column level)
+                              // wavefront fills its 8 of the 61 tile rows in ONE batch of loads (4 wavefronts x 8 pairs before: column level 0.97 -> 0.84 ms, inverse 0.70 -> 0.61; 16 x 2: slower)
 
 struct lvl_args {
     cd *data;
@@ -542,8 +542,8 @@ template <int IMG> __global__ __launch_bounds__(64 * F64_PR_NW) void f64_prime_k
         return post && lane < nt ? ltw[(size_t)k * (size_t)A.ltw_R + (size_t)q] : make_double2(1.0, 0.0);
     };
     // the coefficient addresses are the same for every lane: through the constant address space they become scalar loads; the
-    // table holds one row per j with k running along it, so that the eight coefficient pairs of a step are 128 consecutive bytes
-    // (two wide scalar loads and one pointer step; an index (j k) mod p stepped and wrapped per coefficient cost 7 scalar
+    // table holds one row per j with k running along it, so that the F64_KB coefficient pairs of a step are 64 consecutive bytes
+    // (one wide scalar load and one pointer step; an index (j k) mod p stepped and wrapped per coefficient cost 7 scalar
     // instructions each - more issue slots than the FMAs they feed)
     typedef const __attribute__((address_space(4))) double *scalar_f64_ptr;
     const scalar_f64_ptr ptab = (scalar_f64_ptr)(unsigned long long)A.ptab;
@@ -561,7 +561,7 @@ template <int IMG> __global__ __launch_bounds__(64 * F64_PR_NW) void f64_prime_k
         cd xa = pr_value(sm[T + l]), xb = pr_value(sm[(p - 1) * T + l]);
         // two steps of j per trip, the inputs and coefficients of the next step travelling while the current one is accumulated
         // (registers alternate: no copies; a wavefront issues one instruction per four cycles whatever its kind, so every
-        // instruction that is not one of the 32 FMAs of a step counts)
+        // instruction that is not one of the 4 F64_KB FMAs of a step counts)
         auto fetch = [&](int j, cd &na, cd &nb, cd *nw) {                      // step j (its table column is j - 1)
             na = pr_value(sm[j * T + l]); nb = pr_value(sm[(p - j) * T + l]);
 #pragma unroll
@@ -580,7 +580,7 @@ template <int IMG> __global__ __launch_bounds__(64 * F64_PR_NW) void f64_prime_k
         for (int j = 1; j <= hh; j += 2) {
             cd ya, yb, w1[F64_KB];
             fetch(j + 1, ya, yb, w1);                                          // (j + 1 = h + 1: fetched, never used)
-            __builtin_amdgcn_sched_barrier(0);                                 // the loads stay up here: their latency is the 32 FMAs below
+            __builtin_amdgcn_sched_barrier(0);                                 // the loads stay up here: their latency is the FMAs below
             accumulate(xa, xb, w);
             __builtin_amdgcn_sched_barrier(0);                                 // ... and nothing that waits for them moves in front of the FMAs
             __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0) HERE: LDS and scalar loads share the counter and return
