@@ -3,6 +3,7 @@
 // device call), the asynchronous submission and the batched kernel-size search.  Batched units: api_units.hip.
 #include "api_internal.hpp"
 #include <time.h>
+#include <sys/prctl.h>
 
 #include <cstring>
 
@@ -834,6 +835,9 @@ int km_frame_wait(km_ctx *c, int ticket, const void **block, size_t *bytes)
     if (!slot->done || !slot->pending.load(std::memory_order_acquire)) return KM_E_ARG;
     // The waiting thread has nothing else to do: poll and SLEEP (hipEventSynchronize spins - also on an event created with
     // hipEventBlockingSync - and kept one CPU per rank at 100 %: 0.72 of every 0.91-ms step; eight ranks want those CPUs for RCCL's proxies)
+    // (the kernel rounds a sleep up by the thread's timer slack, 50 us by default: 1 us for the threads that wait here)
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
     for (;;) {
         const hipError_t e = hipEventQuery(slot->done);
         if (e == hipSuccess) break;
