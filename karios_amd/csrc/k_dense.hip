@@ -79,7 +79,8 @@ __device__ __forceinline__ unsigned stretch_u8(T v, double mn, double range, boo
 // over the aligned body of every contiguous span - the whole image when its rows are dense, else row by row (a box of a larger
 // raster: the tiles of `KLT.match` on a resident pair; byte loads there cost 0.27 ms per 30-Mpx tile) - packed 16-bit min / max.
 template <typename T>
-__device__ __forceinline__ void minmax_image(const T *__restrict__ img, int H, int W, ptrdiff_t stride, unsigned blk, unsigned nblk, double *partial_out)
+__device__ __forceinline__ void minmax_image(const T *__restrict__ img, int H, int W, ptrdiff_t stride, unsigned blk, unsigned nblk, double *partial_out,
+                                             bool deep = false)
 {
     using A = typename px_traits<T>::acc;
     A mn, mx;
@@ -124,7 +125,20 @@ __device__ __forceinline__ void minmax_image(const T *__restrict__ img, int H, i
         if (head > n) head = n;
         const size_t nvec = (n - head) / V;
         const uint4 *vp = (const uint4 *)(p + head);
-        for (size_t i = tid; i < nvec; i += nth) take(vp[i]);
+        // `deep` - eight independent 16-byte loads in flight per thread: beside instruction-bound kernels (the next submission's min / max beside
+        // LK .. ZNCC) the kernel runs as ONE workgroup per compute unit - it must reach its bandwidth with four waves per CU, and must
+        // not occupy more: spread over every wave slot LK's retiring waves left, its long-lived workgroups kept the 1024-thread workgroups
+        // of the frame stage waiting for whole CUs until it had drained (fb_compact 5 -> 189 us per submission)
+        size_t i = tid;
+        if (deep)
+        for (; i + 7 * nth < nvec; i += 8 * nth) {
+            uint4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) q[k] = vp[i + k * nth];
+#pragma unroll
+            for (int k = 0; k < 8; k++) take(q[k]);
+        }
+        for (; i < nvec; i += nth) take(vp[i]);
         if (tid < head) upd(p[tid]);
         const size_t tail0 = head + nvec * V;
         if (tail0 + tid < n && tid < (size_t)V) upd(p[tail0 + tid]);
@@ -168,11 +182,11 @@ struct mm_units_args {
     double *out[KM_UNITS_MAX];
 };
 template <typename T>
-__global__ __launch_bounds__(256) void minmax_partial_units_kernel(mm_units_args U, double *partial)
+__global__ __launch_bounds__(256) void minmax_partial_units_kernel(mm_units_args U, double *partial, int deep)
 {
     const unsigned u = blockIdx.z, im = blockIdx.y;
     minmax_image<T>((const T *)U.img[im][u], U.H[u], U.W[u], U.stride[im][u], blockIdx.x, gridDim.x,
-                    partial + (size_t)2 * gridDim.x * (2 * u + im) + 2 * blockIdx.x);
+                    partial + (size_t)2 * gridDim.x * (2 * u + im) + 2 * blockIdx.x, deep != 0);
 }
 
 __device__ __forceinline__ void minmax_final(const double *partial, int nb, double *out)
@@ -207,6 +221,8 @@ static int minmax_launch(km_ctx *c, const void *d_a, const void *d_b, int dtype,
     // workgroups per image.  Beside LK (early min / max: ws_slot != WS_PARTIAL) the kernel is off the critical path and takes
     // fewer wave slots from the kernel it shares the GPU with
     static const int nb_early = [] { const char *e = km_dev_env("KARIOS_HIP_MM_EARLY_NB"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 2048 ? v : 2048; }();
+    // (one pair at a time: the early min / max has only LK .. ZNCC of ONE pair, 0.27 ms, to hide behind - it needs the bandwidth of many
+    // workgroups; a batched submission's runs as one workgroup per CU, kd_minmax_units)
     const int nb = ws_slot == WS_PARTIAL ? 2048 : nb_early, ni = d_b ? 2 : 1;
     double *partial = (double *)km_ws(c, ws_slot, (size_t)2 * nb * ni * sizeof(double));
     if (!partial) return KM_E_NOMEM;
@@ -232,15 +248,23 @@ int kd_minmax_units(km_ctx *c, const km_units &U, double *const *d_out, int ws_s
         A.img[0][u] = U.ref[u]; A.img[1][u] = U.mon[u]; A.stride[0][u] = U.sref[u]; A.stride[1][u] = U.smon[u];
         A.H[u] = U.H[u]; A.W[u] = U.W[u]; A.out[u] = d_out[u];
     }
-    const int nb = U.n >= 8 ? 256 : U.n >= 4 ? 512 : 1024;          // workgroups per raster: ~4096 - 8192 in flight over the batch
+    // workgroups per raster: ~4096 - 8192 over the batch on the critical path.  Beside other kernels (ws_slot != WS_PARTIAL: the early
+    // min / max of a submission behind another one) whole rasters run as ONE workgroup per compute unit over the batch with eight
+    // loads in flight per thread (`deep`); boxes of larger rasters go row by row - too few vectors per thread and row for that
+    int nb = U.n >= 8 ? 256 : U.n >= 4 ? 512 : 1024, deep = 0;
+    if (ws_slot != WS_PARTIAL) {
+        bool flat = true;
+        for (int u = 0; u < U.n; u++) flat = flat && U.sref[u] == U.W[u] && U.smon[u] == U.W[u];
+        if (flat) { nb = std::max(8, c->n_cu / (2 * U.n)); deep = 1; }
+    }
     double *partial = (double *)km_ws(c, ws_slot, (size_t)2 * nb * 2 * U.n * sizeof(double));
     if (!partial) return KM_E_NOMEM;
     const dim3 grid(nb, 2, U.n);
     switch (U.dtype) {
-    case KM_U8: minmax_partial_units_kernel<uint8_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
-    case KM_U16: minmax_partial_units_kernel<uint16_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
-    case KM_I16: minmax_partial_units_kernel<int16_t><<<grid, 256, 0, c->stream>>>(A, partial); break;
-    case KM_F32: minmax_partial_units_kernel<float><<<grid, 256, 0, c->stream>>>(A, partial); break;
+    case KM_U8: minmax_partial_units_kernel<uint8_t><<<grid, 256, 0, c->stream>>>(A, partial, deep); break;
+    case KM_U16: minmax_partial_units_kernel<uint16_t><<<grid, 256, 0, c->stream>>>(A, partial, deep); break;
+    case KM_I16: minmax_partial_units_kernel<int16_t><<<grid, 256, 0, c->stream>>>(A, partial, deep); break;
+    case KM_F32: minmax_partial_units_kernel<float><<<grid, 256, 0, c->stream>>>(A, partial, deep); break;
     default: return km_fail(c, KM_E_ARG, "minmax: bad dtype %d", U.dtype);
     }
     KM_LAUNCH_CHECK(c);
