@@ -373,6 +373,36 @@ def test_phase_correlation_integer_shift(ops, O, shape, shift):
     np.testing.assert_array_equal(got, np.array(shift, np.float64))
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.int16])
+@pytest.mark.parametrize("pad", [0, 1, 2, 4])
+def test_phase_correlation_on_row_strided_rasters_in_both_precisions(ops, O, dtype, pad):
+    """Rows of a wider array (stride != width; odd strides / offsets put the rows off the dword grid): the transforms' first level
+    reads 8- / 16-bit pixels as whole dwords where every row start allows it and one by one otherwise - same answer either way, in
+    float32 and in complex128, for a side with the 61-point level (61 * 12 = 732) and a smooth one."""
+    from karios_amd._lib import default_context
+    ctx = default_context()
+    for (H, W), shift in (((96, 732), (-9, 21)), ((80, 120), (5, -7))):
+        _, ref = synth.make_pair(H, W + 8, 0, 0, seed=H + W + pad)
+        ref = ref[:, 2:2 + W + 4]
+        if dtype is np.uint8:
+            ref = (ref >> 5).clip(0, 255).astype(np.uint8)
+        elif dtype is np.int16:
+            ref = (ref.astype(np.int32) - 4000).astype(np.int16)
+        wide_r = np.zeros((H, W + 4 + pad), dtype); wide_m = np.zeros((H, W + 4 + pad), dtype)
+        off = pad % 3
+        wide_r[:, off:off + W] = ref[:, :W]
+        wide_m[:, off:off + W] = np.roll(ref[:, :W], shift, (0, 1))
+        a, b = wide_m[:, off:off + W], wide_r[:, off:off + W]          # views: row stride W + 4 + pad, first pixel at `off`
+        exp = O.phase_cross_correlation(np.ascontiguousarray(a), np.ascontiguousarray(b))
+        np.testing.assert_array_equal(exp, np.array(shift, np.float64))
+        for fp64 in (0, 1):
+            ctx.set_option("phase_fp64", fp64)
+            try:
+                np.testing.assert_array_equal(ops.phase_cross_correlation(a, b), exp)
+            finally:
+                ctx.set_option("phase_fp64", 0)
+
+
 def test_shift_image_matches_reference_semantics(ops, O):
     rng = np.random.default_rng(9)
     for dtype in (np.uint8, np.uint16, np.float32, np.float64):
