@@ -381,7 +381,7 @@ def test_phase_correlation_on_row_strided_rasters_in_both_precisions(ops, O, dty
     float32 and in complex128, for a side with the 61-point level (61 * 12 = 732) and a smooth one."""
     from karios_amd._lib import default_context
     ctx = default_context()
-    for (H, W), shift in (((96, 732), (-9, 21)), ((80, 120), (5, -7))):
+    for (H, W), shift in (((96, 732), (-9, 21)), ((80, 120), (5, -7)), ((64, 121), (4, 9)), ((61, 122), (-3, 6)), ((40, 183), (2, -5))):   # widths 0 / 1 / 2 / 3 mod 4
         _, ref = synth.make_pair(H, W + 8, 0, 0, seed=H + W + pad)
         ref = ref[:, 2:2 + W + 4]
         if dtype is np.uint8:
