@@ -156,17 +156,22 @@ def _bench(args, env_extra, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 8000, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for ln in r.stdout.splitlines():                 # the detail objects travel on the lines above (bench.py: `detail <name> {...}`)
+        if ln.startswith("detail "):
+            _, name, body = ln.split(" ", 2)
+            line.setdefault(name, json.loads(body))
+    return line
 
 
 def test_bench_headline_with_the_rccl_exchange_in_the_loop():
     """bench.py's N > 1 headline loop (RCCL all-gather of every step's block inside the timed region) on a one-rank group: the device-
     side count of the gathered blocks equals the frames' rows, nothing is flagged, no host wait per step is reported."""
-    common = ["--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-end-to-end", "--no-config3", "--no-config4", "--no-config5",
-              "--no-in-flight", "--no-full-scoring"]
+    common = ["--steps", "40", "--warmup", "5", "--headline-only"]
     exch = _bench(common, {"KARIOS_BENCH_EXCHANGE": "1"})
     e = exch["exchange"]
     assert exch["backend"] == "nccl" and e["host_waits_per_step"] == 0 and e["flagged_blocks_gathered"] == 0 and e["steps_per_collective"] == 4
-    assert e["rows_from_gathered_blocks"] == 40 * exch["matched_keypoints_per_pair"]
+    by_pair = exch["matched_keypoints_by_pair"]                    # four DISTINCT pairs, each the step of 10 of the 40 timed steps
+    assert len(by_pair) == 4 and e["rows_from_gathered_blocks"] == 10 * sum(by_pair.values())
     assert exch["matched_keypoints_per_pair"] > 10000

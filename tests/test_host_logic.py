@@ -581,3 +581,60 @@ def test_release_library_rejects_development_option_names():
         assert (b"\0" + name.encode() + b"\0") not in strings, f"development option name {name!r} is compiled into the release library"
     for name in sorted(accepted):
         assert (b"\0" + name.encode() + b"\0") in strings or name.encode() in strings, name
+
+
+# ---------------------------------------------------------------------------- bench.py: the driver's line stays small
+def _r05_detail():
+    import json
+    return json.loads(open(os.path.join(ROOT, "profiles", "bench_r05.json")).read().strip().splitlines()[-1])
+
+
+def test_bench_small_line_is_small_and_carries_the_contract():
+    """Round 5's 21 KB line did not fit the driver's record (BENCH_r05.json `parsed: null`).  `benchkit.summary.small_line` turns the full
+    detail - here round 5's own line, 21 KB - into the line that is printed LAST: < 8000 B, the contract keys, roofline + cpu_baseline."""
+    import json
+    sys.path.insert(0, ROOT)
+    from benchkit import summary
+    detail = _r05_detail()
+    assert len(json.dumps(detail)) > 20000
+    line = summary.small_line(detail)
+    text = json.dumps(line)
+    assert len(text) < 8000 and len(text) <= summary.MAX_BYTES
+    for key in summary.CONTRACT_KEYS:
+        assert key in line, key
+    assert line["value"] == detail["value"] and line["steps"] == detail["steps"] and line["warmup"] == detail["warmup"]
+    assert isinstance(line["config"]["workload"], str) and 0 < len(line["config"]["workload"]) <= 118
+    roof = line["roofline"]
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_8d_model", "valu_pipe_busy"):
+        assert key in roof, key
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["parity"]["passed"] is True and len(cb["sample"]) <= 118
+    for key in ("one_pair_per_submission_ms", "end_to_end_ms", "config3_fp64_ms", "config4_ms"):
+        assert key in line["summary"], key
+    assert line["gates_all_passed"] is True and line["gates_passed"]["config3"] is True
+    # no string of the line is long enough for the driver to cut it
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert max(len(x) for x in strings(line)) <= 140
+
+
+def test_bench_small_line_guard_drops_optional_parts_first():
+    import json
+    sys.path.insert(0, ROOT)
+    from benchkit import summary
+    detail = _r05_detail()
+    detail["stage_ms"] = {f"stage_{i}": 0.1234 + i for i in range(400)}         # a leg that grew: the guard sheds it, the contract stays
+    line = summary.small_line(detail)
+    assert len(json.dumps(line)) <= summary.MAX_BYTES and "stage_ms" not in line
+    assert all(k in line for k in summary.CONTRACT_KEYS)
+    failed = dict(_r05_detail())
+    failed["config3"] = dict(failed["config3"], gate=dict(failed["config3"]["gate"], passed=False))
+    assert summary.small_line(failed)["gates_all_passed"] is False

@@ -3,7 +3,7 @@
 # statistics of the headline loop (+ full scoring), of the kernels ALONE (blocking calls), of the batched config-4 / e2e shapes, of
 # config 3 and of the entry points the loop does not reach, and the PMC passes (separate --pmc runs, kernel trace only).  Results
 # under gpurun_out/ (the summaries are copied to profiles/ by hand).  Every profiler run sits under `timeout`.
-R=$PWD; TAG=${1:-r05}; COMMIT=${2:-unknown}
+R=$PWD; TAG=${1:-r06}; COMMIT=${2:-unknown}
 python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/bench_${TAG}.err | tail -1 > gpurun_out/bench_${TAG}.json
 python bench.py 2> gpurun_out/bench_${TAG}_default.err | tail -1 > gpurun_out/bench_${TAG}_default.json
 python bench.py --config 3 --steps 10 --warmup 2 2> gpurun_out/bench_${TAG}_config3.err | tail -1 > gpurun_out/bench_${TAG}_config3.json
@@ -12,8 +12,8 @@ prof() {   # prof <tag> <script> [args]: rocprofv3 kernel statistics (csv) of `p
   t=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$t -o $t -- python3 "$@" > $R/gpurun_out/prof_${TAG}_$t.log 2>&1
 }
-prof c2 $R/bench.py --no-one-pair --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-sensitivity --steps 20 --warmup 5
-prof c2one $R/bench.py --pairs-per-submission 1 --no-cpu-baseline --no-end-to-end --no-in-flight --no-config3 --no-config4 --no-config5 --no-sensitivity --no-full-scoring --steps 20 --warmup 5
+prof c2 $R/bench.py --headline-only --steps 20 --warmup 5
+prof c2one $R/bench.py --pairs-per-submission 1 --headline-only --steps 20 --warmup 5
 prof alone $R/tools/blocking_workload.py 12
 prof c4 $R/tools/units_probe.py config4 4
 prof e2e $R/tools/units_probe.py e2e 4
