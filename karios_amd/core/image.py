@@ -44,8 +44,14 @@ class NumpyRasterImage:
             raise ValueError("single-band image")
         return self._array[y_off:y_off + y_size, x_off:x_off + x_size]
 
+    _keeps_array_across_clear_cache = True
+
     def clear_cache(self) -> None:
-        """GdalRasterImage drops its cached array here; the in-memory image keeps its data."""
+        """GdalRasterImage drops its cached array here (image.py:445-447); the in-memory image keeps its data - but the call is the
+        owner's signal that the pixels may change: resident copies shared between the matcher services are invalidated and the
+        array becomes writeable again (`karios_amd.resident.shared_pair`)."""
+        from ..resident import invalidate_raster
+        invalidate_raster(self)
 
 
 class DeviceRasterImage:

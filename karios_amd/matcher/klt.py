@@ -65,7 +65,7 @@ class _Trial:
 class _TileSession:
     """A tile resident on the device for the duration of its trials."""
 
-    def __init__(self, conf, tile: tiling.Tile, mon_box, ref_box, mask_box, nodata_mon, nodata_ref, ctx):
+    def __init__(self, conf, tile: tiling.Tile, mon_box, ref_box, mask_box, nodata_mon, nodata_ref, ctx, rasters=()):
         self.conf, self.tile = conf, tile
         mon_box, ref_box = np.asarray(mon_box), np.asarray(ref_box)
         if mask_box is not None:
@@ -79,7 +79,7 @@ class _TileSession:
             mon_box, ref_box = _stretch_any(mon_box, ctx), _stretch_any(ref_box, ctx)
             nodata_mon = nodata_ref = None
         self.pair = ResidentPair.upload(mon_box, ref_box, mask_box, ctx=ctx, no_data_mon=nodata_mon, no_data_ref=nodata_ref)
-        shared_pair(mon_box, ref_box, ctx, publish=self.pair)      # the scoring services find a whole-image tile resident
+        shared_pair(mon_box, ref_box, ctx, publish=self.pair, rasters=rasters)      # the scoring services find a whole-image tile resident
         self._host = (mon_box, ref_box)
         self.valid_pixels = -1                     # unknown until a fixed-parameter trial has run
 
@@ -257,7 +257,7 @@ class KLT:
     def _open(self, tile: tiling.Tile, mon_img, ref_img, mask) -> _TileSession:
         window = (1, *tile)
         return _TileSession(self._conf, tile, mon_img.read(*window), ref_img.read(*window), mask.read(*window) if mask else None,
-                            getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None), self._ctx)
+                            getattr(mon_img, "no_data_value", None), getattr(ref_img, "no_data_value", None), self._ctx, rasters=(mon_img, ref_img))
 
     def _finish(self, session: _TileSession) -> DataFrame | None:
         x_off, y_off = session.tile[:2]

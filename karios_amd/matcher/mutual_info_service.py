@@ -33,9 +33,11 @@ class MutualInfoService:
                 ref, mon = np.asarray(reference.array), np.asarray(monitored.array)
                 if not _kernel_ready(df, ref, mon):
                     ref, mon = _common_pixel_type(ref, mon)
-                values = _mi_scores(df, ref, mon, self._ctx)[0]
+                values = _mi_scores(df, ref, mon, self._ctx, rasters=(monitored, reference))[0]
         finally:
-            monitored.clear_cache()
-            reference.clear_cache()
+            from ..resident import keep_shared_across
+            with keep_shared_across(monitored, reference):      # (the service's own closing call: nothing was edited since the upload)
+                monitored.clear_cache()
+                reference.clear_cache()
         logger.info("mutual information: %d key points scored", len(df))
         return Series(values, index=df.index, dtype=np.float64)

@@ -15,7 +15,7 @@ from pandas import DataFrame, Series
 
 from .. import ops
 from .._lib import _DTYPES
-from ..resident import shared_pair
+from ..resident import keep_shared_across, shared_pair
 
 logger = logging.getLogger(__name__)
 
@@ -89,16 +89,19 @@ class ZNCCService:
         try:
             if len(df) == 0:
                 return np.empty(0, np.float64)
+            self._rasters = (monitored, reference)
             return scorer(df, np.asarray(reference.array), np.asarray(monitored.array))
         finally:
-            monitored.clear_cache()      # the reference drops both rasters from its cache after scoring (:179-180)
-            reference.clear_cache()
+            self._rasters = ()
+            with keep_shared_across(monitored, reference):      # (this call is the service's own: nothing was edited since the upload)
+                monitored.clear_cache()      # the reference drops both rasters from its cache after scoring (:179-180)
+                reference.clear_cache()
 
     def _zncc_values(self, df, ref, mon) -> np.ndarray:
         if _kernel_ready(df, ref, mon):
             cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
             if ref.shape == mon.shape:
-                return shared_pair(mon, ref, self._ctx).zncc(*cols)      # resident already when KLT.match just ran on them
+                return shared_pair(mon, ref, self._ctx, rasters=getattr(self, "_rasters", ())).zncc(*cols)      # resident already when KLT.match just ran on them
             return ops.zncc_batch(ref, mon, *cols, ctx=self._ctx)
         # cross-sensor pairs / other pixel types / float64 frames: centres on the host, windows by the generic kernel
         u0, v0, u1, v1, inside = _chip_centres(df, self._chip_margin, ref.shape, mon.shape)
@@ -110,19 +113,19 @@ class ZNCCService:
     def _nmi_values(self, df, ref, mon) -> np.ndarray:
         if not _kernel_ready(df, ref, mon):
             ref, mon = _common_pixel_type(ref, mon)
-        return _mi_scores(df, ref, mon, self._ctx)[1]
+        return _mi_scores(df, ref, mon, self._ctx, rasters=getattr(self, "_rasters", ()))[1]
 
     def _extract_chip(self, x: int, y: int, image):
         m = self._chip_margin
         return image.array[y - m:y + m + 1, x - m:x + m + 1]
 
 
-def _mi_scores(df: DataFrame, ref: np.ndarray, mon: np.ndarray, ctx):
+def _mi_scores(df: DataFrame, ref: np.ndarray, mon: np.ndarray, ctx, rasters=()):
     """(Studholme, NMI) of every row; images of equal shape go through the shared resident pair (one upload for all services,
     one kernel run for both scores)."""
     cols = [df[c].to_numpy(dtype=np.float32, copy=False) for c in ("x0", "y0", "dx", "dy")]
     if ref.shape == mon.shape and ref.dtype == mon.dtype:
-        return shared_pair(mon, ref, ctx).mutual_info(*cols)
+        return shared_pair(mon, ref, ctx, rasters=rasters).mutual_info(*cols)
     return ops.mi_batch(ref, mon, *cols, ctx=ctx)
 
 

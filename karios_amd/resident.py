@@ -707,46 +707,134 @@ class ResidentPair:
 # `KariosAPI._handle_klt_results` (core.py:888-907) hands the SAME two rasters to KLT.match, ZNCCService.compute_zncc,
 # MutualInfoService.compute_mutual_info and ZNCCService.compute_mi, one after the other; each of them uploading both images
 # again would cost 3 x 482 MB over PCIe for a Sentinel-2 pair.  The services therefore look the images up here first.
-_SHARED: "dict[tuple, tuple]" = {}
+#
+# A resident copy must never stand in for host pixels that have changed since the upload.  Reading the host arrays again to verify
+# them costs more than uploading them (a 482 MB pair crosses PCIe in 8.5 ms; a host-side checksum of it takes longer), so validity is
+# a TOKEN, not a fingerprint:
+#   * an entry is keyed on the exact buffers that were uploaded (address, shape, strides, dtype) and keeps them alive, so their
+#     addresses cannot be recycled by another array meanwhile;
+#   * while an entry exists its host arrays (and the arrays they are views of) are READ-ONLY: an in-place edit raises numpy's
+#     "assignment destination is read-only" instead of silently scoring against stale HBM data; a lookup through an array that is
+#     writeable again (somebody lifted the guard) is a miss;
+#   * the raster objects carry the token's other half: `NumpyRasterImage.clear_cache()` - and `forget_shared_pairs()` - drop the
+#     entry and give write access back; a `GdalRasterImage.clear_cache()` drops its array, so the next `.array` is a new buffer at a
+#     new address: a miss.  (The services' OWN closing `clear_cache()` calls, zncc_service.py:179-180, keep an in-memory raster's entry:
+#     `keep_shared_across` below - nothing was edited in between.)
+_SHARED: "dict[tuple, _SharedEntry]" = {}
 _SHARED_LIMIT = 2
+shared_pair_uploads = 0           # uploads `shared_pair` had to make (tests, diagnostics)
 
 
-def _identity(arr: np.ndarray) -> tuple:
-    """Cheap fingerprint of a host image: where it lives, its layout and a sparse sample of its content (an array that is
-    overwritten in place between two calls must not be mistaken for its former self)."""
+def _layout(arr: np.ndarray) -> tuple:
     a = np.asarray(arr)
-    step = (max(1, a.shape[0] // 61), max(1, a.shape[1] // 67)) if a.ndim == 2 and a.size else (1, 1)
-    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, hash(a[::step[0], ::step[1]].tobytes()) if a.ndim == 2 else 0)
+    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
 
 
-def shared_pair(mon: np.ndarray, ref: np.ndarray, ctx: Context | None = None, publish: "ResidentPair | None" = None) -> "ResidentPair":
-    """The resident copy of (mon, ref) on `ctx`: a pair published earlier for the same two host arrays (e.g. by `KLT.match` for
-    a tile that covers the whole image), else a fresh upload that is remembered for the next service.  `publish` registers
-    an existing pair instead of looking one up.
+def _base_chain(arr: np.ndarray) -> list:
+    """`arr` and every ndarray it is a view of, outermost owner last."""
+    out, a = [], arr
+    while isinstance(a, np.ndarray):
+        out.append(a)
+        a = a.base
+    return out
 
-    Contract: between the call that published a pair and the last service that looks it up the two host arrays must not be
-    modified in place - the fingerprint samples ~4 000 pixels per image, an edit that misses all of them would be scored
-    against the stale resident copy.  The reference's flow satisfies it (the rasters are read once, `core.py:845-907`, and
-    `clear_cache()` after scoring drops them); a caller that does edit in place calls `forget_shared_pairs()` first.  Likewise
-    an upload from page-locked memory is asynchronous: the source must stay untouched until the pair's first device call
-    (`ResidentPair._ready`) or `Context.sync()`."""
+
+class _SharedEntry:
+    def __init__(self, pair, mon, ref, rasters):
+        self.pair, self.mon, self.ref = pair, mon, ref             # the host arrays stay referenced: their addresses cannot be recycled
+        self.raster_ids = tuple(id(r) for r in rasters if r is not None)
+        self.rasters = tuple(r for r in rasters if r is not None)  # (kept alive too: an id must not be reused by another raster)
+        self.guarded = []
+        seen = set()
+        for a in _base_chain(mon)[::-1] + _base_chain(ref)[::-1]:  # owners first
+            if id(a) not in seen and a.flags.writeable:
+                seen.add(id(a))
+                try:
+                    a.flags.writeable = False
+                    self.guarded.append(a)
+                except ValueError:  # pragma: no cover - an exotic buffer that refuses
+                    pass
+
+    def intact(self, mon, ref) -> bool:
+        """The lookup comes through arrays nobody could have written to since the upload."""
+        return not any(a.flags.writeable for a in _base_chain(np.asarray(mon)) + _base_chain(np.asarray(ref)) + self.guarded)
+
+    def release(self):
+        for a in self.guarded:                                     # owners first: a view cannot become writeable before its base
+            try:
+                a.flags.writeable = True
+            except ValueError:  # pragma: no cover
+                pass
+        self.guarded = []
+
+
+def _drop(key) -> None:
+    ent = _SHARED.pop(key, None)
+    if ent is not None:
+        ent.release()
+
+
+def shared_pair(mon: np.ndarray, ref: np.ndarray, ctx: Context | None = None, publish: "ResidentPair | None" = None, rasters=()) -> "ResidentPair":
+    """The resident copy of (mon, ref) on `ctx`: a pair published earlier for the same two host buffers (e.g. by `KLT.match` for
+    a tile that covers the whole image) and still valid (see the token rules above), else a fresh upload that is remembered for the
+    next service.  `publish` registers an existing pair instead of looking one up; `rasters`: the raster objects the arrays came
+    from (their `clear_cache()` invalidates the entry).
+
+    An upload from page-locked memory is asynchronous: the source must stay untouched until the pair's first device call
+    (`ResidentPair._ready`) or `Context.sync()` - the read-only guard covers that window too."""
+    global shared_pair_uploads
     ctx = ctx if ctx is not None else default_context()
-    key = (id(ctx), _identity(mon), _identity(ref))
+    mon, ref = np.asarray(mon), np.asarray(ref)
+    key = (id(ctx), _layout(mon), _layout(ref))
     if publish is None:
         hit = _SHARED.get(key)
-        if hit is not None:
-            return hit[0]
+        if hit is not None and hit.intact(mon, ref):
+            return hit.pair
+        _drop(key)
         publish = ResidentPair.upload(mon, ref, ctx=ctx)
-    _SHARED.pop(key, None)
+        shared_pair_uploads += 1
+    _drop(key)
     while len(_SHARED) >= _SHARED_LIMIT:
-        _SHARED.pop(next(iter(_SHARED)))
-    _SHARED[key] = (publish, mon, ref)       # the host arrays stay referenced: their addresses cannot be recycled meanwhile
+        _drop(next(iter(_SHARED)))
+    _SHARED[key] = _SharedEntry(publish, mon, ref, rasters)
     return publish
 
 
+def invalidate_raster(raster) -> None:
+    """`raster.clear_cache()` was called by its owner: every shared pair made from it is dropped (write access comes back)."""
+    for key in [k for k, e in _SHARED.items() if id(raster) in e.raster_ids]:
+        _drop(key)
+
+
+class keep_shared_across:
+    """Context manager for the services' own closing `clear_cache()` calls (zncc_service.py:179-180): an in-memory raster keeps its
+    pixels there, so entries whose host buffers are still the raster's current `.array` survive the call."""
+
+    def __init__(self, *rasters):
+        self.rasters = rasters
+
+    def __enter__(self):
+        self.saved = {k: e for k, e in _SHARED.items() if any(id(r) in e.raster_ids for r in self.rasters)}
+        for k in self.saved:
+            _SHARED.pop(k)                                        # (out of reach of invalidate_raster; still guarded)
+        return self
+
+    def __exit__(self, *exc):
+        for k, e in self.saved.items():
+            held = {_layout(e.mon)[0], _layout(e.ref)[0]}
+            # survives iff every raster of the entry is an in-memory one whose current array is still the buffer that was uploaded
+            keeps = all(getattr(r, "_keeps_array_across_clear_cache", False) and _layout(r.array)[0] in held for r in e.rasters)
+            if keeps and len(_SHARED) < _SHARED_LIMIT:
+                _SHARED[k] = e
+            else:
+                e.release()
+        return False
+
+
 def forget_shared_pairs() -> None:
-    """Drop the shared resident pairs (their device buffers return to the context's pool)."""
-    _SHARED.clear()
+    """Drop the shared resident pairs (their device buffers return to the context's pool, their host arrays become writeable again)."""
+    for key in list(_SHARED):
+        _drop(key)
 
 
-__all__ = ["ResidentPair", "DeviceBuffer", "PendingBatch", "submit_units", "shared_pair", "forget_shared_pairs", "_lib"]
+__all__ = ["ResidentPair", "DeviceBuffer", "PendingBatch", "submit_units", "shared_pair", "forget_shared_pairs", "invalidate_raster", "_lib"]

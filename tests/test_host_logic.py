@@ -638,3 +638,63 @@ def test_bench_small_line_guard_drops_optional_parts_first():
     failed = dict(_r05_detail())
     failed["config3"] = dict(failed["config3"], gate=dict(failed["config3"]["gate"], passed=False))
     assert summary.small_line(failed)["gates_all_passed"] is False
+
+
+# ---------------------------------------------------------------------------- shared_pair cannot return stale pixels
+def test_shared_pair_token_never_serves_stale_pixels(monkeypatch):
+    """The resident copy the matcher services share is keyed on the uploaded buffers + a token, not on a sparse sample of the pixels:
+    while it exists the host arrays are read-only (an in-place edit fails loudly), `NumpyRasterImage.clear_cache()` by the owner drops
+    it, and a pixel the old 61 x 67-strided fingerprint never looked at is re-uploaded.  CPU only: the upload is counted, not made."""
+    from karios_amd import resident as R
+    from karios_amd.core import NumpyRasterImage
+    uploads = []
+
+    class FakePair:
+        pass
+
+    monkeypatch.setattr(R.ResidentPair, "upload", classmethod(lambda cls, mon, ref, ctx=None, **kw: uploads.append((mon.copy(), ref.copy())) or FakePair()))
+    R.forget_shared_pairs()
+    ctx = object()
+    mon, ref = np.zeros((610, 670), np.uint16), np.ones((610, 670), np.uint16)
+    mon_img, ref_img = NumpyRasterImage(mon), NumpyRasterImage(ref)
+    # KLT.match publishes the whole-image tile it uploaded (a VIEW of the raster's array, as `read()` returns it) ...
+    pair = R.shared_pair(mon_img.read(1, 0, 0, 670, 610), ref_img.read(1, 0, 0, 670, 610), ctx, publish=FakePair(), rasters=(mon_img, ref_img))
+    # ... and the services find it through `.array`
+    assert R.shared_pair(mon_img.array, ref_img.array, ctx) is pair and not uploads
+    with pytest.raises(ValueError, match="read-only"):
+        mon[3, 5] = 7                                             # (3, 5) is off the old fingerprint's grid (rows % 10, columns % 10)
+    # the services' own closing clear_cache() calls keep the entry of an in-memory raster ...
+    with R.keep_shared_across(mon_img, ref_img):
+        mon_img.clear_cache()
+        ref_img.clear_cache()
+    assert R.shared_pair(mon_img.array, ref_img.array, ctx) is pair and not uploads
+    # ... the OWNER's clear_cache() is the token's other half: write access comes back, the edited pixel is uploaded
+    mon_img.clear_cache()
+    mon[3, 5] = 7
+    fresh = R.shared_pair(mon_img.array, ref_img.array, ctx, rasters=(mon_img, ref_img))
+    assert fresh is not pair and len(uploads) == 1 and uploads[0][0][3, 5] == 7
+    # somebody lifts the guard behind the library's back and edits: the lookup notices the writeable array and uploads again
+    mon.flags.writeable = True
+    mon[4, 6] = 9
+    again = R.shared_pair(mon_img.array, ref_img.array, ctx)
+    assert again is not fresh and len(uploads) == 2 and uploads[1][0][4, 6] == 9
+    # a raster whose clear_cache() drops its array (GdalRasterImage, image.py:445-447) comes back with a NEW buffer: a miss
+    class Reloading:
+        def __init__(self, a):
+            self._a = a
+
+        @property
+        def array(self):
+            return self._a
+
+        def clear_cache(self):
+            self._a = self._a.copy()
+
+    g_mon, g_ref = Reloading(np.zeros((64, 64), np.uint16)), Reloading(np.ones((64, 64), np.uint16))
+    first = R.shared_pair(g_mon.array, g_ref.array, ctx, rasters=(g_mon, g_ref))
+    with R.keep_shared_across(g_mon, g_ref):
+        g_mon.clear_cache()
+        g_ref.clear_cache()
+    assert R.shared_pair(g_mon.array, g_ref.array, ctx) is not first
+    R.forget_shared_pairs()
+    assert mon.flags.writeable and ref.flags.writeable
