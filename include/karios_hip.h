@@ -112,6 +112,13 @@ int km_set_profiling(km_ctx *ctx, int enable);
  *   "mm_early"     1 (default): a unit submitted (km_klt_tile_frame_submit / km_klt_units_frame_submit) directly behind another one
  *                  starts its min / max on the second stream as soon as the previous unit's LK launch starts (KM_PATH_MM_EARLY);
  *                  0: on the library's stream, behind the previous unit's tail
+ *   "units_pipeline" 1: consecutive km_klt_units_frame_submit calls on this context form a SOFTWARE PIPELINE (csrc/api_units.hip): two
+ *                  workspace sets alternate, the dense stages of neighbouring submissions interleave on the library's stream and the
+ *                  latency-bound chains of one (corner selection; frame stage + scores) run on a second stream beside the dense kernels
+ *                  of the other.  The tail of a submission (LK, frame stage, scores, copy-out) is then enqueued by the NEXT submission,
+ *                  by km_frame_flush, by any other entry point or by km_ctx_sync; km_frame_wait on such a frame waits for one of them
+ *                  (and enqueues the tail itself after 100 ms).  Frames are bit-identical.  0 (default): every submission is complete
+ *                  in stream order when the call returns.  karios_amd.stream.FrameStream switches it on for the contexts it drives
  *   "frame_mi"     1: frame blocks that carry the ZNCC column also carry `mutual_info_score` (MutualInfoService,
  *                  mutual_info_service.py:73-130) and `mi_score` (ZNCCService.compute_mi, zncc_service.py:240-287) of the same rows -
  *                  the whole scoring of KariosAPI._handle_klt_results (api/core.py:894-907) in the tile call: two more float64 columns
@@ -233,6 +240,10 @@ typedef struct km_unit {
  * a shrunken test capacity): submit the units one by one then.  No user mask (automatic mask, klt.py:268-273). */
 int km_klt_units_frame_submit(km_ctx *ctx, const km_unit *units, int n_units, int dtype, const double *nodata_ref, const double *nodata_mon,
                               const km_klt_params *prm, double zncc_threshold, int cap, int *ticket);
+/* "units_pipeline": enqueue what the last km_klt_units_frame_submit deferred (its LK, frame stage, scores and copy-out) - if that
+ * submission is frame `ticket` (ticket < 0: whichever it is).  Call it on the submitting thread when no further submission follows
+ * before the frame is waited for; a no-op otherwise. */
+int km_frame_flush(km_ctx *ctx, int ticket);
 
 /* ---- fine-grained mirrors (host buffers) -------------------------------- */
 /* _to_uint8 (matcher/klt.py:42-49) [+ 255-x, klt.py:419]; out_minmax[2] nullable */

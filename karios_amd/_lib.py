@@ -123,6 +123,7 @@ SIGNATURES = {
                                       C.c_float, _vp, _vp, _i, _i, _sz, _sz, _d, _i, C.POINTER(C.c_int)]),
     "km_frame_wait": (_i, [_vp, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "km_frame_stage_ms": (_i, [_vp, _i, _vp, _i, C.POINTER(C.c_int)]),
+    "km_frame_flush": (_i, [_vp, _i]),
     "km_zncc_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp]),
     "km_mi_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "km_klt_auto_ksize_frame_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _vp, _sz, _pd, _pd, C.POINTER(KltParams), _vp, _i, C.c_float,
@@ -333,6 +334,12 @@ class Context:
 
     def sync(self):
         self.check(self.lib.km_ctx_sync(self.handle), "km_ctx_sync")
+
+    def flush(self, ticket: int = -1):
+        """km_frame_flush: with the "units_pipeline" option a batched submission leaves its tail (LK, frame stage, scores, copy-out) to
+        the NEXT submission - call this on the submitting thread when none follows before frame `ticket` is waited for (a no-op when
+        that frame's tail is not the deferred one; -1: whichever is)."""
+        self.check(self.lib.km_frame_flush(self.handle, int(ticket)), "km_frame_flush")
 
     def stats(self) -> KltStats:
         s = KltStats()

@@ -27,9 +27,11 @@ int km_fail(km_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+void *km_ws_peek(km_ctx *c, int slot) { return c->lane ? c->ws_b[slot].p : c->ws[slot].p; }
+
 void *km_ws(km_ctx *c, int slot, size_t bytes)
 {
-    km_buf &b = c->ws[slot];
+    km_buf &b = c->lane ? c->ws_b[slot] : c->ws[slot];
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return b.p;
     if (b.p) {
@@ -140,7 +142,9 @@ int km_ctx_destroy(km_ctx *c)
 {
     if (!c) return KM_OK;
     (void)hipSetDevice(c->device);
+    (void)km_units_flush(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->chain_stream) (void)hipStreamSynchronize(c->chain_stream);
     kp_destroy(c);
     if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     if (c->pinned_rb) (void)hipHostFree(c->pinned_rb);
@@ -164,6 +168,12 @@ int km_ctx_destroy(km_ctx *c)
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
+    if (c->chain_stream) { (void)hipStreamSynchronize(c->chain_stream); (void)hipStreamDestroy(c->chain_stream); }
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 7; i++)
+            if (c->ev_lane[l][i]) (void)hipEventDestroy(c->ev_lane[l][i]);
+    for (int i = 0; i < WS_COUNT; i++)
+        if (c->ws_b[i].p) (void)hipFree(c->ws_b[i].p);
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->ev_lk_start) (void)hipEventDestroy(c->ev_lk_start);
     if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
@@ -172,6 +182,7 @@ int km_ctx_destroy(km_ctx *c)
     for (hipEvent_t e : c->upload_marks) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->free_marks) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    km_units_free(c);
     delete c;
     return KM_OK;
 }
@@ -180,7 +191,9 @@ int km_ctx_sync(km_ctx *c)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
+    { const int rf = km_units_flush(c); if (rf) return rf; }              // (the deferred tail of a pipelined batched submission)
     KM_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->chain_stream) KM_HIP(c, hipStreamSynchronize(c->chain_stream));
     if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));   // frame blocks of submitted tiles
     if (!c->retired.empty()) {
         // workspace buffers replaced by larger ones: nothing of this context uses them any more once its streams are idle
@@ -204,6 +217,11 @@ int km_set_option(km_ctx *c, const char *name, int value)
     if (strcmp(name, "aux_pyramid") == 0) { c->opt_aux_pyramid = value != 0; return KM_OK; }
     if (strcmp(name, "mm_early") == 0) { c->opt_mm_early = value != 0; return KM_OK; }
     if (strcmp(name, "frame_mi") == 0) { c->opt_frame_mi = value != 0; return KM_OK; }
+    if (strcmp(name, "units_pipeline") == 0) {
+        if (!value) { const int rf = km_units_flush(c); if (rf) return rf; }
+        c->opt_units_pipeline = value != 0;
+        return KM_OK;
+    }
     if (strcmp(name, "key_cap") == 0) { c->opt_key_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "stage_cap") == 0) { c->opt_stage_cap = value < 0 ? 0 : value; return KM_OK; }
     if (strcmp(name, "topk_factor") == 0) { c->opt_topk_factor = value < 0 ? 0 : value; return KM_OK; }
@@ -500,6 +518,8 @@ int begin_call(km_ctx *c, int reset)
 {
     if (!c) return km_fail(nullptr, KM_E_ARG, "null context");
     KM_HIP(c, hipSetDevice(c->device));
+    // any entry point other than the next batched submission: the deferred tail of a pipelined submission goes first, in stream order
+    if (!c->in_units_submit) { const int rf = km_units_flush(c); if (rf) return rf; }
     { const int rcj = join_uploads(c); if (rcj) return rcj; }
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->land_jobs.clear(); c->land_used = 0;   // (... and results it queued for a caller buffer that may be gone too: km_d2h_queue without its flush)
@@ -513,7 +533,7 @@ int begin_call(km_ctx *c, int reset)
     static const char *const poison = km_dev_env("KARIOS_HIP_POISON_WS");
     if (poison && reset == RESET_KLT)
         for (int i = 0; i < WS_COUNT; i++)
-            if (c->ws[i].p && i != WS_AUTO && i != WS_MM_EARLY && i != WS_MM_PARTIAL) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
+            if (c->ws[i].p && i != WS_AUTO && i != WS_MM_EARLY && i != WS_MM_PARTIAL && i != WS_UNITS_MM) KM_HIP(c, hipMemsetAsync(c->ws[i].p, atoi(poison) & 0xff, c->ws[i].cap, c->stream));
     if (reset == RESET_KLT) {
         for (int i = ST_MINMAX; i <= ST_LK; i++) c->evs_used[c->ev_cur][i] = false;
         c->evs_used[c->ev_cur][ST_FRAME] = false;

@@ -40,3 +40,6 @@ int klt_tile_dev_impl(km_ctx *c, const void *d_ref, const void *d_mon, int dtype
                       int cap, km_scalars *sc, bool *no_valid);
 int fetch_tracks(km_ctx *c, km_scalars *sc, const float *d_p0, const float *d_p1, const float *d_p0r, float *p0, float *p1, float *p0r, int cap,
                  int *out_n);
+
+// api_units.hip: Laplacian kernel sizes the batched stretch + Laplacian pass covers (k_dense.hip kd_stretch_laplacian_units)
+static inline bool km_units_ksize_supported(int k) { return k == 1 || k == 3 || k == 5 || k == 7; }

@@ -570,7 +570,7 @@ static int tile_frame_impl(km_ctx *c, const void *d_ref, const void *d_mon, int 
     if ((rc = frame_block_free(c))) return rc;
     {
         km_stage_timer t(c, ST_FRAME);
-        if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out, c->spec_used ? sc : nullptr))) return rc;
+        if ((rc = kf_frame(c, d_p0, d_p1, d_p0r, &sc->n_corners, n_max, cap, 0.1f, x_off, y_off, d_out, c->spec_used ? sc : nullptr, W))) return rc;
     }
     if (with_zncc) {
         km_stage_timer t(c, ST_ZNCC);
@@ -772,7 +772,7 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
     {
         km_stage_timer t(c, ST_FRAME);
         if ((rc = kf_frame(c, (const float *)(p0_store + (size_t)br * pts), (const float *)(trk_store + (size_t)(2 * best) * pts),
-                           (const float *)(trk_store + (size_t)(2 * best + 1) * pts), &d_counts[br], n_lim, cap, 0.1f, x_off, y_off, d_out)))
+                           (const float *)(trk_store + (size_t)(2 * best + 1) * pts), &d_counts[br], n_lim, cap, 0.1f, x_off, y_off, d_out, nullptr, W)))
             return rc;
     }
     KM_D2H(c, host_out, d_out, fb);
@@ -836,8 +836,18 @@ int km_frame_wait(km_ctx *c, int ticket, const void **block, size_t *bytes)
     // The waiting thread has nothing else to do: poll and SLEEP (hipEventSynchronize spins - also on an event created with
     // hipEventBlockingSync - and kept one CPU per rank at 100 %: 0.72 of every 0.91-ms step; eight ranks want those CPUs for RCCL's proxies)
     // (the kernel rounds a sleep up by the thread's timer slack, 50 us by default: 1 us for the threads that wait here)
-    static thread_local bool slack_set = false;
-    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
+    // (the slack is this thread's for the duration of the wait only: the caller may be an application thread - ADVICE r5)
+    const int slack_before = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    struct slack_restore { int v; ~slack_restore() { if (v > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)v, 0UL, 0UL, 0UL); } } slack_guard{slack_before};
+    // a pipelined batched submission enqueues its tail (LK .. copy-out) with the NEXT submission or km_frame_flush: wait for that first.
+    // Nobody doing either for 100 ms is a caller that forgot to flush - the tail is then enqueued from here (under the context's
+    // enqueue lock; every other entry point of the submitting thread flushes before it touches the context)
+    for (int spins = 0; slot->deferred.load(std::memory_order_acquire); spins++) {
+        if (spins >= 5000) { const int rf = km_units_flush(c, false); if (rf) return rf; break; }
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
     for (;;) {
         const hipError_t e = hipEventQuery(slot->done);
         if (e == hipSuccess) break;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include <functional>
 #include <string>
 #include <vector>
@@ -151,6 +152,7 @@ struct km_frame_slot {
     hipEvent_t sunk = nullptr;      // the frame's block is in the frame sink (km_set_frame_sink): recorded on the compute stream behind the copy
     bool sunk_valid = false;
     std::atomic<int> pending{0};
+    std::atomic<int> deferred{0};   // pipelined batched submission: the tail (LK .. copy-out) of this frame has not been enqueued yet
 };
 
 // staging.hip: page-locked ring between caller memory and the device (no runtime copy ever reads or writes pageable memory)
@@ -176,6 +178,18 @@ struct km_ctx {
     hipEvent_t ev_copy = nullptr;
     hipStream_t aux_stream = nullptr;    // sync-free tile path: the pyramids (they depend on the Laplacians only) run here next to the
     hipStream_t d2h_stream = nullptr;    // km_klt_tile_frame_submit: the finished frame block travels to the host here
+    // ---- software-pipelined batched submissions ("units_pipeline", api_units.hip): two LANES (workspace sets) alternate; the dense
+    // kernels of both lanes interleave on `stream`, the latency-bound chains (corner selection; frame stage + scores) run on
+    // `chain_stream` beside the other lane's dense kernels; a submission's tail (LK, frame stage, scores, copy-out) is enqueued by
+    // the NEXT submission (or km_frame_flush)
+    hipStream_t chain_stream = nullptr;
+    hipEvent_t ev_lane[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    bool lane_f_recorded[2] = {false, false};   // EV_F_DONE of the lane has been recorded: its next submission waits for it
+    bool in_units_submit = false;
+    bool opt_units_pipeline = false;
+    int lane = 0;                        // workspace set km_ws hands out (0: `ws`, 1: `ws_b`)
+    struct km_units_tail *utail = nullptr;   // the deferred tail (armed: enqueue pending)
+    std::mutex *enqueue_mu = nullptr;    // submit / flush / the fallback flush of km_frame_wait
     hipEvent_t ev_tail = nullptr, frame_copy = nullptr;   // frame_copy: completion of the last block copy (WS_FRAME must not be rewritten before)
     hipEvent_t ev_lk_start = nullptr, ev_mm = nullptr;   // early min/max: the next unit's K1 starts on aux_stream when this unit's LK launch starts
     bool lk_start_valid = false, lk_start_prev = false;   //   ... ev_lk_start was recorded by the tile call that directly preceded this one
@@ -191,6 +205,7 @@ struct km_ctx {
     size_t frame_sink_cap = 0;
     size_t frame_sink_pitch = 0;         // km_set_frame_sink_pitch: distance between the blocks of a batched submission (0: block size)
     km_buf ws[WS_COUNT];
+    km_buf ws_b[WS_COUNT];               // lane 1 of the pipelined batched submissions
     std::vector<void *> retired;         // workspace buffers replaced by larger ones (km_ws): freed at the next km_ctx_sync / destroy
     km_stage_ring ring;                  // host -> device staging (staging.hip)
     void *land = nullptr;                // device -> host landing arena (page-locked), km_d2h_queue / km_d2h_flush
@@ -328,7 +343,10 @@ static inline int km_pick_rows(int H, int nstrips, int halo, long wave_slots, in
     }
     return best;
 }
-void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+void *km_ws(km_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set); the slot of the context's current lane
+void *km_ws_peek(km_ctx *ctx, int slot);           // the slot's current buffer (no growth)
+int km_units_flush(km_ctx *c, bool join = true);   // api_units.hip: enqueue the deferred tail of a pipelined batched submission (no-op without one)
+void km_units_free(km_ctx *c);                     // ... its host-side state (km_ctx_destroy)
 // staging.hip.  Host -> device: returns when `src` has been read completely; the DMAs (from the ring) are ordered on stream s.
 int km_h2d_staged(km_ctx *c, hipStream_t s, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes, size_t rows);
 static inline int km_h2d_small(km_ctx *c, void *dst, const void *src, size_t bytes) { return km_h2d_staged(c, c->stream, dst, bytes, src, bytes, bytes, 1); }
@@ -531,7 +549,7 @@ int kz_zncc_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, in
 int kmi_units(km_ctx *c, const km_score_units &A, int n_units, int dtype, int n, float score_thr);
 // k_frame.hip
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
-             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header = nullptr);   // d_sc_header: header words 2 / 3 = flags, candidate count
+             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header = nullptr, int width = 0);   // d_sc_header: header words 2 / 3 = flags, candidate count; width: corner columns < width (0: unknown)
 int kf_row_checksum(km_ctx *c, const void *d_img, size_t row_bytes, int rows, unsigned long long *d_out);   // diagnosis of host-buffer uploads (staging.hip)
 // k_zncc.hip
 int kz_zncc(km_ctx *c, const void *d_ref, const void *d_mon, int dtype, int Href, int Wref,

@@ -16,7 +16,9 @@
 #include <type_traits>
 
 
-#define FB_T 1024
+// 256-thread workgroups throughout (round 6, see KF_T in k_select2.hip): the frame stage runs beside the dense kernels of the next
+// submission, where a 1024-thread workgroup waits for a whole compute unit (fb_place 23 -> 822 us, fb_compact 5 -> 121 us).
+#define FB_T 256
 
 // What differs between the units of a batch (blockIdx.y = unit; km_klt_units_frame_submit); the single-unit entry point passes one
 struct fb_unit {
@@ -106,13 +108,13 @@ __global__ __launch_bounds__(256) void fb_gather_kernel(fb_units_args A, const u
 }
 
 // Row order of the frame without a library sort (eight launches + a gather for 20 000 rows: ~50 us of mostly launch latency).
-// Every workgroup buckets ALL kept rows by their x0 (a few columns per bucket; counting sort in LDS: histogram, scan, fill - the
-// same in every workgroup, 160 KB of keys from L2, each thread's keys loaded in one batch) and then places its own slice of the
+// Every workgroup buckets ALL kept rows by their x0 (a few tens of columns per bucket; counting sort in LDS: histogram, scan, fill - the
+// same in every workgroup, 160 KB of keys from L2, eight loads in flight per thread) and then places its own slice of the
 // rows: position = rows in lower buckets + rows of the same bucket with a smaller (x0, y0) key - ties (possible only with
 // caller-supplied points) by their position in the kept list, like pandas' stable multi-column sort.  Corners keep a minimum
 // distance, so a bucket holds a handful of rows.  One launch, no global synchronisation.
-#define FBP_T 1024
-template <int RPT>
+#define FBP_T 256
+#define FBP_BINS 2048         // buckets of x0 at most (16 KB of counters + cursors; 2 B per row behind them)
 __global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int cap, int shift, int nbins)
 {
     const fb_unit &U = A.u[blockIdx.y];
@@ -125,12 +127,8 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int ca
     unsigned short *items = (unsigned short *)(start + nbins + 1);
     __shared__ unsigned s_wave[FBP_T / 64];
     const int m = hdr[0], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int slice = (m + (int)gridDim.x - 1) / (int)gridDim.x;      // rows this workgroup places: [r0, r1), at most one per thread
-    const int r0 = blockIdx.x * slice, r1 = min(r0 + slice, m);
+    const int r0 = blockIdx.x * FBP_T;                            // rows this workgroup places: [r0, r0 + FBP_T), one per thread
     if (r0 >= m) return;
-    unsigned long long k[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; u++) k[u] = keys[min(u * FBP_T + tid, m - 1)];
     const int mine_r = r0 + tid;
     const unsigned long long my_key = keys[min(mine_r, m - 1)];
     float col[5];
@@ -138,10 +136,18 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int ca
     for (int c2 = 0; c2 < 5; c2++) col[c2] = tmp[(size_t)c2 * cap + min(mine_r, m - 1)];
     for (int b = tid; b < nbins; b += FBP_T) cnt[b] = 0u;
     __syncthreads();
-    // 1. histogram of the buckets
+    // bucket of a row: its column inside the unit (x0 - tile origin) >> shift, clamped - a monotonic map of x0, so the order is exact for any column
+    const unsigned xo = (unsigned)(int)U.x_off;
+    auto bucket = [&](unsigned long long k) { return min(((unsigned)(k >> 32) - xo) >> shift, (unsigned)nbins - 1u); };
+    // 1. histogram of the buckets (all m keys, 160 KB from L2; eight loads in flight per thread)
+    for (int r = tid; r < m; r += 8 * FBP_T) {
+        unsigned long long k[8];
 #pragma unroll
-    for (int u = 0; u < RPT; u++)
-        if (u * FBP_T + tid < m) atomicAdd(&cnt[min((unsigned)(k[u] >> 32) >> shift, (unsigned)nbins - 1u)], 1u);   // (clamped: a monotonic bucket map keeps the order exact for any column)
+        for (int u = 0; u < 8; u++) k[u] = keys[min(r + u * FBP_T, m - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (r + u * FBP_T < m) atomicAdd(&cnt[bucket(k[u])], 1u);
+    }
     __syncthreads();
     // 2. exclusive scan: every thread owns a run of consecutive buckets
     const int per = (nbins + FBP_T - 1) / FBP_T, b0 = min(tid * per, nbins), b1 = min(b0 + per, nbins);
@@ -158,21 +164,29 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int ca
     if (tid == FBP_T - 1) start[nbins] = run;
     __syncthreads();
     // 3. fill the buckets
+    for (int r = tid; r < m; r += 8 * FBP_T) {
+        unsigned long long k[8];
 #pragma unroll
-    for (int u = 0; u < RPT; u++) {
-        const int r = u * FBP_T + tid;
-        if (r < m) items[atomicAdd(&cnt[min((unsigned)(k[u] >> 32) >> shift, (unsigned)nbins - 1u)], 1u)] = (unsigned short)r;
+        for (int u = 0; u < 8; u++) k[u] = keys[min(r + u * FBP_T, m - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (r + u * FBP_T < m) items[atomicAdd(&cnt[bucket(k[u])], 1u)] = (unsigned short)(r + u * FBP_T);
     }
     __syncthreads();
     // 4. rank inside the bucket, write the row to its place
-    if (mine_r < r1) {
-        const unsigned b = min((unsigned)(my_key >> 32) >> shift, (unsigned)nbins - 1u);
+    if (mine_r < m) {
+        const unsigned b = bucket(my_key);
         const unsigned lo = start[b], hi = start[b + 1];
         unsigned pos = lo;
-        for (unsigned t = lo; t < hi; t++) {
-            const int j = (int)items[t];
-            const unsigned long long kj = keys[j];
-            pos += (kj < my_key || (kj == my_key && j < mine_r)) ? 1u : 0u;
+        for (unsigned t = lo; t < hi; t += 4) {                 // four dependent (item -> key) loads in flight
+            int j[4];
+            unsigned long long kj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) j[u] = (int)items[min(t + u, hi - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kj[u] = keys[j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pos += (t + u < hi && (kj[u] < my_key || (kj[u] == my_key && j[u] < mine_r))) ? 1u : 0u;
         }
 #pragma unroll
         for (int c2 = 0; c2 < 5; c2++) out[(size_t)c2 * cap + pos] = col[c2];
@@ -183,7 +197,8 @@ __global__ __launch_bounds__(FBP_T) void fb_place_kernel(fb_units_args A, int ca
 // d_out: [header 4 ints: n_rows, n_init, flags, candidates][6 * cap floats: x0 | y0 | dx | dy | score | index bits]
 // n units at once (n = 1: kf_frame): scratch = unit k's slices of WS_MISC0 / WS_MISC1 / WS_MISC2 / WS_FRAME_CNT
 static int frame_launch(km_ctx *c, int n, const float *const *d_p0, const float *const *d_p1, const float *const *d_p0r, const int *const *d_n, int n_max,
-                        int cap, float back_thr, const float *x_off, const float *y_off, void *const *d_out, const km_scalars *const *d_sc_header)
+                        int cap, float back_thr, const float *x_off, const float *y_off, void *const *d_out, const km_scalars *const *d_sc_header,
+                        const int *width /* columns of each unit (corner columns < width), nullptr: unknown */ = nullptr)
 {
     if (cap <= 0 || n_max <= 0) return km_fail(c, KM_E_ARG, "frame: empty capacity");
     // the tile origin is added to the corner coordinates and the sum becomes the (x0, y0) ordering key: a pair of non-negative
@@ -215,29 +230,21 @@ static int frame_launch(km_ctx *c, int n, const float *const *d_p0, const float 
     fb_compact_kernel<true><<<dim3(nblk, n), FB_T, 0, c->stream>>>(A, n_max, back_thr, cap, (int)n_sort);
     KM_LAUNCH_CHECK(c);
     if (n_sort <= 32768u) {
-        // up to a few 10^4 rows (maxCorners of a tile): one workgroup, buckets of x0 in LDS (<= 64 KB of buckets + 2 B per row)
-        const unsigned x_max = (unsigned)x_hi + 70000u;          // x0 = corner column + tile offset, columns < 65536
+        // up to a few 10^4 rows (maxCorners of a tile): every workgroup buckets all rows by x0 in LDS (<= 16 KB of buckets + 2 B per row) and
+        // places 256 of them
+        unsigned x_max = 65535u;                                 // corner columns (x0 - tile origin) < 65536
+        if (width) { x_max = 1u; for (int k = 0; k < n; k++) x_max = (unsigned)width[k] > x_max ? (unsigned)width[k] : x_max; }
+        (void)x_hi;
         int shift = 0;
-        while (((x_max >> shift) + 1u) > 8192u) shift++;
+        while (((x_max >> shift) + 1u) > (unsigned)FBP_BINS) shift++;
         const int nbins = (int)(x_max >> shift) + 1;
         const size_t smem = ((size_t)2 * nbins + 1) * sizeof(unsigned) + (size_t)n_sort * sizeof(unsigned short);
-        const int rpt = (int)((n_sort + FBP_T - 1) / FBP_T);
-        auto launch = [&](auto rpt_tag) -> int {
-            constexpr int RPT = decltype(rpt_tag)::value;
-            static unsigned long long opted = 0;   // per instantiation and per DEVICE
-            if (smem > 48 * 1024 && !(opted & (1ull << (c->device & 63)))) {
-                KM_HIP(c, hipFuncSetAttribute((const void *)fb_place_kernel<RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-                opted |= 1ull << (c->device & 63);
-            }
-            fb_place_kernel<RPT><<<dim3(32, n), FBP_T, smem, c->stream>>>(A, cap, shift, nbins);   // (32 x 1024 threads: one row per thread)
-            return KM_OK;
-        };
-        int rl;
-        if (rpt <= 8) rl = launch(std::integral_constant<int, 8>{});
-        else if (rpt <= 16) rl = launch(std::integral_constant<int, 16>{});
-        else if (rpt <= 24) rl = launch(std::integral_constant<int, 24>{});
-        else rl = launch(std::integral_constant<int, 32>{});
-        if (rl) return rl;
+        static unsigned long long opted = 0;   // per DEVICE
+        if (smem > 48 * 1024 && !(opted & (1ull << (c->device & 63)))) {
+            KM_HIP(c, hipFuncSetAttribute((const void *)fb_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            opted |= 1ull << (c->device & 63);
+        }
+        fb_place_kernel<<<dim3((n_sort + FBP_T - 1) / FBP_T, n), FBP_T, smem, c->stream>>>(A, cap, shift, nbins);   // (one row per thread)
         KM_LAUNCH_CHECK(c);
         return KM_OK;
     }
@@ -250,9 +257,10 @@ static int frame_launch(km_ctx *c, int n, const float *const *d_p0, const float 
 }
 
 int kf_frame(km_ctx *c, const float *d_p0, const float *d_p1, const float *d_p0r, const int *d_n, int n_max, int cap, float back_thr,
-             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header)
+             float x_off, float y_off, void *d_out, const km_scalars *d_sc_header, int width)
 {
-    return frame_launch(c, 1, &d_p0, &d_p1, &d_p0r, &d_n, n_max, cap, back_thr, &x_off, &y_off, &d_out, d_sc_header ? &d_sc_header : nullptr);
+    return frame_launch(c, 1, &d_p0, &d_p1, &d_p0r, &d_n, n_max, cap, back_thr, &x_off, &y_off, &d_out, d_sc_header ? &d_sc_header : nullptr,
+                        width > 0 ? &width : nullptr);
 }
 
 // FB test + frame of every unit of a batch: three launches for all of them
@@ -263,7 +271,7 @@ int kf_frame_units(km_ctx *c, const km_units &U, int n_max, int cap, float back_
     void *out[KM_UNITS_MAX];
     const km_scalars *sc[KM_UNITS_MAX];
     for (int k = 0; k < U.n; k++) { p0[k] = U.p0[k]; p1[k] = U.p1[k]; p0r[k] = U.p0r[k]; dn[k] = &U.sc[k]->n_corners; out[k] = U.frame[k]; sc[k] = U.sc[k]; }
-    return frame_launch(c, U.n, p0, p1, p0r, dn, n_max, cap, back_thr, U.x_off, U.y_off, out, sc);
+    return frame_launch(c, U.n, p0, p1, p0r, dn, n_max, cap, back_thr, U.x_off, U.y_off, out, sc, U.W);
 }
 
 // ---- K13: DN-value filter of KariosAPI._filter_by_dn_values (reference karios/api/core.py:650-737): a key point is

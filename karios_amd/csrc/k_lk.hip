@@ -827,7 +827,7 @@ int kl_units_prepare(km_ctx *c, const km_units &U, int n_max, int win, int max_c
 int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
 {
     if (n_max <= 0 || n_units <= 0) return KM_OK;
-    const lk_args *table = (const lk_args *)c->ws[WS_UNITS_LK].p;
+    const lk_args *table = (const lk_args *)km_ws_peek(c, WS_UNITS_LK);
     const int runs = win * ((win + LK_RUN - 1) / LK_RUN), nr = (runs + 63) / 64;
     const lk2_geo<0> geo(win);
     const size_t sm2 = (size_t)4 * geo.bytes();

@@ -318,7 +318,11 @@ __global__ __launch_bounds__(256) void mi_int_units_kernel(km_score_units A, int
 
 static const double *mi_table(km_ctx *c)
 {
+    // (a table that outlives the call: always the context's lane-0 slot - the lanes of pipelined batched submissions share it)
+    const int lane = c->lane;
+    c->lane = 0;
     double *d = (double *)km_ws(c, WS_MI_TABLE, (size_t)(MI_NPX + 1) * sizeof(double));
+    c->lane = lane;
     if (!d) return nullptr;
     if (!c->mi_table_ready) {
         std::vector<double> h((size_t)MI_NPX + 1);

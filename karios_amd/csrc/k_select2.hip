@@ -24,6 +24,14 @@
 #define KF_SWEEPS 4            // sweeps per launch of the cell-walking form (more neighbours than KF_NBR)
 #define KF_POLLS 32           // state polls per launch of the register form: a poll is one round of <= KF_NBR parallel loads
 #define KF_SLICE 4u           // the ranked top slice holds (at least) KF_SLICE * maxCorners keys (the exact path starts from 8x and can grow)
+// Workgroup size of every kernel of the chain.  256, not 1024 (round 6): the chain is latency-bound and is meant to run BESIDE the dense
+// kernels of another submission (second context), whose long-lived waves hold every VGPR of a SIMD.  A 1024-thread workgroup needs a
+// whole compute unit drained at once and starved there (f_hist_cut 85 -> 551 us, f_acc_count_scan 8 -> 661 us beside a dense kernel of
+// another queue; the 256-thread f_sweep 6 -> 18 us: tools/overlap_stats.py); a 256-thread workgroup takes the slots ONE retiring dense
+// workgroup leaves.
+#define KF_T 256
+#define KF_NW (KF_T / 64)
+#define KF_BPT (KF_NB / KF_T)  // value bins per thread in the one-workgroup scans
 
 namespace {
 
@@ -93,7 +101,7 @@ __device__ __forceinline__ bool kf_last_workgroup(unsigned *ticket, unsigned n_w
 // between; workgroup 0 publishes the result); histogram of its keys by value bin.  The LAST workgroup then cuts:
 // hist[KF_NB] -> cut[0] = D (last kept bin), cut[1] = kept keys, cut[3] = exact candidate count, bin_off[b] = first slot of
 // bin b in the kept list; overflow flags of the emission stage.
-__global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsigned cap, double quality, unsigned k_target, unsigned kept_cap,
+__global__ __launch_bounds__(KF_T) void f_hist_cut_kernel(kf_units_args A, unsigned cap, double quality, unsigned k_target, unsigned kept_cap,
                                                           unsigned test_flags)
 {
     const kf_unit &U = A.u[blockIdx.z];
@@ -105,23 +113,23 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsig
     const size_t n_zero16 = U.n_zero16;
     unsigned *__restrict__ acc_zero = U.acc_cnt;
     __shared__ unsigned h[KF_NB];
-    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_wave[KF_NW];
     __shared__ unsigned s_first, s_maxkey;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
-    for (size_t i = (size_t)wg * 1024 + t; i < n_zero16; i += (size_t)n_wg * 1024) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (unsigned i = wg * 1024 + t; i < 2 * KF_NB; i += n_wg * 1024) acc_zero[i] = 0u;      // acc_cnt + acc_cur of the ranking behind the sweeps
-    for (int i = t; i < KF_NB; i += 1024) h[i] = 0;
+    for (size_t i = (size_t)wg * KF_T + t; i < n_zero16; i += (size_t)n_wg * KF_T) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (unsigned i = wg * KF_T + t; i < 2 * KF_NB; i += n_wg * KF_T) acc_zero[i] = 0u;      // acc_cnt + acc_cur of the ranking behind the sweeps
+    for (int i = t; i < KF_NB; i += KF_T) h[i] = 0;
     unsigned maxkey;
     if (max_partial) {
         unsigned m = 0;
-        for (unsigned i = t; i < n_partial; i += 1024) m = max(m, max_partial[i]);
+        for (unsigned i = t; i < n_partial; i += KF_T) m = max(m, max_partial[i]);
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
         if (lane == 0) s_wave[wv] = m;
         __syncthreads();
         if (t == 0) {
             unsigned mm = 0;
-            for (int i = 0; i < 16; i++) mm = max(mm, s_wave[i]);
+            for (int i = 0; i < KF_NW; i++) mm = max(mm, s_wave[i]);
             s_maxkey = mm;
             if (wg == 0) sc->max_eig_key = mm;         // for the launches that follow (every workgroup here has its own copy)
         }
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsig
         const unsigned n = min(sc->shard_cnt[blockIdx.y], cap_s);
         const unsigned long long *kk = keys + (size_t)blockIdx.y * cap_s;
         unsigned tail = 0;                              // the clamp bin collects the bulk of the (weak) candidates: counted per wave
-        for (unsigned b = blockIdx.x * 1024; b < n; b += gridDim.x * 1024) {
+        for (unsigned b = blockIdx.x * KF_T; b < n; b += gridDim.x * KF_T) {
             const unsigned i = b + t;
             unsigned d = 0xffffffffu;
             if (i < n) { const unsigned long long k = kk[i]; if (kf_above(k, thr)) d = kf_bin(k, top); }
@@ -151,13 +159,14 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsig
         if (lane == 0 && tail) atomicAdd(&h[KF_NB - 1], tail);
     }
     __syncthreads();
-    for (int i = t; i < KF_NB; i += 1024)
+    for (int i = t; i < KF_NB; i += KF_T)
         if (h[i]) atomicAdd(&sc->hist[i], h[i]);
     if (!kf_last_workgroup(&sc->tickets[0], n_wg)) return;
-    // ---- the cut (one workgroup, every histogram complete)
-    const unsigned a = __hip_atomic_load(&sc->hist[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned b = __hip_atomic_load(&sc->hist[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned v = a + b;
+    // ---- the cut (one workgroup, every histogram complete): thread t owns the KF_BPT consecutive bins from KF_BPT * t
+    unsigned hv[KF_BPT], v = 0;
+#pragma unroll
+    for (int j = 0; j < KF_BPT; j++) { hv[j] = __hip_atomic_load(&sc->hist[KF_BPT * t + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v += hv[j]; }
+    const unsigned mine_sum = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = __shfl_up(v, o);
@@ -167,20 +176,21 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsig
     if (t == 0) s_first = 0xffffffffu;
     __syncthreads();
     unsigned base = 0, total = 0;
-    for (int w = 0; w < 16; w++) { if (w < wv) base += s_wave[w]; total += s_wave[w]; }
-    const unsigned incl_b = base + v, incl_a = incl_b - b;
-    sc->bin_off[2 * t] = incl_a - a;
-    sc->bin_off[2 * t + 1] = incl_b - b;
+    for (int w = 0; w < KF_NW; w++) { if (w < wv) base += s_wave[w]; total += s_wave[w]; }
+    unsigned run = base + v - mine_sum;                 // keys in the bins before this thread's
     unsigned mine = 0xffffffffu;
-    if (incl_a >= k_target) mine = 2 * t;
-    else if (incl_b >= k_target) mine = 2 * t + 1;
+#pragma unroll
+    for (int j = 0; j < KF_BPT; j++) {
+        sc->bin_off[KF_BPT * t + j] = run;
+        run += hv[j];
+        if (mine == 0xffffffffu && run >= k_target) mine = KF_BPT * t + j;     // first bin whose inclusive count reaches the target
+    }
     if (mine != 0xffffffffu) atomicMin(&s_first, mine);
     __syncthreads();
     const unsigned D = s_first == 0xffffffffu ? KF_NB - 1 : s_first;
-    unsigned kept = 0xffffffffu;
-    if (D == (unsigned)(2 * t)) kept = incl_a;
-    else if (D == (unsigned)(2 * t + 1)) kept = s_first == 0xffffffffu ? total : incl_b;
-    if (kept != 0xffffffffu) {
+    if (D / KF_BPT == (unsigned)t) {
+        unsigned kept = base + v - mine_sum;
+        for (unsigned j = 0; j <= D % KF_BPT; j++) kept += hv[j];              // inclusive count at bin D (= total when no bin reaches the target)
         sc->cut[0] = D; sc->cut[1] = kept; sc->cut[2] = 0;
         if (kept > kept_cap) atomicOr(&sc->flags, KM_FLAG_KEPT_OVERFLOW);
     }
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(1024) void f_hist_cut_kernel(kf_units_args A, unsig
 // (+ 90 us).  A cell's record holds its population AND its first candidate: nearly every occupied cell holds exactly one (160 000
 // candidates on 1.2 million cells), and the sweeps then reach a neighbour's key with two dependent loads instead of three.
 // (The cell records were zeroed by launch 1.)
-#define KF_STASH 3072
-__global__ __launch_bounds__(1024) void f_scatter_cells_kernel(kf_units_args A, unsigned cap, double quality, unsigned kept_cap, int cell,
+#define KF_STASH 1024         // (a workgroup reads ~3 500 keys, ~4 % of them above the cut)
+__global__ __launch_bounds__(KF_T) void f_scatter_cells_kernel(kf_units_args A, unsigned cap, double quality, unsigned kept_cap, int cell,
                                                                unsigned stash_cap /* <= KF_STASH (test knob: small values force the second read) */)
 {
     const kf_unit &U = A.u[blockIdx.z];
@@ -223,10 +233,10 @@ __global__ __launch_bounds__(1024) void f_scatter_cells_kernel(kf_units_args A, 
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
     const unsigned D = sc->cut[0];
     if (sc->cut[1] > kept_cap) return;                   // flagged: the exact path takes over
-    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T) s_cnt[i] = 0;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+    for (unsigned i = blockIdx.x * KF_T + threadIdx.x; i < n; i += gridDim.x * KF_T) {
         const unsigned long long k = keys[i];
         if (!kf_above(k, thr)) continue;
         const unsigned b = kf_bin(k, top);
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(1024) void f_scatter_cells_kernel(kf_units_args A, 
         if (e < stash_cap) s_stash[e] = k;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < KF_NB; i += 1024) {
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T) {
         const unsigned cnt = s_cnt[i];
         s_base[i] = cnt ? sc->bin_off[i] + atomicAdd(&sc->bin_cur[i], cnt) : 0u;
         s_cnt[i] = 0;
@@ -256,10 +266,10 @@ __global__ __launch_bounds__(1024) void f_scatter_cells_kernel(kf_units_args A, 
     };
     const unsigned kept_here = s_n;
     if (kept_here <= stash_cap) {
-        for (unsigned e = threadIdx.x; e < kept_here; e += 1024) place(s_stash[e]);
+        for (unsigned e = threadIdx.x; e < kept_here; e += KF_T) place(s_stash[e]);
     } else {
         // more keys above the cut than the stash holds (a tile whose strong corners crowd into one part of the key buffer): second read
-        for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+        for (unsigned i = blockIdx.x * KF_T + threadIdx.x; i < n; i += gridDim.x * KF_T) {
             const unsigned long long k = keys[i];
             if (kf_above(k, thr) && kf_bin(k, top) <= D) place(k);
         }
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(256) void f_sweep_kernel(kf_units_args A, int cell,
 // accepted corners per value bin.  Workgroup-aggregated like the scatter: thousands of accepted corners share a handful of bins
 // (equal eigenvalues), and one device-scope atomic per corner on the same address took 300 us.  The LAST workgroup then scans:
 // acc_off = exclusive scan of acc_cnt, chunk_off = exclusive scan of the bins' 64-corner chunks; corner count, flags.
-__global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(kf_units_args A, unsigned kept_cap, int max_corners, unsigned und_slot)
+__global__ __launch_bounds__(KF_T) void f_acc_count_scan_kernel(kf_units_args A, unsigned kept_cap, int max_corners, unsigned und_slot)
 {
     const kf_unit &U = A.u[blockIdx.z];
     const unsigned long long *__restrict__ keys = U.kept;
@@ -381,22 +391,26 @@ __global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(kf_units_args A,
     km_scalars *sc = U.sc;
     unsigned *__restrict__ acc_cnt = U.acc_cnt, *__restrict__ acc_off = U.acc_off, *__restrict__ chunk_off = U.chunk_off;
     __shared__ unsigned s_cnt[KF_NB];
-    __shared__ unsigned s_wave[16], s_wave2[16];
+    __shared__ unsigned s_wave[KF_NW], s_wave2[KF_NW];
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
-    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T) s_cnt[i] = 0;
     __syncthreads();
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+    for (unsigned i = blockIdx.x * KF_T + threadIdx.x; i < n; i += gridDim.x * KF_T)
         if (state[i] == S_ACCEPT) atomicAdd(&s_cnt[kf_bin(keys[i], top)], 1u);
     __syncthreads();
-    for (int i = threadIdx.x; i < KF_NB; i += 1024)
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T)
         if (s_cnt[i]) atomicAdd(&acc_cnt[i], s_cnt[i]);
     if (!kf_last_workgroup(&sc->tickets[1], gridDim.x)) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned a = __hip_atomic_load(&acc_cnt[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned b = __hip_atomic_load(&acc_cnt[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned ca = (a + 63) / 64, cb = (b + 63) / 64;
-    unsigned v = a + b, w = ca + cb;
+    unsigned cv[KF_BPT], v = 0, w = 0;                 // thread t owns the KF_BPT consecutive bins from KF_BPT * t
+#pragma unroll
+    for (int j = 0; j < KF_BPT; j++) {
+        cv[j] = __hip_atomic_load(&acc_cnt[KF_BPT * t + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += cv[j];
+        w += (cv[j] + 63) / 64;
+    }
+    const unsigned mine_v = v, mine_w = w;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned u = __shfl_up(v, o), u2 = __shfl_up(w, o);
@@ -405,11 +419,15 @@ __global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(kf_units_args A,
     if (lane == 63) { s_wave[wv] = v; s_wave2[wv] = w; }
     __syncthreads();
     unsigned base = 0, total = 0, base2 = 0, total2 = 0;
-    for (int k = 0; k < 16; k++) { if (k < wv) { base += s_wave[k]; base2 += s_wave2[k]; } total += s_wave[k]; total2 += s_wave2[k]; }
-    acc_off[2 * t] = base + v - a - b;
-    acc_off[2 * t + 1] = base + v - b;
-    chunk_off[2 * t] = base2 + w - ca - cb;
-    chunk_off[2 * t + 1] = base2 + w - cb;
+    for (int k = 0; k < KF_NW; k++) { if (k < wv) { base += s_wave[k]; base2 += s_wave2[k]; } total += s_wave[k]; total2 += s_wave2[k]; }
+    unsigned run = base + v - mine_v, run2 = base2 + w - mine_w;
+#pragma unroll
+    for (int j = 0; j < KF_BPT; j++) {
+        acc_off[KF_BPT * t + j] = run;
+        chunk_off[KF_BPT * t + j] = run2;
+        run += cv[j];
+        run2 += (cv[j] + 63) / 64;
+    }
     if (t == 0) {
         acc_off[KF_NB] = total;
         chunk_off[KF_NB] = total2;
@@ -423,7 +441,7 @@ __global__ __launch_bounds__(1024) void f_acc_count_scan_kernel(kf_units_args A,
 }
 
 // accepted keys grouped by bin (any order inside a bin)
-__global__ __launch_bounds__(1024) void f_acc_fill_kernel(kf_units_args A, unsigned kept_cap)
+__global__ __launch_bounds__(KF_T) void f_acc_fill_kernel(kf_units_args A, unsigned kept_cap)
 {
     const kf_unit &U = A.u[blockIdx.z];
     const unsigned long long *__restrict__ keys = U.kept;
@@ -435,18 +453,18 @@ __global__ __launch_bounds__(1024) void f_acc_fill_kernel(kf_units_args A, unsig
     __shared__ unsigned s_cnt[KF_NB], s_base[KF_NB];
     const unsigned n = kf_count(sc, kept_cap);
     const unsigned top = (sc->max_eig_key & 0x7fffffffu) >> KF_SHIFT;
-    for (int i = threadIdx.x; i < KF_NB; i += 1024) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T) s_cnt[i] = 0;
     __syncthreads();
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+    for (unsigned i = blockIdx.x * KF_T + threadIdx.x; i < n; i += gridDim.x * KF_T)
         if (state[i] == S_ACCEPT) atomicAdd(&s_cnt[kf_bin(keys[i], top)], 1u);
     __syncthreads();
-    for (int i = threadIdx.x; i < KF_NB; i += 1024) {
+    for (int i = threadIdx.x; i < KF_NB; i += KF_T) {
         const unsigned cnt = s_cnt[i];
         s_base[i] = cnt ? acc_off[i] + atomicAdd(&acc_cur[i], cnt) : 0u;
         s_cnt[i] = 0;
     }
     __syncthreads();
-    for (unsigned i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+    for (unsigned i = blockIdx.x * KF_T + threadIdx.x; i < n; i += gridDim.x * KF_T)
         if (state[i] == S_ACCEPT) {
             const unsigned long long k = keys[i];
             const unsigned b = kf_bin(k, top);
@@ -456,17 +474,17 @@ __global__ __launch_bounds__(1024) void f_acc_fill_kernel(kf_units_args A, unsig
 
 // Position of an accepted corner in OpenCV's output order = accepted corners in stronger bins + accepted corners of its own bin
 // with a larger key; the first maxCorners positions are the result.  One WORKGROUP per chunk of 64 corners of ONE bin: each of
-// its 16 wavefronts compares the 64 corners (one per lane) with a sixteenth of the bin - keys at wave-uniform addresses, scalar
+// its KF_NW wavefronts compares the 64 corners (one per lane) with its share of the bin - keys at wave-uniform addresses, scalar
 // loads, eight per instruction - and the partial counts meet in LDS.  (One wavefront walking a 10 000-corner bin alone - equal
 // eigenvalues are common in a quantised Laplacian image - took 73 us.)
-__global__ __launch_bounds__(1024) void f_acc_emit_kernel(kf_units_args A, int max_corners, int cap)
+__global__ __launch_bounds__(KF_T) void f_acc_emit_kernel(kf_units_args A, int max_corners, int cap)
 {
     const kf_unit &U = A.u[blockIdx.z];
     const unsigned long long *__restrict__ acc_keys = U.acc_keys;
     const unsigned *__restrict__ acc_off = U.acc_off, *__restrict__ chunk_off = U.chunk_off;
     const int W = U.W;
     float *__restrict__ out_xy = U.out_xy;
-    __shared__ unsigned s_part[16][64];
+    __shared__ unsigned s_part[KF_NW][64];
     const unsigned chunk = blockIdx.x;
     if (chunk >= chunk_off[KF_NB]) return;
     unsigned lo_b = 0, hi_b = KF_NB;                           // bin of this chunk: last b with chunk_off[b] <= chunk
@@ -481,7 +499,7 @@ __global__ __launch_bounds__(1024) void f_acc_emit_kernel(kf_units_args A, int m
     const unsigned s = lo + (chunk - chunk_off[b]) * 64 + lane;
     const bool live = s < hi;
     const unsigned long long k = live ? acc_keys[s] : 0ull;
-    const unsigned len = hi - lo, per = (len + 15) / 16;
+    const unsigned len = hi - lo, per = (len + KF_NW - 1) / KF_NW;
     const unsigned t0 = lo + min(wv * per, len), t1 = lo + min((wv + 1) * per, len);
     unsigned p = 0;
     for (unsigned t = t0; t < t1; t++) p += acc_keys[t] > k ? 1u : 0u;      // uniform index: scalar loads
@@ -490,7 +508,7 @@ __global__ __launch_bounds__(1024) void f_acc_emit_kernel(kf_units_args A, int m
     if (wv == 0) {
         unsigned pos = lo;
 #pragma unroll
-        for (int w = 0; w < 16; w++) pos += s_part[w][lane];
+        for (int w = 0; w < KF_NW; w++) pos += s_part[w][lane];
         if (live && pos < (unsigned)max_corners && pos < (unsigned)cap) {
             int x, y;
             kf_xy(k, W, x, y);
@@ -552,11 +570,11 @@ static int kf_rank_launch(km_ctx *c, const kf_units_args &A, int n, size_t cap_k
 {
     static const int gx = [] { const char *e = km_dev_env("KARIOS_HIP_RANK_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 16; }();   // tuning override
     // (a batch keeps ~256 workgroups per launch in flight: 16 x 16 per unit alone, fewer columns per unit as the units multiply)
-    const int gxu = n >= 8 ? (gx + 3) / 4 : n >= 3 ? (gx + 1) / 2 : gx;
-    f_hist_cut_kernel<<<dim3(gxu, KM_NSHARD, n), 1024, 0, c->stream>>>(A, (unsigned)cap_keys, quality, (unsigned)max_corners * KF_SLICE, z.kept_cap,
+    const int gxu = (n >= 8 ? (gx + 3) / 4 : n >= 3 ? (gx + 1) / 2 : gx) * (1024 / KF_T);
+    f_hist_cut_kernel<<<dim3(gxu, KM_NSHARD, n), KF_T, 0, c->stream>>>(A, (unsigned)cap_keys, quality, (unsigned)max_corners * KF_SLICE, z.kept_cap,
                                                                      (unsigned)c->opt_spec_flag);
     KM_LAUNCH_CHECK(c);
-    f_scatter_cells_kernel<<<dim3(gxu, KM_NSHARD, n), 1024, 0, c->stream>>>(A, (unsigned)cap_keys, quality, z.kept_cap, z.cell,
+    f_scatter_cells_kernel<<<dim3(gxu, KM_NSHARD, n), KF_T, 0, c->stream>>>(A, (unsigned)cap_keys, quality, z.kept_cap, z.cell,
                                                                           c->opt_stash_cap > 0 && c->opt_stash_cap < KF_STASH ? (unsigned)c->opt_stash_cap : (unsigned)KF_STASH);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
@@ -572,13 +590,13 @@ static int kf_select_launch(km_ctx *c, const kf_units_args &A, int n, int max_co
         f_sweep_kernel<<<dim3(g256, 1, n), 256, 0, c->stream>>>(A, z.cell, md2, g, z.kept_cap);
         KM_LAUNCH_CHECK(c);
     }
-    const int gb = n >= 8 ? 8 : n >= 3 ? 16 : 32;
-    f_acc_count_scan_kernel<<<dim3(gb, 1, n), 1024, 0, c->stream>>>(A, z.kept_cap, max_corners, (unsigned)(KF_LAUNCHES - 1));
+    const int gb = (n >= 8 ? 8 : n >= 3 ? 16 : 32) * (1024 / KF_T);
+    f_acc_count_scan_kernel<<<dim3(gb, 1, n), KF_T, 0, c->stream>>>(A, z.kept_cap, max_corners, (unsigned)(KF_LAUNCHES - 1));
     KM_LAUNCH_CHECK(c);
-    f_acc_fill_kernel<<<dim3(gb, 1, n), 1024, 0, c->stream>>>(A, z.kept_cap);
+    f_acc_fill_kernel<<<dim3(gb, 1, n), KF_T, 0, c->stream>>>(A, z.kept_cap);
     KM_LAUNCH_CHECK(c);
     // chunks of 64 accepted corners: at most kept_cap / 64 + one partial chunk per bin
-    f_acc_emit_kernel<<<dim3(z.kept_cap / 64 + KF_NB, 1, n), 1024, 0, c->stream>>>(A, max_corners, cap);
+    f_acc_emit_kernel<<<dim3(z.kept_cap / 64 + KF_NB, 1, n), KF_T, 0, c->stream>>>(A, max_corners, cap);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

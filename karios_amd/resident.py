@@ -144,16 +144,22 @@ class PendingBatch:
     `wait()` (any thread) -> the units' `RawFrame`s in submission order; `redo(i)` repeats unit i alone through the exact path."""
 
     def __init__(self, ctx: Context, ticket: int, cap: int, with_zncc, redos):
+        import threading
         self.ctx, self.ticket, self.cap, self.with_zncc = ctx, ticket, cap, with_zncc
         self._redos = redos
         self._raws = None
+        self._submitter = threading.get_ident()
 
     def __len__(self):
         return len(self._redos)
 
     def wait(self) -> "list[RawFrame]":
         if self._raws is None:
+            import threading
             c = self.ctx
+            if threading.get_ident() == self._submitter:
+                c.flush(self.ticket)        # ("units_pipeline": the submitting thread waits and no further submission came - the deferred tail goes now;
+                                 #  a worker thread just waits: the submitting thread submits the next batch or flushes - FrameStream does)
             blk, nbytes = C.c_void_p(), C.c_size_t()
             rc = c.lib.km_frame_wait(c.handle, self.ticket, C.byref(blk), C.byref(nbytes))
             if rc != 0:

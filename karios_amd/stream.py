@@ -73,6 +73,11 @@ class FrameStream:
     host_stage          optional callable(frame, pair) -> frame run on the CALLING thread when a frame is collected (a stage that
                         calls back into the library - mutual information, ZNCC of rows the device did not score - must not run
                         beside `submit`: a context is not thread-safe)
+    pipeline            batched submissions (`submit_many`) run as a SOFTWARE PIPELINE on their context (km_set_option "units_pipeline",
+                        csrc/api_units.hip): the dense stages of consecutive submissions interleave, the latency-bound chains of one run
+                        beside the dense kernels of the next; a submission's tail is enqueued by the next one - the stream flushes it
+                        (`Context.flush`) before it blocks on the newest submission and in `drain`.  Needs depth >= 1; frames are
+                        bit-identical.  Default: on.
     gil_switch_interval the submitting thread spends ~0.1 ms per unit inside the library and the rest in Python next to the worker;
                         with CPython's default 5 ms switch interval a thread that needs the GIL can wait that long for the other to
                         yield it.  The stream lowers the (process-global!) interval while it is open; the value found by the first
@@ -80,7 +85,7 @@ class FrameStream:
     """
 
     def __init__(self, confidence_threshold: float | None = None, depth: int = 1, host_stage=None, want_spans: bool = False,
-                 gil_switch_interval: float | None = 1e-4, score_columns: bool | None = None, mutual_info: bool = False):
+                 gil_switch_interval: float | None = 1e-4, score_columns: bool | None = None, mutual_info: bool = False, pipeline: bool = True):
         self.threshold, self.depth, self.host_stage, self.want_spans = confidence_threshold, max(0, int(depth)), host_stage, want_spans
         self.mutual_info = bool(mutual_info) and confidence_threshold is not None
         self.score_columns = (confidence_threshold is not None) if score_columns is None else bool(score_columns)
@@ -90,6 +95,8 @@ class FrameStream:
         if gil_switch_interval is not None:
             _gil_interval_acquire(gil_switch_interval)
             self._holds_interval = True
+        self.pipeline = bool(pipeline) and self.depth >= 1
+        self._piped = {}               # contexts whose "units_pipeline" option this stream switched on -> (context, previous value)
         self.units_redone = 0
         self.worker_cpu_s = 0.0        # CPU time of the worker thread's host halves (time.thread_time): what a rank's frames cost its host
 
@@ -102,6 +109,13 @@ class FrameStream:
         return False
 
     def close(self):
+        for ctx, before in self._piped.values():
+            try:
+                if getattr(ctx, "handle", None):
+                    ctx.set_option("units_pipeline", before)      # (0 flushes what is still deferred)
+            except Exception:  # pragma: no cover - a context that was closed under the stream
+                pass
+        self._piped = {}
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
@@ -178,6 +192,9 @@ class FrameStream:
 
     def _collect(self, item):
         if isinstance(item[1], PendingBatch):
+            # the NEWEST submission of a pipelined context still lacks its tail: enqueue it before blocking on its frame
+            if self._piped:
+                item[1].ctx.flush(item[1].ticket)
             return self._collect_batch(item)
         return [self._collect_one(item)]
 
@@ -230,6 +247,11 @@ class FrameStream:
         i = 0
         while i < len(units):
             chunk, chunk_tags = units[i:i + UNITS_PER_SUBMISSION], tags[i:i + UNITS_PER_SUBMISSION]
+            if self.pipeline and len(chunk) > 1:
+                ctx = chunk[0][0].ctx
+                if id(ctx) not in self._piped:
+                    self._piped[id(ctx)] = (ctx, ctx.get_option("units_pipeline", 0))
+                    ctx.set_option("units_pipeline", 1)
             pend = submit_units(chunk, conf, self.threshold, self.mutual_info) if len(chunk) > 1 else None
             if pend is None:               # not batchable: unit by unit
                 for (pair, box, origin), tag in zip(chunk, chunk_tags):

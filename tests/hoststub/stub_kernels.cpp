@@ -288,7 +288,7 @@ int kf_dn_keep(km_ctx *, const void *, const void *, int, int H, int W, ptrdiff_
     return KM_OK;
 }
 // frame block: 16-byte header + 6 * cap float32 columns (x0 | y0 | dx | dy | score | index bits); every column written to `cap`
-int kf_frame(km_ctx *, const float *p0, const float *p1, const float *p0r, const int *d_n, int n_max, int cap, float thr, float xo, float yo, void *out, const km_scalars *hdr)
+int kf_frame(km_ctx *, const float *p0, const float *p1, const float *p0r, const int *d_n, int n_max, int cap, float thr, float xo, float yo, void *out, const km_scalars *hdr, int /*width*/)
 {
     const int n = std::min(*d_n, n_max);
     int *h = (int *)out;

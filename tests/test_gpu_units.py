@@ -160,3 +160,99 @@ def test_what_the_batch_form_does_not_cover_goes_one_by_one(ops):
             b += s.submit(p, conf, bx, o)
         b += s.drain()
     assert len(a) == 2 and all(x.frame.equals(y.frame) for x, y in zip(a, b))
+
+
+# ---------------------------------------------------------------------------- software pipeline over consecutive submissions (round 6)
+def test_pipelined_submissions_equal_unpipelined_ones_bit_for_bit(ops):
+    """km_set_option("units_pipeline", 1): two workspace lanes alternate, the dense stages of consecutive submissions interleave and the
+    latency-bound chains of one run beside the dense kernels of the next; the tail of a submission is enqueued by the next one, by a
+    flush, by any other entry point or by the context's sync.  Same kernels on the same data: every frame block is the unpipelined
+    submission's bit for bit - across alternating batches of different shape, with all score columns, through every way a tail can be
+    enqueued."""
+    import threading
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import submit_units
+    ctx, pa, pb, _ = _pairs(ops)
+    conf = KLTConfiguration(maxCorners=1200)
+    batch_x = [(pa, b, None) for b in UNITS_A[:3]] + [(pb, None, None)]
+    batch_y = [(pb, (100, 50, 900, 700), (5100, 7050)), (pa, UNITS_A[3], None), (pa, None, None)]
+    want = {}
+    for name, units in (("x", batch_x), ("y", batch_y)):
+        b = submit_units(units, conf, 0.4, True)
+        want[name] = [r if not r.flags else b.redo(k) for k, r in enumerate(b.wait())]
+    assert all(w.n_rows > 200 for v in want.values() for w in v)
+
+    def check(batch, name, phase=""):
+        got = batch.wait()
+        for k, (g, w) in enumerate(zip(got, want[name])):
+            if g.flags:
+                g = batch.redo(k)
+            assert same_rows(g, w), (phase, name, k, g.block[:4].view(np.int32).tolist(), w.block[:4].view(np.int32).tolist())
+
+    ctx.set_option("units_pipeline", 1)
+    try:
+        # 1. a stream: submission i is waited for after submission i + 1 went in (its tail travelled with that one)
+        seq = ["x", "y", "x", "x", "y", "y", "x"]
+        prev = None
+        for name in seq:
+            cur = (submit_units(batch_x if name == "x" else batch_y, conf, 0.4, True), name)
+            if prev is not None:
+                check(*prev, "stream")
+            prev = cur
+        check(*prev, "stream-last")                                      # the last one: PendingBatch.wait() on the submitting thread flushes its tail
+        # 2. waited for at once, every time (flush per submission: the pipeline degenerates, the frames do not)
+        for name in ("y", "x", "y"):
+            check(submit_units(batch_x if name == "x" else batch_y, conf, 0.4, True), name, "at-once")
+        # 3. another entry point between two submissions enqueues the deferred tail first (stream order is kept)
+        a = submit_units(batch_x, conf, 0.4, True)
+        single = pa.match_tile_raw(conf, UNITS_A[3], 0.4, mutual_info=True)
+        b = submit_units(batch_y, conf, 0.4, True)
+        ctx.sync()                                        # ... and so does the context's sync
+        check(a, "x", "entry-point")
+        check(b, "y", "entry-point")
+        assert same_rows(single, want["y"][1])
+        # 4. a worker thread waits while the submitting thread goes on: the next submission releases it
+        a = submit_units(batch_x, conf, 0.4, True)
+        out = {}
+        t = threading.Thread(target=lambda: out.setdefault("raws", a.wait()))
+        t.start()
+        b = submit_units(batch_y, conf, 0.4, True)
+        t.join(timeout=30)
+        assert not t.is_alive() and len(out["raws"]) == len(batch_x)
+        check(a, "x")
+        check(b, "y")
+        # 5. nobody flushes: km_frame_wait enqueues the tail itself after 100 ms instead of waiting for ever
+        a = submit_units(batch_y, conf, 0.4, True)
+        t = threading.Thread(target=lambda: out.setdefault("late", a.wait()))
+        t.start()
+        t.join(timeout=30)
+        assert not t.is_alive() and len(out["late"]) == len(batch_y)
+        check(a, "y")
+    finally:
+        ctx.set_option("units_pipeline", 0)
+    check(submit_units(batch_x, conf, 0.4, True), "x")     # and back
+
+
+def test_framestream_pipelines_batched_submissions_and_yields_the_same_frames(ops):
+    """FrameStream switches the pipeline on for the contexts it drives (depth >= 1) and flushes before it blocks on the newest
+    submission: frames equal the unpipelined stream's, the option is restored when the stream closes."""
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.stream import FrameStream
+    ctx, pa, pb, _ = _pairs(ops)
+    conf = KLTConfiguration(maxCorners=1200)
+    units = [(pa, b, None) for b in UNITS_A[:4]] + [(pb, None, None)]
+    runs = {}
+    for piped in (False, True):
+        frames = []
+        with FrameStream(0.4, depth=2, pipeline=piped) as s:
+            for _ in range(5):
+                frames += [d.frame for d in s.submit_many(units, conf)]
+                assert ctx.get_option("units_pipeline", 0) == int(piped)
+            frames += [d.frame for d in s.drain()]
+        assert ctx.get_option("units_pipeline", 0) == 0
+        runs[piped] = frames
+    assert len(runs[True]) == len(runs[False]) == 25
+    for a, b in zip(runs[True], runs[False]):
+        assert list(a.columns) == list(b.columns) and len(a) == len(b) > 200
+        for col in a.columns:
+            np.testing.assert_array_equal(a[col].to_numpy(), b[col].to_numpy())

@@ -16,14 +16,18 @@ from karios_amd.resident import ResidentPair
 from karios_amd.stream import FrameStream
 
 S = 10980
+REPS = 4
 dev = torch.device("cuda", 0)
 mon, ref = synth.make_pair_torch(S, S, 0.5, 0.25, device=dev)
 torch.cuda.synchronize()
 conf = KLTConfiguration()
 for n_ctx in [int(v) for v in sys.argv[1:]] or [1, 2]:
     ctxs = [Context(0) for _ in range(n_ctx)]
+    if os.environ.get("KARIOS_PROBE_HP") == "1":
+        for c in ctxs:
+            c.set_option("chain_hp", 1)
     pairs = [ResidentPair.from_device_pointers(mon.data_ptr(), ref.data_ptr(), np.uint16, S, S, ctx=c, keepalive=(mon, ref)) for c in ctxs]
-    SUBS = 12
+    SUBS = int(os.environ.get("KARIOS_PROBE_SUBS", "50"))
     barrier = threading.Barrier(n_ctx + 1)
     rows = [0] * n_ctx
 
@@ -37,19 +41,22 @@ for n_ctx in [int(v) for v in sys.argv[1:]] or [1, 2]:
                 ctxs[k].sync()
                 return r
             go(3)
-            barrier.wait()
-            rows[k] = go(SUBS)
-            barrier.wait()
+            for _rep in range(REPS):
+                barrier.wait()
+                rows[k] = go(SUBS)
+                barrier.wait()
 
     th = [threading.Thread(target=worker, args=(k,)) for k in range(n_ctx)]
     for t in th:
         t.start()
-    barrier.wait()
-    t0 = time.perf_counter()
-    barrier.wait()
-    dt = time.perf_counter() - t0
+    res = []
+    for _rep in range(REPS):
+        barrier.wait()
+        t0 = time.perf_counter()
+        barrier.wait()
+        res.append((time.perf_counter() - t0) / (SUBS * 4 * n_ctx) * 1e3)
     for t in th:
         t.join()
-    print(f"{n_ctx} context(s), 4 pairs per submission each: {dt / (SUBS * 4 * n_ctx) * 1e3:.4f} ms per pair, rows per pair {sum(rows) // (SUBS * 4 * n_ctx)}", flush=True)
+    print(f"{n_ctx} context(s), 4 pairs per submission each: {min(res):.4f} ms per pair (runs: {' '.join(f'{v:.4f}' for v in res)}), rows per pair {sum(rows) // (SUBS * 4 * n_ctx)}", flush=True)
     for c in ctxs:
         c.close()
