@@ -305,9 +305,16 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         KM_HIP(c, hipStreamWaitEvent(c->aux_stream, ev[EV_F_DONE], 0));
         c->lane_f_recorded[lane] = false;
     }
-    KM_HIP(c, hipMemsetAsync(sc, 0, sc_stride * n, c->stream));
+    // the scalar blocks' reset and the LK table's small copy.  Pipelined: on the second stream, in front of the min / max the main stream
+    // waits for anyway - on the main stream they sat between the previous eigenvalue pass and these Laplacians (two tiny operations
+    // that each wait for the stream to drain: 0.06 ms per submission, profiles/timeline_r06_a.txt)
     const int n_max = prm->max_corners < cap ? prm->max_corners : cap;
-    if ((rc = kl_units_prepare(c, U, n_max, prm->win_size, prm->max_count, prm->epsilon))) return rc;   // (the table's small copy: off the critical path here)
+    const bool setup_on_aux = piped && dtype != KM_U8;
+    if (setup_on_aux) c->stream = c->aux_stream;
+    rc = hipMemsetAsync(sc, 0, sc_stride * n, c->stream) == hipSuccess ? KM_OK : km_fail(c, KM_E_HIP, "hipMemsetAsync(scalars)");
+    if (rc == KM_OK) rc = kl_units_prepare(c, U, n_max, prm->win_size, prm->max_count, prm->epsilon);
+    c->stream = main_stream;
+    if (rc) return rc;
 
     // ---- K1: min / max of every raster, on the second stream.  Pipelined: at once - beside whatever dense kernel the older submissions
     // are in (HBM-bound work under instruction-bound kernels).  Unpipelined, directly behind another submission: beside its LK.

@@ -736,6 +736,13 @@ def _layout(arr: np.ndarray) -> tuple:
     return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
 
 
+def _same_buffer(a: np.ndarray, b: np.ndarray) -> bool:
+    """Cheap necessary condition for two arrays to share memory: their byte ranges overlap."""
+    (a0, a1), (b0, b1) = np.byte_bounds(a) if hasattr(np, "byte_bounds") else np.lib.array_utils.byte_bounds(a), \
+        np.byte_bounds(b) if hasattr(np, "byte_bounds") else np.lib.array_utils.byte_bounds(b)
+    return a0 < b1 and b0 < a1
+
+
 def _base_chain(arr: np.ndarray) -> list:
     """`arr` and every ndarray it is a view of, outermost owner last."""
     out, a = [], arr
@@ -752,7 +759,14 @@ class _SharedEntry:
         self.rasters = tuple(r for r in rasters if r is not None)  # (kept alive too: an id must not be reused by another raster)
         self.guarded = []
         seen = set()
-        for a in _base_chain(mon)[::-1] + _base_chain(ref)[::-1]:  # owners first
+        # the arrays that were uploaded, the arrays they are views of, and the array objects the rasters hand out as `.array` when
+        # they are cached views of the same memory (`NumpyRasterImage._array`; a raster's cache is looked at, never loaded)
+        cached = [a for a in (getattr(r, "_array", None) for r in self.rasters) if isinstance(a, np.ndarray)
+                  and any(np.shares_memory(a, b, max_work=1) for b in (mon, ref) if _same_buffer(a, b))]
+        chains = _base_chain(mon)[::-1] + _base_chain(ref)[::-1]
+        for a in cached:
+            chains += _base_chain(a)[::-1]
+        for a in chains:  # owners first
             if id(a) not in seen and a.flags.writeable:
                 seen.add(id(a))
                 try:

@@ -698,3 +698,13 @@ def test_shared_pair_token_never_serves_stale_pixels(monkeypatch):
     assert R.shared_pair(g_mon.array, g_ref.array, ctx) is not first
     R.forget_shared_pairs()
     assert mon.flags.writeable and ref.flags.writeable
+    # rasters over page-locked memory (karios_amd.pinned_empty: np.frombuffer(...).reshape - the raster's `.array` is a VIEW object of its
+    # own, not on the base chain of what `read()` returns): found again through `.array`, guarded, released
+    import ctypes
+    bufs = [(ctypes.c_char * (2 * 48 * 64))() for _ in range(2)]
+    p_mon, p_ref = (NumpyRasterImage(np.frombuffer(b, dtype=np.uint16, count=48 * 64).reshape(48, 64)) for b in bufs)
+    n_up = len(uploads)
+    pinned = R.shared_pair(p_mon.read(1, 0, 0, 64, 48), p_ref.read(1, 0, 0, 64, 48), ctx, publish=FakePair(), rasters=(p_mon, p_ref))
+    assert R.shared_pair(p_mon.array, p_ref.array, ctx) is pinned and len(uploads) == n_up and not p_mon.array.flags.writeable
+    R.forget_shared_pairs()
+    assert p_mon.array.flags.writeable and p_ref.array.flags.writeable
