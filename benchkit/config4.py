@@ -117,10 +117,10 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False, warmu
     # ---- batched mode: the steps are PIPELINED like the headline's (FrameStream): step k + 1 is submitted before step k is collected - its
     # blocks arrive in the page-locked slot (header flags on the host: no read-back of the send buffer), flagged units are repeated,
     # the step's send buffer (two alternate) is gathered.  The device never waits for the host between steps.
-    send2 = [send, send.clone()] if batched else None
+    send2 = [send, send.clone(), send.clone()] if batched else None      # (three steps may be in flight: two submitted ahead of the one collected)
 
     def submit_step(k):
-        buf = send2[k % 2]
+        buf = send2[k % 3]
         out = []
         c0 = ctxs[0]
         for lo in range(0, len(resident), 16):
@@ -136,7 +136,7 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False, warmu
     span = {"ms": 0.0, "n": 0, "units": 0, "cand": 0}
 
     def collect_step(k, batches):
-        buf = send2[k % 2]
+        buf = send2[k % 3]
         for lo, batch in batches:
             raws = batch.wait()
             if timed_stage is not None:
@@ -163,14 +163,21 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False, warmu
             for _ in range(n):
                 r = step()
             return r
-        prev, r = None, (0, 0)
+        # steps k + 1 and k + 2 are submitted before step k is collected: the host's collect (wait, gather, header read-back) and the next
+        # submission's min / max must not sit between two steps' dense kernels (0.66 ms per step with one step ahead, timeline_r06_c4.txt)
+        from collections import deque
+        pend, r = deque(), (0, 0)
         for k in range(n):
-            cur = submit_step(k) if resident else []
-            if prev is not None:
-                r = collect_step(k - 1, prev)
-            prev = cur
-        return collect_step(n - 1, prev)
+            pend.append((k, submit_step(k) if resident else []))
+            while len(pend) > 2:
+                r = collect_step(*pend.popleft())
+        while pend:
+            r = collect_step(*pend.popleft())
+        return r
 
+    if batched:
+        for c in ctxs:
+            c.set_option("units_pipeline", 1)      # consecutive steps interleave on the device (csrc/api_units.hip); collect_step waits for step k - 1 behind step k's submission
     rows, got = run(max(1, warmup))
     if timed_stage is not None and batched:
         names = [ctxs[0].lib.km_stage_name(i).decode() for i in range(16)]

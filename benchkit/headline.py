@@ -243,6 +243,16 @@ def run(a, env, conf, pairs, S: int):
     run_steps(stage_steps)
     take(stream.drain())
     fence()
+    stage_piped = {k: v / stage_steps for k, v in stage_sum.items()}
+    # ... and the same pass with the software pipeline OFF: every kernel with the GPU to itself (plus the second stream's pyramids /
+    # min-max, as in rounds 1 - 5) - what a kernel costs, against what it takes while it shares the GPU with the other lane's chains
+    piped_before = ctx.get_option("units_pipeline", 0)
+    ctx.set_option("units_pipeline", 0)
+    stage_sum.clear()
+    run_steps(stage_steps)
+    take(stream.drain())
+    fence()
+    ctx.set_option("units_pipeline", piped_before)
     ctx.set_profiling(False)
     stream.close()
     if ex is not None:
@@ -274,11 +284,22 @@ def run(a, env, conf, pairs, S: int):
         n_init = int(round(np.mean(list(totals["n_init"].values())))) if totals["n_init"] else int(stats.n_init)
         n_cand = int(round(np.mean(list(totals["n_cand"].values())))) if totals["n_cand"] else int(stats.n_candidates)
         n_zncc = int(round(np.mean([(f["score"].to_numpy() >= 0.4).sum() for f in frames]))) if frames else 0
-        stage_ms = {k: v / stage_steps for k, v in stage_sum.items()}
+        stage_alone = {k: v / stage_steps for k, v in stage_sum.items()}
+        stage_ms = dict(stage_piped)
         if timed_ms > 0:
             stage_ms[timed_stage] = timed_ms      # the roofline kernel: its average over the TIMED region
         roof = roofline_of(stage_ms, S, n_init, n_cand, n_zncc, "min_eigen_candidates_fused" if timed_stage == "min_eigen" else timed_stage,
                            minmax_early=mm_early)
+        alone = roofline_of(stage_alone, S, n_init, n_cand, n_zncc, None, minmax_early=mm_early)
+        if piped_before and roof["kernel"] in alone["kernels"]:
+            k_alone = alone["kernels"][roof["kernel"]]
+            roof["kernel_ms_alone"], roof["frac_alone"] = k_alone["ms"], k_alone["frac"]
+            roof["note"] = ("frac / achieved / kernel_ms: the kernel's launches inside the timed region, where the software pipeline runs the other "
+                            "lane's latency-bound chains beside it; *_alone: the same launch with the pipeline off")
+        # the whole step against the HBM roof: every stage's algorithmic bytes / the step's wall time
+        roof["whole_step"] = {"bytes_per_pair": alone["all_stages"]["bytes"], "ms_per_pair": ms_per_step,
+                              "achieved": alone["all_stages"]["bytes"] / (ms_per_step * 1e-3) / 1e9, "peak": roof["peak"],
+                              "frac": alone["all_stages"]["bytes"] / (ms_per_step * 1e-3) / 1e9 / roof["peak"]}
         if G > 1:
             # a launch of the batched pipeline serves the G pairs of its submission: bytes and duration both scale by G; `achieved` is
             # bytes per launch / launch duration either way; `kernel_ms` (and the stage table) are quoted per PAIR
@@ -293,7 +314,10 @@ def run(a, env, conf, pairs, S: int):
             "n_init": n_init, "n_candidates": n_cand,
             "median_dx_dy": (None if not frames else [float(np.median(frames[0]["dx"])), float(np.median(frames[0]["dy"]))]),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_note": f"per PAIR.  {timed_stage}: HIP events on {timed_samples} submissions of the timed region (every second one); the other stages: "
-                             f"an untimed pass of {stage_steps} steps right after (bracketing every stage costs ~0.07 ms per pair)",
+            "stage_ms_alone": {k: round(v, 4) for k, v in stage_alone.items()},
+            "stage_ms_note": f"per PAIR.  stage_ms: the pipelined loop ({timed_stage}: HIP events on {timed_samples} submissions of the timed region, every "
+                             f"second one; the other stages: an untimed pass of {stage_steps} steps right after - a stage's span includes what the other "
+                             "lane's chains take from it); stage_ms_alone: the same pass with the software pipeline off (bracketing every stage costs "
+                             "~0.07 ms per pair)",
             "roofline": roof})
     return out

@@ -11,7 +11,8 @@ MAX_BYTES = 6000
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config", "roofline", "cpu_baseline")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_8d_model", "frac_of_measured_traffic",
-                 "valu_pipe_busy", "launch_ms", "pairs_per_launch", "units_per_launch", "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_source")
+                 "valu_pipe_busy", "launch_ms", "pairs_per_launch", "units_per_launch", "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_source",
+                 "kernel_ms_alone", "frac_alone")
 GATED = ("hard_content", "tie_heavy", "e2e_shape", "config3", "config5", "auto_ksize")
 
 
@@ -33,9 +34,13 @@ def small_roofline(roof: dict | None) -> dict | None:
     unf = k.get("unfused_model")
     if unf and "frac_8d_model" not in out:
         out["frac_8d_model"] = unf["frac"]          # SURVEY 8(d) P3 + P4 (10 B/px): what the two unfused steps would move
-    for key in ("achieved", "frac", "frac_8d_model", "frac_of_measured_traffic", "launch_ms", "kernel_ms"):
+    for key in ("achieved", "frac", "frac_8d_model", "frac_of_measured_traffic", "launch_ms", "kernel_ms", "kernel_ms_alone", "frac_alone"):
         if key in out:
             out[key] = _r(out[key], 5)
+    ws = roof.get("whole_step")
+    if ws:
+        out["whole_step_frac"] = _r(ws["frac"], 4)          # every stage's algorithmic bytes / the step's wall time / peak
+        out["whole_step_GBps"] = _r(ws["achieved"], 1)
     if "traffic_source" in out:
         out["traffic_source"] = _short(out["traffic_source"], 90)
     return out

@@ -103,30 +103,37 @@ static int units_tail(km_ctx *c, km_units_tail &T)
             if ((rc = kmi_units(c, S, n, T.dtype, T.n_max, (float)T.zncc_threshold))) return rc;
         }
     }
-    if (T.piped) {      // the lane's next submission may rewrite its scalars / points / frame buffers once this chain is through
-        KM_HIP(c, hipEventRecord(c->ev_lane[T.lane][EV_F_DONE], c->chain_stream));
-        c->lane_f_recorded[T.lane] = true;
-    }
-    // ---- the blocks leave: one strided device copy into the frame sink, one copy into the slot's page-locked buffer
+    // ---- the blocks leave: one strided device copy into the frame sink, one copy into the slot's page-locked buffer.  Unpipelined: on the
+    // block-copy stream (the next submission's dense kernels queue behind this tail on the main stream).  Pipelined: in the chain stream's
+    // own order - one stream fewer: the runtime maps streams onto FOUR hardware queues, and whenever the copy stream shared one with the
+    // main stream its device-side wait for this chain held the next eigenvalue pass up (1 ms per 16-unit step, profiles/timeline_r06_c4.txt)
     const size_t ob = T.ob, ob_al = T.ob_al;
     if (!slot->done) KM_HIP(c, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
-    if (!c->d2h_stream) {
-        KM_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-        KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    hipStream_t out_stream = c->stream;
+    if (!T.piped) {
+        if (!c->d2h_stream) {
+            KM_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+            KM_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+        }
+        KM_HIP(c, hipEventRecord(c->ev_tail, c->stream));
+        KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_tail, 0));
+        out_stream = c->d2h_stream;
     }
-    KM_HIP(c, hipEventRecord(c->ev_tail, c->stream));
-    KM_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_tail, 0));
     slot->sunk_valid = false;
     if (T.sink) {
         const size_t pitch = T.sink_pitch ? T.sink_pitch : ob;
-        KM_HIP(c, hipMemcpy2DAsync(T.sink, pitch, T.d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToDevice, c->d2h_stream));
+        KM_HIP(c, hipMemcpy2DAsync(T.sink, pitch, T.d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToDevice, out_stream));
         if (!slot->sunk) KM_HIP(c, hipEventCreateWithFlags(&slot->sunk, hipEventDisableTiming));
-        KM_HIP(c, hipEventRecord(slot->sunk, c->d2h_stream));
+        KM_HIP(c, hipEventRecord(slot->sunk, out_stream));
         slot->sunk_valid = true;
     }
-    KM_HIP(c, hipMemcpy2DAsync(slot->host, ob, T.d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToHost, c->d2h_stream));
-    KM_HIP(c, hipEventRecord(slot->done, c->d2h_stream));
-    c->frame_copy = slot->done;
+    KM_HIP(c, hipMemcpy2DAsync(slot->host, ob, T.d_out, ob_al, ob, (size_t)n, hipMemcpyDeviceToHost, out_stream));
+    KM_HIP(c, hipEventRecord(slot->done, out_stream));
+    if (T.piped) {      // the lane's next submission may rewrite its scalars / points / frame buffers once this chain (copies included) is through
+        KM_HIP(c, hipEventRecord(c->ev_lane[T.lane][EV_F_DONE], c->chain_stream));
+        c->lane_f_recorded[T.lane] = true;
+    }
+    c->frame_copy = T.piped ? nullptr : slot->done;     // (pipelined: every lane owns its frame buffer and waits for EV_F_DONE)
     slot->bytes = ob * n;
     slot->deferred.store(0, std::memory_order_release);
     return KM_OK;

@@ -1225,27 +1225,23 @@ static int lap_radius(int ksize) { return ksize == 1 ? 1 : ksize / 2; }
 
 // ---- batched units: stretch + Laplacians + automatic mask of every unit in ONE launch; the per-item counts of valid pixels are summed
 // per unit by kd_valid_sum_units (one workgroup per unit, on whatever stream c->stream is: the caller puts it beside the pyramids)
-__global__ __launch_bounds__(1024) void valid_sum_units_kernel(km_valid_units J)
+// (ONE wavefront per unit: the kernel runs beside the previous submission's LK, whose single-wave workgroups refill every slot a
+// retiring wave leaves - a 1024-thread workgroup waited there for the whole launch, 2.6 ms with the pyramids queued behind it, and a
+// 256-thread one still 2.4 ms: profiles/timeline_r06_c4.txt)
+__global__ __launch_bounds__(64) void valid_sum_units_kernel(km_valid_units J)
 {
     const unsigned *partial = J.partial[blockIdx.x];
     const unsigned n = J.n_partial[blockIdx.x];
     unsigned long long s = 0;
-    for (unsigned i = threadIdx.x; i < n; i += 1024) s += partial[i];
+    for (unsigned i = threadIdx.x; i < n; i += 64) s += partial[i];
     s = wave_sum_u64(s);
-    __shared__ unsigned long long sh[16];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int i = 0; i < 16; i++) t += sh[i];
-        *J.out[blockIdx.x] = t;
-    }
+    if (threadIdx.x == 0) *J.out[blockIdx.x] = s;
 }
 
 int kd_valid_sum_units(km_ctx *c, const km_valid_units &J)
 {
     if (J.n <= 0) return KM_OK;
-    valid_sum_units_kernel<<<J.n, 1024, 0, c->stream>>>(J);
+    valid_sum_units_kernel<<<J.n, 64, 0, c->stream>>>(J);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }

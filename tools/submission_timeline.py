@@ -6,7 +6,7 @@ f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if 'lap_march_units_kernel' in r['Kernel_Name']]
-k=len(idx)//2
+k=len(idx)//2+(int(sys.argv[2]) if len(sys.argv)>2 else 0)
 a,b=idx[k],idx[k+1]
 t0=int(rows[a]['Start_Timestamp']); prev=t0
 print('submission span us', (int(rows[b]['Start_Timestamp'])-t0)/1e3)
