@@ -322,10 +322,37 @@ def config5_object(ctx, dev, S, steps):
         rows = run(stream, steps)
         dt = time.perf_counter() - t0
         redone = stream.units_redone
+    # the same masked pair TILED (tile_size 5490: the units config 4 deals to the ranks), the four tiles - each with its box of the user
+    # mask - as ONE batched submission per pair (FrameStream.submit_many -> km_klt_units_frame_submit, km_unit.d_mask)
+    from karios_amd import tiling
+    conf_t = KLTConfiguration(tile_size=5490)
+    boxes = [tuple(t) for t in tiling.tile_grid(S, S, conf_t.tile_size, conf_t.xStart)]
+    tiled = {"rows": 0, "units": 0, "redone": 0}
+
+    def run_tiled(stream, n):
+        for _ in range(n):
+            for d in stream.submit_many([(pair, b, None) for b in boxes], conf_t):
+                tiled["rows"] += d.raw.n_rows
+                tiled["units"] += 1
+        for d in stream.drain():
+            tiled["rows"] += d.raw.n_rows
+            tiled["units"] += 1
+        ctx.sync()
+
+    with FrameStream(0.4, depth=2) as stream:
+        run_tiled(stream, 2)
+        tiled.update(rows=0, units=0)
+        t0 = time.perf_counter()
+        run_tiled(stream, steps)
+        dt_t = time.perf_counter() - t0
+        tiled["redone"] = stream.units_redone
     f = last[0]
     masked = float((mask_t == 0).float().mean().item())
     return {"workload": f"BASELINE config 5 stand-in: {S}x{S} uint16 pair, monitored image with a 30 m look (3x3 block mean, nearest x3), gamma 0.8, "
                         "shift (0.4, -0.3) px, user mask, KLT + ZNCC on one GPU; inputs resident in HBM",
             "value": S * S / 1e6 / (dt / steps), "unit": "Mpx/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
             "masked_fraction": round(masked, 4), "matched_keypoints_per_pair": rows // steps, "tiles_redone": redone,
-            "median_dx_dy": None if f is None or not len(f) else [float(np.median(f["dx"])), float(np.median(f["dy"]))]}
+            "median_dx_dy": None if f is None or not len(f) else [float(np.median(f["dx"])), float(np.median(f["dy"]))],
+            "tiled_with_mask": {"ms_per_pair": round(dt_t / steps * 1e3, 4), "tiles_per_pair": len(boxes), "tile_size": conf_t.tile_size,
+                                "matched_keypoints_per_pair": tiled["rows"] // steps, "units_batched": tiled["units"], "units_repeated_exactly": tiled["redone"],
+                                "note": "the masked pair as four 5490^2 units per batched submission (each unit its box of the user mask), pairs pipelined"}}

@@ -228,6 +228,8 @@ typedef struct km_unit {
     int32_t Hf, Wf;                         /* size of the full rasters */
     float x_off, y_off;                     /* origin added to the key points (klt.py:341-342) */
     int32_t win_ox, win_oy, win_H, win_W;
+    const uint8_t *d_mask;                  /* user mask of the box (klt.py:258-266; != 0: valid), NULL: the automatic mask (klt.py:268-273); all units alike */
+    ptrdiff_t smask;                        /* its row stride in bytes */
 } km_unit;
 #define KM_UNITS_PER_SUBMISSION 16
 /* km_klt_tile_frame_submit for n <= KM_UNITS_PER_SUBMISSION independent units of one pixel type and one parameter set in ONE device
@@ -237,7 +239,7 @@ typedef struct km_unit {
  * unit did not fit the fixed capacities of the synchronisation-free corner path - repeat it alone through km_klt_tile_frame_zncc_dev
  * with "speculative" 0.  Returns KM_E_UNSUPPORTED (no error text) when the batch form does not cover the case (maxCorners 0,
  * minDistance < 1, a unit narrower than 512 columns or without a level-1 pyramid, Laplacian kernels 9 / 11, float32 score columns,
- * a shrunken test capacity): submit the units one by one then.  No user mask (automatic mask, klt.py:268-273). */
+ * a shrunken test capacity): submit the units one by one then.  Either every unit carries a user mask (km_unit.d_mask) or none. */
 int km_klt_units_frame_submit(km_ctx *ctx, const km_unit *units, int n_units, int dtype, const double *nodata_ref, const double *nodata_mon,
                               const km_klt_params *prm, double zncc_threshold, int cap, int *ticket);
 /* "units_pipeline": enqueue what the last km_klt_units_frame_submit deferred (its LK, frame stage, scores and copy-out) - if that

@@ -47,7 +47,8 @@ class KmUnit(C.Structure):
     _fields_ = [("d_ref", C.c_void_p), ("d_mon", C.c_void_p), ("sref", C.c_ssize_t), ("smon", C.c_ssize_t),
                 ("d_ref_full", C.c_void_p), ("d_mon_full", C.c_void_p), ("sref_f", C.c_ssize_t), ("smon_f", C.c_ssize_t),
                 ("H", C.c_int32), ("W", C.c_int32), ("Hf", C.c_int32), ("Wf", C.c_int32), ("x_off", C.c_float), ("y_off", C.c_float),
-                ("win_ox", C.c_int32), ("win_oy", C.c_int32), ("win_H", C.c_int32), ("win_W", C.c_int32)]
+                ("win_ox", C.c_int32), ("win_oy", C.c_int32), ("win_H", C.c_int32), ("win_W", C.c_int32),
+                ("d_mask", C.c_void_p), ("smask", C.c_ssize_t)]
 
 
 UNITS_PER_SUBMISSION = 16      # KM_UNITS_PER_SUBMISSION

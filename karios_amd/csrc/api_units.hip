@@ -203,6 +203,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         return KM_E_UNSUPPORTED;
     if (!km_units_ksize_supported(prm->ksize_ref) || !km_units_ksize_supported(prm->ksize_mon)) return KM_E_UNSUPPORTED;
     const bool with_zncc = units[0].d_ref_full != nullptr;
+    const bool user_mask = units[0].d_mask != nullptr;
     const bool with_mi = with_zncc && c->opt_frame_mi;
     if (with_zncc && dtype == KM_F32) return KM_E_UNSUPPORTED;
     for (int u = 0; u < n; u++) {
@@ -210,6 +211,8 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         if ((rc = check_image(c, q.d_ref, q.H, q.W, q.sref, "klt_units_frame_submit")) || (rc = check_image(c, q.d_mon, q.H, q.W, q.smon, "klt_units_frame_submit")))
             return rc;
         if ((q.d_ref_full != nullptr) != with_zncc) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: either every unit carries full rasters or none");
+        if ((q.d_mask != nullptr) != user_mask) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: either every unit carries a user mask or none");
+        if (user_mask && q.smask < q.W) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: mask stride %td < width %d", q.smask, q.W);
         if (with_zncc && ((rc = check_image(c, q.d_ref_full, q.Hf, q.Wf, q.sref_f, "klt_units_frame_submit")) ||
                           (rc = check_image(c, q.d_mon_full, q.Hf, q.Wf, q.smon_f, "klt_units_frame_submit"))))
             return rc;
@@ -258,7 +261,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
 
     // ---- layout: unit u's slices of the lane's workspace slots
     km_units U;
-    U.n = n; U.dtype = dtype;
+    U.n = n; U.dtype = dtype; U.has_user_mask = user_mask;
     size_t px_total = 0, pyr_total = 0, max_px = 0;
     size_t px_off[KM_UNITS_MAX], pyr_off[KM_UNITS_MAX];
     for (int u = 0; u < n; u++) {
@@ -266,6 +269,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         U.H[u] = q.H; U.W[u] = q.W; U.ref[u] = q.d_ref; U.mon[u] = q.d_mon; U.sref[u] = q.sref; U.smon[u] = q.smon; U.x_off[u] = q.x_off; U.y_off[u] = q.y_off;
         U.ref_full[u] = q.d_ref_full; U.mon_full[u] = q.d_mon_full; U.Hf[u] = q.Hf; U.Wf[u] = q.Wf; U.sref_f[u] = q.sref_f; U.smon_f[u] = q.smon_f;
         U.win[u].ox = q.win_ox; U.win[u].oy = q.win_oy; U.win[u].H = q.win_H; U.win[u].W = q.win_W;
+        U.user_mask[u] = q.d_mask; U.user_smask[u] = q.smask;
         const size_t px = (size_t)q.H * q.W;
         px_off[u] = px_total; px_total += up256(px);
         max_px = px > max_px ? px : max_px;

@@ -513,6 +513,9 @@ struct km_units {
     km_scalars *sc[KM_UNITS_MAX];
     const double *mm[KM_UNITS_MAX];              // {min_ref, max_ref, min_mon, max_mon} the stretch reads (sc->mm, or the early slot)
     uint8_t *lap_ref[KM_UNITS_MAX], *lap_mon[KM_UNITS_MAX], *mask[KM_UNITS_MAX];
+    const uint8_t *user_mask[KM_UNITS_MAX];      // user mask of the box (nullptr: the automatic mask is derived, klt.py:268-273) ...
+    ptrdiff_t user_smask[KM_UNITS_MAX];          // ... and its row stride; it is packed into `mask` (dense rows) by the Laplacian pass
+    bool has_user_mask = false;
     unsigned long long *keys[KM_UNITS_MAX];      // candidate keys (KM_NSHARD regions of capk / KM_NSHARD slots)
     size_t capk = 0;                             // ... the same capacity for every unit (sized for the largest)
     const unsigned *eig_partial[KM_UNITS_MAX];   // per-wave maxima the fused eigenvalue pass leaves for the ranking's first launch

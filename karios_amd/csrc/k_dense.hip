@@ -1246,6 +1246,47 @@ int kd_valid_sum_units(km_ctx *c, const km_valid_units &J)
     return KM_OK;
 }
 
+// User masks of a batch (klt.py:258-266: the caller's raster instead of the automatic mask): every unit's box of its mask raster is
+// packed into the unit's dense mask plane (the eigenvalue pass indexes masks with the image width) and its non-zero pixels are counted
+// - what hipMemcpy2DAsync + kd_count_nonzero do for a single unit, for all units in one launch.  blockIdx.y = unit; a workgroup takes
+// every gridDim.x-th group of rows; 16 bytes per thread at whatever address a row has.
+struct mask_units_args {
+    const uint8_t *src[KM_UNITS_MAX];
+    uint8_t *dst[KM_UNITS_MAX];
+    ptrdiff_t stride[KM_UNITS_MAX];
+    unsigned *partial[KM_UNITS_MAX];
+    int H[KM_UNITS_MAX], W[KM_UNITS_MAX];
+};
+__global__ __launch_bounds__(256) void mask_pack_units_kernel(mask_units_args A)
+{
+    const int u = blockIdx.y, H = A.H[u], W = A.W[u];
+    const uint8_t *__restrict__ src = A.src[u];
+    uint8_t *__restrict__ dst = A.dst[u];
+    const ptrdiff_t stride = A.stride[u];
+    unsigned cnt = 0;
+    for (int y = blockIdx.x; y < H; y += gridDim.x) {
+        const uint8_t *r = src + (size_t)y * stride;
+        uint8_t *w = dst + (size_t)y * W;
+        for (int x = 16 * threadIdx.x; x < W; x += 16 * 256) {
+            if (x + 16 <= W) {
+                uint4 q;
+                __builtin_memcpy(&q, r + x, 16);
+                __builtin_memcpy(w + x, &q, 16);
+                const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) cnt += (unsigned)__popc(((d[k] | ((d[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u));   // bytes != 0
+            } else {
+                for (int k = x; k < W; k++) { const uint8_t b = r[k]; w[k] = b; cnt += b != 0; }
+            }
+        }
+    }
+    const unsigned long long s = wave_sum_u64((unsigned long long)cnt);
+    __shared__ unsigned sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (unsigned)s;
+    __syncthreads();
+    if (threadIdx.x == 0) A.partial[u][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 template <typename T>
 static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap_coef &cf, int invert1, const nodata_t &nd, km_valid_units *job)
 {
@@ -1279,14 +1320,36 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     A.item0[0] = 0;
     for (int u = 0; u < U.n; u++) A.item0[u + 1] = A.item0[u] + A.nstrips[u] * ((U.H[u] + rows - 1) / rows);
     const int total = A.item0[U.n];
-    unsigned *valid = (unsigned *)km_ws(c, WS_LAP_VALID, ((size_t)total + 4 * KM_UNITS_MAX) * sizeof(unsigned));
+    const int mask_wgs = 256;                         // workgroups per unit of the user-mask pack
+    const size_t n_partial = U.has_user_mask ? (size_t)mask_wgs * U.n : (size_t)total + 4 * KM_UNITS_MAX;
+    unsigned *valid = (unsigned *)km_ws(c, WS_LAP_VALID, n_partial * sizeof(unsigned));
     if (!valid) return KM_E_NOMEM;
     job->n = U.n;
+    const dim3 grid(km_xcd_grid((unsigned)(total + 3) / 4u));
+    if (U.has_user_mask) {
+        // the caller's mask: packed + counted here, the Laplacian pass derives none (MASK = false: it neither reads nor writes a mask)
+        mask_units_args M;
+        for (int u = 0; u < U.n; u++) {
+            M.src[u] = U.user_mask[u]; M.dst[u] = U.mask[u]; M.stride[u] = U.user_smask[u]; M.H[u] = U.H[u]; M.W[u] = U.W[u];
+            M.partial[u] = valid + (size_t)mask_wgs * u;
+            A.valid[u] = nullptr;
+            job->partial[u] = M.partial[u]; job->n_partial[u] = (unsigned)mask_wgs; job->out[u] = &U.sc[u]->valid;
+        }
+        mask_pack_units_kernel<<<dim3(mask_wgs, U.n), 256, 0, c->stream>>>(M);
+        KM_LAUNCH_CHECK(c);
+        switch (R) {
+        case 1: lap_march_units_kernel<1, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+        case 2: lap_march_units_kernel<2, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+        case 3: lap_march_units_kernel<3, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+        default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
+        }
+        KM_LAUNCH_CHECK(c);
+        return KM_OK;
+    }
     for (int u = 0; u < U.n; u++) {
         A.valid[u] = valid + A.item0[u];
         job->partial[u] = A.valid[u]; job->n_partial[u] = (unsigned)(A.item0[u + 1] - A.item0[u]); job->out[u] = &U.sc[u]->valid;
     }
-    const dim3 grid(km_xcd_grid((unsigned)(total + 3) / 4u));
     switch (R) {
     case 1: lap_march_units_kernel<1, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     case 2: lap_march_units_kernel<2, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;

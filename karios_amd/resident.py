@@ -183,18 +183,19 @@ class PendingBatch:
 
 def submit_units(units, conf, zncc_threshold=None, mutual_info: bool = False) -> "PendingBatch | None":
     """`ResidentPair.submit_tile` for up to 16 independent units at once - `units` = [(pair, box | None, origin | None), ...], all on
-    ONE context, one pixel type, no user mask: the tiles of `KLT.match` (klt.py:220-253), of one pair or of several bands.  Every
+    ONE context, one pixel type, all with a user mask or none: the tiles of `KLT.match` (klt.py:220-253), of one pair or of several bands.  Every
     dense kernel, the corner-selection chain, LK, the frame stage and the scores are launched ONCE for all units
     (csrc/api_units.hip); the frames are the unit-by-unit frames bit for bit.  Returns None when the batch form does not cover the
     case (the library answers KM_E_UNSUPPORTED: maxCorners 0, a unit narrower than 512 columns, Laplacian kernels 9 / 11 ...) or the
-    units do not share a context / pixel type / carry a user mask - submit them one by one then."""
+    units do not share a context / pixel type, or only some carry a user mask - submit them one by one then."""
     if not units or len(units) > _lib.UNITS_PER_SUBMISSION:
         return None
     if conf.laplacian_kernel_size == "auto" or conf.laplacian_invert_polarity == "auto" or getattr(conf, "outliers_filtering", False) or conf.maxCorners <= 0:
         return None
     first = units[0][0]
     c = first.ctx
-    if any(p.ctx is not c or p.code != first.code or p.mask_ptr or p.no_data_mon != first.no_data_mon or p.no_data_ref != first.no_data_ref for p, _, _ in units):
+    if any(p.ctx is not c or p.code != first.code or bool(p.mask_ptr) != bool(first.mask_ptr) or p.no_data_mon != first.no_data_mon
+           or p.no_data_ref != first.no_data_ref for p, _, _ in units):
         return None
     with_zncc = zncc_threshold is not None
     n_scores = 0 if not with_zncc else (3 if mutual_info else 1)
@@ -213,6 +214,8 @@ def submit_units(units, conf, zncc_threshold=None, mutual_info: bool = False) ->
             u.d_ref_full, u.d_mon_full, u.sref_f, u.smon_f, u.Hf, u.Wf = pair.ref_ptr, pair.mon_ptr, pair.x_size, pair.x_size, pair.y_size, pair.x_size
         if pair.window is not None:
             u.win_ox, u.win_oy, u.win_H, u.win_W = (int(v) for v in pair.window)
+        if pair.mask_ptr:                     # the user mask of the box (klt.py:258-266): a uint8 raster of the pair's shape
+            u.d_mask, u.smask = pair.mask_ptr + off, pair.x_size
 
         def exact(pair=pair, box=box, origin=(x_off, y_off)):
             before = c.get_option("speculative", int(os.environ.get("KARIOS_HIP_SPECULATIVE", "1") or 0))

@@ -256,3 +256,51 @@ def test_framestream_pipelines_batched_submissions_and_yields_the_same_frames(op
         assert list(a.columns) == list(b.columns) and len(a) == len(b) > 200
         for col in a.columns:
             np.testing.assert_array_equal(a[col].to_numpy(), b[col].to_numpy())
+
+
+# ---------------------------------------------------------------------------- user masks in a batch (klt.py:258-266)
+def test_units_with_a_user_mask_equal_the_masked_tiles_one_by_one_and_the_oracle(ops, O):
+    """A pair with a user mask (the caller's uint8 raster instead of the automatic mask) tiled into a batched submission: every unit's
+    box of the mask is packed and counted inside the batch's Laplacian stage.  Frames = the masked tile calls' bit for bit, pipelined or
+    not, and one tile against the oracle with the same mask box; units that mix masked and unmasked pairs go one by one (None)."""
+    from karios_amd.core import KLTConfiguration
+    from karios_amd.resident import ResidentPair, submit_units
+    from karios_amd.stream import FrameStream
+    ctx = ops._lib.default_context()
+    mon, ref = synth.make_pair(1300, 1480, 0.4, -0.3, seed=21)
+    rng = np.random.default_rng(5)
+    mask = np.ones(mon.shape, np.uint8)
+    for _ in range(14):                                           # seeded rectangles zeroing ~ a fifth (BASELINE config 5's mask)
+        y, x = int(rng.integers(0, 1200)), int(rng.integers(0, 1380))
+        mask[y:y + int(rng.integers(40, 260)), x:x + int(rng.integers(40, 300))] = 0
+    mask[::7, ::5] *= 3                                            # any non-zero byte is "valid" (klt.py:266 reads the raster as is)
+    pair = ResidentPair.upload(mon, ref, mask, ctx=ctx)
+    plain = ResidentPair.upload(mon, ref, ctx=ctx)
+    conf = KLTConfiguration(maxCorners=1500)
+    boxes = [(0, 0, 740, 650), (740, 0, 740, 650), (0, 650, 740, 650), (740, 650, 740, 650), (101, 77, 1011, 901)]
+    units = [(pair, b, None) for b in boxes]
+    want = [pair.submit_tile(conf, box=b, zncc_threshold=0.4).result() for b in boxes]
+    assert all(w.n_rows > 300 and w.flags == 0 for w in want)
+    unmasked = plain.submit_tile(conf, box=boxes[0], zncc_threshold=0.4).result()
+    assert not same_rows(unmasked, want[0])                       # the mask matters on this content
+    for piped in (0, 1):
+        ctx.set_option("units_pipeline", piped)
+        try:
+            pend = [submit_units(units, conf, 0.4) for _ in range(3)]
+            assert all(p is not None for p in pend)
+            for p in pend:
+                for k, (g, w) in enumerate(zip(p.wait(), want)):
+                    g = p.redo(k) if g.flags else g
+                    assert same_rows(g, w), (piped, k)
+        finally:
+            ctx.set_option("units_pipeline", 0)
+    assert submit_units(units[:2] + [(plain, boxes[2], None)], conf, 0.4) is None          # masked and unmasked units do not mix
+    with FrameStream(0.4, depth=1) as s:                          # ... FrameStream then submits those one by one, in order
+        mixed = s.submit_many(units[:2] + [(plain, boxes[2], None)], conf) + s.drain()
+    assert len(mixed) == 3 and same_rows(mixed[0].raw, want[0]) and same_rows(mixed[1].raw, want[1])
+    x, y, w, h = boxes[4]
+    exp = O.klt_tile(mon[y:y + h, x:x + w], ref[y:y + h, x:x + w], O.default_conf(maxCorners=1500), mask_box=mask[y:y + h, x:x + w])
+    f = want[4].to_frame()
+    np.testing.assert_array_equal(f["x0"].to_numpy(), exp["x0"] + x)
+    np.testing.assert_array_equal(f["y0"].to_numpy(), exp["y0"] + y)
+    np.testing.assert_array_equal(f["dx"].to_numpy(), exp["dx"])

@@ -32,6 +32,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(KltParams) == 8 * 4 + 3 * 8
     assert ctypes.sizeof(KltStats) == 2 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 2 * 4 and KltStats.path_flags.offset == 64
     assert KltParams.quality_level.offset == 32 and KltStats.min_ref.offset == 24
+    from karios_amd._lib import KmUnit                            # km_unit of include/karios_hip.h: 8 pointers / strides, 10 int32 / float, mask pointer + stride
+    assert ctypes.sizeof(KmUnit) == 8 * 8 + 10 * 4 + 2 * 8 and KmUnit.H.offset == 64 and KmUnit.win_ox.offset == 88 and KmUnit.d_mask.offset == 104
 
 
 def test_no_device_fails_loudly_without_fallback():
