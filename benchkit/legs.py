@@ -356,3 +356,65 @@ def config5_object(ctx, dev, S, steps):
             "tiled_with_mask": {"ms_per_pair": round(dt_t / steps * 1e3, 4), "tiles_per_pair": len(boxes), "tile_size": conf_t.tile_size,
                                 "matched_keypoints_per_pair": tiled["rows"] // steps, "units_batched": tiled["units"], "units_repeated_exactly": tiled["redone"],
                                 "note": "the masked pair as four 5490^2 units per batched submission (each unit its box of the user mask), pairs pipelined"}}
+
+
+# ---------------------------------------------------------------------------------------------------- auto-ksize search
+def auto_ksize_object(ctx, pair, data, S, runs=3):
+    """The Laplacian kernel-size search of the reference (KLT._match_tile_auto_ksize, klt.py:465-545: 5 x 5 (mon, ref) kernel pairs, the
+    pair with the highest inlier ratio wins, `.jules/bolt.md` names it the reference's hotspot) on the headline's first resident pair as
+    ONE device pipeline (csrc/api_tile.hip km_klt_auto_ksize_frame_dev: every Laplacian pair in one launch, the five corner detections
+    as one batch of units, the 25 tracker runs as ONE LK launch).  Gate: on a >= 1024-row box the winner, every ratio and the winner's
+    frame equal the reference's procedure carried out with the oracle."""
+    import itertools
+    from karios_amd import tiling
+    from karios_amd.core import KLTConfiguration
+    from oracle import oracle as O
+    conf = KLTConfiguration(laplacian_kernel_size="auto")
+    cands = list(tiling.AUTO_KSIZE_CANDIDATES)
+    pair.match_tile_auto_ksize(conf)                         # (workspace of the search: 6 GB of Laplacians, pyramids, tracks)
+    ctx.sync()
+    times = []
+    for _ in range(max(1, runs)):
+        t0 = time.perf_counter()
+        frame, ratios, best, n_init = pair.match_tile_auto_ksize(conf)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    out = {"workload": f"kernel-size search on one resident {S}x{S} pair: 5 x 5 (mon, ref) Laplacian kernels {cands}, maxCorners 20000, one tile",
+           "ms_per_pair": dt * 1e3, "runs_ms": [round(t * 1e3, 3) for t in times], "best_mon_ref": list(best) if best else None,
+           "best_inlier_ratio": max(ratios.values()) if ratios else None, "corners_of_the_winner": int(n_init),
+           "matched_keypoints": 0 if frame is None else len(frame)}
+    # ---- gate on a box of the same rasters
+    rows, cols = min(S, 1024), min(S, 4096)
+    y0, x0 = max(0, (S - rows) // 2), max(0, (S - cols) // 2)
+    box = (x0, y0, cols, rows)
+    g_frame, g_ratios, g_best, _ = pair.match_tile_auto_ksize(conf, box=box)
+    mon_b = data[0][y0:y0 + rows, x0:x0 + cols].cpu().numpy().view(np.uint16)
+    ref_b = data[1][y0:y0 + rows, x0:x0 + cols].cpu().numpy().view(np.uint16)
+    O.set_threads(min(O.usable_cpus(), int(os.environ.get("KARIOS_ORACLE_THREADS", "1024"))))
+    oc = O.default_conf(maxCorners=conf.maxCorners)
+    mask, _ = O.auto_mask(mon_b, ref_b)
+    u8_m, u8_r = O.to_uint8(mon_b), O.to_uint8(ref_b)
+    laps_m = {k: O.laplacian_u8(u8_m, k) for k in cands}
+    laps_r = {k: O.laplacian_u8(u8_r, k) for k in cands}
+    p0s = {k: O.good_features(laps_r[k], mask, oc.maxCorners, oc.qualityLevel, oc.minDistance, oc.blocksize) for k in cands}
+    o_ratios, o_best, o_best_ratio, o_res = {}, None, -1.0, None
+    for mk, rk in itertools.product(cands, repeat=2):
+        res = None if p0s[rk] is None else O.klt_tracker(laps_r[rk], laps_m[mk], mask, oc, p0=p0s[rk])
+        ratio = 0.0 if res is None or not res[1] else len(res[0]["x0"]) / res[1]
+        o_ratios[(mk, rk)] = ratio
+        if res is not None and ratio > o_best_ratio:
+            o_best_ratio, o_best, o_res = ratio, (mk, rk), res
+    O.set_threads(min(O.max_threads(), O.team_size()))
+    same_ratios = all(g_ratios.get(k) == v for k, v in o_ratios.items())
+    same_frame = False
+    if o_res is not None and g_frame is not None:
+        pts = o_res[0]
+        order = np.lexsort((pts["y0"], pts["x0"]))
+        same_frame = len(g_frame) == len(order) and all(
+            np.array_equal(g_frame[c].to_numpy(), (np.asarray(pts[c], np.float32) + np.float32(x0 if c == "x0" else y0 if c == "y0" else 0))[order])
+            for c in ("x0", "y0", "dx", "dy", "score"))
+    out["gate"] = {"box_x_y_w_h": list(box), "winner_gpu": list(g_best) if g_best else None, "winner_oracle": list(o_best) if o_best else None,
+                   "all_25_ratios_identical": bool(same_ratios), "winner_frame_identical": bool(same_frame),
+                   "rows": 0 if g_frame is None else len(g_frame),
+                   "passed": bool(same_ratios and same_frame and g_best == o_best)}
+    return out

@@ -662,17 +662,19 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
     if (prm->max_corners > 0 && cap < prm->max_corners) return km_fail(c, KM_E_ARG, "capacity %d < maxCorners %d", cap, prm->max_corners);
     memset(&c->stats, 0, sizeof c->stats);
     const size_t n = (size_t)H * W, na = (n + 255) & ~(size_t)255;
-    km_scalars *sc = scalars(c);
-    uint8_t *u8_ref = (uint8_t *)km_ws(c, WS_U8_A, n), *u8_mon = (uint8_t *)km_ws(c, WS_U8_B, n);
-    if (!sc || !u8_ref || !u8_mon) return KM_E_NOMEM;
-    KM_HIP(c, hipMemsetAsync(sc, 0, sizeof *sc, c->stream));
-    // ---- mask (user mask packed to the box, or the automatic one) and uint8 stretch
+    // scalar blocks: [0] the call's own (min / max, valid pixels, the exact corner path), [1 + k] the corner detection of reference kernel k
+    const size_t sc_stride = (sizeof(km_scalars) + 255) & ~(size_t)255;
+    char *sc_base = (char *)km_ws(c, WS_SCALARS, sc_stride * (size_t)(nk + 1));
+    km_scalars *sc = (km_scalars *)sc_base;
+    if (!sc) return KM_E_NOMEM;
+    KM_HIP(c, hipMemsetAsync(sc_base, 0, sc_stride * (size_t)(nk + 1), c->stream));
+    // ---- mask: the user's (packed to the box) - or the automatic one, which the FIRST Laplacian pass below derives from the raw rasters
     const uint8_t *mask = d_mask;
+    uint8_t *mask_auto = nullptr;
     if (!d_mask) {
-        uint8_t *m = (uint8_t *)km_ws(c, WS_MASK, n);
-        if (!m) return KM_E_NOMEM;
-        if ((rc = kd_auto_mask(c, d_mon, d_ref, dtype, H, W, smon, sref, nodata_mon, nodata_ref, m, &sc->valid))) return rc;
-        mask = m;
+        mask_auto = (uint8_t *)km_ws(c, WS_MASK, n);
+        if (!mask_auto) return KM_E_NOMEM;
+        mask = mask_auto;
     } else {
         if (smask < W) return km_fail(c, KM_E_ARG, "mask stride %td < width %d", smask, W);
         if (smask != W) {
@@ -684,14 +686,13 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
         if ((rc = kd_count_nonzero(c, mask, n, &sc->valid))) return rc;
     }
     if (dtype != KM_U8) {
-        if ((rc = kd_minmax(c, d_ref, dtype, H, W, sref, &sc->mm[0])) || (rc = kd_minmax(c, d_mon, dtype, H, W, smon, &sc->mm[2]))) return rc;
+        km_stage_timer t(c, ST_MINMAX);
+        if ((rc = kd_minmax_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, &sc->mm[0]))) return rc;
     }
-    if ((rc = kd_to_uint8(c, d_ref, dtype, H, W, sref, &sc->mm[0], 0, u8_ref)) || (rc = kd_to_uint8(c, d_mon, dtype, H, W, smon, &sc->mm[2], prm->invert_mon, u8_mon)))
-        return rc;
     // ---- arena: 2*nk Laplacians, 2*nk pyramids, nk corner lists, nk*nk track pairs, counters
     km_pyr probe;
     size_t pyr_bytes = 0;
-    build_pyramid_single(c, u8_ref, H, W, prm->win_size, prm->max_level, nullptr, &probe, &pyr_bytes);
+    build_pyramid_single(c, nullptr, H, W, prm->win_size, prm->max_level, nullptr, &probe, &pyr_bytes);
     const size_t pts = ((size_t)cap * 2 * sizeof(float) + 255) & ~(size_t)255;
     const size_t total = (size_t)2 * nk * (na + pyr_bytes) + (size_t)nk * pts + (size_t)2 * nk * nk * pts + 4096;
     uint8_t *arena = (uint8_t *)km_ws(c, WS_AUTO, total);
@@ -702,34 +703,122 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
     KM_HIP(c, hipMemsetAsync(d_counts, 0, (size_t)(nk + nk * nk) * sizeof(int), c->stream));
     km_pyr PR[8], PM[8];
     {
+        // the uint8 stretch (klt.py:42-49; [+ 255 - x, klt.py:419]) rides in every Laplacian pass, as in the tile pipeline: both images
+        // of a kernel size in ONE launch from the raw rasters - the marching kernel for k <= 7; no uint8 copies of the rasters exist
         km_stage_timer t(c, ST_LAPLACIAN);
-        for (int k = 0; k < nk; k++)
-            if ((rc = kd_laplacian_u8(c, u8_ref, H, W, ksizes[k], lap_ref + (size_t)k * na)) ||
-                (rc = kd_laplacian_u8(c, u8_mon, H, W, ksizes[k], lap_mon + (size_t)k * na)))
+        for (int k = 0; k < nk; k++) {
+            const bool first = k == 0 && mask_auto != nullptr;
+            if ((rc = kd_stretch_laplacian_pair(c, d_ref, d_mon, dtype, H, W, sref, smon, sc->mm, ksizes[k], ksizes[k], prm->invert_mon, nodata_ref, nodata_mon,
+                                                lap_ref + (size_t)k * na, lap_mon + (size_t)k * na, first ? mask_auto : nullptr, first ? &sc->valid : nullptr)))
                 return rc;
+        }
     }
-    {
-        km_stage_timer t(c, ST_PYRAMID);
-        for (int k = 0; k < nk; k++)
-            if ((rc = build_pyramid_single(c, lap_ref + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k) * pyr_bytes, &PR[k], nullptr)) ||
-                (rc = build_pyramid_single(c, lap_mon + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k + 1) * pyr_bytes, &PM[k], nullptr)))
-                return rc;
-    }
-    // ---- corners of every reference Laplacian (klt.py:494)
-    int n_p0[8];
-    for (int k = 0; k < nk; k++) {
-        float *p0 = (float *)(p0_store + (size_t)k * pts);
-        // gftt_dev starts from a clean scalar block; the min/max and the valid-pixel count gathered above stay
-        KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
-        if ((rc = gftt_dev(c, lap_ref + (size_t)k * na, mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, p0, cap, sc)))
-            return rc;
-        KM_HIP(c, hipMemcpyAsync(&d_counts[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-        KM_D2H(c, &n_p0[k], &sc->n_corners, sizeof(int));
-    }
-    KM_FLUSH(c);
-    // ---- nk*nk tracker runs (mon kernel outer, ref kernel inner), all queued before one synchronisation
     const int n_lim = prm->max_corners > 0 && prm->max_corners < cap ? prm->max_corners : cap;
-    {
+    // ---- ONE pipeline for the whole search where the batched forms cover the case (round 6; two-level pyramids, maxCorners > 0, the
+    // synchronisation-free corner path): the 2 nk pyramids in one launch, the nk corner detections as one batch of units (fused
+    // eigenvalue pass + selection chains side by side, nothing read back in between), the nk^2 tracker runs as ONE LK launch and one
+    // count launch.  Two host synchronisations per search (corner counts + flags; inlier counts) instead of nk + 2, 4 + 2 nk launches of
+    // dense kernels instead of 7 nk + 2 nk^2.  Anything the batched forms refuse goes through the loops below, run by run.
+    int n_p0[8];
+    const int *d_np0[8];                                             // device word holding the corner count of reference kernel k
+    bool corners_done = false, tracks_done = false;
+    const bool batchable = prm->max_level == 1 && probe.levels == 1 && nk <= KM_UNITS_MAX && nk * nk <= KM_LK_JOBS_MAX && prm->max_corners > 0 &&
+                           prm->min_distance >= 1 && c->opt_speculative && c->fused_eig && !c->opt_key_cap && !c->opt_stage_cap && !c->opt_topk_factor &&
+                           !c->opt_select_first && c->opt_eig3 && c->opt_lk2 && W >= 512 && H >= 2 * prm->block_size + 8;
+    km_units U;
+    if (batchable) {
+        U.n = nk; U.dtype = KM_U8; U.capk = n / 8 + 4096 * KM_NSHARD;
+        unsigned long long *keys = (unsigned long long *)km_ws(c, WS_KEYS0, U.capk * sizeof(unsigned long long) * (size_t)nk);
+        if (!keys) return KM_E_NOMEM;
+        for (int k = 0; k < nk; k++) {
+            U.H[k] = H; U.W[k] = W; U.x_off[k] = 0.f; U.y_off[k] = 0.f;
+            U.lap_ref[k] = lap_ref + (size_t)k * na; U.lap_mon[k] = lap_mon + (size_t)k * na; U.mask[k] = const_cast<uint8_t *>(mask);
+            U.sc[k] = (km_scalars *)(sc_base + sc_stride * (size_t)(k + 1));
+            U.keys[k] = keys + U.capk * (size_t)k;
+            U.p0[k] = (float *)(p0_store + (size_t)k * pts);
+            U.eig_partial[k] = nullptr; U.eig_npartial[k] = 0;
+            km_pyr &A = U.A[k], &B = U.B[k];
+            A.img[0] = U.lap_ref[k]; B.img[0] = U.lap_mon[k];
+            A.H[0] = B.H[0] = H; A.W[0] = B.W[0] = W;
+            A.img[1] = pyr_store + (size_t)(2 * k) * pyr_bytes; B.img[1] = pyr_store + (size_t)(2 * k + 1) * pyr_bytes;
+            A.H[1] = B.H[1] = (H + 1) / 2; A.W[1] = B.W[1] = (W + 1) / 2;
+            A.levels = B.levels = 1;
+            d_np0[k] = &U.sc[k]->n_corners;
+        }
+        {
+            km_stage_timer t(c, ST_PYRAMID);
+            if ((rc = kd_pyrdown_units(c, U, 1))) return rc;
+        }
+        for (int k = 0; k < nk; k++) { PR[k] = U.A[k]; PM[k] = U.B[k]; }
+        {
+            km_stage_timer t(c, ST_EIGEN);
+            rc = k3_eig_candidates_units(c, U, prm->block_size, prm->quality_level);
+        }
+        if (rc == KM_OK) {
+            km_stage_timer t(c, ST_SELECT);
+            rc = kf_rank_select_units(c, U, prm->max_corners, prm->quality_level, prm->min_distance, cap);
+        }
+        if (rc != KM_OK && rc != KM_E_UNSUPPORTED) return rc;
+        if (rc == KM_OK) {
+            unsigned flags[8];
+            for (int k = 0; k < nk; k++) { KM_D2H(c, &n_p0[k], &U.sc[k]->n_corners, sizeof(int)); KM_D2H(c, &flags[k], &U.sc[k]->flags, sizeof(unsigned)); }
+            KM_FLUSH(c);
+            for (int k = 0; k < nk; k++) {
+                if (!flags[k]) continue;
+                // the unit did not fit the fixed capacities of the synchronisation-free corner path: its corners through the exact one
+                c->stats.path_flags |= KM_PATH_SPEC_RETRY;
+                KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
+                if ((rc = gftt_dev(c, lap_ref + (size_t)k * na, mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, U.p0[k], cap, sc)))
+                    return rc;
+                KM_HIP(c, hipMemcpyAsync(&U.sc[k]->n_corners, &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                KM_D2H(c, &n_p0[k], &sc->n_corners, sizeof(int));
+                KM_FLUSH(c);
+            }
+            corners_done = true;
+        }
+    }
+    if (!corners_done) {
+        {
+            km_stage_timer t(c, ST_PYRAMID);
+            for (int k = 0; k < nk; k++)
+                if ((rc = build_pyramid_single(c, lap_ref + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k) * pyr_bytes, &PR[k], nullptr)) ||
+                    (rc = build_pyramid_single(c, lap_mon + (size_t)k * na, H, W, prm->win_size, prm->max_level, pyr_store + (size_t)(2 * k + 1) * pyr_bytes, &PM[k], nullptr)))
+                    return rc;
+        }
+        // ---- corners of every reference Laplacian (klt.py:494), one after the other
+        for (int k = 0; k < nk; k++) {
+            float *p0 = (float *)(p0_store + (size_t)k * pts);
+            // gftt_dev starts from a clean scalar block; the min/max and the valid-pixel count gathered above stay
+            KM_HIP(c, hipMemsetAsync(&sc->max_eig_key, 0, sizeof(km_scalars) - offsetof(km_scalars, max_eig_key), c->stream));
+            if ((rc = gftt_dev(c, lap_ref + (size_t)k * na, mask, H, W, prm->max_corners, prm->quality_level, prm->min_distance, prm->block_size, p0, cap, sc)))
+                return rc;
+            KM_HIP(c, hipMemcpyAsync(&d_counts[k], &sc->n_corners, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+            KM_D2H(c, &n_p0[k], &sc->n_corners, sizeof(int));
+            d_np0[k] = &d_counts[k];
+        }
+        KM_FLUSH(c);
+    }
+    // ---- nk*nk tracker runs (mon kernel outer, ref kernel inner)
+    if (corners_done) {
+        km_lk_job jobs[KM_LK_JOBS_MAX];
+        km_count_jobs CJ;
+        for (int im = 0; im < nk; im++)
+            for (int ir = 0; ir < nk; ir++) {
+                const int combo = im * nk + ir;
+                km_lk_job &j = jobs[combo];
+                j.A = PR[ir]; j.B = PM[im]; j.pts_in = (const float *)(p0_store + (size_t)ir * pts); j.d_n = d_np0[ir];
+                j.p1 = (float *)(trk_store + (size_t)(2 * combo) * pts); j.p0r = (float *)(trk_store + (size_t)(2 * combo + 1) * pts);
+                CJ.p0[combo] = j.pts_in; CJ.p0r[combo] = j.p0r; CJ.d_n[combo] = j.d_n;      // (a reference kernel without corners: 0 points, count 0)
+            }
+        {
+            km_stage_timer t(c, ST_LK);
+            rc = kl_jobs_launch(c, jobs, nk * nk, n_lim, prm->win_size, prm->max_count, prm->epsilon);
+            if (rc == KM_OK) rc = kf_count_kept_jobs(c, CJ, nk * nk, n_lim, 0.1f, &d_counts[nk]);
+        }
+        if (rc != KM_OK && rc != KM_E_UNSUPPORTED) return rc;
+        tracks_done = rc == KM_OK;
+    }
+    if (!tracks_done) {
         km_stage_timer t(c, ST_LK);
         for (int im = 0; im < nk; im++)
             for (int ir = 0; ir < nk; ir++) {
@@ -737,8 +826,8 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
                 const int combo = im * nk + ir;
                 float *p0 = (float *)(p0_store + (size_t)ir * pts);
                 float *p1 = (float *)(trk_store + (size_t)(2 * combo) * pts), *p0r = (float *)(trk_store + (size_t)(2 * combo + 1) * pts);
-                if ((rc = kl_track(c, PR[ir], PM[im], p0, &d_counts[ir], n_lim, prm->win_size, prm->max_count, prm->epsilon, true, p1, p0r)) ||
-                    (rc = kf_count_kept(c, p0, p0r, &d_counts[ir], n_lim, 0.1f, &d_counts[nk + combo])))
+                if ((rc = kl_track(c, PR[ir], PM[im], p0, d_np0[ir], n_lim, prm->win_size, prm->max_count, prm->epsilon, true, p1, p0r)) ||
+                    (rc = kf_count_kept(c, p0, p0r, d_np0[ir], n_lim, 0.1f, &d_counts[nk + combo])))
                     return rc;
             }
     }
@@ -772,7 +861,7 @@ int km_klt_auto_ksize_frame_dev(km_ctx *c, const void *d_ref, const void *d_mon,
     {
         km_stage_timer t(c, ST_FRAME);
         if ((rc = kf_frame(c, (const float *)(p0_store + (size_t)br * pts), (const float *)(trk_store + (size_t)(2 * best) * pts),
-                           (const float *)(trk_store + (size_t)(2 * best + 1) * pts), &d_counts[br], n_lim, cap, 0.1f, x_off, y_off, d_out, nullptr, W)))
+                           (const float *)(trk_store + (size_t)(2 * best + 1) * pts), d_np0[br], n_lim, cap, 0.1f, x_off, y_off, d_out, nullptr, W)))
             return rc;
     }
     KM_D2H(c, host_out, d_out, fb);

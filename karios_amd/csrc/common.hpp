@@ -497,6 +497,21 @@ int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in,
              int n_max, int win, int max_count, double epsilon, bool backward_too, float *d_p1,
              float *d_p0r, int *d_left_band = nullptr);
 int kl_oscillation_probe(km_ctx *c, const float *d_q, int n, uint8_t *d_out);   // test hook of the LK kernels' oscillation predicate
+// independent forward + backward tracker runs in one launch (k_lk.hip kl_jobs_launch; the kernel-size search of klt.py:465-545)
+#define KM_LK_JOBS_MAX 64
+struct km_lk_job {
+    km_pyr A, B;                  // pyramids of the image the points live in / the image they are tracked into
+    const float *pts_in;
+    const int *d_n;
+    float *p1, *p0r;
+};
+int kl_jobs_launch(km_ctx *c, const km_lk_job *jobs, int n_jobs, int n_max, int win, int max_count, double epsilon);
+// forward-backward inlier counts of n_jobs tracker runs in one launch: counts[j] += tracks of job j with max |p0 - p0r| < thr
+struct km_count_jobs {
+    const float *p0[KM_LK_JOBS_MAX], *p0r[KM_LK_JOBS_MAX];
+    const int *d_n[KM_LK_JOBS_MAX];
+};
+int kf_count_kept_jobs(km_ctx *c, const km_count_jobs &J, int n_jobs, int n_max, float back_thr, int *d_counts);
 // ---- batched units (km_klt_units_frame_submit, api_units.hip): U independent work units - tiles of one or several pairs, klt.py:220-253 -
 // through ONE set of launches: the dense kernels take the unit as part of their linear work-item space (items tall enough to amortise
 // their halo, one launch's worth of waves instead of U thin ones), the corner-selection chain runs its U latency chains side by side

@@ -337,6 +337,28 @@ int kf_count_kept(km_ctx *c, const float *d_p0, const float *d_p0r, const int *d
     return KM_OK;
 }
 
+__global__ __launch_bounds__(256) void fb_count_jobs_kernel(km_count_jobs J, int n_max, float back_thr, int *__restrict__ counts)
+{
+    const int j = blockIdx.y;
+    const float *__restrict__ p0 = J.p0[j], *__restrict__ p0r = J.p0r[j];
+    const int n = min(J.d_n[j] ? *J.d_n[j] : n_max, n_max);
+    int local = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float d = fmaxf(fabsf(__fsub_rn(p0[2 * i], p0r[2 * i])), fabsf(__fsub_rn(p0[2 * i + 1], p0r[2 * i + 1])));
+        local += d < back_thr ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counts[j], local);
+}
+
+int kf_count_kept_jobs(km_ctx *c, const km_count_jobs &J, int n_jobs, int n_max, float back_thr, int *d_counts)
+{
+    if (n_max <= 0 || n_jobs <= 0) return KM_OK;
+    fb_count_jobs_kernel<<<dim3(16, n_jobs), 256, 0, c->stream>>>(J, n_max, back_thr, d_counts);   // counts zeroed by the caller
+    KM_LAUNCH_CHECK(c);
+    return KM_OK;
+}
+
 // ------------------------------------------------------------------ KARIOS_HIP_UPLOAD_CHECKSUM (staging.hip): what does a kernel right behind an upload see?
 // out[y] = sum over the bytes b_i of row y of (b_i + 1) * (2 i + 1)  (mod 2^64; the host evaluates the same sum on the source rows)
 __global__ __launch_bounds__(256) void row_checksum_kernel(const uint8_t *__restrict__ img, size_t row_bytes, int rows, unsigned long long *__restrict__ out)

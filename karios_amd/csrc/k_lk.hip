@@ -844,6 +844,30 @@ int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
     return KM_OK;
 }
 
+// Independent tracker runs in ONE launch (unit = blockIdx.y): the 25 (mon kernel, ref kernel) runs of the Laplacian kernel-size search
+// (klt.py:465-545) - every job its own pyramids, corner list and outputs.  Forward + backward, two-level pyramids (the lk2 form).
+// KM_E_UNSUPPORTED (no message): a job without a level-1 pyramid, lk2 off, a window the form does not hold - the caller runs kl_track
+// job by job.
+int kl_jobs_launch(km_ctx *c, const km_lk_job *jobs, int n_jobs, int n_max, int win, int max_count, double epsilon)
+{
+    if (n_max <= 0 || n_jobs <= 0) return KM_OK;
+    if (n_jobs > KM_LK_JOBS_MAX || win <= 2 || win > 40 || !c->opt_lk2) return KM_E_UNSUPPORTED;
+    lk_args host[KM_LK_JOBS_MAX];
+    const double e = epsilon < 0 ? 0 : epsilon > 10 ? 10 : epsilon;
+    for (int j = 0; j < n_jobs; j++) {
+        if (jobs[j].A.levels != 1 || jobs[j].B.levels != 1) return KM_E_UNSUPPORTED;
+        lk_args &g = host[j];
+        g.A = jobs[j].A; g.B = jobs[j].B; g.pts_in = jobs[j].pts_in; g.d_n = jobs[j].d_n; g.n_max = n_max; g.win = win;
+        g.max_count = max_count < 0 ? 0 : max_count > 100 ? 100 : max_count;
+        g.backward = 1; g.epsilon = e * e; g.p1 = jobs[j].p1; g.p0r = jobs[j].p0r; g.left_band = nullptr;
+        g.general_templates = km_dev_env("KARIOS_HIP_LK_GENERAL") ? 1 : 0;
+    }
+    lk_args *table = (lk_args *)km_ws(c, WS_UNITS_LK, sizeof(lk_args) * KM_LK_JOBS_MAX);
+    if (!table) return KM_E_NOMEM;
+    { const int rc = km_h2d_small(c, table, host, sizeof(lk_args) * (size_t)n_jobs); if (rc) return rc; }
+    return kl_units_launch(c, n_jobs, n_max, win);
+}
+
 int kl_track(km_ctx *c, const km_pyr &A, const km_pyr &B, const float *d_pts_in, const int *d_n, int n_max, int win, int max_count,
              double epsilon, bool backward_too, float *d_p1, float *d_p0r, int *d_left_band)
 {

@@ -399,6 +399,8 @@ int kf_rank_select_units(km_ctx *, const km_units &U, int max_corners, double, d
     }
     return KM_OK;
 }
+int kl_jobs_launch(km_ctx *, const km_lk_job *, int, int, int, int, double) { return KM_E_UNSUPPORTED; }   // (the search then runs its trackers one by one)
+int kf_count_kept_jobs(km_ctx *, const km_count_jobs &, int, int, float, int *) { return KM_OK; }
 static km_units g_lk_units;
 int kl_units_prepare(km_ctx *, const km_units &U, int, int, int, double) { g_lk_units = U; return KM_OK; }
 int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
