@@ -256,6 +256,23 @@ def test_framestream_pipelines_batched_submissions_and_yields_the_same_frames(op
         assert list(a.columns) == list(b.columns) and len(a) == len(b) > 200
         for col in a.columns:
             np.testing.assert_array_equal(a[col].to_numpy(), b[col].to_numpy())
+    # every second submission of a pipelined stream flagged ("spec_flag"): its units are repeated exactly while the neighbours' tails are
+    # still deferred / in flight on the other lane - the repeat (a blocking entry point) enqueues them first; frames unchanged
+    frames, redone = [], []
+    with FrameStream(0.4, depth=2) as s:
+        for k in range(6):
+            ctx.set_option("spec_flag", 32 if k % 2 else 0)
+            done = s.submit_many(units, conf)
+            ctx.set_option("spec_flag", 0)
+            frames += [d.frame for d in done]
+            redone += [d.redone for d in done]
+        done = s.drain()
+        frames += [d.frame for d in done]
+        redone += [d.redone for d in done]
+    assert len(frames) == 30 and all(redone[10 * k + 5:10 * k + 10] == [True] * 5 for k in range(3))    # (an unflagged unit may still exceed the fixed capacities by itself)
+    for a, b in zip(frames, runs[False] + runs[False][:5]):
+        for col in a.columns:
+            np.testing.assert_array_equal(a[col].to_numpy(), b[col].to_numpy())
 
 
 # ---------------------------------------------------------------------------- user masks in a batch (klt.py:258-266)
