@@ -47,3 +47,14 @@ def test_random_batched_submission_matches_oracle_unit_by_unit(ops, O, seed):
     from karios_amd.resident import ResidentPair
     fails = fuzz.run_units_case(seed, ops, O, ResidentPair)
     assert not fails, fails
+
+
+@pytest.mark.gpu
+def test_random_pipelined_streams_equal_the_units_alone():
+    """A fixed slice of tools/fuzz_pipeline.py: random streams of batched submissions (masked or not, every third one artificially
+    flagged) through the software pipeline of csrc/api_units.hip against every unit submitted alone through the exact path."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_pipeline.py"), "--rounds", "24", "--seed", "7001"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 FAILED" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
