@@ -154,6 +154,23 @@ __device__ __forceinline__ long long wave_sum_split(int v)
     const int lo = v & 0xffff, hi = v >> 16;
     return ((long long)wave_sum_i32_dpp(hi) << 16) + (long long)wave_sum_i32_dpp(lo);
 }
+// the same for a per-lane magnitude < 2^29 (the mismatch sums: <= 10 pixels x 8160 x 4080 = 3.3e8): the first two steps of the scan add
+// at most four lanes - still an int32 - so they run once, unsplit; only the remaining four steps need the two 16-bit halves
+__device__ __forceinline__ long long wave_sum_split4(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    int lo = v & 0xffff, hi = v >> 16;
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false);
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false);
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+    return ((long long)__builtin_amdgcn_readlane(hi, 63) << 16) + (long long)__builtin_amdgcn_readlane(lo, 63);
+}
 
 // Eight patch bytes from a byte-aligned LDS address as three ALIGNED dwords + two v_alignbyte.  A ds_read_b64 whose address is
 // not a multiple of 8 takes the LDS unit's unaligned path: ~55 cycles per wave instruction against ~4 aligned (PMC, round 5:
@@ -516,6 +533,9 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
         const bool need_mask = !(ipx >= 0 && ipy >= 0 && ipx + win <= IW - 1 && ipy + win <= IH - 1);
         uint32_t IvP[NR][3], IxP[NR][3], IyP[NR][3];
         int sA11 = 0, sA12 = 0, sA22 = 0;
+        // The template's share of the mismatch vector does not change over the iterations: b = sum (J - I) (Ix, Iy) = sum J (Ix, Iy) - cI,
+        // cI = sum I (Ix, Iy) per lane, once per pass (round 6: three packed subtractions per run and iteration less; exact integers either way)
+        int cI1 = 0, cI2 = 0;
         // The bilinear weights of the TEMPLATE are often degenerate: a key point of the forward pass is an integer position (a corner
         // of goodFeaturesToTrack) and winSize is odd, so at level 0 the weights are exactly (16384, 0, 0, 0) and at level 1 multiples of
         // 4096 - I = 32 p, Ix / Iy = the Scharr values themselves, CV_DESCALE changes nothing.  MODE 2 (w01 = w10 =
@@ -587,6 +607,8 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                         sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
                         sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
                         sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
+                        cI1 = __builtin_amdgcn_sdot2(lk_as_s2(IvP[t][q]), lk_as_s2(IxP[t][q]), cI1, false);
+                        cI2 = __builtin_amdgcn_sdot2(lk_as_s2(IvP[t][q]), lk_as_s2(IyP[t][q]), cI2, false);
                     }
                 } else {
                 int iv[LK_RUN + 1], ixv[LK_RUN + 1], iyv[LK_RUN + 1];
@@ -620,6 +642,8 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                     sA11 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IxP[t][q]), sA11, false);
                     sA12 = __builtin_amdgcn_sdot2(lk_as_s2(IxP[t][q]), lk_as_s2(IyP[t][q]), sA12, false);
                     sA22 = __builtin_amdgcn_sdot2(lk_as_s2(IyP[t][q]), lk_as_s2(IyP[t][q]), sA22, false);
+                    cI1 = __builtin_amdgcn_sdot2(lk_as_s2(IvP[t][q]), lk_as_s2(IxP[t][q]), cI1, false);
+                    cI2 = __builtin_amdgcn_sdot2(lk_as_s2(IvP[t][q]), lk_as_s2(IyP[t][q]), cI2, false);
                 }
                 }
             }
@@ -656,7 +680,7 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
             lk_weights(a, b, w00, w01, w10, w11);
             const lk_s2 wc0 = lk_as_s2(lk_pack16(w00, w10)), wc1 = lk_as_s2(lk_pack16(w01, w11));   // (column k, column k + 1); signed: w11 may be -1
             const uint8_t *jb = Y + (iny - jy0) * PP + (inx - jx0);
-            int sb1 = 0, sb2 = 0;
+            int sb1 = -cI1, sb2 = -cI2;
 #pragma unroll
             for (int t = 0; t < NR; t++) {
                 const int y = run_desc[t] & 0xff, x0 = (run_desc[t] >> 8) & 0xff;
@@ -678,12 +702,12 @@ __device__ void lk2_track_point(const km_pyr &I, const km_pyr &J, uint8_t *pI, u
                     val[k] = __builtin_amdgcn_sdot2(V[k], wc0, lk_dot2_k(V[k + 1], wc1, k_half9), false) >> (14 - 5);
 #pragma unroll
                 for (int q2 = 0; q2 < 3; q2++) {
-                    const lk_s2 diff = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1])) - lk_as_s2(IvP[t][q2]);
-                    sb1 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IxP[t][q2]), sb1, false);
-                    sb2 = __builtin_amdgcn_sdot2(diff, lk_as_s2(IyP[t][q2]), sb2, false);
+                    const lk_s2 jv = lk_as_s2(lk_pack16(val[2 * q2], val[2 * q2 + 1]));      // (positions beyond the run meet a zero Ix / Iy)
+                    sb1 = __builtin_amdgcn_sdot2(jv, lk_as_s2(IxP[t][q2]), sb1, false);
+                    sb2 = __builtin_amdgcn_sdot2(jv, lk_as_s2(IyP[t][q2]), sb2, false);
                 }
             }
-            const long long ib1 = wave_sum_split(sb1), ib2 = wave_sum_split(sb2);
+            const long long ib1 = wave_sum_split4(sb1), ib2 = wave_sum_split4(sb2);
             const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
             const float ddx = (A12 * b2 - A22 * b1) * D;
             const float ddy = (A12 * b1 - A11 * b2) * D;
