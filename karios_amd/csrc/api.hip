@@ -201,6 +201,7 @@ int km_ctx_sync(km_ctx *c)
         if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
         for (void *p : c->retired) (void)hipFree(p);
         c->retired.clear();
+        c->retired_mark = 0;
     }
     return KM_OK;
 }
@@ -524,6 +525,7 @@ int begin_call(km_ctx *c, int reset)
     km_upload_check_drop(c);   // (checks armed by a call that failed half-way: their sources may be gone)
     c->land_jobs.clear(); c->land_used = 0;   // (... and results it queued for a caller buffer that may be gone too: km_d2h_queue without its flush)
     c->spec_used = false; c->spec_flags = 0;
+    c->retired_mark = c->retired.size();        // (km_d2h_flush inside this call frees only what was retired before it)
     c->valid_job_pending = false;      // (a call that failed between the Laplacian pass and the fork)
     // early min / max (klt_tile_dev_impl): only a tile call that DIRECTLY follows a tile call may start its K1 beside the previous
     // unit's LK - any call in between may have produced the rasters on the main stream (km_shift_image_dev ...)

@@ -207,6 +207,7 @@ struct km_ctx {
     km_buf ws[WS_COUNT];
     km_buf ws_b[WS_COUNT];               // lane 1 of the pipelined batched submissions
     std::vector<void *> retired;         // workspace buffers replaced by larger ones (km_ws): freed at the next km_ctx_sync / destroy
+    size_t retired_mark = 0;             // ... the first `retired_mark` of them were retired before the running entry point began (begin_call)
     km_stage_ring ring;                  // host -> device staging (staging.hip)
     void *land = nullptr;                // device -> host landing arena (page-locked), km_d2h_queue / km_d2h_flush
     size_t land_cap = 0, land_used = 0;

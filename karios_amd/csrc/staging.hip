@@ -255,14 +255,19 @@ int km_d2h_flush(km_ctx *c)
     for (const km_land_job &j : c->land_jobs) copy_rows((char *)j.dst, j.bytes, (const char *)j.pinned, j.bytes, j.bytes, 1);
     c->land_jobs.clear();
     c->land_used = 0;
-    if (!c->retired.empty()) {
-        // workspace buffers replaced by larger ones (km_ws): the compute stream is idle here; once the other streams are too, nothing
-        // of this context can still use them - callers of the blocking entry points alone never reach km_ctx_sync
+    if (c->retired_mark > 0 && !c->retired.empty()) {
+        // workspace buffers replaced by larger ones (km_ws) BEFORE this entry point began: the compute stream is idle here; once the other
+        // streams are too, nothing of this context can still use them - callers of the blocking entry points alone never reach
+        // km_ctx_sync.  Buffers retired INSIDE the running call stay: a pointer the call obtained before the slot was regrown is still
+        // valid until the call returns (a flush in the middle of an entry point must not leave it dangling).
         if (c->aux_stream) KM_HIP(c, hipStreamSynchronize(c->aux_stream));
+        if (c->chain_stream) KM_HIP(c, hipStreamSynchronize(c->chain_stream));
         if (c->copy_stream) KM_HIP(c, hipStreamSynchronize(c->copy_stream));
         if (c->d2h_stream) KM_HIP(c, hipStreamSynchronize(c->d2h_stream));
-        for (void *p : c->retired) (void)hipFree(p);
-        c->retired.clear();
+        const size_t n = c->retired_mark < c->retired.size() ? c->retired_mark : c->retired.size();
+        for (size_t i = 0; i < n; i++) (void)hipFree(c->retired[i]);
+        c->retired.erase(c->retired.begin(), c->retired.begin() + (ptrdiff_t)n);
+        c->retired_mark = 0;
     }
     return km_upload_check_verify(c);
 }

@@ -289,7 +289,7 @@ class RankBlockExchange:
                 old = self.slot_step[half][j + k]
                 if old is not None:
                     raise RuntimeError(f"RankBlockExchange: step {first_step + k} would overwrite the block of step {old}, which has not been gathered yet "
-                                       f"(keep the stream's depth x units per submission <= the ring's {2 * self.batch} slots)")
+                                       f"(keep the stream's depth x units per submission <= the ring's {self.halves * self.batch} slots)")
                 self.slot_step[half][j + k] = first_step + k
         if j == 0 and self.used[half]:
             self.done[half].synchronize()

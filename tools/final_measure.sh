@@ -12,8 +12,9 @@ prof() {   # prof <tag> <script> [args]: rocprofv3 kernel statistics (csv) of `p
   t=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$t -o $t -- python3 "$@" > $R/gpurun_out/prof_${TAG}_$t.log 2>&1
 }
-prof c2 $R/bench.py --headline-only --steps 20 --warmup 5
+prof c2 $R/bench.py --headline-only --steps 60 --warmup 5
 prof c2one $R/bench.py --pairs-per-submission 1 --headline-only --steps 20 --warmup 5
+prof c4loop $R/tools/config4_probe.py
 prof alone $R/tools/blocking_workload.py 12
 prof c4 $R/tools/units_probe.py config4 4
 prof e2e $R/tools/units_probe.py e2e 4
@@ -25,6 +26,7 @@ sumr() { f=$(find gpurun_out/prof_${TAG}_$1 -name "$1_kernel_stats.csv" | head -
 sumr f64 phase_fp64 5
 sumr c2 config2
 sumr c2one config2_one_pair_per_submission
+sumr c4loop config4_pipelined_loop
 sumr alone kernels_alone 12
 sumr c4 config4_batched
 sumr e2e e2e_shape_batched
@@ -35,6 +37,13 @@ PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c2 tools/pairs_b
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_ep tools/entry_points_workload.py 10980 scoring,dn
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_c3 bench.py --config 3 --steps 4 --warmup 1
 PMC_COMMIT=$COMMIT timeout 900 bash tools/pmc_collect.sh ${TAG}_f64 tools/phase64_workload.py 10980 3
+# round 6: timelines of one period of the pipelined loops, the probes, the pipeline fuzz
+TL_OFFSET=3 bash tools/timeline_run.sh headline > gpurun_out/${TAG}_timeline_headline.log 2>&1
+TL_OFFSET=4 bash tools/timeline_run.sh c4 $R/tools/config4_probe.py > gpurun_out/${TAG}_timeline_config4.log 2>&1
+python tools/two_contexts_probe.py 1 2 > gpurun_out/${TAG}_contexts_probe.log 2>&1
+python tools/config4_probe.py > gpurun_out/${TAG}_config4_probe.log 2>&1
+python tools/auto_ksize_probe.py > gpurun_out/${TAG}_auto_ksize.json 2> /dev/null
+python tools/fuzz_pipeline.py --rounds 100000 --seed 500000 --budget-s 240 > gpurun_out/${TAG}_fuzz_pipeline.log 2>&1
 tail -1 gpurun_out/bench_${TAG}.json | cut -c1-300
 head -30 gpurun_out/${TAG}_kernel_stats_config2.md
 head -24 gpurun_out/${TAG}_kernel_stats_kernels_alone.md
