@@ -249,6 +249,41 @@ sunk3 = np.zeros(3 * pitch // 4, np.float32)
 ok(lib.km_d2h(ctx, P(sunk3), sink3, 3 * pitch), "d2h sink3")
 for k in range(3):
     assert np.array_equal(sunk3[k * pitch // 4:k * pitch // 4 + blk_bytes // 4].view(np.int32), got3[k].view(np.int32))
+# ---- the same submissions as a SOFTWARE PIPELINE ("units_pipeline": two workspace lanes, the tail of a submission enqueued by the next
+# one / km_frame_flush / any other entry point / km_ctx_sync), with and without a user mask per unit
+mask_img = np.ones((H, W), np.uint8)
+mask_img[50:90, 100:300] = 0
+dmask = C.c_void_p()
+ok(lib.km_dev_alloc(ctx, H * W, C.byref(dmask)), "dev_alloc mask")
+ok(lib.km_h2d(ctx, dmask, P(mask_img), H * W), "h2d mask")
+ok(lib.km_set_option(ctx, b"units_pipeline", 1), "pipeline on")
+for masked in (False, True):
+    for u, (bx, by, bw, bh) in zip(units, boxes):
+        u.d_mask, u.smask = (dmask.value + by * W + bx, W) if masked else (None, 0)
+    tickets = []
+    for k in range(6):
+        t = C.c_int(-1)
+        ok(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units submit (pipelined)")
+        tickets.append(t.value)
+        if k == 3:
+            ok(lib.km_frame_flush(ctx, t.value), "flush the newest")           # (its tail goes now; the next submission finds none deferred)
+            ok(lib.km_frame_flush(ctx, t.value), "flush again: no-op")
+        if k >= 1:                                                             # the previous submission: its tail travelled with this one
+            assert lib.km_frame_wait(ctx, tickets[k - 1], C.byref(blk), C.byref(nb)) == 0 and nb.value == 3 * blk_bytes
+            h3 = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_float)), shape=(3 * blk_bytes // 4,)).copy().reshape(3, -1)[:, :4].view(np.int32)
+            assert (h3[:, 1] == [40, 41, 42]).all() and (h3[:, 0] > 0).all(), h3
+    ok(lib.km_ctx_sync(ctx), "ctx_sync enqueues the last tail")
+    assert lib.km_frame_wait(ctx, tickets[-1], C.byref(blk), C.byref(nb)) == 0 and nb.value == 3 * blk_bytes
+t = C.c_int(-1)
+ok(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units submit (tail deferred)")
+ok(lib.km_klt_tile_frame_dev(ctx, dr, dm, 1, H, W, W, W, None, 0, None, None, C.byref(prm), 0.0, 0.0, P(np.zeros(4 + 6 * cap, np.float32)), cap), "another entry point enqueues the deferred tail first")
+assert lib.km_frame_wait(ctx, t.value, C.byref(blk), C.byref(nb)) == 0
+units[1].d_mask = None
+err(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: mixed masks", KM_E_ARG)
+for u in units:
+    u.d_mask, u.smask = None, 0
+ok(lib.km_set_option(ctx, b"units_pipeline", 0), "pipeline off")
+ok(lib.km_dev_free(ctx, dmask), "dev_free mask")
 ok(lib.km_set_frame_sink_pitch(ctx, sink3, 2 * pitch, pitch), "sink too small for three")
 err(lib.km_klt_units_frame_submit(ctx, units, 3, 1, None, None, C.byref(prm), 0.4, cap, C.byref(t)), "units: sink too small", KM_E_ARG)
 ok(lib.km_set_frame_sink(ctx, None, 0), "sink off")

@@ -401,11 +401,11 @@ int kf_rank_select_units(km_ctx *, const km_units &U, int max_corners, double, d
 }
 int kl_jobs_launch(km_ctx *, const km_lk_job *, int, int, int, int, double) { return KM_E_UNSUPPORTED; }   // (the search then runs its trackers one by one)
 int kf_count_kept_jobs(km_ctx *, const km_count_jobs &, int, int, float, int *) { return KM_OK; }
-static km_units g_lk_units;
-int kl_units_prepare(km_ctx *, const km_units &U, int, int, int, double) { g_lk_units = U; return KM_OK; }
+static km_units g_lk_units[2];       // (per workspace lane: a pipelined submission prepares its table before the previous one's LK is launched)
+int kl_units_prepare(km_ctx *c, const km_units &U, int, int, int, double) { g_lk_units[c->lane & 1] = U; return KM_OK; }
 int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
 {
-    const km_units &U = g_lk_units;
+    const km_units &U = g_lk_units[c->lane & 1];
     for (int u = 0; u < n_units; u++) {
         const int rc = kl_track(c, U.A[u], U.B[u], U.p0[u], &U.sc[u]->n_corners, n_max, win, 30, 0.03, true, U.p1[u], U.p0r[u], nullptr);
         if (rc) return rc;
@@ -415,7 +415,7 @@ int kl_units_launch(km_ctx *c, int n_units, int n_max, int win)
 int kf_frame_units(km_ctx *c, const km_units &U, int n_max, int cap, float thr)
 {
     for (int u = 0; u < U.n; u++) {
-        const int rc = kf_frame(c, U.p0[u], U.p1[u], U.p0r[u], &U.sc[u]->n_corners, n_max, cap, thr, U.x_off[u], U.y_off[u], U.frame[u], U.sc[u]);
+        const int rc = kf_frame(c, U.p0[u], U.p1[u], U.p0r[u], &U.sc[u]->n_corners, n_max, cap, thr, U.x_off[u], U.y_off[u], U.frame[u], U.sc[u], U.W[u]);
         if (rc) return rc;
     }
     return KM_OK;
