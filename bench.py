@@ -57,6 +57,10 @@ def parse(argv=None):
     ap.add_argument("--pairs-per-submission", type=int, default=4, choices=(1, 2, 4),
                     help="DISTINCT band pairs that travel in ONE batched submission (FrameStream.submit_many -> km_klt_units_frame_submit); "
                          "1: one pair per submission (rounds 1 - 4), which the line reports too (`one_pair_per_submission_ms`)")
+    ap.add_argument("--contexts", type=int, default=1, choices=(1, 2, 3),
+                    help="library contexts (streams + workspace) the N = 1 headline's submissions go to in turn, each with its own software pipeline "
+                         "(the rasters are shared).  Default 1: submitted in turn from ONE thread two contexts measure 0.93 ms per pair against 0.87 "
+                         "(three: 0.99); a thread per context (tools/two_contexts_probe.py) gains 4 % over one context (0.785 against 0.822)")
     ap.add_argument("--timed-stage", default="auto", help="stage bracketed by HIP events inside the timed region (auto: the largest kernel; none)")
     ap.add_argument("--detail-file", default=None, help="where the full detail goes (default: gpurun_out/bench_detail.json if that directory exists, else ./bench_detail.json)")
     a = ap.parse_args(argv)
@@ -199,11 +203,15 @@ def main():
         if c4_is_value:                                  # side number: a short run of the weak-scaling stream
             aa = copy.copy(a)
             aa.steps, aa.warmup = max(G, min(a.steps, 12)), min(a.warmup, 4)
-        head = headline.run(aa, env, conf, pairs, S)
+        extra_ctxs = [Context(env.dev_index) for _ in range(max(0, a.contexts - 1))] if world == 1 and not env.force_exchange else []
+        head = headline.run(aa, env, conf, pairs, S, more_pairs=[headline.pairs_on(c, data, S) for c in extra_ctxs])
+        for c in extra_ctxs:
+            c.close()
         last_frames = head.pop("last_frames")
         if rank == 0:
             head_cfg = {"workload": f"BASELINE config 2: {G} distinct S2-sized pairs {S}x{S} u16 resident in HBM, one per step, {G} per batched submission, KLT + ZNCC",
                         "pairs_per_step": world, "pairs_per_submission": head["pairs_per_submission"], "distinct_pairs_resident": head["distinct_pairs_resident"],
+                        "contexts": 1 + len(extra_ctxs),
                         "seeds": [headline.pair_seed(0, G, b) for b in range(G)], "klt": "Laplacian k=7, maxCorners 20000, one tile, ZNCC of rows with score >= 0.4",
                         "parallelism": f"{world} rank(s), each a stream of independent band pairs" + (", RCCL all-gather of key-point frames" if world > 1 else "")}
             if detail is None:

@@ -40,8 +40,16 @@ def make_pairs(env, S: int, G: int):
     return data, pairs, dt
 
 
-def run(a, env, conf, pairs, S: int):
+def pairs_on(ctx, data, S):
+    """The same resident rasters as `ResidentPair`s of another library context (a context = streams + workspace; the pixels are shared)."""
+    from karios_amd.resident import ResidentPair
+    return [ResidentPair.from_device_pointers(m.data_ptr(), r.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(m, r)) for m, r in data]
+
+
+def run(a, env, conf, pairs, S: int, more_pairs=()):
     """W warm-up steps, settle, EXACTLY K timed steps between fences (barrier + synchronize), max over ranks.
+    `more_pairs`: the same pairs on further library contexts (`pairs_on`) - consecutive submissions then go to the contexts in turn:
+    each context runs its own software pipeline (csrc/api_units.hip) and the GPU interleaves them (N = 1 without the exchange only).
     -> dict of everything measured (rank 0 fills the roofline), including `last_frames` (pair index -> DataFrame of its last step)."""
     import torch
     import torch.distributed as dist
@@ -52,7 +60,11 @@ def run(a, env, conf, pairs, S: int):
     exchanging = world > 1 or env.force_exchange
     G = max(1, min(int(a.pairs_per_submission), len(pairs)))
     P = len(pairs)
-    depth = max(0, min(2, a.depth))
+    by_ctx = [pairs] + ([] if exchanging else [list(p) for p in more_pairs])
+    ctxs = [p[0].ctx for p in by_ctx]
+    n_ctx = len(by_ctx)
+    depth = max(0, min(2, a.depth)) * n_ctx         # (a context holds at most three frames in flight)
+    sub_no = [0]
     stage_sum = {}
     totals = {"rows": 0, "frames": 0, "redone": 0, "redone_rows": 0, "last": {}, "n_init": {}, "n_cand": {}}
     # the path's only exchange step: one all-gather of every rank's key-point block per step.  RCCL: issued on a side
@@ -75,7 +87,9 @@ def run(a, env, conf, pairs, S: int):
             return stream.submit(pairs[k % P], conf, tag=k)
         if on_gpu:
             ex.arm_many(k, n)
-        return stream.submit_many([(pairs[(k + i) % P], None, None) for i in range(n)], conf, tags=list(range(k, k + n)),
+        mine = by_ctx[sub_no[0] % n_ctx]
+        sub_no[0] += 1
+        return stream.submit_many([(mine[(k + i) % P], None, None) for i in range(n)], conf, tags=list(range(k, k + n)),
                                   on_submitted=(lambda pend, _i, k=k, n=n: pend_of.__setitem__(k, (pend, n))) if on_gpu else None)
 
     def run_steps(n, marks=None):
@@ -121,7 +135,8 @@ def run(a, env, conf, pairs, S: int):
                 totals["span_units"] = totals.get("span_units", 0) + gs
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if exchanging:
             dist.barrier()
@@ -134,6 +149,16 @@ def run(a, env, conf, pairs, S: int):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item()) or cap_hit
 
+    class _All:                                   # (options / profiling switches go to every context of the loop)
+        def set_option(self, name, value):
+            for c in ctxs:
+                c.set_option(name, value)
+
+        def set_profiling(self, on):
+            for c in ctxs:
+                c.set_profiling(on)
+
+    every = _All()
     stream = FrameStream(0.4, depth=depth, want_spans=True)
     run_steps(a.warmup)
     take(stream.drain())
@@ -163,8 +188,8 @@ def run(a, env, conf, pairs, S: int):
     # run HERE, in front of the probe steps and a second settle, which bring clocks and caches back under load
     gc.collect()
     gc.disable()
-    ctx.set_option("profile_stage", -1)
-    ctx.set_profiling(True)
+    every.set_option("profile_stage", -1)
+    every.set_profiling(True)
     stage_sum.clear()
     run_steps(2 * G)
     take(stream.drain())
@@ -173,10 +198,10 @@ def run(a, env, conf, pairs, S: int):
     timed_stage = max(probe, key=probe.get) if probe else "min_eigen"
     if a.timed_stage not in ("auto", "none"):
         timed_stage = a.timed_stage
-    ctx.set_option("profile_stage", stage_names.index(timed_stage))
-    ctx.set_option("profile_every", 2)            # the timed steps are SAMPLED: every second submission records the stage's two events
+    every.set_option("profile_stage", stage_names.index(timed_stage))
+    every.set_option("profile_every", 2)            # the timed steps are SAMPLED: every second submission records the stage's two events
     if a.timed_stage == "none":
-        ctx.set_profiling(False)
+        every.set_profiling(False)
     t_s2, prev2, settle["post_gc_windows"] = time.perf_counter(), None, 0
     while True:
         fence()
@@ -235,9 +260,9 @@ def run(a, env, conf, pairs, S: int):
     redone_timed = totals["redone"]
     last_frames = dict(totals["last"])
     # untimed pass: every stage bracketed
-    ctx.set_profiling(True)
-    ctx.set_option("profile_stage", -1)
-    ctx.set_option("profile_every", 1)
+    every.set_profiling(True)
+    every.set_option("profile_stage", -1)
+    every.set_option("profile_every", 1)
     stage_steps = max(G, min(a.steps, 12) // G * G)
     stage_sum.clear()
     run_steps(stage_steps)
@@ -247,13 +272,13 @@ def run(a, env, conf, pairs, S: int):
     # ... and the same pass with the software pipeline OFF: every kernel with the GPU to itself (plus the second stream's pyramids /
     # min-max, as in rounds 1 - 5) - what a kernel costs, against what it takes while it shares the GPU with the other lane's chains
     piped_before = ctx.get_option("units_pipeline", 0)
-    ctx.set_option("units_pipeline", 0)
+    every.set_option("units_pipeline", 0)
     stage_sum.clear()
     run_steps(stage_steps)
     take(stream.drain())
     fence()
-    ctx.set_option("units_pipeline", piped_before)
-    ctx.set_profiling(False)
+    every.set_option("units_pipeline", piped_before)
+    every.set_profiling(False)
     stream.close()
     if ex is not None:
         ex.finish()                    # (the untimed pass armed the frame sink again: gathered, sink off)
@@ -297,9 +322,15 @@ def run(a, env, conf, pairs, S: int):
             roof["note"] = ("frac / achieved / kernel_ms: the kernel's launches inside the timed region, where the software pipeline runs the other "
                             "lane's latency-bound chains beside it; *_alone: the same launch with the pipeline off")
         # the whole step against the HBM roof: every stage's algorithmic bytes / the step's wall time
-        roof["whole_step"] = {"bytes_per_pair": alone["all_stages"]["bytes"], "ms_per_pair": ms_per_step,
-                              "achieved": alone["all_stages"]["bytes"] / (ms_per_step * 1e-3) / 1e9, "peak": roof["peak"],
-                              "frac": alone["all_stages"]["bytes"] / (ms_per_step * 1e-3) / 1e9 / roof["peak"]}
+        b_fused = alone["all_stages"]["bytes"]
+        fused_eig = alone["kernels"].get("min_eigen_candidates_fused")
+        # SURVEY 8(d) prices the eigenvalue map round trip the fusion removed (P3 + P4 = 10 B/px instead of 2 B/px + 8 B per key)
+        b_8d = b_fused if fused_eig is None else b_fused - fused_eig["bytes"] + fused_eig["unfused_model"]["bytes"]
+        roof["whole_step"] = {"bytes_per_pair": b_fused, "bytes_per_pair_8d_model": b_8d, "ms_per_pair": ms_per_step,
+                              "achieved": b_fused / (ms_per_step * 1e-3) / 1e9, "peak": roof["peak"],
+                              "frac": b_fused / (ms_per_step * 1e-3) / 1e9 / roof["peak"],
+                              "frac_8d_model": b_8d / (ms_per_step * 1e-3) / 1e9 / roof["peak"],
+                              "note": "every stage's must-move bytes / the step's wall time; 8d model: SURVEY 8(d)'s 23.5 B/px + sparse terms"}
         if G > 1:
             # a launch of the batched pipeline serves the G pairs of its submission: bytes and duration both scale by G; `achieved` is
             # bytes per launch / launch duration either way; `kernel_ms` (and the stage table) are quoted per PAIR

@@ -41,6 +41,8 @@ def small_roofline(roof: dict | None) -> dict | None:
     if ws:
         out["whole_step_frac"] = _r(ws["frac"], 4)          # every stage's algorithmic bytes / the step's wall time / peak
         out["whole_step_GBps"] = _r(ws["achieved"], 1)
+        if "frac_8d_model" in ws:
+            out["whole_step_frac_8d_model"] = _r(ws["frac_8d_model"], 4)
     if "traffic_source" in out:
         out["traffic_source"] = _short(out["traffic_source"], 90)
     return out
