@@ -161,6 +161,7 @@ extern "C++" int km_units_flush(km_ctx *c, bool join)
 {
     if (!c || !c->utail || !c->enqueue_mu) return KM_OK;
     std::lock_guard<std::mutex> lk(*c->enqueue_mu);
+    if (c->utail->armed) KM_HIP(c, hipSetDevice(c->device));      // (the fallback of km_frame_wait runs on a thread of the caller's)
     const int rc = units_flush_locked(c);
     if (rc || !join) return rc;
     for (int l = 0; l < 2; l++)
