@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void lap_kernel(const T *__restrict__ img0, co
                 }
                 kdp[i][h] = (int)a; ksp[i][h] = (int)b;
             }
-            bias[i] = 128 * sum;
+            bias[i] = R == 4 ? 0 : 128 * sum;
 #pragma unroll
             for (int t = 0; t <= 2 * R; t++) vk[i][t] = (cf.ks[i][t] & 0xffff) | (cf.kd[i][t] << 16);
         }
@@ -900,10 +900,13 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     const unsigned ugx = (unsigned)gx0;                           // used by output lanes only (gx0 >= 0 there)
     // FAST path (W % 4 == 0, aligned rows): a lane left of the image or right of it loads the 4 columns of its
     // in-image neighbour (clamped address) and mirrors the stretched bytes (REFLECT_101) with one byte permute:
-    //   left  [c0 c1 c2 c3] -> [ . c3 c2 c1]   (columns -4..-1; -4 is never a tap for R <= 3)
+    //   left  [c0 c1 c2 c3] -> [ . c3 c2 c1]   (columns -4..-1; -4 is never a tap for R <= 3; R = 4: below)
     //   right [c0 c1 c2 c3] -> [c2 c1 c0  . ]  (columns W..W+3)
-    const unsigned ugx_load = (unsigned)min(max(gx0, 0), W - 4);
-    const unsigned edge_sel = gx0 < 0 ? 0x01020300u : gx0 >= W ? 0x03000102u : 0x03020100u;
+    // R = 4 (ksize 9): column -4 / W + 3 IS a tap - the border lane loads the four columns ONE further inside (1..4 / W-5..W-2) and
+    // reverses them: [c1 c2 c3 c4] -> [c4 c3 c2 c1] = columns -4..-1, [W-5 .. W-2] -> [W-2 .. W-5] = columns W..W+3
+    const unsigned ugx_load = R == 4 ? (unsigned)(gx0 < 0 ? 1 : gx0 >= W ? W - 5 : gx0) : (unsigned)min(max(gx0, 0), W - 4);
+    const unsigned edge_sel = R == 4 ? ((gx0 < 0 || gx0 >= W) ? 0x00010203u : 0x03020100u)
+                                     : (gx0 < 0 ? 0x01020300u : gx0 >= W ? 0x03000102u : 0x03020100u);
     const bool col_inside = gx0 >= 0 && gx0 + 3 < W;
     const bool vec0 = col_inside && (stride0 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0);
     const bool vec1 = col_inside && (stride1 % 4 == 0) && ((uintptr_t)img1 % (4 * sizeof(T)) == 0);
@@ -914,12 +917,15 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     const int y0 = rowblock * rows_per_item, y1 = min(H, y0 + rows_per_item);
 
     // packed coefficients
-    int kdp[2][2], ksp[2][2], bias[2], vk[2][NR];
+    // (R = 4: nine taps = three dwords; the smoothing sum stays SIGNED there - sum ks (u - 128) spans [-32768, 32512], exactly an int16 -
+    //  and needs no bias: the vertical derivative taps sum to zero, so a constant added to every smoothed row cancels in kd * hs)
+    constexpr int NH = R == 4 ? 3 : 2;
+    int kdp[2][NH], ksp[2][NH], bias[2], vk[2][NR];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         int sum = 0;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             unsigned a = 0, b = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1060,6 +1066,15 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     constexpr int dummy = 0; (void)dummy;
+                    if constexpr (R == 4) {
+                        // nine taps: bytes [o, o + 9) of (lw | cw | rw)
+                        const int g0 = (int)__builtin_amdgcn_alignbyte(cw, lw, o), g1 = (int)__builtin_amdgcn_alignbyte(rw, cw, o),
+                                  g2 = (int)__builtin_amdgcn_alignbyte(0u, rw, o);
+                        const int vd = __builtin_amdgcn_sdot4(g0, kdp[i][0], __builtin_amdgcn_sdot4(g1, kdp[i][1], dot4_seed0(g2, kdp[i][2]), false), false);
+                        const int vs = __builtin_amdgcn_sdot4(g0, ksp[i][0], __builtin_amdgcn_sdot4(g1, ksp[i][1], dot4_seed0(g2, ksp[i][2]), false), false);
+                        ring[i][k][o] = (int)__builtin_amdgcn_perm((uint32_t)vs, (uint32_t)vd, 0x05040100u);
+                        continue;
+                    }
                     const int sft = 4 + o - R;                 // 1..4 for R = 3, 3..6 for R = 1
                     int g0, g1;
                     if (sft < 4) {
@@ -1178,7 +1193,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     };
     constexpr bool SPLIT = LAPM_SPLIT != 0;
     const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK, SPLIT> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK, SPLIT>
-                                                                                         : (const void *)lap_march_kernel<3, T, MASK, SPLIT>;
+                   : R == 3 ? (const void *)lap_march_kernel<3, T, MASK, SPLIT> : (const void *)lap_march_kernel<4, T, MASK, SPLIT>;
     int rows = km_pick_rows(H, (SPLIT ? 2 : 1) * nstrips, 2 * R, slots_of(fn), 32, 160);
     if (const char *e = km_dev_env("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
@@ -1195,6 +1210,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     case 1: lap_march_kernel<1, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     case 2: lap_march_kernel<2, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     case 3: lap_march_kernel<3, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 4: lap_march_kernel<4, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
@@ -1299,7 +1315,7 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     }
     int wg_per_cu = 0;
     const void *fn = R == 1 ? (const void *)lap_march_units_kernel<1, T, true> : R == 2 ? (const void *)lap_march_units_kernel<2, T, true>
-                                                                                       : (const void *)lap_march_units_kernel<3, T, true>;
+                   : R == 3 ? (const void *)lap_march_units_kernel<3, T, true> : (const void *)lap_march_units_kernel<4, T, true>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, fn, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 4;
     const long slots = (long)c->n_cu * 4 * wg_per_cu;
     // rows per item: the value in [32, 160] that minimises whole rounds of resident waves x the work of one item, over ALL units' strips
@@ -1341,6 +1357,7 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
         case 1: lap_march_units_kernel<1, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         case 2: lap_march_units_kernel<2, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         case 3: lap_march_units_kernel<3, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+        case 4: lap_march_units_kernel<4, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
         }
         KM_LAUNCH_CHECK(c);
@@ -1354,13 +1371,14 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     case 1: lap_march_units_kernel<1, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     case 2: lap_march_units_kernel<2, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     case 3: lap_march_units_kernel<3, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+    case 4: lap_march_units_kernel<4, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
-// KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (kernel sizes 9 / 11, tiny units): the caller submits the
+// KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (kernel size 11, tiny units): the caller submits the
 // units one by one instead
 int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int ksize_mon, int invert_mon, const double *nodata_ref,
                                const double *nodata_mon, km_valid_units *job)
@@ -1370,7 +1388,7 @@ int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int 
     auto okk = [](int k) { return k >= 1 && k <= 11 && (k & 1); };
     if (!okk(ksize_ref) || !okk(ksize_mon) || !fill_coef(ksize_ref, R, cf.kd[0], cf.ks[0]) || !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
-    if (R > 3) return KM_E_UNSUPPORTED;
+    if (R > 4) return KM_E_UNSUPPORTED;
     for (int u = 0; u < U.n; u++)
         if (U.W[u] < 8 || U.H[u] < 8) return KM_E_UNSUPPORTED;
     const nodata_t nd = make_nodata(nodata_mon, nodata_ref);
@@ -1406,7 +1424,7 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
     nodata_t nd = make_nodata(nodata_mon, nodata_ref);
-    if (R <= 3 && W >= 8 && H >= 8) {
+    if (R <= 4 && W >= 8 && H >= 8) {
 #define KM_PAIRM(T)                                                                                                              \
     (d_mask_out ? launch_lap_march<T, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                             d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                           \

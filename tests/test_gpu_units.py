@@ -150,7 +150,15 @@ def test_what_the_batch_form_does_not_cover_goes_one_by_one(ops):
     narrow = [(pa, (0, 0, 400, 600), None), (pa, (400, 0, 500, 600), None)]          # narrower than 512 columns
     assert submit_units(narrow, KLTConfiguration(maxCorners=500)) is None
     assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=0)) is None
-    assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=500, laplacian_kernel_size=9)) is None
+    assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=500, laplacian_kernel_size=11)) is None
+    # kernel size 9 IS covered since round 6 (the marching Laplacian pass holds nine taps): the batch equals the units one by one
+    conf9 = KLTConfiguration(maxCorners=500, laplacian_kernel_size={"mon": 9, "ref": 7})
+    nine = submit_units([(pa, None, None), (pb, None, None)], conf9, 0.4)
+    assert nine is not None
+    for k, (g, p) in enumerate(zip(nine.wait(), (pa, pb))):
+        w = p.submit_tile(conf9, zncc_threshold=0.4).result()
+        g = nine.redo(k) if g.flags else g
+        assert w.n_rows > 100 and same_rows(g, w), k
     conf = KLTConfiguration(maxCorners=500)
     with FrameStream(None, depth=1) as s:
         a = s.submit_many(narrow, conf) + s.drain()
