@@ -99,7 +99,7 @@ def small_line(detail: dict) -> dict:
         line["stage_ms"] = {k: _r(v) for k, v in detail["stage_ms"].items() if v}
     g = gates(detail)
     line["gates_passed"] = g
-    line["gates_all_passed"] = bool(g) and all(g.values())
+    line["gates_all_passed"] = all(g.values()) if g else None        # (None: no gate ran - N > 1 lines, --headline-only)
 
     def ms(name, key="ms_per_pair"):
         v = (detail.get(name) or {}).get(key)
