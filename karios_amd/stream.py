@@ -268,6 +268,15 @@ class FrameStream:
         return out
 
     def drain(self) -> list[StreamResult]:
+        # no further submission follows: the newest batch of every pipelined context gets its tail NOW (its LK then queues right behind
+        # its eigenvalue pass instead of waiting until the older batches have been collected)
+        if self._piped:
+            newest = {}
+            for item in self._pending:
+                if isinstance(item[1], PendingBatch):
+                    newest[id(item[1].ctx)] = item[1]
+            for pend in newest.values():
+                pend.ctx.flush(pend.ticket)
         out = []
         while self._pending:
             out += self._collect(self._pending.popleft())
