@@ -238,7 +238,7 @@ typedef struct km_unit {
  * km_frame_wait(ticket) hands out n consecutive blocks, a frame sink receives them at its pitch.  Header word 2 of a block != 0: that
  * unit did not fit the fixed capacities of the synchronisation-free corner path - repeat it alone through km_klt_tile_frame_zncc_dev
  * with "speculative" 0.  Returns KM_E_UNSUPPORTED (no error text) when the batch form does not cover the case (maxCorners 0,
- * minDistance < 1, a unit narrower than 512 columns or without a level-1 pyramid, Laplacian kernel 11, float32 score columns,
+ * minDistance < 1, a unit narrower than 512 columns or without a level-1 pyramid, float32 score columns,
  * a shrunken test capacity): submit the units one by one then.  Either every unit carries a user mask (km_unit.d_mask) or none. */
 int km_klt_units_frame_submit(km_ctx *ctx, const km_unit *units, int n_units, int dtype, const double *nodata_ref, const double *nodata_mon,
                               const km_klt_params *prm, double zncc_threshold, int cap, int *ticket);

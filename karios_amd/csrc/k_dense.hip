@@ -1378,8 +1378,45 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     return KM_OK;
 }
 
-// KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (kernel size 11, tiny units): the caller submits the
-// units one by one instead
+// Kernel size 11 in a batch (sum ks = 1024: its horizontal sums need 18 bits, the marching kernel's ring holds 16-bit pairs): the LDS
+// kernel, one launch per unit, its per-workgroup counts of valid pixels summed with the other units' by kd_valid_sum_units - the rest
+// of the submission (eigenvalue pass, chains, LK, frames, the software pipeline) is the batch's own.
+template <typename T>
+static int launch_lap_lds_units(km_ctx *c, int R, const km_units &U, const lap_coef &cf, int invert1, const nodata_t &nd, km_valid_units *job)
+{
+    if (R != 5) return km_fail(c, KM_E_INTERNAL, "lap_lds_units radius %d", R);
+    const int mask_wgs = 256;
+    size_t off[KM_UNITS_MAX + 1];
+    off[0] = 0;
+    for (int u = 0; u < U.n; u++)
+        off[u + 1] = off[u] + (U.has_user_mask ? (size_t)mask_wgs : (size_t)((U.W[u] + LAP_TW - 1) / LAP_TW) * ((U.H[u] + LAP_TH - 1) / LAP_TH));
+    unsigned *valid = (unsigned *)km_ws(c, WS_LAP_VALID, off[U.n] * sizeof(unsigned));
+    if (!valid) return KM_E_NOMEM;
+    job->n = U.n;
+    if (U.has_user_mask) {
+        mask_units_args M;
+        for (int u = 0; u < U.n; u++) {
+            M.src[u] = U.user_mask[u]; M.dst[u] = U.mask[u]; M.stride[u] = U.user_smask[u]; M.H[u] = U.H[u]; M.W[u] = U.W[u];
+            M.partial[u] = valid + off[u];
+        }
+        mask_pack_units_kernel<<<dim3(mask_wgs, U.n), 256, 0, c->stream>>>(M);
+        KM_LAUNCH_CHECK(c);
+    }
+    for (int u = 0; u < U.n; u++) {
+        const dim3 grid((U.W[u] + LAP_TW - 1) / LAP_TW, (U.H[u] + LAP_TH - 1) / LAP_TH);
+        if (U.has_user_mask)
+            lap_kernel<5, T, 2, false><<<grid, 256, 0, c->stream>>>((const T *)U.ref[u], (const T *)U.mon[u], U.H[u], U.W[u], U.sref[u], U.smon[u], U.mm[u], cf,
+                                                                      invert1, nd, U.lap_ref[u], U.lap_mon[u], nullptr, nullptr);
+        else
+            lap_kernel<5, T, 2, true><<<grid, 256, 0, c->stream>>>((const T *)U.ref[u], (const T *)U.mon[u], U.H[u], U.W[u], U.sref[u], U.smon[u], U.mm[u], cf,
+                                                                     invert1, nd, U.lap_ref[u], U.lap_mon[u], U.mask[u], valid + off[u]);
+        KM_LAUNCH_CHECK(c);
+        job->partial[u] = valid + off[u]; job->n_partial[u] = (unsigned)(off[u + 1] - off[u]); job->out[u] = &U.sc[u]->valid;
+    }
+    return KM_OK;
+}
+
+// KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (tiny units): the caller submits the units one by one instead
 int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int ksize_mon, int invert_mon, const double *nodata_ref,
                                const double *nodata_mon, km_valid_units *job)
 {
@@ -1388,10 +1425,17 @@ int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int 
     auto okk = [](int k) { return k >= 1 && k <= 11 && (k & 1); };
     if (!okk(ksize_ref) || !okk(ksize_mon) || !fill_coef(ksize_ref, R, cf.kd[0], cf.ks[0]) || !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
-    if (R > 4) return KM_E_UNSUPPORTED;
     for (int u = 0; u < U.n; u++)
         if (U.W[u] < 8 || U.H[u] < 8) return KM_E_UNSUPPORTED;
     const nodata_t nd = make_nodata(nodata_mon, nodata_ref);
+    if (R > 4)
+        switch (U.dtype) {
+        case KM_U8: return launch_lap_lds_units<uint8_t>(c, R, U, cf, invert_mon, nd, job);
+        case KM_U16: return launch_lap_lds_units<uint16_t>(c, R, U, cf, invert_mon, nd, job);
+        case KM_I16: return launch_lap_lds_units<int16_t>(c, R, U, cf, invert_mon, nd, job);
+        case KM_F32: return launch_lap_lds_units<float>(c, R, U, cf, invert_mon, nd, job);
+        default: return km_fail(c, KM_E_ARG, "stretch_laplacian: bad dtype %d", U.dtype);
+        }
     switch (U.dtype) {
     case KM_U8: return launch_lap_march_units<uint8_t>(c, R, U, cf, invert_mon, nd, job);
     case KM_U16: return launch_lap_march_units<uint16_t>(c, R, U, cf, invert_mon, nd, job);

@@ -186,7 +186,7 @@ def submit_units(units, conf, zncc_threshold=None, mutual_info: bool = False) ->
     ONE context, one pixel type, all with a user mask or none: the tiles of `KLT.match` (klt.py:220-253), of one pair or of several bands.  Every
     dense kernel, the corner-selection chain, LK, the frame stage and the scores are launched ONCE for all units
     (csrc/api_units.hip); the frames are the unit-by-unit frames bit for bit.  Returns None when the batch form does not cover the
-    case (the library answers KM_E_UNSUPPORTED: maxCorners 0, a unit narrower than 512 columns, Laplacian kernel 11 ...) or the
+    case (the library answers KM_E_UNSUPPORTED: maxCorners 0, a unit narrower than 512 columns ...) or the
     units do not share a context / pixel type, or only some carry a user mask - submit them one by one then."""
     if not units or len(units) > _lib.UNITS_PER_SUBMISSION:
         return None

@@ -150,15 +150,16 @@ def test_what_the_batch_form_does_not_cover_goes_one_by_one(ops):
     narrow = [(pa, (0, 0, 400, 600), None), (pa, (400, 0, 500, 600), None)]          # narrower than 512 columns
     assert submit_units(narrow, KLTConfiguration(maxCorners=500)) is None
     assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=0)) is None
-    assert submit_units([(pa, None, None), (pb, None, None)], KLTConfiguration(maxCorners=500, laplacian_kernel_size=11)) is None
-    # kernel size 9 IS covered since round 6 (the marching Laplacian pass holds nine taps): the batch equals the units one by one
-    conf9 = KLTConfiguration(maxCorners=500, laplacian_kernel_size={"mon": 9, "ref": 7})
-    nine = submit_units([(pa, None, None), (pb, None, None)], conf9, 0.4)
-    assert nine is not None
-    for k, (g, p) in enumerate(zip(nine.wait(), (pa, pb))):
-        w = p.submit_tile(conf9, zncc_threshold=0.4).result()
-        g = nine.redo(k) if g.flags else g
-        assert w.n_rows > 100 and same_rows(g, w), k
+    # kernel sizes 9 and 11 ARE covered since round 6 (9: the marching Laplacian pass holds nine taps; 11: the LDS kernel, a launch per
+    # unit inside the batch): the batch equals the units one by one
+    for ks in ({"mon": 9, "ref": 7}, 11, {"mon": 9, "ref": 11}):
+        confk = KLTConfiguration(maxCorners=500, laplacian_kernel_size=ks)
+        got = submit_units([(pa, None, None), (pb, None, None)], confk, 0.4)
+        assert got is not None, ks
+        for k, (g, p) in enumerate(zip(got.wait(), (pa, pb))):
+            w = p.submit_tile(confk, zncc_threshold=0.4).result()
+            g = got.redo(k) if g.flags else g
+            assert w.n_rows > 100 and same_rows(g, w), (ks, k)
     conf = KLTConfiguration(maxCorners=500)
     with FrameStream(None, depth=1) as s:
         a = s.submit_many(narrow, conf) + s.drain()
@@ -319,6 +320,12 @@ def test_units_with_a_user_mask_equal_the_masked_tiles_one_by_one_and_the_oracle
                     assert same_rows(g, w), (piped, k)
         finally:
             ctx.set_option("units_pipeline", 0)
+    conf11 = KLTConfiguration(maxCorners=1500, laplacian_kernel_size={"mon": 11, "ref": 5})   # (kernel 11: the batch's LDS-kernel form)
+    p11 = submit_units(units[:3], conf11, 0.4)
+    assert p11 is not None
+    for k, g in enumerate(p11.wait()):
+        w = pair.submit_tile(conf11, box=boxes[k], zncc_threshold=0.4).result()
+        assert w.n_rows > 200 and same_rows(p11.redo(k) if g.flags else g, w), k
     assert submit_units(units[:2] + [(plain, boxes[2], None)], conf, 0.4) is None          # masked and unmasked units do not mix
     with FrameStream(0.4, depth=1) as s:                          # ... FrameStream then submits those one by one, in order
         mixed = s.submit_many(units[:2] + [(plain, boxes[2], None)], conf) + s.drain()

@@ -326,8 +326,8 @@ def run_units_case(seed, ops, O, ResidentPair):
     nodata_ref = None if rng.random() < 0.8 else 0.0
     for p, _, _ in pairs:
         p.no_data_mon, p.no_data_ref = nodata_mon, nodata_ref
-    k_mon = int(rng.choice([1, 3, 5, 7, 7]))
-    k_ref = k_mon if rng.random() < 0.6 else int(rng.choice([1, 3, 5, 7]))
+    k_mon = int(rng.choice([1, 3, 5, 7, 7, 9, 11]))
+    k_ref = k_mon if rng.random() < 0.6 else int(rng.choice([1, 3, 5, 7, 9, 11]))
     invert = bool(rng.random() < 0.25)
     win = int(WINS[rng.integers(len(WINS))])
     conf = O.default_conf(maxCorners=int(rng.choice([40, 500, 5000, 20000])), blocksize=int(rng.choice([3, 5, 7, 9, 15, 15])), matching_winsize=win,

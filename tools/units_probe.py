@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage spans of ONE batched submission (km_klt_units_frame_submit) against the same units submitted one by one: the config-4 shape
 (4 bands x tile_size 5490 = 16 units) or the e2e shape (one pair, tile_size 6000: four unequal tiles).
-    python tools/units_probe.py [config4|e2e] [reps]"""
+    python tools/units_probe.py [config4|e2e|w=<width>] [reps]      (w=<width>: the config-4 shape with 2 x 2 boxes of that side per band)"""
 import os
 import sys
 import time
@@ -19,7 +19,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 S = 10980
 dev = torch.device("cuda", 0)
 ctx = Context(0)
-if shape == "config4":
+side = int(shape[2:]) if shape.startswith("w=") else 0
+if shape == "config4" or side:
     conf = KLTConfiguration(tile_size=5490)
     bands = 4
 else:
@@ -31,7 +32,8 @@ for b in range(bands):
     torch.cuda.synchronize()
     pair = ResidentPair.from_device_pointers(mon.data_ptr(), ref.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon, ref))
     keep.append(pair)
-    units += [(pair, tuple(t), None) for t in tiling.tile_grid(S, S, conf.tile_size)]
+    units += ([(pair, (x, y, side, side), None) for x in (0, side) for y in (0, side)] if side
+              else [(pair, tuple(t), None) for t in tiling.tile_grid(S, S, conf.tile_size)])
 print(f"{shape}: {len(units)} units", flush=True)
 
 
