@@ -896,7 +896,14 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     const int rowblock = wave_id / nstrips, strip = wave_id - rowblock * nstrips;
     stretcher<T> st[2];
     st[0].init(mm, 0, nullptr); st[1].init(mm, 1, nullptr);
-    const int gx0 = strip * LAPM_VALID - 4 + 4 * lane;           // first of this lane's 4 columns
+    // A width that is no multiple of 4 would leave the last strip's border lane straddling the right edge (the per-lane general path:
+    // 1 strip in 23 of a 5490-column unit, and + 22 % on the launch).  That strip is SHIFTED left instead so that its lane 63 starts
+    // exactly at column W: it recomputes - and rewrites, byte for byte the same - columns of its left neighbour and counts valid
+    // pixels only from `cnt_from` on.
+    const bool shifted = (W % 4 != 0) && strip == nstrips - 1 && W >= 256;      // (its lane 0 at column W - 252 lies inside the image)
+    const int gx0 = (shifted ? W - 252 : strip * LAPM_VALID - 4) + 4 * lane;           // first of this lane's 4 columns
+    const int cnt_from = shifted ? (nstrips - 1) * LAPM_VALID : 0;
+    const uint32_t cnt_mask = gx0 >= cnt_from ? 0xffffffffu : gx0 + 4 <= cnt_from ? 0u : (0xffffffffu << (8 * (cnt_from - gx0)));
     const unsigned ugx = (unsigned)gx0;                           // used by output lanes only (gx0 >= 0 there)
     // FAST path (W % 4 == 0, aligned rows): a lane left of the image or right of it loads the 4 columns of its
     // in-image neighbour (clamped address) and mirrors the stretched bytes (REFLECT_101) with one byte permute:
@@ -1032,7 +1039,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                         return __builtin_bit_cast(uint32_t, mn2);
                     };
                     const uint32_t mp = __builtin_amdgcn_perm(nz2(qm.y, qr.y), nz2(qm.x, qr.x), 0x06040200u);
-                    cnt += (unsigned)__popc(mp);
+                    cnt += (unsigned)__popc(mp & cnt_mask);
                     __builtin_memcpy((mask_out + (size_t)m * W) + opaque_lane_offset(ugx), &mp, 4);
                 }
             } else if constexpr (MASK && IMG != 1) {
@@ -1042,7 +1049,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                     for (int j = 0; j < 4; j++) {
                         const bool ok = (gx0 + j < W) && px_valid<T>(v[1][j], v[0][j], nd);
                         mp |= (ok ? 1u : 0u) << (8 * j);
-                        cnt += ok;
+                        cnt += ok && gx0 + j >= cnt_from;
                     }
                     const size_t o = (size_t)m * W + gx0;
                     if (FAST) __builtin_memcpy(mask_out + o, &mp, 4);
@@ -1119,9 +1126,10 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     };  // march
     // FAST: every lane of the item either lies inside the image with its 4 columns or is a whole-lane mirror of its in-image neighbour
     // (wave-uniform).  Rows need no alignment - loads and stores are 4-column accesses at whatever address the row has (a 5490-column
-    // tile: every other row sits off the dword grid; the per-pixel path there cost 1.75x).  Only a width that is no multiple of 4 sends
-    // the strips that reach the right border through the general path (their border lane straddles the edge).
-    const bool fast = (W % 4 == 0) || (strip * LAPM_VALID - 4 + 4 * 64 <= W);
+    // tile: every other row sits off the dword grid; the per-pixel path there cost 1.75x).  The last strip of a width that is no multiple
+    // of 4 is shifted (above); only a last strip of fewer than 4 columns (its left neighbour's border lane straddles the edge) and images of
+    // a single strip still take the general path.
+    const bool fast = (W % 4 == 0) || shifted || (strip * LAPM_VALID - 4 + 4 * 64 <= W);
     if constexpr (SPLIT) {
         if (img_sel == 0) { if (fast) march(std::true_type{}, std::integral_constant<int, 0>{}); else march(std::false_type{}, std::integral_constant<int, 0>{}); }
         else { if (fast) march(std::true_type{}, std::integral_constant<int, 1>{}); else march(std::false_type{}, std::integral_constant<int, 1>{}); }
