@@ -32,7 +32,7 @@ for b in range(bands):
     torch.cuda.synchronize()
     pair = ResidentPair.from_device_pointers(mon.data_ptr(), ref.data_ptr(), np.uint16, S, S, ctx=ctx, keepalive=(mon, ref))
     keep.append(pair)
-    units += ([(pair, (x, y, side, side), None) for x in (0, side) for y in (0, side)] if side
+    units += ([(pair, (x, y, side, side), None) for x in (0, min(side, S - side)) for y in (0, min(side, S - side))] if side
               else [(pair, tuple(t), None) for t in tiling.tile_grid(S, S, conf.tile_size)])
 print(f"{shape}: {len(units)} units", flush=True)
 
