@@ -2036,57 +2036,100 @@ __device__ __forceinline__ void pyr_hsum(const uint32_t (&w)[4], int (&h)[4])
     h[3] = (int)__builtin_amdgcn_udot4(w[2], coef, w[3] & 0xffu, false);          // bytes 8..11 + byte 12
 }
 
-__device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H, int W, int dh, int dw, int nquads)
+// One thread: output columns 4q .. 4q+3 of rows [y0, y1).  FAST (block-uniform): one 16-byte load per source row at whatever alignment
+// the row has (a level of odd width - 5490 -> 2745 - puts three rows in four off the dword grid; the hardware reads unaligned just as
+// well); otherwise byte by byte with REFLECT_101 columns.
+template <bool FAST>
+__device__ __forceinline__ void pyrdown_quad(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H, int W, int dw, int q, int y0, int y1)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nquads) return;
-    const int y0 = blockIdx.y * PYR_RS, y1 = min(dh, y0 + PYR_RS);
-    if (y0 >= dh) return;
     const int sx0 = 8 * q - 4;                                  // first source byte loaded
-    // interior threads: one 16-byte load per source row at whatever alignment the row has (a level of odd width - 5490 -> 2745 - puts three
-    // rows in four off the dword grid; per-byte loads there made the kernel five times slower: the hardware reads unaligned just as well)
-    const bool fast = sx0 >= 0 && sx0 + 16 <= W;
     auto load_row = [&](int sy, uint32_t (&w)[4]) {
         const uint8_t *row = src + (size_t)km_reflect101(sy, H) * W;
-        if (fast) {
+        if (FAST) {
             __builtin_memcpy(w, row + sx0, 16);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 uint32_t v = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) v |= (uint32_t)row[km_reflect101(sx0 + 4 * k + b, W)] << (8 * b);
-                w[k] = v;
+#pragma unroll 1
+                for (int b = 0; b < 4; b++) v |= (uint32_t)row[km_reflect101(sx0 + 4 * k + b, W)] << (8 * b);     // (one byte at a time: these
+                w[k] = v;                                                                                              // few lanes must not set the kernel's register count)
             }
         }
     };
-    // ring of horizontal sums for source rows 2y-2 .. 2y+2
-    int h0[4], h1[4], h2[4], h3[4], h4[4];
+    // ring of horizontal sums for source rows 2y-2 .. 2y+2, two outputs per dword (a sum is at most 16 x 255 = 4080, the vertical
+    // [1 4 6 4 1] of five of them at most 65 280, + 128 for the rounding: everything stays inside 16 bits - packed arithmetic)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto hsum2 = [&](const uint32_t (&w)[4], u16x2 (&h)[2]) {
+        int t[4];
+        pyr_hsum(w, t);
+        h[0] = __builtin_bit_cast(u16x2, (uint32_t)t[0] | ((uint32_t)t[1] << 16));
+        h[1] = __builtin_bit_cast(u16x2, (uint32_t)t[2] | ((uint32_t)t[3] << 16));
+    };
+    u16x2 h0[2], h1[2], h2[2], h3[2], h4[2];
     uint32_t wa[4], wb[4];
-    load_row(2 * y0 - 2, wa); pyr_hsum(wa, h0);
-    load_row(2 * y0 - 1, wa); pyr_hsum(wa, h1);
-    load_row(2 * y0, wa); pyr_hsum(wa, h2);
+    load_row(2 * y0 - 2, wa); hsum2(wa, h0);
+    load_row(2 * y0 - 1, wa); hsum2(wa, h1);
+    load_row(2 * y0, wa); hsum2(wa, h2);
     load_row(2 * y0 + 1, wa);
     load_row(2 * y0 + 2, wb);
-    for (int y = y0; y < y1; y++) {
-        pyr_hsum(wa, h3);
-        pyr_hsum(wb, h4);
+    auto step = [&](int y) {
+        hsum2(wa, h3);
+        hsum2(wb, h4);
         if (y + 1 < y1) { load_row(2 * y + 3, wa); load_row(2 * y + 4, wb); }   // next step's rows, in flight during the math
-        uint32_t packed = 0;
+        uint32_t r[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int s = h0[j] + 4 * h1[j] + 6 * h2[j] + 4 * h3[j] + h4[j];
-            packed |= (uint32_t)((s + 128) >> 8) << (8 * j);
+        for (int j = 0; j < 2; j++) {
+            const u16x2 s = (h0[j] + h4[j]) + (h1[j] + h3[j]) * (u16x2)(4) + h2[j] * (u16x2)(6) + (u16x2)(128);
+            r[j] = __builtin_bit_cast(uint32_t, s >> (u16x2)(8));
         }
+        const uint32_t packed = __builtin_amdgcn_perm(r[1], r[0], 0x06040200u);
         const int ox = 4 * q;
         const size_t o = (size_t)y * dw + ox;
-        if (ox + 3 < dw) __builtin_memcpy(dst + o, &packed, 4);          // (one dword store, aligned or not)
+        if (FAST || ox + 3 < dw) __builtin_memcpy(dst + o, &packed, 4);  // (one dword store, aligned or not)
         else {
             for (int j = 0; j < 4 && ox + j < dw; j++) dst[o + j] = (uint8_t)(packed >> (8 * j));
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) { h0[j] = h2[j]; h1[j] = h3[j]; h2[j] = h4[j]; }
+        for (int j = 0; j < 2; j++) { h0[j] = h2[j]; h1[j] = h3[j]; h2[j] = h4[j]; }
+    };
+    if constexpr (FAST) {
+#pragma unroll
+        for (int t = 0; t < PYR_RS; t++) {                       // (unrolled: the ring rotates by renaming)
+            if (y0 + t >= y1) break;
+            step(y0 + t);
+        }
+    } else {
+#pragma unroll 1
+        for (int y = y0; y < y1; y++) step(y);
     }
+}
+
+// Work split of one image (blockIdx.x, blockIdx.y): the x-blocks [0, gx_fast) hold the INTERIOR quads 1 .. q_hi - every lane on the
+// 16-byte path, no per-lane border code in those waves; the quads that touch the left / right border (quad 0 and the one or two behind
+// q_hi) of ALL row blocks are gathered into the x-block gx_fast, 256 (row block, border quad) items per workgroup.  (With the border
+// code behind a per-lane test, the first and the last wave of every row of workgroups ran the byte-by-byte path for one or two live
+// lanes - 2 waves in 22 of a 5490-column level, and 40 % of the launch's vector instructions.)
+__device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H, int W, int dh, int dw, int nquads)
+{
+    const int q_hi = W >= 28 ? (W - 12) / 8 : 0;                // interior quads: 1 <= q <= q_hi  (8q - 4 >= 0, 8q + 12 <= W; 4q + 3 < dw follows)
+    const int gx_fast = (q_hi + 255) / 256;
+    if ((int)blockIdx.x < gx_fast) {
+        const int q = 1 + blockIdx.x * 256 + threadIdx.x;
+        const int y0 = blockIdx.y * PYR_RS, y1 = min(dh, y0 + PYR_RS);
+        if (q > q_hi || y0 >= dh) return;
+        pyrdown_quad<true>(src, dst, H, W, dw, q, y0, y1);
+        return;
+    }
+    if ((int)blockIdx.x > gx_fast) return;
+    const int nb = nquads - q_hi;                               // border quads: 0, q_hi + 1 .. nquads - 1
+    const int nrb = (dh + PYR_RS - 1) / PYR_RS;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= nb * nrb) return;
+    const int rb = i / nb, b = i - rb * nb;
+    const int q = b == 0 ? 0 : q_hi + b;
+    const int y0 = rb * PYR_RS, y1 = min(dh, y0 + PYR_RS);
+    pyrdown_quad<false>(src, dst, H, W, dw, q, y0, y1);
 }
 
 __global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
@@ -2106,6 +2149,13 @@ __global__ __launch_bounds__(256) void pyrdown_units_kernel(pyr_units_args P)
     pyrdown_item(P.src[blockIdx.z], P.dst[blockIdx.z], H, W, dh, dw, (dw + 3) / 4);
 }
 
+// grid.x of pyrdown_item's work split for a level of width W: the interior x-blocks + the one that gathers the border quads
+static inline int pyr_grid_x(int W)
+{
+    const int q_hi = W >= 28 ? (W - 12) / 8 : 0;
+    return (q_hi + 255) / 256 + 1;
+}
+
 // level l of both pyramids of every unit from level l - 1 (units whose pyramid ends below l are skipped by the caller: H = 0)
 int kd_pyrdown_units(km_ctx *c, const km_units &U, int level)
 {
@@ -2116,13 +2166,13 @@ int kd_pyrdown_units(km_ctx *c, const km_units &U, int level)
         P.src[2 * n] = U.A[u].img[level - 1]; P.src[2 * n + 1] = U.B[u].img[level - 1];
         P.dst[2 * n] = (uint8_t *)U.A[u].img[level]; P.dst[2 * n + 1] = (uint8_t *)U.B[u].img[level];
         P.H[n] = U.A[u].H[level - 1]; P.W[n] = U.A[u].W[level - 1];
-        const int dh = (P.H[n] + 1) / 2, dw = (P.W[n] + 1) / 2;
+        const int dh = (P.H[n] + 1) / 2;
         max_dh = dh > max_dh ? dh : max_dh;
-        max_q = (dw + 3) / 4 > max_q ? (dw + 3) / 4 : max_q;
+        max_q = pyr_grid_x(P.W[n]) > max_q ? pyr_grid_x(P.W[n]) : max_q;       // (x-blocks, not quads)
         n++;
     }
     if (n == 0) return KM_OK;
-    const dim3 grid((max_q + 255) / 256, (max_dh + PYR_RS - 1) / PYR_RS, 2 * n);
+    const dim3 grid(max_q, (max_dh + PYR_RS - 1) / PYR_RS, 2 * n);
     pyrdown_units_kernel<<<grid, 256, 0, c->stream>>>(P);
     KM_LAUNCH_CHECK(c);
     return KM_OK;
@@ -2132,7 +2182,7 @@ static int launch_pyrdown(km_ctx *c, const pyr_pair &pp, int nimg, int H, int W)
 {
     const int dh = (H + 1) / 2, dw = (W + 1) / 2;
     const int nquads = (dw + 3) / 4;
-    dim3 grid((nquads + 255) / 256, (dh + PYR_RS - 1) / PYR_RS, nimg);
+    dim3 grid(pyr_grid_x(W), (dh + PYR_RS - 1) / PYR_RS, nimg);
     pyrdown_kernel<<<grid, 256, 0, c->stream>>>(pp, H, W, dh, dw, nquads);
     KM_LAUNCH_CHECK(c);
     return KM_OK;

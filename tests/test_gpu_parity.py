@@ -133,7 +133,9 @@ def test_min_eigen_bit_exact(ops, O, block):
 
 
 def test_pyrdown_bit_exact(ops, O):
-    for i, shape in enumerate(SHAPES + [(255, 300)]):
+    # (widths around the work split of the kernel: interior quads 1 .. (W - 12) / 8 in clean waves, the border quads gathered; W < 28 has
+    #  no interior; 2073 = more than 256 interior quads; heights that are no multiple of the 8-row item)
+    for i, shape in enumerate(SHAPES + [(255, 300), (9, 27), (17, 28), (33, 29), (40, 35), (21, 36), (70, 2073), (19, 2061), (3, 5), (2, 2), (131, 4099)]):
         img = rand_u8(shape, seed=50 + i)
         np.testing.assert_array_equal(ops.pyr_down(img), O.pyrdown_u8(img), err_msg=str(shape))
 
