@@ -4,15 +4,17 @@
 # config 3 and of the entry points the loop does not reach, and the PMC passes (separate --pmc runs, kernel trace only).  Results
 # under gpurun_out/ (the summaries are copied to profiles/ by hand).  Every profiler run sits under `timeout`.
 R=$PWD; TAG=${1:-r06}; COMMIT=${2:-unknown}
-python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/bench_${TAG}.err | tail -1 > gpurun_out/bench_${TAG}.json
-python bench.py 2> gpurun_out/bench_${TAG}_default.err | tail -1 > gpurun_out/bench_${TAG}_default.json
-python bench.py --config 3 --steps 10 --warmup 2 2> gpurun_out/bench_${TAG}_config3.err | tail -1 > gpurun_out/bench_${TAG}_config3.json
+# (the LAST stdout line is the driver's record; the `detail <name> {...}` lines above it and the detail file are kept beside it)
+python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/bench_${TAG}_detail.json > gpurun_out/bench_${TAG}.out 2> gpurun_out/bench_${TAG}.err; tail -1 gpurun_out/bench_${TAG}.out > gpurun_out/bench_${TAG}.json
+python bench.py --detail-file gpurun_out/bench_${TAG}_default_detail.json > gpurun_out/bench_${TAG}_default.out 2> gpurun_out/bench_${TAG}_default.err; tail -1 gpurun_out/bench_${TAG}_default.out > gpurun_out/bench_${TAG}_default.json
+python bench.py --config 3 --steps 10 --warmup 2 --detail-file gpurun_out/bench_${TAG}_config3_detail.json > gpurun_out/bench_${TAG}_config3.out 2> gpurun_out/bench_${TAG}_config3.err; tail -1 gpurun_out/bench_${TAG}_config3.out > gpurun_out/bench_${TAG}_config3.json
 cd /tmp && export TMPDIR=/tmp
 prof() {   # prof <tag> <script> [args]: rocprofv3 kernel statistics (csv) of `python3 <script> args`
   t=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$t -o $t -- python3 "$@" > $R/gpurun_out/prof_${TAG}_$t.log 2>&1
 }
 prof c2 $R/bench.py --headline-only --steps 60 --warmup 5
+prof c2drv $R/bench.py --gpus 1 --steps 20 --warmup 5 --headline-only      # (the driver's flags, the headline object alone)
 prof c2one $R/bench.py --pairs-per-submission 1 --headline-only --steps 20 --warmup 5
 prof c4loop $R/tools/config4_probe.py
 prof alone $R/tools/blocking_workload.py 12
@@ -25,6 +27,7 @@ cd $R
 sumr() { f=$(find gpurun_out/prof_${TAG}_$1 -name "$1_kernel_stats.csv" | head -1); [ -n "$f" ] && python3 tools/summarize_rocprof.py $f gpurun_out/${TAG}_kernel_stats_$2.md $3; }
 sumr f64 phase_fp64 5
 sumr c2 config2
+sumr c2drv config2_driver_flags
 sumr c2one config2_one_pair_per_submission
 sumr c4loop config4_pipelined_loop
 sumr alone kernels_alone 12
