@@ -167,12 +167,22 @@ def config4(dev, rank, world, coll_dev, steps, n_ctx_max=3, batched=False, warmu
         # submission's min / max must not sit between two steps' dense kernels (0.66 ms per step with one step ahead, timeline_r06_c4.txt)
         from collections import deque
         pend, r = deque(), (0, 0)
+        trace = [] if os.environ.get("KARIOS_C4_TRACE") == "1" else None      # host-side times of every submit / collect (tools/config4_probe.py)
         for k in range(n):
+            t_a = time.perf_counter()
             pend.append((k, submit_step(k) if resident else []))
+            t_b = time.perf_counter()
             while len(pend) > 2:
                 r = collect_step(*pend.popleft())
+            if trace is not None:
+                trace.append((k, t_a, t_b, time.perf_counter()))
         while pend:
             r = collect_step(*pend.popleft())
+        if trace:
+            t0_ = trace[0][1]
+            print("config4 host trace (ms): step, submit at, submit took, collect took", flush=True)
+            for k, t_a, t_b, t_c in trace:
+                print(f"   {k:3d} {1e3 * (t_a - t0_):9.3f} {1e3 * (t_b - t_a):7.3f} {1e3 * (t_c - t_b):7.3f}", flush=True)
         return r
 
     if batched:

@@ -170,7 +170,7 @@ int km_ctx_destroy(km_ctx *c)
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->chain_stream) { (void)hipStreamSynchronize(c->chain_stream); (void)hipStreamDestroy(c->chain_stream); }
     for (int l = 0; l < 2; l++)
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < KM_LANE_EVENTS; i++)
             if (c->ev_lane[l][i]) (void)hipEventDestroy(c->ev_lane[l][i]);
     for (int i = 0; i < WS_COUNT; i++)
         if (c->ws_b[i].p) (void)hipFree(c->ws_b[i].p);

@@ -28,7 +28,8 @@ static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 // submission (K, F, copy-out) is therefore enqueued by the NEXT submission - or by km_frame_flush / any other entry point / km_ctx_sync.
 // The chains' workgroups are 256 threads (k_select2.hip KF_T): they take the slots single retiring dense workgroups leave.
 // Same kernels on the same data in the same per-submission order: frames are bit-identical to the unpipelined form.
-enum { EV_MM = 0, EV_FORK, EV_JOIN, EV_E_DONE, EV_C_DONE, EV_K_DONE, EV_F_DONE };
+enum { EV_MM = 0, EV_FORK, EV_JOIN, EV_E_DONE, EV_C_DONE, EV_K_DONE, EV_F_DONE, EV_SETUP };
+static_assert(EV_SETUP < KM_LANE_EVENTS, "lane events");
 
 struct km_units_tail {
     bool armed = false;
@@ -255,7 +256,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         KM_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         KM_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < KM_LANE_EVENTS; i++)
         if (!c->ev_lane[lane][i]) KM_HIP(c, hipEventCreateWithFlags(&c->ev_lane[lane][i], hipEventDisableTiming));
     if (piped && !c->chain_stream) KM_HIP(c, hipStreamCreateWithFlags(&c->chain_stream, hipStreamNonBlocking));
     hipEvent_t *ev = c->ev_lane[lane];
@@ -311,22 +312,27 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
         KM_HIP(c, hipHostMalloc(&slot->host, ob * n + ob / 8, hipHostMallocDefault));
         slot->cap = ob * n + ob / 8;
     }
-    // (the lane's previous submission has left its frame stage: its scalars, points and frame buffers are free)
-    if (c->lane_f_recorded[lane]) {
-        KM_HIP(c, hipStreamWaitEvent(c->stream, ev[EV_F_DONE], 0));
-        KM_HIP(c, hipStreamWaitEvent(c->aux_stream, ev[EV_F_DONE], 0));
-        c->lane_f_recorded[lane] = false;
-    }
-    // the scalar blocks' reset and the LK table's small copy.  Pipelined: on the second stream, in front of the min / max the main stream
-    // waits for anyway - on the main stream they sat between the previous eigenvalue pass and these Laplacians (two tiny operations
-    // that each wait for the stream to drain: 0.06 ms per submission, profiles/timeline_r06_a.txt)
+    // The lane's previous submission must have left its frame stage before its scalars, points and frame buffers are reset - the scalar
+    // blocks' reset and the LK table's small copy ("setup").  Unpipelined: here, on the main stream.  Pipelined: on the second stream
+    // BEHIND the min / max (below): the min / max touches none of those buffers, and with the wait in front of it the Laplacians of this
+    // submission - which need the min / max only - stood behind the other lane's frame stage, which runs beside the previous
+    // eigenvalue pass and outlasts it (16 units of 5490^2: 0.8 ms of an idle main stream per step, tools/stage_order.py).  The main
+    // stream waits for the setup in front of the eigenvalue pass, the first kernel of this submission that touches the scalars.
     const int n_max = prm->max_corners < cap ? prm->max_corners : cap;
     const bool setup_on_aux = piped && dtype != KM_U8;
-    if (setup_on_aux) c->stream = c->aux_stream;
-    rc = hipMemsetAsync(sc, 0, sc_stride * n, c->stream) == hipSuccess ? KM_OK : km_fail(c, KM_E_HIP, "hipMemsetAsync(scalars)");
-    if (rc == KM_OK) rc = kl_units_prepare(c, U, n_max, prm->win_size, prm->max_count, prm->epsilon);
-    c->stream = main_stream;
-    if (rc) return rc;
+    auto setup = [&]() -> int {
+        int r = hipMemsetAsync(sc, 0, sc_stride * n, c->stream) == hipSuccess ? KM_OK : km_fail(c, KM_E_HIP, "hipMemsetAsync(scalars)");
+        if (r == KM_OK) r = kl_units_prepare(c, U, n_max, prm->win_size, prm->max_count, prm->epsilon);
+        return r;
+    };
+    if (!setup_on_aux) {
+        if (c->lane_f_recorded[lane]) {
+            KM_HIP(c, hipStreamWaitEvent(c->stream, ev[EV_F_DONE], 0));
+            KM_HIP(c, hipStreamWaitEvent(c->aux_stream, ev[EV_F_DONE], 0));
+            c->lane_f_recorded[lane] = false;
+        }
+        if ((rc = setup())) return rc;
+    }
 
     // ---- K1: min / max of every raster, on the second stream.  Pipelined: at once - beside whatever dense kernel the older submissions
     // are in (HBM-bound work under instruction-bound kernels).  Unpipelined, directly behind another submission: beside its LK.
@@ -344,6 +350,14 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
                 rc = kd_minmax_units(c, U, out, WS_MM_PARTIAL);
             }
             if (rc == KM_OK && hipEventRecord(ev[EV_MM], c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(min/max)");
+            if (rc == KM_OK && setup_on_aux) {      // the setup, behind the min / max and behind the lane's previous frame stage
+                if (c->lane_f_recorded[lane]) {
+                    if (hipStreamWaitEvent(c->aux_stream, ev[EV_F_DONE], 0) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipStreamWaitEvent(lane)");
+                    c->lane_f_recorded[lane] = false;
+                }
+                if (rc == KM_OK) rc = setup();
+                if (rc == KM_OK && hipEventRecord(ev[EV_SETUP], c->aux_stream) != hipSuccess) rc = km_fail(c, KM_E_HIP, "hipEventRecord(setup)");
+            }
             c->stream = main_stream;
             if (rc) return rc;
             KM_HIP(c, hipStreamWaitEvent(c->stream, ev[EV_MM], 0));
@@ -378,6 +392,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
     // scores follow on the chain stream, beside this submission's eigenvalue pass)
     if (piped && (rc = units_flush_locked(c))) { (void)hipStreamWaitEvent(c->stream, ev[EV_JOIN], 0); return rc; }
     c->lane = lane; c->ev_cur = 1 + k;
+    if (setup_on_aux) KM_HIP(c, hipStreamWaitEvent(c->stream, ev[EV_SETUP], 0));     // (scalars reset, the lane's previous frame stage through)
     // ---- K3 + K4 fused
     {
         km_stage_timer t(c, ST_EIGEN);

@@ -144,6 +144,7 @@ struct km_window {
 };
 
 // One frame in flight of km_klt_tile_frame_submit: pinned host block, completion event.
+#define KM_LANE_EVENTS 8      // events of one lane of the batched units' software pipeline (api_units.hip)
 #define KM_FRAME_SLOTS 3
 struct km_frame_slot {
     void *host = nullptr;
@@ -183,7 +184,7 @@ struct km_ctx {
     // `chain_stream` beside the other lane's dense kernels; a submission's tail (LK, frame stage, scores, copy-out) is enqueued by
     // the NEXT submission (or km_frame_flush)
     hipStream_t chain_stream = nullptr;
-    hipEvent_t ev_lane[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    hipEvent_t ev_lane[2][KM_LANE_EVENTS] = {};
     bool lane_f_recorded[2] = {false, false};   // EV_F_DONE of the lane has been recorded: its next submission waits for it
     bool in_units_submit = false;
     bool opt_units_pipeline = false;
