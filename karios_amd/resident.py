@@ -577,7 +577,7 @@ class ResidentPair:
                     c.set_frame_sink(*sink)
         return PendingFrame(c, ticket.value, cap, n_scores, redo=exact)
 
-    def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None, with_empty: bool = False):
+    def match_pipelined(self, conf, boxes=None, zncc_threshold=None, host_stage=None, with_empty: bool = False, split_small_grids: bool = True):
         """`match` as a pipeline (`karios_amd.stream.FrameStream`): tile i+1 is submitted to the device (`submit_tile`) while a
         worker thread waits for tile i and builds its DataFrame.  `host_stage(frame)` (e.g. `score_frame`) runs on the CALLING
         thread when the frame is collected: a context is not thread-safe, and a stage that calls back into the library (ZNCC /
@@ -588,10 +588,16 @@ class ResidentPair:
             boxes = tiling.tile_grid(self.x_size, self.y_size, conf.tile_size, conf.xStart)
         stage = None if host_stage is None else (lambda frame, _pair: host_stage(frame))
         with FrameStream(zncc_threshold, depth=1, host_stage=stage, score_columns=False) as stream:
-            # the tiles travel as batched submissions (one set of device launches per <= 16 tiles) where the batch form covers them
-            for done in stream.submit_many([(self, box, None) for box in boxes], conf):
-                if done.frame is not None or with_empty:              # (with_empty: None for a tile without valid pixels / corners)
-                    yield done.frame
+            # the tiles travel as batched submissions (one set of device launches per <= 16 tiles) where the batch form covers them.  A grid
+            # of 8 .. 16 tiles goes as TWO submissions: the device pipelines them (csrc/api_units.hip) and the first half's DataFrames are
+            # built while the second half is on the device - as one submission every frame waited for the last tile (tools/e2e_shape_probe.py:
+            # 16 tiles of 3000^2 15.0 -> 14.45 ms per pair; four tiles gain nothing: 2.45 against 2.52)
+            units = [(self, box, None) for box in boxes]
+            halves = [units[:len(units) // 2], units[len(units) // 2:]] if split_small_grids and 8 <= len(units) <= 16 else [units]
+            for part in halves:
+                for done in stream.submit_many(part, conf):
+                    if done.frame is not None or with_empty:          # (with_empty: None for a tile without valid pixels / corners)
+                        yield done.frame
             for done in stream.drain():
                 if done.frame is not None or with_empty:
                     yield done.frame
