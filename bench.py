@@ -248,7 +248,7 @@ def main():
         sens = os.path.join(ROOT, SENS_FILE)
         if os.path.exists(sens):
             try:
-                detail["oracle_sensitivity"] = dict(json.load(open(sens)), source=f"precomputed: {SENS_FILE} (tools/oracle_sensitivity.py, round 2)")
+                detail["oracle_sensitivity"] = dict(json.load(open(sens)), source=f"precomputed: {SENS_FILE} (tools/investigations/oracle_sensitivity.py, round 2)")
             except Exception:
                 pass
         emit(detail, a)

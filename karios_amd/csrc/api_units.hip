@@ -316,7 +316,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
     // blocks' reset and the LK table's small copy ("setup").  Unpipelined: here, on the main stream.  Pipelined: on the second stream
     // BEHIND the min / max (below): the min / max touches none of those buffers, and with the wait in front of it the Laplacians of this
     // submission - which need the min / max only - stood behind the other lane's frame stage, which runs beside the previous
-    // eigenvalue pass and outlasts it (16 units of 5490^2: 0.8 ms of an idle main stream per step, tools/stage_order.py).  The main
+    // eigenvalue pass and outlasts it (16 units of 5490^2: 0.8 ms of an idle main stream per step, tools/investigations/stage_order.py).  The main
     // stream waits for the setup in front of the eigenvalue pass, the first kernel of this submission that touches the scalars.
     const int n_max = prm->max_corners < cap ? prm->max_corners : cap;
     const bool setup_on_aux = piped && dtype != KM_U8;

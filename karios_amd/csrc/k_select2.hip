@@ -27,7 +27,7 @@
 // Workgroup size of every kernel of the chain.  256, not 1024 (round 6): the chain is latency-bound and is meant to run BESIDE the dense
 // kernels of another submission (second context), whose long-lived waves hold every VGPR of a SIMD.  A 1024-thread workgroup needs a
 // whole compute unit drained at once and starved there (f_hist_cut 85 -> 551 us, f_acc_count_scan 8 -> 661 us beside a dense kernel of
-// another queue; the 256-thread f_sweep 6 -> 18 us: tools/overlap_stats.py); a 256-thread workgroup takes the slots ONE retiring dense
+// another queue; the 256-thread f_sweep 6 -> 18 us: tools/investigations/overlap_stats.py); a 256-thread workgroup takes the slots ONE retiring dense
 // workgroup leaves.
 #define KF_T 256
 #define KF_NW (KF_T / 64)

@@ -590,7 +590,7 @@ class ResidentPair:
         with FrameStream(zncc_threshold, depth=1, host_stage=stage, score_columns=False) as stream:
             # the tiles travel as batched submissions (one set of device launches per <= 16 tiles) where the batch form covers them.  A grid
             # of 8 .. 16 tiles goes as TWO submissions: the device pipelines them (csrc/api_units.hip) and the first half's DataFrames are
-            # built while the second half is on the device - as one submission every frame waited for the last tile (tools/e2e_shape_probe.py:
+            # built while the second half is on the device - as one submission every frame waited for the last tile (tools/investigations/e2e_shape_probe.py:
             # 16 tiles of 3000^2 15.0 -> 14.45 ms per pair; four tiles gain nothing: 2.45 against 2.52)
             units = [(self, box, None) for box in boxes]
             halves = [units[:len(units) // 2], units[len(units) // 2:]] if split_small_grids and 8 <= len(units) <= 16 else [units]

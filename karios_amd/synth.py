@@ -219,7 +219,7 @@ def make_cross_sensor_pair_torch(H: int, W: int, sx: float = 0.4, sy: float = -0
 # The pairs above are the friendliest content there is: every corner survives the forward-backward test and LK stops after two
 # iterations.  The reference's one real run keeps 37 448 of <= 80 000 corners (tests/end_to_end/ref_data/test_full/KLT_matcher_*.csv,
 # klt.py:134-144), and SURVEY App. A.1 warns that k = 7 Laplacians of real scenes are near-binary.  The two generators below produce
-# that kind of content; torch on any device (the CPU build serves the tests and tools/calibrate_workloads.py).
+# that kind of content; torch on any device (the CPU build serves the tests and tools/investigations/calibrate_workloads.py).
 def _smooth_field_torch(H: int, W: int, cell: int, seed: int, device):
     """Smooth random field in [0, 1], correlation length ~`cell` px: a coarse uniform grid, bicubically enlarged."""
     import torch
@@ -237,7 +237,7 @@ def make_hard_pair_torch(H: int, W: int, sx: float = 0.5, sy: float = 0.25, seed
     """`hard_content`: the monitored image is decorrelated from the reference until about half of the tracks fail the 0.1-px round
     trip: (1) a smooth sub-pixel warp - the content moves by (sx + u warp, sy + v warp) with u, v smooth fields in [0, 1] of ~400 px
     correlation length (a blend of the four corner shifts with bilinear weights); (2) `mix` of an independent texture of the same
-    spectrum; (3) strong additive noise.  Defaults calibrated on the MI355X at 10980^2 (tools/hard_probe.py): 48 % of the 20 000
+    spectrum; (3) strong additive noise.  Defaults calibrated on the MI355X at 10980^2 (tools/investigations/hard_probe.py): 48 % of the 20 000
     corners survive (mix 0.45 / sigma 120: 79 %, 0.57 / 250: 42 %, 0.6 / 300: 34 %).  -> (mon, ref) int16-storage uint16 bit patterns like `make_pair_torch`."""
     import torch
 

@@ -17,7 +17,7 @@
  *
  * Neither formulation is "the" reference bit for bit: OpenCV's result also depends on its build (FMA contraction in the
  * AVX2 dispatch, SIMD width).  `fma` = 1 evaluates the places where an AVX2/FMA3 build would contract with fmaf.
- * tools/oracle_sensitivity.py runs both formulations on the same images and reports how far the results can move apart:
+ * tools/investigations/oracle_sensitivity.py runs both formulations on the same images and reports how far the results can move apart:
  * that spread, not either value, is what "parity unpinned" costs.
  */
 #include <float.h>

@@ -218,7 +218,7 @@ def min_eigen(img, block: int):
 def min_eigen_cv(img, block: int, fma: bool = False):
     """cornerMinEigenVal the way OpenCV rounds it (float32 Sobel with the scale in the smoothing taps, float32 products,
     double box sums cast to float32): karios_oracle_cvlit.c.  NOT the definition the kernels follow - the second opinion that
-    tools/oracle_sensitivity.py compares against."""
+    tools/investigations/oracle_sensitivity.py compares against."""
     a = np.ascontiguousarray(img, np.uint8)
     out = np.empty(a.shape, np.float32)
     if lib().kl_min_eigen_cv(_p(a), a.shape[0], a.shape[1], int(block), _p(out), int(bool(fma))) != 0:

@@ -302,7 +302,7 @@ def test_dn_filter_reference_known_answers():
 
 def test_opencv_literal_second_opinion_stays_close(O):
     """oracle/karios_oracle_cvlit.c (OpenCV's float32 evaluation order) vs the exact-integer definition the kernels follow:
-    the two may differ by float32 rounding noise only (tools/oracle_sensitivity.py quantifies it at full size)."""
+    the two may differ by float32 rounding noise only (tools/investigations/oracle_sensitivity.py quantifies it at full size)."""
     from karios_amd import synth
     mon, ref = synth.make_pair(300, 340, 0.5, 0.25, seed=7)
     lap_ref, lap_mon = O.laplacian_u8(O.to_uint8(ref), 7), O.laplacian_u8(O.to_uint8(mon), 7)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU calibration of the non-best-case bench workloads (karios_amd.synth.make_hard_pair_torch / make_tie_heavy_pair_torch) with the
 oracle: forward-backward survival, LK iteration histograms per level and direction, how binary the Laplacians are, how many exact
-ties the candidate list holds.  `python tools/calibrate_workloads.py hard --size 3072 --mix 0.45 --noise 120`"""
+ties the candidate list holds.  `python tools/investigations/calibrate_workloads.py hard --size 3072 --mix 0.45 --noise 120`"""
 from __future__ import annotations
 
 import argparse
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def lk_report(O, lap_ref, lap_mon, p0, win=25):

@@ -2,7 +2,7 @@
 """The end_to_end object of the bench alone (page-locked host rasters -> KLT.match -> DataFrame + ZNCC), and the same with the
 read-only guard of karios_amd.resident.shared_pair switched off: what the guard costs per pair."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from benchkit import legs
 from karios_amd import synth, resident

@@ -2,7 +2,7 @@
 """GPU probe: forward-backward survival of karios_amd.synth.make_hard_pair_torch at full size for a list of (mix, noise, warp) settings."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from karios_amd import synth

@@ -1,5 +1,5 @@
 """Where a rank's host CPU goes in the batched headline loop: CPU time of the worker's frame wait against its wall time (a spinning wait
-shows cpu == wall), per-thread CPU of the process.  python tools/host_cpu_probe.py  (GPU box)"""
+shows cpu == wall), per-thread CPU of the process.  python tools/investigations/host_cpu_probe.py  (GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

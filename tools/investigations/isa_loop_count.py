@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction mix of the hot loop of a kernel from the compiler's assembly (`hipcc -save-temps`): the innermost backward-branch loop
-that contains a marker instruction.  python tools/isa_loop_count.py <file.s> <kernel-symbol-substring> <marker-instruction> [rows per trip]"""
+that contains a marker instruction.  python tools/investigations/isa_loop_count.py <file.s> <kernel-symbol-substring> <marker-instruction> [rows per trip]"""
 import collections
 import re
 import sys

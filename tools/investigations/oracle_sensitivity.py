@@ -15,7 +15,7 @@ pair (default: BASELINE config 2, 10980 x 10980, SURVEY 8d generator) and report
 CPU only (the oracle), a few minutes at full size.  Writes profiles/r02_oracle_sensitivity.json, which bench.py attaches to its
 JSON line as `oracle_sensitivity`.
 
-    python tools/oracle_sensitivity.py [--size 10980] [--out profiles/r02_oracle_sensitivity.json]
+    python tools/investigations/oracle_sensitivity.py [--size 10980] [--out profiles/r02_oracle_sensitivity.json]
 """
 import argparse
 import json
@@ -25,7 +25,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

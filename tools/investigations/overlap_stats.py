@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """From a rocprofv3 kernel trace of several contexts in flight: duration of every latency-bound chain kernel when a DENSE kernel of another
-queue was running for its whole span, against when none was.  python tools/overlap_stats.py <rocprofv3 output dir>"""
+queue was running for its whole span, against when none was.  python tools/investigations/overlap_stats.py <rocprofv3 output dir>"""
 import csv, glob, sys, collections, bisect
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnosis: which columns of which unit differ between a pipelined and an unpipelined stream of batched submissions."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from karios_amd import synth, _lib
 from karios_amd.core import KLTConfiguration

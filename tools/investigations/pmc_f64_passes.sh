@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the complex128 phase correlation, printed PER DISPATCH in launch order for the last call (the nine level passes of a
-# call share two kernel names).  usage: bash tools/pmc_f64_passes.sh "<counters pass 1>" ["<counters pass 2>" ...]
+# call share two kernel names).  usage: bash tools/investigations/pmc_f64_passes.sh "<counters pass 1>" ["<counters pass 2>" ...]
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE case of tools/fuzz_parity.py many times on the GPU and compare every run with the oracle's (single) result:
-hunts timing-dependent defects.    python tools/repeat_case.py --seed 40917 --max-size 1200 --reps 3000"""
+hunts timing-dependent defects.    python tools/investigations/repeat_case.py --seed 40917 --max-size 1200 --reps 3000"""
 import argparse
 import os
 import sys
@@ -8,8 +8,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tools/: fuzz_parity
 import fuzz_parity as F   # noqa: E402
 
 

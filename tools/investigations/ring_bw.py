@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Upload rate of a PAGEABLE 10980^2 uint16 raster through the library's staging ring (csrc/staging.hip) against the page-locked
-rate: `KARIOS_HIP_COPY_THREADS=N python tools/ring_bw.py` (the pool's size is read once per process)."""
+rate: `KARIOS_HIP_COPY_THREADS=N python tools/investigations/ring_bw.py` (the pool's size is read once per process)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from karios_amd import pinned_empty
 from karios_amd._lib import Context
 from karios_amd.resident import DeviceBuffer

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Stage spans of BLOCKING tile calls on the headline pair (every kernel alone): median over n calls.  For same-box A/B runs of one
-build with different KARIOS_HIP_* development variables (KARIOS_HIP_LIB=karios_amd/libkarios_hip_dev.so).  python tools/stage_ab.py [n] [hard|plain]"""
+build with different KARIOS_HIP_* development variables (KARIOS_HIP_LIB=karios_amd/libkarios_hip_dev.so).  python tools/investigations/stage_ab.py [n] [hard|plain]"""
 import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from karios_amd import synth

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which submission does a kernel belong to?  The j-th launch of a stage's kernel in a window IS submission j: lists, per submission of the
 last window of a rocprofv3 kernel trace, start / end of its min-max, Laplacian pass, LK and eigenvalue pass - who waits for whom.
-python tools/stage_order.py <rocprofv3 output dir>"""
+python tools/investigations/stage_order.py <rocprofv3 output dir>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))

@@ -13,8 +13,8 @@ No oracle runs: the detector is KARIOS_HIP_UPLOAD_CHECKSUM=1 (csrc/staging.hip) 
 on the same stream, compared with the host's checksum of the source when the call completes, and re-evaluated after the stream
 has drained on a miss.  That is ~50x more tile calls per minute than an oracle-checked soak.
 
-    python tools/upload_stress.py --mode old  --seconds 600     # the ORIGINAL upload: hipMemcpy2DAsync from pageable rows
-    python tools/upload_stress.py --mode ring --seconds 300     # the library's page-locked staging ring (default build)
+    python tools/investigations/upload_stress.py --mode old  --seconds 600     # the ORIGINAL upload: hipMemcpy2DAsync from pageable rows
+    python tools/investigations/upload_stress.py --mode ring --seconds 300     # the library's page-locked staging ring (default build)
 
 Writes gpurun_out/upload_stress_<mode>.json and one log per worker.
 """
@@ -25,7 +25,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of ONE whole window of the pipelined loop (from an idle GPU to an idle GPU: fill, steady periods, drain) from a rocprofv3
 kernel trace: the dense kernels and every idle gap of the main queue - where the fixed cost of a timed region goes.
-python tools/window_timeline.py <rocprofv3 output dir> [window index from the end, default 1]"""
+python tools/investigations/window_timeline.py <rocprofv3 output dir> [window index from the end, default 1]"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
