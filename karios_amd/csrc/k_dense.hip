@@ -2107,7 +2107,7 @@ __device__ __forceinline__ void pyrdown_quad(const uint8_t *__restrict__ src, ui
 
 // Work split of one image (blockIdx.x, blockIdx.y): the x-blocks [0, gx_fast) hold the INTERIOR quads 1 .. q_hi - every lane on the
 // 16-byte path, no per-lane border code in those waves; the quads that touch the left / right border (quad 0 and the one or two behind
-// q_hi) of ALL row blocks are gathered into the x-block gx_fast, 256 (row block, border quad) items per workgroup.  (With the border
+// q_hi) of ALL rows are gathered into the x-block gx_fast, 256 (output row, border quad) items per workgroup.  (With the border
 // code behind a per-lane test, the first and the last wave of every row of workgroups ran the byte-by-byte path for one or two live
 // lanes - 2 waves in 22 of a 5490-column level, and 40 % of the launch's vector instructions.)
 __device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int H, int W, int dh, int dw, int nquads)
@@ -2122,14 +2122,14 @@ __device__ __forceinline__ void pyrdown_item(const uint8_t *__restrict__ src, ui
         return;
     }
     if ((int)blockIdx.x > gx_fast) return;
+    // (ONE output row per border thread: its byte loads are issued one at a time - a thread marching 8 rows that way was the launch's
+    //  tail: 124 us alone where the interior needs 80)
     const int nb = nquads - q_hi;                               // border quads: 0, q_hi + 1 .. nquads - 1
-    const int nrb = (dh + PYR_RS - 1) / PYR_RS;
     const int i = blockIdx.y * 256 + threadIdx.x;
-    if (i >= nb * nrb) return;
-    const int rb = i / nb, b = i - rb * nb;
+    if (i >= nb * dh) return;
+    const int y = i / nb, b = i - y * nb;
     const int q = b == 0 ? 0 : q_hi + b;
-    const int y0 = rb * PYR_RS, y1 = min(dh, y0 + PYR_RS);
-    pyrdown_quad<false>(src, dst, H, W, dw, q, y0, y1);
+    pyrdown_quad<false>(src, dst, H, W, dw, q, y, y + 1);
 }
 
 __global__ __launch_bounds__(256) void pyrdown_kernel(pyr_pair pp, int H, int W, int dh, int dw, int nquads)
