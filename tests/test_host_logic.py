@@ -642,6 +642,39 @@ def test_bench_small_line_guard_drops_optional_parts_first():
     assert summary.small_line(failed)["gates_all_passed"] is False
 
 
+def test_committed_bench_records_are_single_small_lines_with_the_contract():
+    """The round's committed records (profiles/bench_r06*.json = the LAST stdout line of the three bench commands of tools/final_measure.sh):
+    one JSON line each, < 6 KB, every contract key, the roofline and cpu_baseline objects, every in-run gate passed."""
+    import json
+    sys.path.insert(0, ROOT)
+    from benchkit import summary
+    for name, with_cpu in (("bench_r06.json", True), ("bench_r06_default.json", True), ("bench_r06_config3.json", False)):
+        raw = open(os.path.join(ROOT, "profiles", name)).read()
+        assert raw.count("\n") <= 1 and len(raw) < summary.MAX_BYTES, name
+        line = json.loads(raw)
+        for key in summary.CONTRACT_KEYS:
+            assert key in line, (name, key)
+        assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None and line["data"] == "synthetic"
+        assert line["gates_all_passed"] is True and all(line["gates_passed"].values()), name
+        if with_cpu:
+            roof, cb = line["roofline"], line["cpu_baseline"]
+            assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4 and roof["traffic"] > 0
+            assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["parity"]["passed"] is True and cb["parity"]["pairs_gated"] == 4
+            assert abs(line["value"] - 10980 * 10980 / 1e6 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    first = json.loads(open(os.path.join(ROOT, "profiles", "bench_r06.json")).read())
+    assert first["steps"] == 20 and first["warmup"] == 5                     # (the driver's flags)
+    stdout = open(os.path.join(ROOT, "profiles", "bench_r06_stdout.txt")).read().strip().splitlines()
+    assert json.loads(stdout[-1]) == first and all(l.startswith("detail ") for l in stdout[:-1] if l.strip())
+
+
+def test_every_tool_is_listed_in_the_tools_readme():
+    readme = open(os.path.join(ROOT, "tools", "README.md")).read()
+    for sub in ("", "investigations"):
+        for f in sorted(os.listdir(os.path.join(ROOT, "tools", sub))):
+            if f.endswith((".py", ".sh")):
+                assert f"`{f}" in readme, f"tools/{sub}/{f} is not described in tools/README.md"
+
+
 # ---------------------------------------------------------------------------- shared_pair cannot return stale pixels (VERDICT r5 item 10)
 def test_shared_pair_token_never_serves_stale_pixels(monkeypatch):
     """The resident copy the matcher services share is keyed on the uploaded buffers + a token, not on a sparse sample of the pixels:
