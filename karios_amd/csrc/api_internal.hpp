@@ -42,4 +42,4 @@ int fetch_tracks(km_ctx *c, km_scalars *sc, const float *d_p0, const float *d_p1
                  int *out_n);
 
 // api_units.hip: Laplacian kernel sizes the batched stretch + Laplacian pass covers (k_dense.hip kd_stretch_laplacian_units)
-static inline bool km_units_ksize_supported(int k) { return k >= 1 && k <= 11 && (k & 1); }      // (11: the LDS kernel, a launch per unit)
+static inline bool km_units_ksize_supported(int k) { return k >= 1 && k <= 11 && (k & 1); }

@@ -477,6 +477,7 @@ __global__ __launch_bounds__(1024) void max_u32_kernel(const unsigned *__restric
 struct lap_coef {
     int kd[2][11];
     int ks[2][11];
+    int b3[2] = {0, 0};      // marching kernel, radius 5: image i is kernel 11 = its 9-tap pass + a 3 x 3 binomial (lap_march_item)
 };
 
 template <typename T> struct stretcher {
@@ -869,7 +870,7 @@ __device__ __forceinline__ unsigned opaque_lane_offset(unsigned x)
     return x;
 }
 
-#define LAPM_VALID 248
+#define LAPM_VALID_OF(R) ((R) == 5 ? 240 : 248)      // output columns of a strip: 64 lanes x 4 columns less the halo lanes (two either side for radius 5)
 #ifndef LAPM_SPLIT
 #define LAPM_SPLIT 0   // 1: one image per wavefront (88 VGPRs, 5 waves/SIMD) - measured SLOWER (0.30 vs 0.264 ms: loop, address and mask work duplicated); 0: both images in one wave
 #endif
@@ -888,7 +889,16 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                                                int rows_per_item, int nitems, int wave_lin /* wave-uniform: this wavefront's work item (x 2 with SPLIT) */)
 {
     typedef short short2v __attribute__((ext_vector_type(2)));
-    constexpr int NR = 2 * R + 1;
+    // R = 5 (kernel 11; sum ks = 1024: a horizontal smoothing sum needs 18 bits, the ring holds 16-bit pairs): the kernels of size 11 are
+    // those of size 9 convolved with [1 2 1] (OpenCV's getSobelKernels recurrence), so
+    //     Laplacian_11 = ([1 2 1] x [1 2 1]) * (kd9 x ks9 + ks9 x kd9)          (before the saturation)
+    // - the 9-tap pass (radius RH = 4) of this kernel, its 32-bit row kept unsaturated, then a 3 x 3 binomial on those integers.  REFLECT_101
+    // commutes with it: a symmetric filter maps the whole-sample-symmetric extension of the image onto the extension of its own output.
+    // Two halo lanes either side (the binomial needs the 9-tap value one column outside the strip), one row more either end of an item.
+    constexpr int RH = R == 5 ? 4 : R;
+    constexpr int NR = 2 * RH + 1;
+    constexpr int HALO = R == 5 ? 8 : 4, VALID = 256 - 2 * HALO;
+    static_assert(VALID == LAPM_VALID_OF(R), "strip geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_id = SPLIT ? wave_lin >> 1 : wave_lin;           // work item (row arithmetic, loop control and row bases stay scalar)
     const int img_sel = SPLIT ? __builtin_amdgcn_readfirstlane(wave_lin & 1) : -1;
@@ -901,8 +911,8 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     // exactly at column W: it recomputes - and rewrites, byte for byte the same - columns of its left neighbour and counts valid
     // pixels only from `cnt_from` on.
     const bool shifted = (W % 4 != 0) && strip == nstrips - 1 && W >= 256;      // (its lane 0 at column W - 252 lies inside the image)
-    const int gx0 = (shifted ? W - 252 : strip * LAPM_VALID - 4) + 4 * lane;           // first of this lane's 4 columns
-    const int cnt_from = shifted ? (nstrips - 1) * LAPM_VALID : 0;
+    const int gx0 = (shifted ? W - (256 - HALO) : strip * VALID - HALO) + 4 * lane;           // first of this lane's 4 columns
+    const int cnt_from = shifted ? (nstrips - 1) * VALID : 0;
     const uint32_t cnt_mask = gx0 >= cnt_from ? 0xffffffffu : gx0 + 4 <= cnt_from ? 0u : (0xffffffffu << (8 * (cnt_from - gx0)));
     const unsigned ugx = (unsigned)gx0;                           // used by output lanes only (gx0 >= 0 there)
     // FAST path (W % 4 == 0, aligned rows): a lane left of the image or right of it loads the 4 columns of its
@@ -911,22 +921,24 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     //   right [c0 c1 c2 c3] -> [c2 c1 c0  . ]  (columns W..W+3)
     // R = 4 (ksize 9): column -4 / W + 3 IS a tap - the border lane loads the four columns ONE further inside (1..4 / W-5..W-2) and
     // reverses them: [c1 c2 c3 c4] -> [c4 c3 c2 c1] = columns -4..-1, [W-5 .. W-2] -> [W-2 .. W-5] = columns W..W+3
-    const unsigned ugx_load = R == 4 ? (unsigned)(gx0 < 0 ? 1 : gx0 >= W ? W - 5 : gx0) : (unsigned)min(max(gx0, 0), W - 4);
-    const unsigned edge_sel = R == 4 ? ((gx0 < 0 || gx0 >= W) ? 0x00010203u : 0x03020100u)
-                                     : (gx0 < 0 ? 0x01020300u : gx0 >= W ? 0x03000102u : 0x03020100u);
+    // (RH = 4 in general: the lane at columns g .. g + 3 outside the image holds the reversed columns -g - 3 .. -g / 2W - 5 - g .. 2W - 2 - g;
+    //  lanes further out than the halo hold columns nobody reads - clamped into the image)
+    const unsigned ugx_load = RH == 4 ? (unsigned)min(max(gx0 < 0 ? -gx0 - 3 : gx0 >= W ? 2 * W - 5 - gx0 : gx0, 0), W - 4) : (unsigned)min(max(gx0, 0), W - 4);
+    const unsigned edge_sel = RH == 4 ? ((gx0 < 0 || gx0 >= W) ? 0x00010203u : 0x03020100u)
+                                      : (gx0 < 0 ? 0x01020300u : gx0 >= W ? 0x03000102u : 0x03020100u);
     const bool col_inside = gx0 >= 0 && gx0 + 3 < W;
     const bool vec0 = col_inside && (stride0 % 4 == 0) && ((uintptr_t)img0 % (4 * sizeof(T)) == 0);
     const bool vec1 = col_inside && (stride1 % 4 == 0) && ((uintptr_t)img1 % (4 * sizeof(T)) == 0);
     int rc[4];                                                    // REFLECT_101 columns for lanes on the border
 #pragma unroll
     for (int k = 0; k < 4; k++) rc[k] = km_reflect101(gx0 + k, W);
-    const bool out_lane = lane >= 1 && lane <= 62 && gx0 < W;
+    const bool out_lane = lane >= HALO / 4 && lane <= 63 - HALO / 4 && gx0 < W;
     const int y0 = rowblock * rows_per_item, y1 = min(H, y0 + rows_per_item);
 
     // packed coefficients
     // (R = 4: nine taps = three dwords; the smoothing sum stays SIGNED there - sum ks (u - 128) spans [-32768, 32512], exactly an int16 -
     //  and needs no bias: the vertical derivative taps sum to zero, so a constant added to every smoothed row cancels in kd * hs)
-    constexpr int NH = R == 4 ? 3 : 2;
+    constexpr int NH = RH == 4 ? 3 : 2;
     int kdp[2][NH], ksp[2][NH], bias[2], vk[2][NR];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -999,6 +1011,14 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
         }
     };
 
+    int hp[2][2][4];                                  // (R = 5) the binomial's two previous rows of horizontal sums
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) hp[i][r][j] = 0;
+    (void)hp;
     int ring[2][NR][4];
 #pragma unroll
     for (int i = I0; i < I1; i++)
@@ -1073,7 +1093,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     constexpr int dummy = 0; (void)dummy;
-                    if constexpr (R == 4) {
+                    if constexpr (RH == 4) {
                         // nine taps: bytes [o, o + 9) of (lw | cw | rw)
                         const int g0 = (int)__builtin_amdgcn_alignbyte(cw, lw, o), g1 = (int)__builtin_amdgcn_alignbyte(rw, cw, o),
                                   g2 = (int)__builtin_amdgcn_alignbyte(0u, rw, o);
@@ -1099,6 +1119,49 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                 }
             }
             // ---- vertical combine for output row y = m - R (ring slot of source row y - R + j is (k + 1 + j) mod NR)
+            if constexpr (R == 5) {
+                // kernel 11: the 9-tap row yy = m - 4 unsaturated (every lane: the binomial reads the neighbour lanes' values through DPP), its
+                // horizontal [1 2 1], then the vertical [1 2 1] over the rows yy - 2 .. yy: output row yo = yy - 1.  An image whose kernel is
+                // smaller (b3 = 0) passes its 9-tap-padded row through unchanged, one row late like the other.
+                const int yy = m - RH, yo = yy - 1;
+                if (yy >= y0 - 1) {
+#pragma unroll
+                    for (int i = I0; i < I1; i++) {
+                        int a[4], h[4];
+#pragma unroll
+                        for (int o = 0; o < 4; o++) {
+                            int acc = dot2_seed0(ring[i][(k + 1) % NR][o], vk[i][0]);
+#pragma unroll
+                            for (int j = 1; j < NR; j++)
+                                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ring[i][(k + 1 + j) % NR][o]),
+                                                             __builtin_bit_cast(short2v, vk[i][j]), acc, false);
+                            a[o] = acc;
+                        }
+                        uint32_t packed = 0;
+                        if (cf.b3[i]) {
+                            const int al = __builtin_amdgcn_update_dpp(0, a[3], 0x138, 0xf, 0xf, false);      // lane - 1: the column left of this lane's
+                            const int ar = __builtin_amdgcn_update_dpp(0, a[0], 0x130, 0xf, 0xf, false);      // lane + 1
+#pragma unroll
+                            for (int o = 0; o < 4; o++) h[o] = (o == 0 ? al : a[o - 1]) + 2 * a[o] + (o == 3 ? ar : a[o + 1]);
+#pragma unroll
+                            for (int o = 0; o < 4; o++) packed |= (uint32_t)min(max(hp[i][1][o] + 2 * hp[i][0][o] + h[o], 0), 255) << (8 * o);
+                        } else {
+#pragma unroll
+                            for (int o = 0; o < 4; o++) { h[o] = a[o]; packed |= (uint32_t)min(max(hp[i][0][o], 0), 255) << (8 * o); }
+                        }
+#pragma unroll
+                        for (int o = 0; o < 4; o++) { hp[i][1][o] = hp[i][0][o]; hp[i][0][o] = h[o]; }
+                        if (yo >= y0 && out_lane) {
+                            const size_t off = (size_t)yo * W + gx0;
+                            if (FAST) __builtin_memcpy((outs[i] + (size_t)yo * W) + opaque_lane_offset(ugx), &packed, 4);
+                            else if (gx0 + 3 < W && (off & 3) == 0) *(uint32_t *)(outs[i] + off) = packed;
+                            else {
+                                for (int j = 0; j < 4 && gx0 + j < W; j++) outs[i][off + j] = (uint8_t)(packed >> (8 * j));
+                            }
+                        }
+                    }
+                }
+            } else {
             const int y = m - R;
             if (y >= y0 && out_lane) {
 #pragma unroll
@@ -1121,6 +1184,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
                     }
                 }
             }
+            }
         }
     }
     };  // march
@@ -1129,7 +1193,7 @@ __device__ __forceinline__ void lap_march_item(const T *__restrict__ img0, const
     // tile: every other row sits off the dword grid; the per-pixel path there cost 1.75x).  The last strip of a width that is no multiple
     // of 4 is shifted (above); only a last strip of fewer than 4 columns (its left neighbour's border lane straddles the edge) and images of
     // a single strip still take the general path.
-    const bool fast = (W % 4 == 0) || shifted || (strip * LAPM_VALID - 4 + 4 * 64 <= W);
+    const bool fast = (W % 4 == 0) || shifted || (strip * VALID - HALO + 4 * 64 <= W);
     if constexpr (SPLIT) {
         if (img_sel == 0) { if (fast) march(std::true_type{}, std::integral_constant<int, 0>{}); else march(std::false_type{}, std::integral_constant<int, 0>{}); }
         else { if (fast) march(std::true_type{}, std::integral_constant<int, 1>{}); else march(std::false_type{}, std::integral_constant<int, 1>{}); }
@@ -1192,7 +1256,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
                             const lap_coef &cf, int invert1, const nodata_t &nd, uint8_t *oa, uint8_t *ob,
                             uint8_t *mask, unsigned long long *valid_out)
 {
-    const int nstrips = (W + LAPM_VALID - 1) / LAPM_VALID;
+    const int nstrips = (W + LAPM_VALID_OF(R) - 1) / LAPM_VALID_OF(R);
     // resident waves: 4 SIMDs per CU x the waves per SIMD the register budget of this instantiation allows
     auto slots_of = [&](const void *fn) -> long {
         int wg_per_cu = 0;
@@ -1201,7 +1265,8 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     };
     constexpr bool SPLIT = LAPM_SPLIT != 0;
     const void *fn = R == 1 ? (const void *)lap_march_kernel<1, T, MASK, SPLIT> : R == 2 ? (const void *)lap_march_kernel<2, T, MASK, SPLIT>
-                   : R == 3 ? (const void *)lap_march_kernel<3, T, MASK, SPLIT> : (const void *)lap_march_kernel<4, T, MASK, SPLIT>;
+                   : R == 3 ? (const void *)lap_march_kernel<3, T, MASK, SPLIT> : R == 4 ? (const void *)lap_march_kernel<4, T, MASK, SPLIT>
+                   : (const void *)lap_march_kernel<5, T, MASK, SPLIT>;
     int rows = km_pick_rows(H, (SPLIT ? 2 : 1) * nstrips, 2 * R, slots_of(fn), 32, 160);
     if (const char *e = km_dev_env("KARIOS_HIP_LAP_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096) rows = v; }   // tuning override
     const int nitems = nstrips * ((H + rows - 1) / rows);
@@ -1219,6 +1284,7 @@ static int launch_lap_march(km_ctx *c, int R, const T *a, const T *b, int H, int
     case 2: lap_march_kernel<2, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     case 3: lap_march_kernel<3, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     case 4: lap_march_kernel<4, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
+    case 5: lap_march_kernel<5, T, MASK, SPLIT><<<grid, 256, 0, c->stream>>>(a, b, H, W, sa, sb, mm, cf, invert1, nd, oa, ob, mask, valid, nstrips, rows, nitems); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
@@ -1319,11 +1385,12 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     for (int u = 0; u < U.n; u++) {
         A.img0[u] = U.ref[u]; A.img1[u] = U.mon[u]; A.s0[u] = U.sref[u]; A.s1[u] = U.smon[u]; A.mm[u] = U.mm[u];
         A.out0[u] = U.lap_ref[u]; A.out1[u] = U.lap_mon[u]; A.mask[u] = U.mask[u];
-        A.H[u] = U.H[u]; A.W[u] = U.W[u]; A.nstrips[u] = (U.W[u] + LAPM_VALID - 1) / LAPM_VALID;
+        A.H[u] = U.H[u]; A.W[u] = U.W[u]; A.nstrips[u] = (U.W[u] + LAPM_VALID_OF(R) - 1) / LAPM_VALID_OF(R);
     }
     int wg_per_cu = 0;
     const void *fn = R == 1 ? (const void *)lap_march_units_kernel<1, T, true> : R == 2 ? (const void *)lap_march_units_kernel<2, T, true>
-                   : R == 3 ? (const void *)lap_march_units_kernel<3, T, true> : (const void *)lap_march_units_kernel<4, T, true>;
+                   : R == 3 ? (const void *)lap_march_units_kernel<3, T, true> : R == 4 ? (const void *)lap_march_units_kernel<4, T, true>
+                   : (const void *)lap_march_units_kernel<5, T, true>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, fn, 256, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 4;
     const long slots = (long)c->n_cu * 4 * wg_per_cu;
     // rows per item: the value in [32, 160] that minimises whole rounds of resident waves x the work of one item, over ALL units' strips
@@ -1366,6 +1433,7 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
         case 2: lap_march_units_kernel<2, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         case 3: lap_march_units_kernel<3, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         case 4: lap_march_units_kernel<4, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+        case 5: lap_march_units_kernel<5, T, false><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
         default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
         }
         KM_LAUNCH_CHECK(c);
@@ -1380,48 +1448,19 @@ static int launch_lap_march_units(km_ctx *c, int R, const km_units &U, const lap
     case 2: lap_march_units_kernel<2, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     case 3: lap_march_units_kernel<3, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     case 4: lap_march_units_kernel<4, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
+    case 5: lap_march_units_kernel<5, T, true><<<grid, 256, 0, c->stream>>>(A, cf, invert1, nd); break;
     default: return km_fail(c, KM_E_INTERNAL, "lap_march radius %d", R);
     }
     KM_LAUNCH_CHECK(c);
     return KM_OK;
 }
 
-// Kernel size 11 in a batch (sum ks = 1024: its horizontal sums need 18 bits, the marching kernel's ring holds 16-bit pairs): the LDS
-// kernel, one launch per unit, its per-workgroup counts of valid pixels summed with the other units' by kd_valid_sum_units - the rest
-// of the submission (eigenvalue pass, chains, LK, frames, the software pipeline) is the batch's own.
-template <typename T>
-static int launch_lap_lds_units(km_ctx *c, int R, const km_units &U, const lap_coef &cf, int invert1, const nodata_t &nd, km_valid_units *job)
+// The marching kernel at radius 5: every image's kernel as a 9-tap pass, kernel 11 as the 9-tap pass of kernel 9 + the 3 x 3 binomial
+// (lap_march_item).  Coefficients centred at radius 4.
+static bool fill_coef_march5(int ksize, int *kd, int *ks, int *b3)
 {
-    if (R != 5) return km_fail(c, KM_E_INTERNAL, "lap_lds_units radius %d", R);
-    const int mask_wgs = 256;
-    size_t off[KM_UNITS_MAX + 1];
-    off[0] = 0;
-    for (int u = 0; u < U.n; u++)
-        off[u + 1] = off[u] + (U.has_user_mask ? (size_t)mask_wgs : (size_t)((U.W[u] + LAP_TW - 1) / LAP_TW) * ((U.H[u] + LAP_TH - 1) / LAP_TH));
-    unsigned *valid = (unsigned *)km_ws(c, WS_LAP_VALID, off[U.n] * sizeof(unsigned));
-    if (!valid) return KM_E_NOMEM;
-    job->n = U.n;
-    if (U.has_user_mask) {
-        mask_units_args M;
-        for (int u = 0; u < U.n; u++) {
-            M.src[u] = U.user_mask[u]; M.dst[u] = U.mask[u]; M.stride[u] = U.user_smask[u]; M.H[u] = U.H[u]; M.W[u] = U.W[u];
-            M.partial[u] = valid + off[u];
-        }
-        mask_pack_units_kernel<<<dim3(mask_wgs, U.n), 256, 0, c->stream>>>(M);
-        KM_LAUNCH_CHECK(c);
-    }
-    for (int u = 0; u < U.n; u++) {
-        const dim3 grid((U.W[u] + LAP_TW - 1) / LAP_TW, (U.H[u] + LAP_TH - 1) / LAP_TH);
-        if (U.has_user_mask)
-            lap_kernel<5, T, 2, false><<<grid, 256, 0, c->stream>>>((const T *)U.ref[u], (const T *)U.mon[u], U.H[u], U.W[u], U.sref[u], U.smon[u], U.mm[u], cf,
-                                                                      invert1, nd, U.lap_ref[u], U.lap_mon[u], nullptr, nullptr);
-        else
-            lap_kernel<5, T, 2, true><<<grid, 256, 0, c->stream>>>((const T *)U.ref[u], (const T *)U.mon[u], U.H[u], U.W[u], U.sref[u], U.smon[u], U.mm[u], cf,
-                                                                     invert1, nd, U.lap_ref[u], U.lap_mon[u], U.mask[u], valid + off[u]);
-        KM_LAUNCH_CHECK(c);
-        job->partial[u] = valid + off[u]; job->n_partial[u] = (unsigned)(off[u + 1] - off[u]); job->out[u] = &U.sc[u]->valid;
-    }
-    return KM_OK;
+    *b3 = ksize == 11 ? 1 : 0;
+    return fill_coef(ksize == 11 ? 9 : ksize, 4, kd, ks);
 }
 
 // KM_E_UNSUPPORTED (no message) when the batch form does not cover the case (tiny units): the caller submits the units one by one instead
@@ -1436,14 +1475,12 @@ int kd_stretch_laplacian_units(km_ctx *c, const km_units &U, int ksize_ref, int 
     for (int u = 0; u < U.n; u++)
         if (U.W[u] < 8 || U.H[u] < 8) return KM_E_UNSUPPORTED;
     const nodata_t nd = make_nodata(nodata_mon, nodata_ref);
-    if (R > 4)
-        switch (U.dtype) {
-        case KM_U8: return launch_lap_lds_units<uint8_t>(c, R, U, cf, invert_mon, nd, job);
-        case KM_U16: return launch_lap_lds_units<uint16_t>(c, R, U, cf, invert_mon, nd, job);
-        case KM_I16: return launch_lap_lds_units<int16_t>(c, R, U, cf, invert_mon, nd, job);
-        case KM_F32: return launch_lap_lds_units<float>(c, R, U, cf, invert_mon, nd, job);
-        default: return km_fail(c, KM_E_ARG, "stretch_laplacian: bad dtype %d", U.dtype);
-        }
+    if (R == 5) {
+        for (int u = 0; u < U.n; u++)
+            if (U.W[u] < 16 || U.H[u] < 16) return KM_E_UNSUPPORTED;
+        if (!fill_coef_march5(ksize_ref, cf.kd[0], cf.ks[0], &cf.b3[0]) || !fill_coef_march5(ksize_mon, cf.kd[1], cf.ks[1], &cf.b3[1]))
+            return km_fail(c, KM_E_INTERNAL, "laplacian coefficients");
+    }
     switch (U.dtype) {
     case KM_U8: return launch_lap_march_units<uint8_t>(c, R, U, cf, invert_mon, nd, job);
     case KM_U16: return launch_lap_march_units<uint16_t>(c, R, U, cf, invert_mon, nd, job);
@@ -1476,7 +1513,11 @@ int kd_stretch_laplacian_pair(km_ctx *c, const void *d_ref, const void *d_mon, i
         !fill_coef(ksize_mon, R, cf.kd[1], cf.ks[1]))
         return km_fail(c, KM_E_UNSUPPORTED, "Laplacian ksize ref=%d mon=%d (supported: 1,3,5,7,9,11)", ksize_ref, ksize_mon);
     nodata_t nd = make_nodata(nodata_mon, nodata_ref);
-    if (R <= 4 && W >= 8 && H >= 8) {
+    lap_coef cf5;
+    const bool march5 = R == 5 && W >= 16 && H >= 16 && fill_coef_march5(ksize_ref, cf5.kd[0], cf5.ks[0], &cf5.b3[0]) &&
+                        fill_coef_march5(ksize_mon, cf5.kd[1], cf5.ks[1], &cf5.b3[1]);
+    if (march5) cf = cf5;
+    if ((R <= 4 && W >= 8 && H >= 8) || march5) {
 #define KM_PAIRM(T)                                                                                                              \
     (d_mask_out ? launch_lap_march<T, true>(c, R, (const T *)d_ref, (const T *)d_mon, H, W, sref, smon, d_mm, cf, invert_mon, nd, \
                                             d_lap_ref, d_lap_mon, d_mask_out, d_valid)                                           \
