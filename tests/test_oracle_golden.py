@@ -118,6 +118,35 @@ def test_laplacian_vs_scipy(O, ksize):
     np.testing.assert_array_equal(O.laplacian_u8(img, ksize), np.clip(full, 0, 255).astype(np.uint8))
 
 
+def test_laplacian_11_is_the_binomial_of_the_unsaturated_laplacian_9(O):
+    """What the marching kernel's radius-5 form rests on (k_dense.hip lap_march_item): OpenCV's size-11 derivative / smoothing kernels
+    are the size-9 kernels convolved with [1 2 1], so Laplacian_11 = ([1 2 1] x [1 2 1]) * (kd9 x ks9 + ks9 x kd9) on the REFLECT_101
+    extension, saturated once at the end - also for images smaller than the kernel (multiple reflections)."""
+    kd9, ks9, kd11, ks11 = (O.sobel_kernel(9, 2), O.sobel_kernel(9, 0), O.sobel_kernel(11, 2), O.sobel_kernel(11, 0))
+    assert np.array_equal(np.convolve(kd9, [1, 2, 1]), kd11) and np.array_equal(np.convolve(ks9, [1, 2, 1]), ks11)
+
+    def sep(img, kx, ky):             # rows filtered with kx, columns with ky, REFLECT_101, int64
+        def along(a, k, axis):
+            r = len(k) // 2
+            n = a.shape[axis]
+            idx = np.arange(-r, n + r)
+            per = max(1, 2 * n - 2)
+            idx = np.abs((idx % per + per) % per)
+            idx = np.where(idx >= n, per - idx, idx) if n > 1 else np.zeros_like(idx)
+            ext = np.take(a, idx, axis=axis)
+            out = np.zeros_like(a)
+            for t, c in enumerate(k):
+                out += int(c) * np.take(ext, np.arange(t, t + n), axis=axis)
+            return out
+        return along(along(img.astype(np.int64), kx, 1), ky, 0)
+
+    for seed, shape in enumerate([(40, 53), (64, 64), (7, 9), (3, 30), (21, 5)]):
+        img = rand_u8(shape, seed=300 + seed)
+        l9 = sep(img, kd9, ks9) + sep(img, ks9, kd9)                                     # unsaturated
+        composite = np.clip(sep(l9, [1, 2, 1], [1, 2, 1]), 0, 255).astype(np.uint8)
+        np.testing.assert_array_equal(composite, O.laplacian_u8(img, 11), err_msg=str(shape))
+
+
 def test_laplacian_kats(O):
     ramp = np.tile(np.arange(40, dtype=np.uint8) * 3, (30, 1))
     for k in (1, 3, 5, 7):
