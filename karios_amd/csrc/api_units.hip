@@ -220,6 +220,7 @@ int km_klt_units_frame_submit(km_ctx *c, const km_unit *units, int n, int dtype,
             return rc;
         if (q.W > 65535) return km_fail(c, KM_E_ARG, "klt_units_frame_submit: unit of %d columns (the device-side frame ordering holds at most 65535)", q.W);
         if (q.W < 512 || q.H < 2 * prm->block_size + 8 || (q.W + 1) / 2 <= prm->win_size || (q.H + 1) / 2 <= prm->win_size) return KM_E_UNSUPPORTED;
+        if ((prm->ksize_ref == 11 || prm->ksize_mon == 11) && q.H < 16) return KM_E_UNSUPPORTED;      // (the marching kernel's radius-5 form: kd_stretch_laplacian_units)
     }
     if (!c->enqueue_mu) c->enqueue_mu = new std::mutex;
     if (!c->utail) c->utail = new km_units_tail;
