@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 DTYPES = (np.uint16, np.uint16, np.uint8, np.int16, np.float32)
-KSIZES = (1, 3, 5, 7, 7, 9, 11)
+KSIZES = tuple(int(v) for v in os.environ["KARIOS_FUZZ_KSIZES"].split(",")) if os.environ.get("KARIOS_FUZZ_KSIZES") else (1, 3, 5, 7, 7, 9, 11)   # (env: bias a sweep towards some kernel sizes)
 BLOCKS = (3, 5, 7, 9, 15, 15, 4, 8, 21)
 WINS = (9, 15, 21, 25, 25, 31)
 MAXC = (0, 40, 500, 5000, 20000)
@@ -326,8 +326,8 @@ def run_units_case(seed, ops, O, ResidentPair):
     nodata_ref = None if rng.random() < 0.8 else 0.0
     for p, _, _ in pairs:
         p.no_data_mon, p.no_data_ref = nodata_mon, nodata_ref
-    k_mon = int(rng.choice([1, 3, 5, 7, 7, 9, 11]))
-    k_ref = k_mon if rng.random() < 0.6 else int(rng.choice([1, 3, 5, 7, 9, 11]))
+    k_mon = int(rng.choice(KSIZES))
+    k_ref = k_mon if rng.random() < 0.6 else int(rng.choice(KSIZES))
     invert = bool(rng.random() < 0.25)
     win = int(WINS[rng.integers(len(WINS))])
     conf = O.default_conf(maxCorners=int(rng.choice([40, 500, 5000, 20000])), blocksize=int(rng.choice([3, 5, 7, 9, 15, 15])), matching_winsize=win,

@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+KSIZES = [int(v) for v in os.environ["KARIOS_FUZZ_KSIZES"].split(",")] if os.environ.get("KARIOS_FUZZ_KSIZES") else [1, 3, 5, 7, 7, 9, 11]
+
 def same_rows(a, b) -> bool:
     ia, ib = a.block.view(np.int32), b.block.view(np.int32)
     # (header word 3 - the candidate count of the synchronisation-free corner path - is a diagnostic: 0 for a unit that was repeated exactly)
@@ -65,7 +67,7 @@ def main():
                     y, x = int(rng.integers(0, H - 20)), int(rng.integers(0, W - 20))
                     mask[y:y + int(rng.integers(20, 300)), x:x + int(rng.integers(20, 400))] = 0
             pairs.append(ResidentPair.upload(mon, ref, mask, ctx=ctx))
-        conf = KLTConfiguration(maxCorners=int(rng.choice([40, 500, 3000])), laplacian_kernel_size=int(rng.choice([1, 3, 5, 7, 7, 9, 11])),
+        conf = KLTConfiguration(maxCorners=int(rng.choice([40, 500, 3000])), laplacian_kernel_size=int(rng.choice(KSIZES)),
                                 blocksize=int(rng.choice([3, 5, 7, 9, 15, 15])), matching_winsize=int(rng.choice([9, 15, 21, 25, 25, 31])),
                                 qualityLevel=float(rng.choice([0.01, 0.1, 0.1, 0.3])), minDistance=int(rng.choice([1, 3, 10, 10, 14])),
                                 laplacian_invert_polarity=bool(rng.random() < 0.2))
