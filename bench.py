@@ -278,7 +278,7 @@ def run_solo_legs(a, env, conf, detail, data, pairs, last_frames, S, G):
         detail["same_pair_repeated"] = dict({kk: same[kk] for kk in ("ms_per_pair", "windows_ms_per_pair")},
                                             note=f"round 5's headline form: ONE resident pair {G} times per batched submission (cache reuse between the units)")
     if not a.no_full_scoring:
-        detail["full_scoring"], env.scored_frame = legs.full_scoring(ctx, pairs[0], conf, S, max(6, min(20, k)))
+        detail["full_scoring"], env.scored_frame = legs.full_scoring(ctx, pairs[0], conf, S, max(6, min(20, k)), pairs=pairs)
     if not a.no_auto_ksize and hasattr(legs, "auto_ksize_object"):
         detail["auto_ksize"] = legs.auto_ksize_object(ctx, pairs[0], data[0], S)
     if not a.no_in_flight:

@@ -110,6 +110,7 @@ def small_line(detail: dict) -> dict:
         "one_pair_per_submission_ms": ms("one_pair_per_submission"),
         "same_pair_repeated_ms": ms("same_pair_repeated"),
         "full_scoring_ms": ms("full_scoring"),
+        "full_scoring_batched_ms": _r(((detail.get("full_scoring") or {}).get("batched") or {}).get("ms_per_pair")),
         "in_flight_ms": ms("in_flight"),
         "end_to_end_ms": ms("end_to_end"),
         "end_to_end_note": "PCIe-inclusive (482 MB per pair from page-locked host rasters through KLT.match): what an unmodified KARIOS sees; never `value`" if detail.get("end_to_end") else None,
